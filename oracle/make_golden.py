@@ -1,0 +1,120 @@
+"""Generate tests/golden/*.npz from the UPSTREAM reference module (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Each case instantiates the reference ``VoiceSplit`` / ``VoiceFilter``
+(models/voicesplit/model.py:9, models/voicefilter/model.py:11) from a config
+``AttrDict`` (utils/generic_utils.py:560-563), loads a seeded state_dict, runs
+``model(x, dvec)`` (the call made by train.py:94) and records the returned mask
+plus the outputs of ``model.conv`` / ``model.lstm`` / ``model.fc2`` captured by
+forward hooks.  Weights are NOT stored (5x 64x64x5x5 conv kernels are 2 MB even
+for the tiny cases); they are re-derived by ``reference_forward.build_state_dict``
+from the recorded seed, and the fixture carries a SHA-256 of the state_dict bytes
+so RNG drift is reported as such and not as a parity failure.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import reference_forward as R            # noqa: E402
+from oracle._refimport import import_reference      # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+SMALL = dict(num_freq=37, emb_dim=16, lstm_dim=24, fc1_dim=40, fc2_dim=37)
+
+# name, model, dims, B, T, seed, training, gain
+CASES = [
+    ("vs_small_eval",   "voicesplit",  SMALL, 3, 50, 11, False, 6.0),
+    ("vf_small_eval",   "voicefilter", SMALL, 5, 33, 12, False, 6.0),
+    ("vs_small_train",  "voicesplit",  SMALL, 4, 40, 13, True,  6.0),
+    ("vs_short_T",      "voicesplit",  SMALL, 2, 20, 14, False, 6.0),   # T < dilation halo (2*16)
+    ("vs_T1",           "voicesplit",  SMALL, 1, 1,  15, False, 6.0),   # single frame
+    ("vs_full_b1",      "voicesplit",  R.default_dims(), 1, 301, 0, False, 8.0),
+    ("vf_full_b1",      "voicefilter", R.default_dims(), 1, 301, 1, False, 8.0),
+]
+
+
+def make_config(AttrDict, dims):
+    c = AttrDict()
+    c.update({
+        "model_name": "voicesplit",
+        "audio": {"backend": "voicefilter", "voicefilter": {"num_freq": dims["num_freq"]}},
+        "model": {k: dims[k] for k in ("lstm_dim", "fc1_dim", "fc2_dim", "emb_dim")},
+    })
+    return c
+
+
+def state_dict_digest(sd) -> str:
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def thin(name, arr, full):
+    """Full-size cases keep strided slices of the big intermediates."""
+    if not full:
+        return arr
+    if name == "cnn8":
+        return arr[:, :, ::16, ::4]
+    if name in ("lstm_out", "logits"):
+        return arr[:, ::4]
+    return arr
+
+
+def main():
+    VoiceSplit, VoiceFilter, _Mish, _load_config, AttrDict = import_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    for name, model_name, dims, B, T, seed, training, gain in CASES:
+        sd = R.spread_logits(R.build_state_dict(dims, seed), gain)
+        x, dvec = R.synthetic_inputs(B, T, dims, seed)
+        cls = VoiceSplit if model_name == "voicesplit" else VoiceFilter
+        model = cls(make_config(AttrDict, dims))
+        model.load_state_dict(sd, strict=True)
+        model.train(training)
+        grabbed = {}
+        hooks = [
+            model.conv.register_forward_hook(lambda m, i, o: grabbed.__setitem__("cnn8", o.detach())),
+            model.lstm.register_forward_hook(lambda m, i, o: grabbed.__setitem__("lstm_out", o[0].detach())),
+            model.fc2.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach())),
+        ]
+        with torch.no_grad():
+            mask = model(x, dvec)
+        for h in hooks:
+            h.remove()
+        full = dims["num_freq"] > 100
+        out = {
+            "model": np.array(model_name), "B": B, "T": T, "seed": seed,
+            "training": training, "gain": gain,
+            "dims": np.array([dims[k] for k in ("num_freq", "emb_dim", "lstm_dim", "fc1_dim", "fc2_dim")]),
+            "sd_sha256": np.array(state_dict_digest(sd)),
+            "torch_version": np.array(torch.__version__),
+            "mask": mask.numpy(),
+        }
+        for k, v in grabbed.items():
+            out[k] = thin(k, v.numpy(), full)
+        if training:   # BN buffers after the step (momentum 0.1, unbiased var)
+            after = model.state_dict()
+            for k in after:
+                if "running_" in k or "num_batches" in k:
+                    out["after/" + k] = after[k].numpy()
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez(path, **out)
+        lg = grabbed["logits"]
+        print(f"{name}: mask[{mask.min():.3f},{mask.max():.3f}] logits std {lg.std():.3f} "
+              f"-> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""CPU: pin the oracle (oracle/reference_forward.py) to the upstream reference.
+
+1. against the committed golden tensors produced by the upstream nn.Module
+   (oracle/make_golden.py) -- bit-for-bit;
+2. against the live upstream module when /root/reference is mounted;
+3. the explicit LSTM recurrence / Mish restatements against torch's own ops.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, load_golden
+from oracle import reference_forward as R
+from oracle._refimport import import_reference, reference_available
+
+
+def _digest(sd):
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _thin(name, arr, full):
+    if not full:
+        return arr
+    if name == "cnn8":
+        return arr[:, :, ::16, ::4]
+    if name in ("lstm_out", "logits"):
+        return arr[:, ::4]
+    return arr
+
+
+def case_tensors(g):
+    sd = R.spread_logits(R.build_state_dict(g["dims"], g["seed"]), g["gain"])
+    x, dvec = R.synthetic_inputs(g["B"], g["T"], g["dims"], g["seed"])
+    return sd, x, dvec
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_reproduces_upstream_golden(name):
+    g = load_golden(name)
+    sd, x, dvec = case_tensors(g)
+    assert _digest(sd) == g["sd_sha256"], "seeded weights differ from the run that made the fixture (torch RNG drift)"
+    act = "mish" if g["model"] == "voicesplit" else "relu"
+    bn_out = {}
+    with torch.no_grad():
+        out = R.forward(sd, x, dvec, act=act, training=g["training"], bn_out=bn_out)
+    full = g["dims"]["num_freq"] > 100
+    for k in ("cnn8", "lstm_out", "logits", "mask"):
+        got = _thin(k, out[k].numpy(), full)
+        assert got.shape == g[k].shape
+        assert np.array_equal(got, g[k]), f"{name}:{k} max|d|={np.abs(got - g[k]).max()}"
+    if g["training"]:
+        for k, v in bn_out.items():
+            assert np.array_equal(v.numpy(), g["after/" + k]), k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted")
+@pytest.mark.parametrize("model_name,act", [("voicesplit", "mish"), ("voicefilter", "relu")])
+def test_oracle_matches_live_upstream(model_name, act):
+    from oracle.make_golden import SMALL, make_config
+    VoiceSplit, VoiceFilter, Mish, _lc, AttrDict = import_reference()
+    cls = VoiceSplit if model_name == "voicesplit" else VoiceFilter
+    torch.manual_seed(5)
+    model = cls(make_config(AttrDict, SMALL)).eval()
+    # constructor order / RNG consumption of build_state_dict == upstream __init__
+    mine = R.build_state_dict(SMALL, seed=5, randomize_bn=False)
+    up = model.state_dict()
+    assert list(mine) == list(up)
+    for k in up:
+        assert torch.equal(mine[k], up[k]), k
+    sd = R.spread_logits(R.build_state_dict(SMALL, seed=5), 4.0)
+    model.load_state_dict(sd, strict=True)
+    x, dvec = R.synthetic_inputs(2, 45, SMALL, seed=5)
+    with torch.no_grad():
+        ref = model(x, dvec)
+        got = R.forward(sd, x, dvec, act=act)["mask"]
+    assert torch.equal(ref, got)
+    xs = torch.randn(1000) * 12
+    assert torch.equal(Mish()(xs), R.mish(xs))
+
+
+def test_explicit_lstm_matches_aten():
+    dims = dict(num_freq=9, emb_dim=8, lstm_dim=16, fc1_dim=8, fc2_dim=9)
+    sd = R.cast_state_dict(R.build_state_dict(dims, 3), torch.float64)
+    xs = torch.randn(3, 17, 8 * 9 + 8, dtype=torch.float64)
+    a = R.bilstm_aten(xs, sd)
+    b = R.bilstm(xs, sd)
+    assert (a - b).abs().max() < 1e-12
+
+
+def test_mish_closed_form():
+    # the HIP kernels use mish(x) = x * n/(n+2), n = e^x (e^x + 2); same function
+    x = torch.linspace(-30, 30, 4001, dtype=torch.float64)
+    u = torch.exp(torch.clamp(x, max=20.0))
+    n = u * (u + 2)
+    closed = torch.where(x > 20, x, x * n / (n + 2))
+    assert (closed - R.mish(x)).abs().max() < 1e-12
+
+
+def test_dvec_fold_identity():
+    # cat(x, dvec) @ W_ih^T == x @ W_ih[:, :8F]^T + dvec @ W_ih[:, 8F:]^T
+    dims = dict(num_freq=9, emb_dim=8, lstm_dim=16, fc1_dim=8, fc2_dim=9)
+    sd = R.cast_state_dict(R.build_state_dict(dims, 4), torch.float64)
+    W = sd["lstm.weight_ih_l0"]
+    x = torch.randn(2, 5, 72, dtype=torch.float64)
+    d = torch.randn(2, 8, dtype=torch.float64)
+    full = torch.cat((x, d[:, None].repeat(1, 5, 1)), 2) @ W.t()
+    fold = x @ W[:, :72].t() + (d @ W[:, 72:].t())[:, None]
+    assert (full - fold).abs().max() < 1e-12
