@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Throughput of the hot path on MI355X: utterances/s of the VoiceSplit mask-prediction forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--model voicesplit]
+
+Workload (BASELINE.json configs[1]): B=64 synthetic [64,301,601] spectrograms + 256-d d-vectors
+per GPU, fp32, forward only, eval-mode BatchNorm, random-init weights of the reference
+architecture.  A "step" is one forward pass over one batch already resident in HBM.
+N>1 (launched by torch.distributed.run, one rank per GPU): the batch dimension shards across
+ranks -- every rank runs its own 64 utterances, no data-path collective; the
+only collectives are the timing barrier and the MAX reduction of the elapsed time.
+
+Rank 0 prints ONE JSON line with the whole-job utterances/s plus
+  roofline     -- the five 5x5 dilated conv launches (89 % of the FLOPs): algorithmic FLOPs per
+                  launch / mean launch time from HIP events recorded inside the timed region
+  cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic work per utterance at T=301, F=601; FLOP = 2*MAC
+T_FRAMES, N_FREQ, EMB = 301, 601, 256
+GFLOP_CONV5X5 = 2 * 64 * 64 * 25 * T_FRAMES * N_FREQ / 1e9       # 37.05 per layer per utterance
+GFLOP_FWD_TOTAL = 206.995
+PEAK_FP32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle forward (reference restatement, torch CPU ops, nn.LSTM) on the host cores."""
+    from oracle import reference_forward as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dims = R.default_dims()
+    sd = R.build_state_dict(dims, 0)
+    x, dvec = R.synthetic_inputs(1, T_FRAMES, dims, 0)
+    with torch.no_grad():
+        R.forward(sd, x, dvec, act="mish")                     # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.forward(sd, x, dvec, act="mish")
+            n += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget or n >= 20:
+                break
+    return {"value": round(n / el, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forward passes of one [1,301,601] utterance (B=1, fp32, eval), "
+                      f"{el:.1f} s, torch {torch.__version__} CPU ops, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import voicesplit_amd as V
+    from voicesplit_amd import _lib, ops
+    lib = _lib.load()
+
+    B = args.batch
+    torch.manual_seed(0)
+    cls = V.VoiceSplit if args.model == "voicesplit" else V.VoiceFilter
+    model = cls(V.default_config()).eval()
+    with torch.no_grad():                                           # non-trivial BN statistics
+        g = torch.Generator().manual_seed(1000)
+        for m in model.conv:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(77 + rank)
+    spec = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)      # resident in HBM before timing
+    dvec = torch.randn(B, EMB, generator=g)
+    dvec = (dvec / dvec.norm(dim=1, keepdim=True)).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(spec, dvec)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    if rank == 0:
+        rc = lib.vs_profile_begin(args.steps)
+        _lib.check(rc, "vs_profile_begin")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms = (ctypes.c_float * _lib.PROF_SLOTS)()
+        calls = (ctypes.c_int * _lib.PROF_SLOTS)()
+        _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
+        stage_ms = {n: (ms[i] / calls[i] if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
+        # dominant kernel: conv64_mfma_kernel<5,5,...>, five launches per forward (cnn3..cnn7)
+        conv_ms = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
+        mean_launch_ms = sum(conv_ms) / 5.0
+        achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # GFLOP / ms == TFLOP/s
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "utterances/sec (3 s clips, B=64/GPU) forward, fp32",
+            "value": round(value, 2), "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
+                                   f"{args.model} forward-only, eval BN, random-init weights",
+                       "batch_per_gpu": B, "frames": T_FRAMES, "num_freq": N_FREQ,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "conv64_mfma_kernel<5,5> (cnn3..cnn7)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launch_ms": [round(v, 3) for v in conv_ms],
+                         "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)},
+            "stage_ms": {k: (round(v, 3) if v is not None else None) for k, v in stage_ms.items()},
+            "whole_forward_tflops": round(value / world * GFLOP_FWD_TOTAL / 1e3, 2),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

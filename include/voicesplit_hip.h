@@ -1,0 +1,163 @@
+/* voicesplit_hip.h -- C ABI of libvoicesplit_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of Edresson/VoiceSplit: the speaker-conditioned
+ * mask-prediction forward pass
+ *     mask = model(mixed_spec[B,T,F], dvec[B,E])          train.py:94
+ *                                                         utils/generic_utils.py:495,545
+ * i.e. VoiceSplit.forward  (models/voicesplit/model.py:66-89) and
+ *      VoiceFilter.forward (models/voicefilter/model.py:67-90).
+ * The reference has no native layer at all (it dispatches to torch.nn / cuDNN), so there is no
+ * upstream FFI to mirror; every entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer (fp32 unless noted) owned by the
+ *    caller; the library never allocates device memory and keeps no pointer after return.
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
+ *    synchronisation, no global mutable state; safe to call concurrently on different streams
+ *    with disjoint workspaces.
+ *  - return 0 on success, <0 on error (-1 bad argument, -2 HIP runtime error); the message is
+ *    available from vs_last_error() (thread-local).  No exceptions cross the ABI.
+ *  - tensors are dense row-major with the reference's layouts: spectrogram [B][T][F]
+ *    (F contiguous), conv activations [B][C][T][F], LSTM features [B][T][8F] with feature
+ *    index c*F+f, nn.Linear / nn.LSTM weights [out][in].
+ */
+#ifndef VOICESPLIT_HIP_H
+#define VOICESPLIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_ABI_VERSION 1
+
+/* activation codes */
+#define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
+#define VS_ACT_MISH 1     /* VoiceSplit conv stack  (utils/generic_utils.py:395-399)           */
+#define VS_ACT_NONE 2
+#define VS_ACT_SIGMOID 3
+
+/* BatchNorm mode */
+#define VS_BN_EVAL 0      /* running statistics (model.eval(), utils/generic_utils.py:479,533) */
+#define VS_BN_TRAIN 1     /* batch statistics + running-stat update (model.train(), train.py:84) */
+
+typedef struct vs_dims {
+  int B;    /* utterances in the batch                                  */
+  int T;    /* frames (301 for 3 s)                                     */
+  int F;    /* config.audio[backend].num_freq (601)                     */
+  int E;    /* config.model.emb_dim  (256)                              */
+  int H;    /* config.model.lstm_dim (400); must be a multiple of 8     */
+  int FC1;  /* config.model.fc1_dim  (600)                              */
+  int FC2;  /* config.model.fc2_dim  (601)                              */
+} vs_dims;
+
+/* One Conv2d + BatchNorm2d pair of the nn.Sequential (state_dict conv.{i}.*, conv.{i+1}.*). */
+typedef struct vs_conv_layer {
+  const float* weight;        /* [Cout][Cin][KT][KF]                       */
+  const float* bias;          /* [Cout]                                    */
+  const float* bn_weight;     /* [Cout] gamma                              */
+  const float* bn_bias;       /* [Cout] beta                               */
+  float* bn_running_mean;     /* [Cout] read in eval, updated in train     */
+  float* bn_running_var;      /* [Cout]                                    */
+} vs_conv_layer;
+
+/* Every parameter of VoiceSplit/VoiceFilter.__init__ (models/voicesplit/model.py:10-64). */
+typedef struct vs_params {
+  vs_conv_layer conv[8];      /* cnn1..cnn8 = conv.{1,5,9,13,17,21,25,28}          */
+  const float* w_ih[2];       /* lstm.weight_ih_l0, _reverse   [4H][8F+E]          */
+  const float* w_hh[2];       /* lstm.weight_hh_l0, _reverse   [4H][H]             */
+  const float* b_ih[2];       /* lstm.bias_ih_l0, _reverse     [4H]                */
+  const float* b_hh[2];       /* lstm.bias_hh_l0, _reverse     [4H]                */
+  const float* fc1_w;         /* [FC1][2H] */
+  const float* fc1_b;         /* [FC1]     */
+  const float* fc2_w;         /* [FC2][FC1]*/
+  const float* fc2_b;         /* [FC2]     */
+} vs_params;
+
+/* Byte offsets of the intermediates inside the caller-provided workspace (for inspection and
+ * stage-level parity tests).  Filled by vs_workspace_layout(). */
+typedef struct vs_ws_layout {
+  size_t total_bytes;
+  size_t act0, act1;          /* ping-pong [B][64][T][F]                           */
+  size_t feat;                /* cnn8 output == LSTM features [B][T][8F]           */
+  size_t dvbias;              /* dvec @ W_ih[:,8F:]^T + b_ih + b_hh   [B][8H]      */
+  size_t xg;                  /* gate pre-activations [B][T][2*4H]                 */
+  size_t lstm_out;            /* [B][T][2H]                                        */
+  size_t fc1_out;             /* relu(fc1) [B*T][FC1]                              */
+  size_t conv_packed[6];      /* fragment-ordered weights of cnn2..cnn7            */
+  size_t bn_scale, bn_shift;  /* [8][64] folded BatchNorm                          */
+  size_t bn_stats;            /* [8][64][2] double: sum, sum of squares (train)    */
+  size_t lstm_packed;         /* fragment-ordered W_hh, both directions            */
+  size_t lstm_state;          /* h ping/pong + c, [3][2][H][Bpad]                  */
+} vs_ws_layout;
+
+int vs_abi_version(void);
+const char* vs_last_error(void);
+
+/* Opt-in per-stage GPU timing (HIP events on the caller's stream, no synchronisation while
+ * enabled).  Slots: cnn1..cnn8 (0-7), LSTM input GEMMs (8), LSTM recurrence (9), head (10).
+ * Instrumentation for bench.py only: process-global, not thread safe. */
+#define VS_PROF_CNN1 0
+#define VS_PROF_CNN2 1      /* cnn2..cnn7 = 1..6 */
+#define VS_PROF_CNN8 7
+#define VS_PROF_LSTM_GEMM 8
+#define VS_PROF_LSTM_REC 9
+#define VS_PROF_HEAD 10
+#define VS_PROF_SLOTS 11
+int vs_profile_begin(int max_calls);
+int vs_profile_end(float* ms_total /* [VS_PROF_SLOTS] */, int* calls /* [VS_PROF_SLOTS] */);
+
+/* Workspace the caller must provide to the stage / whole-forward calls. */
+int vs_workspace_layout(const vs_dims* dims, vs_ws_layout* out);
+size_t vs_workspace_bytes(const vs_dims* dims);
+
+/* ---- whole path: replaces VoiceSplit.forward / VoiceFilter.forward ----------------------
+ * x [B][T][F], dvec [B][E] -> mask [B][T][FC2].  conv_act = VS_ACT_MISH (VoiceSplit) or
+ * VS_ACT_RELU (VoiceFilter). */
+int vs_forward(const vs_dims* dims, const vs_params* params, const float* x, const float* dvec,
+               int conv_act, int bn_mode, void* workspace, size_t workspace_bytes,
+               float* mask, void* stream);
+
+/* ---- stages (each is what vs_forward runs, in order) --------------------------------------- */
+/* self.conv(x.unsqueeze(1)) + transpose/view: models/voicesplit/model.py:68-74 -> feat [B][T][8F] */
+int vs_conv_stack_fwd(const vs_dims* dims, const vs_params* params, const float* x, int conv_act,
+                      int bn_mode, void* workspace, size_t workspace_bytes, float* feat, void* stream);
+/* repeat/cat d-vector + self.lstm: models/voicesplit/model.py:77-82 -> lstm_out [B][T][2H] */
+int vs_bilstm_fwd(const vs_dims* dims, const vs_params* params, const float* feat, const float* dvec,
+                  void* workspace, size_t workspace_bytes, float* lstm_out, void* stream);
+/* relu/fc1/relu/fc2/sigmoid: models/voicesplit/model.py:83-87; logits may be NULL */
+int vs_head_fwd(const vs_dims* dims, const vs_params* params, const float* lstm_out,
+                void* workspace, size_t workspace_bytes, float* logits, float* mask, void* stream);
+
+/* ---- kernels (unit-test surface) --------------------------------------------------------- */
+/* BN(conv+bias) = conv*scale + shift */
+int vs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+               const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
+/* cnn1: [B][T][F] -> [B][64][T][F], weight [64][1][1][7] */
+int vs_conv_first_fwd(const float* x, const float* w, const float* scale, const float* shift,
+                      float* out, int B, int T, int F, int act, void* stream);
+/* cnn2..cnn7: 64->64, (KT,KF) in {(7,1),(5,5)}, time dilation dil, "same" zero padding */
+size_t vs_conv64_packed_floats(int KT, int KF);
+int vs_conv64_pack(const float* w, float* packed, int KT, int KF, void* stream);
+int vs_conv64_fwd(const float* in, const float* packed, const float* scale, const float* shift,
+                  float* out, int B, int T, int F, int KT, int KF, int dil, int act, void* stream);
+/* cnn8: [B][64][T][F] -> [B][T][8][F], weight [8][64][1][1] */
+int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift,
+                     float* out, int B, int T, int F, int act, void* stream);
+/* C[M][N] = act(opA(A)[M][K] @ W[N][K]^T + bias1[n] + bias2[n] + rowbias[m/group][n]) */
+int vs_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+               const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+               int a_relu, int act, void* stream);
+/* recurrence over precomputed gate inputs xg [B][T][8H] -> out [B][T][2H] */
+size_t vs_lstm_packed_floats(int H);
+size_t vs_lstm_state_floats(int B, int H);
+int vs_lstm_pack(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, void* stream);
+int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, float* out,
+                        int B, int T, int H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOICESPLIT_HIP_H */

@@ -1,0 +1,99 @@
+"""CPU: the C-ABI library loads and exports every symbol include/voicesplit_hip.h declares; the
+host-side mirror of the reference interface behaves (no compute calls here -- no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import reference_forward as R
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "voicesplit_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from voicesplit_amd import _lib
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.vs_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_layout_and_argument_errors():
+    from voicesplit_amd import _lib, ops
+    lib = _lib.load()
+    d = ops.make_dims(64, 301, 601, 256, 400, 600, 601)
+    lay = ops.workspace_layout(d)
+    assert lay.total_bytes == lib.vs_workspace_bytes(ctypes.byref(d))
+    act = 64 * 64 * 301 * 601 * 4
+    assert lay.act1 - lay.act0 >= act and lay.total_bytes > 2 * act
+    offs = [lay.act0, lay.act1, lay.feat, lay.dvbias, lay.xg, lay.lstm_out, lay.fc1_out, *lay.conv_packed,
+            lay.bn_scale, lay.bn_shift, lay.bn_stats, lay.lstm_packed, lay.lstm_state]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    # bad arguments: error code + message, no exception across the ABI
+    bad = ops.make_dims(1, 10, 37, 16, 30, 40, 37)          # H not a multiple of 8
+    assert lib.vs_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"multiple of 8" in lib.vs_last_error()
+    with pytest.raises(_lib.VoiceSplitHipError):
+        ops.workspace_layout(bad)
+    assert lib.vs_conv64_packed_floats(5, 5) == (8 * 25 + 1) * 512
+    assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from voicesplit_amd import _lib
+    with pytest.raises(_lib.VoiceSplitHipError, match="no PyTorch/CPU fallback"):
+        _lib.load(str(tmp_path / "libvoicesplit_hip.so"))
+
+
+@pytest.mark.parametrize("cls_name", ["VoiceSplit", "VoiceFilter"])
+def test_module_surface_matches_reference(cls_name):
+    import voicesplit_amd
+    from models.voicefilter.model import VoiceFilter   # reference import paths (train.py:21-22)
+    from models.voicesplit.model import VoiceSplit
+    cls = {"VoiceSplit": VoiceSplit, "VoiceFilter": VoiceFilter}[cls_name]
+    assert cls is getattr(voicesplit_amd, cls_name)
+    dims = R.default_dims()
+    torch.manual_seed(0)
+    m = cls(voicesplit_amd.default_config())
+    ref = R.build_state_dict(dims, 0, randomize_bn=False)
+    sd = m.state_dict()
+    assert list(sd) == list(ref)                         # same keys, same order
+    for k in sd:
+        assert sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype, k
+        assert torch.equal(sd[k], ref[k]), k              # same default init under the same seed
+    assert sum(p.numel() for p in m.parameters()) == 18876001
+    m.load_state_dict(R.build_state_dict(dims, 3), strict=True)
+    assert m.training and not m.eval().training
+    # CPU tensors are refused, not silently computed some other way
+    from voicesplit_amd._lib import VoiceSplitHipError
+    with pytest.raises(VoiceSplitHipError, match="no CPU fallback"):
+        m(torch.rand(1, 4, 601), torch.rand(1, 256))
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/config.json"), reason="/root/reference not mounted")
+def test_reference_config_json_is_accepted():
+    from voicesplit_amd import VoiceSplit, load_config
+    c = load_config("/root/reference/config.json")
+    m = VoiceSplit(c)
+    assert m.lstm.input_size == 8 * 601 + 256 and m.fc2.out_features == 601
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "voicesplit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle/" not in text and "reference_forward" not in text, f

@@ -1,0 +1,177 @@
+"""GPU: every HIP kernel against the CPU oracle (fp64 torch ops on the same seeded inputs),
+called through the C ABI.  Tolerance: the path's contract is <= 1e-4 relative in fp32
+(BASELINE.json north_star); single kernels are held to 2e-5 of the output's max magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import reference_forward as R
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    ref = ref.to(torch.float64)
+    return ((got.detach().cpu().to(torch.float64) - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def _bn(c, g):
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1,
+            torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5)
+
+
+def _ref_bn_act(y, gamma, beta, mean, var, act):
+    y = (y - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5)
+    y = y * gamma[None, :, None, None] + beta[None, :, None, None]
+    return R.activation(y, act)
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("B,T,Fq", [(2, 9, 37), (1, 3, 601), (3, 1, 5)])
+def test_conv_first(act, B, T, Fq):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, T, Fq, generator=g)
+    w = torch.randn(64, 1, 1, 7, generator=g) * 0.4
+    b = torch.randn(64, generator=g) * 0.1
+    gamma, beta, mean, var = _bn(64, g)
+    d = dev()
+    scale, shift = ops.bn_fold(gamma.to(d), beta.to(d), mean.to(d), var.to(d), b.to(d))
+    got = ops.conv_first(x.to(d), w.to(d).contiguous(), scale, shift, act)
+    y = F.conv2d(F.pad(x.double().unsqueeze(1), (3, 3, 0, 0)), w.double(), b.double())
+    ref = _ref_bn_act(y, gamma.double(), beta.double(), mean.double(), var.double(), act)
+    assert rel_err(got, ref) < TOL
+
+
+CONV64_CASES = [
+    # KT, KF, dil, B, T, F
+    (7, 1, 1, 2, 19, 37),
+    (5, 5, 1, 2, 19, 37),
+    (5, 5, 2, 1, 23, 70),
+    (5, 5, 4, 2, 21, 33),
+    (5, 5, 8, 1, 50, 37),
+    (5, 5, 16, 2, 40, 31),
+    (5, 5, 16, 1, 20, 37),     # T shorter than the dilation halo
+    (5, 5, 1, 1, 1, 5),        # single frame, single partial tile
+    (5, 5, 2, 1, 301, 64),     # full T, exact F tile
+    (7, 1, 1, 1, 8, 601),      # full F
+]
+
+
+@pytest.mark.parametrize("KT,KF,dil,B,T,Fq", CONV64_CASES)
+@pytest.mark.parametrize("act", ["mish", "relu"])
+def test_conv64_mfma(KT, KF, dil, B, T, Fq, act):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(KT * 100 + dil)
+    x = torch.randn(B, 64, T, Fq, generator=g)
+    w = torch.randn(64, 64, KT, KF, generator=g) * (1.0 / (64 * KT * KF) ** 0.5)
+    b = torch.randn(64, generator=g) * 0.1
+    gamma, beta, mean, var = _bn(64, g)
+    d = dev()
+    scale, shift = ops.bn_fold(gamma.to(d), beta.to(d), mean.to(d), var.to(d), b.to(d))
+    got = ops.conv64(x.to(d), w.to(d), scale, shift, dil, act)
+    pt, pf = dil * (KT // 2), KF // 2
+    y = F.conv2d(F.pad(x.double(), (pf, pf, pt, pt)), w.double(), b.double(), dilation=(dil, 1))
+    ref = _ref_bn_act(y, gamma.double(), beta.double(), mean.double(), var.double(), act)
+    assert rel_err(got, ref) < TOL
+
+
+def test_conv64_weight_layout_is_not_symmetric_blind():
+    """One-hot weight: out[co] must equal the shifted in[ci] for exactly one (co,ci,kt,kf)."""
+    from voicesplit_amd import ops
+    d = dev()
+    x = torch.randn(1, 64, 12, 40, generator=torch.Generator().manual_seed(3))
+    for (co, ci, kt, kf) in [(5, 11, 0, 4), (63, 0, 4, 0), (33, 62, 2, 3)]:
+        w = torch.zeros(64, 64, 5, 5)
+        w[co, ci, kt, kf] = 1.0
+        ones, zeros = torch.ones(64, device=d), torch.zeros(64, device=d)
+        got = ops.conv64(x.to(d), w.to(d), ones, zeros, 2, "none").cpu()
+        ref = F.conv2d(F.pad(x, (2, 2, 4, 4)), w, dilation=(2, 1))
+        assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+def test_conv_last_writes_lstm_feature_layout(act):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, Fq = 2, 7, 37
+    x = torch.randn(B, 64, T, Fq, generator=g)
+    w = torch.randn(8, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(8, generator=g) * 0.1
+    gamma, beta, mean, var = _bn(8, g)
+    d = dev()
+    scale, shift = ops.bn_fold(gamma.to(d), beta.to(d), mean.to(d), var.to(d), b.to(d))
+    got = ops.conv_last(x.to(d), w.to(d).contiguous(), scale, shift, act)
+    y = F.conv2d(x.double(), w.double(), b.double())
+    ref = _ref_bn_act(y, gamma.double(), beta.double(), mean.double(), var.double(), act)
+    ref = ref.transpose(1, 2).contiguous().view(B, T, -1)      # models/voicesplit/model.py:72-74
+    assert got.shape == ref.shape and rel_err(got, ref) < TOL
+
+
+GEMM_CASES = [
+    # M, N, K, lda_pad, ldw_pad
+    (64, 96, 256, 0, 0),
+    (301, 1600, 296, 0, 16),      # small-config LSTM projection: W_ih slice of a wider matrix
+    (130, 601, 600, 0, 0),        # fc2 shape class (N, K not multiples of the tile)
+    (257, 33, 70, 0, 0),          # K % 4 != 0 -> scalar-load path
+    (5, 7, 3, 1, 2),
+    (1000, 600, 800, 0, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,pa,pw", GEMM_CASES)
+def test_gemm_nt(M, N, K, pa, pw):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K + pa, generator=g)
+    W = torch.randn(N, K + pw, generator=g) / K ** 0.5
+    b1, b2 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    group = 37
+    rb = torch.randn((M + group - 1) // group, N, generator=g)
+    d = dev()
+    got = ops.gemm_nt(A.to(d), W.to(d), b1.to(d), b2.to(d), rb.to(d), group=group, a_relu=True, act="sigmoid", K=K)
+    rows = torch.arange(M) // group
+    ref = torch.sigmoid(torch.relu(A[:, :K].double()) @ W[:, :K].double().t() + b1.double() + b2.double() + rb.double()[rows])
+    assert rel_err(got, ref) < TOL
+    got = ops.gemm_nt(A.to(d), W.to(d), K=K)
+    assert rel_err(got, A[:, :K].double() @ W[:, :K].double().t()) < TOL
+
+
+def test_gemm_transpose_detecting():
+    from voicesplit_amd import ops
+    d = dev()
+    A = torch.eye(64, 64)
+    W = torch.arange(96 * 64, dtype=torch.float32).reshape(96, 64) / 100.0   # asymmetric
+    got = ops.gemm_nt(A.to(d), W.to(d)).cpu()
+    assert torch.equal(got, W.t().contiguous())
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 11, 24), (1, 1, 8), (33, 5, 16), (2, 40, 400)])
+def test_bilstm_recurrent(B, T, H):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + H)
+    xg = torch.randn(B, T, 8 * H, generator=g)
+    whf = torch.randn(4 * H, H, generator=g) * (1.5 / H ** 0.5)
+    whb = torch.randn(4 * H, H, generator=g) * (1.5 / H ** 0.5)
+    d = dev()
+    got = ops.bilstm_recurrent(xg.to(d), whf.to(d), whb.to(d))
+
+    def one(xgd, w, reverse):
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
+        out = torch.zeros(B, T, H, dtype=torch.float64)
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            i, f, gg, o = (xgd[:, t] + h @ w.t()).split(H, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out[:, t] = h
+        return out
+
+    ref = torch.cat((one(xg[..., :4 * H].double(), whf.double(), False),
+                     one(xg[..., 4 * H:].double(), whb.double(), True)), dim=2)
+    assert rel_err(got, ref) < TOL

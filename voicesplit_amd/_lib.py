@@ -1,0 +1,105 @@
+"""ctypes binding of libvoicesplit_hip.so (C ABI declared in include/voicesplit_hip.h).
+
+Plain pointers and sizes only -- no torch types cross this boundary.  torch is used by callers
+for device memory and streams; it must be imported (and HIP initialised) before the library is
+loaded so that both resolve the same ``libamdhip64`` already mapped into the process.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvoicesplit_hip.so")
+
+ACT_RELU, ACT_MISH, ACT_NONE, ACT_SIGMOID = 0, 1, 2, 3
+BN_EVAL, BN_TRAIN = 0, 1
+PROF_SLOTS = 11
+PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head")
+ABI_VERSION = 1
+
+
+class VsDims(Structure):
+    _fields_ = [(n, c_int) for n in ("B", "T", "F", "E", "H", "FC1", "FC2")]
+
+
+class VsConvLayer(Structure):
+    _fields_ = [(n, c_void_p) for n in ("weight", "bias", "bn_weight", "bn_bias",
+                                        "bn_running_mean", "bn_running_var")]
+
+
+class VsParams(Structure):
+    _fields_ = [
+        ("conv", VsConvLayer * 8),
+        ("w_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_ih", c_void_p * 2), ("b_hh", c_void_p * 2),
+        ("fc1_w", c_void_p), ("fc1_b", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p),
+    ]
+
+
+class VsWsLayout(Structure):
+    _fields_ = [
+        ("total_bytes", c_size_t), ("act0", c_size_t), ("act1", c_size_t), ("feat", c_size_t),
+        ("dvbias", c_size_t), ("xg", c_size_t), ("lstm_out", c_size_t), ("fc1_out", c_size_t),
+        ("conv_packed", c_size_t * 6), ("bn_scale", c_size_t), ("bn_shift", c_size_t),
+        ("bn_stats", c_size_t), ("lstm_packed", c_size_t), ("lstm_state", c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/voicesplit_hip.h declares
+_P = c_void_p
+SIGNATURES = {
+    "vs_abi_version": (c_int, []),
+    "vs_last_error": (c_char_p, []),
+    "vs_profile_begin": (c_int, [c_int]),
+    "vs_profile_end": (c_int, [POINTER(c_float), POINTER(c_int)]),
+    "vs_workspace_layout": (c_int, [POINTER(VsDims), POINTER(VsWsLayout)]),
+    "vs_workspace_bytes": (c_size_t, [POINTER(VsDims)]),
+    "vs_forward": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_int, c_int, _P, c_size_t, _P, _P]),
+    "vs_conv_stack_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, c_int, c_int, _P, c_size_t, _P, _P]),
+    "vs_bilstm_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, _P, c_size_t, _P, _P]),
+    "vs_head_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_size_t, _P, _P, _P]),
+    "vs_bn_fold": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
+    "vs_conv_first_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vs_conv64_packed_floats": (c_size_t, [c_int, c_int]),
+    "vs_conv64_pack": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vs_conv64_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_conv_last_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vs_gemm_nt": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int,
+                           c_int, c_int, _P]),
+    "vs_lstm_packed_floats": (c_size_t, [c_int]),
+    "vs_lstm_state_floats": (c_size_t, [c_int, c_int]),
+    "vs_lstm_pack": (c_int, [_P, _P, _P, c_int, _P]),
+    "vs_bilstm_recurrent": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+}
+
+_lib = None
+
+
+class VoiceSplitHipError(RuntimeError):
+    pass
+
+
+def load(path: str = None) -> ctypes.CDLL:
+    """Load the HIP library; raises (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
+        raise VoiceSplitHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C voicesplit_amd/csrc`. There is no PyTorch/CPU fallback for this path.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.vs_abi_version() != ABI_VERSION:
+        raise VoiceSplitHipError(f"{path}: ABI version {lib.vs_abi_version()} != {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vs_last_error()
+        raise VoiceSplitHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

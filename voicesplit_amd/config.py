@@ -1,0 +1,37 @@
+"""Config object consumed by the model constructors.
+
+Mirror of the reference's ``AttrDict`` / ``load_config`` (utils/generic_utils.py:560-573): a dict
+whose keys are also attributes, read from JSON that may carry ``//`` comments.  Only what the hot
+path's constructor reads is required: ``config.audio[config.audio['backend']]['num_freq']`` and
+``config.model['emb_dim'|'lstm_dim'|'fc1_dim'|'fc2_dim']`` (models/voicesplit/model.py:13,57-64).
+"""
+import json
+import re
+
+
+class AttrDict(dict):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def load_config(config_path: str) -> AttrDict:
+    with open(config_path, "r") as fh:
+        text = fh.read()
+    text = re.sub(r"\\\n", "", text)
+    text = re.sub(r"//.*\n", "\n", text)
+    cfg = AttrDict()
+    cfg.update(json.loads(text))
+    return cfg
+
+
+def default_config(num_freq: int = 601, emb_dim: int = 256, lstm_dim: int = 400,
+                   fc1_dim: int = 600, fc2_dim: int = 601, model_name: str = "voicesplit") -> AttrDict:
+    """The hot-path subset of the reference's config.json (lines 2, 37-42, 44, 83-86)."""
+    cfg = AttrDict()
+    cfg.update({
+        "model_name": model_name,
+        "model": {"lstm_dim": lstm_dim, "fc1_dim": fc1_dim, "fc2_dim": fc2_dim, "emb_dim": emb_dim},
+        "audio": {"backend": "voicefilter", "voicefilter": {"num_freq": num_freq}},
+    })
+    return cfg

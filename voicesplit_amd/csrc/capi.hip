@@ -1,0 +1,352 @@
+// extern "C" surface of libvoicesplit_hip.so (declared in include/voicesplit_hip.h) and the
+// orchestration of the forward pass: which kernel runs on which buffer, in which order.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/voicesplit_hip.h"
+#include "vs_common.h"
+
+// ---- implemented in the kernel files ----------------------------------------------------------
+int vs_conv64_pack_impl(const float*, float*, int, int, hipStream_t);
+int vs_conv64_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
+int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int vs_bn_train_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
+int vs_bn_train_feat_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
+int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
+int vs_bilstm_recurrent_impl(const float*, const float*, float*, float*, int, int, int, hipStream_t);
+
+// ---- error string --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void vs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- opt-in per-stage timing (bench.py roofline leg) -------------------------------------------
+// vs_profile_begin(n) pre-creates HIP events for n forward calls; while enabled every stage of
+// vs_conv_stack_fwd / vs_bilstm_fwd / vs_head_fwd is bracketed by two events recorded on the
+// caller's stream (no synchronisation, ~1 us each).  vs_profile_end() synchronises the events,
+// sums the elapsed time per slot and frees them.  Instrumentation only: process-global, not
+// thread safe, off by default.
+namespace {
+struct Prof {
+  bool on = false;
+  int max_calls = 0;
+  int calls[VS_PROF_SLOTS] = {0};
+  hipEvent_t* ev = nullptr;   // [max_calls][VS_PROF_SLOTS][2]
+} g_prof;
+
+struct ProfScope {
+  hipStream_t s; int slot; int idx;
+  ProfScope(int slot_, hipStream_t s_) : s(s_), slot(slot_), idx(-1) {
+    if (!g_prof.on || g_prof.calls[slot] >= g_prof.max_calls) return;
+    idx = (g_prof.calls[slot]++ * VS_PROF_SLOTS + slot) * 2;
+    (void)hipEventRecord(g_prof.ev[idx], s);
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.ev[idx + 1], s); }
+};
+}  // namespace
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;       // nn.BatchNorm2d default (models/voicesplit/model.py:19)
+constexpr float kBnMomentum = 0.1f;
+
+// conv-stack table (models/voicesplit/model.py:15-52): KT, KF, time dilation
+struct Spec { int kt, kf, dil; };
+constexpr Spec kMid[6] = {{7, 1, 1}, {5, 5, 1}, {5, 5, 2}, {5, 5, 4}, {5, 5, 8}, {5, 5, 16}};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+int check_dims(const vs_dims* d) {
+  VS_REQUIRE(d != nullptr, "dims is NULL");
+  VS_REQUIRE(d->B > 0 && d->T > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->FC1 > 0 && d->FC2 > 0,
+             "dims must be positive: B=%d T=%d F=%d E=%d H=%d FC1=%d FC2=%d", d->B, d->T, d->F, d->E, d->H, d->FC1, d->FC2);
+  VS_REQUIRE(d->H % 8 == 0, "lstm_dim H=%d must be a multiple of 8", d->H);
+  VS_REQUIRE((long long)d->B * d->T < 2147483647LL / 8, "B*T too large");
+  return 0;
+}
+
+int layout(const vs_dims* d, vs_ws_layout* L) {
+  if (int rc = check_dims(d)) return rc;
+  const size_t B = d->B, T = d->T, F = d->F, H = d->H;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  L->act0 = take(B * 64 * T * F * 4);
+  L->act1 = take(B * 64 * T * F * 4);
+  L->feat = take(B * T * 8 * F * 4);
+  L->dvbias = take(B * 8 * H * 4);
+  L->xg = take(B * T * 8 * H * 4);
+  L->lstm_out = take(B * T * 2 * H * 4);
+  L->fc1_out = take(B * T * (size_t)d->FC1 * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
+  L->bn_scale = take(8 * 64 * 4);
+  L->bn_shift = take(8 * 64 * 4);
+  L->bn_stats = take(8 * 64 * 2 * 8);
+  L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
+  L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
+  L->total_bytes = off;
+  return 0;
+}
+
+template <typename T>
+inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
+  if (int rc = layout(d, L)) return rc;
+  VS_REQUIRE(ws != nullptr, "workspace is NULL");
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be 256-byte aligned");
+  VS_REQUIRE(ws_bytes >= L->total_bytes, "workspace too small: %zu < %zu bytes", ws_bytes, L->total_bytes);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vs_abi_version(void) { return VS_ABI_VERSION; }
+
+int vs_profile_begin(int max_calls) {
+  VS_REQUIRE(!g_prof.on, "profile: already enabled");
+  VS_REQUIRE(max_calls > 0 && max_calls <= 4096, "profile: max_calls=%d out of range", max_calls);
+  const int n = max_calls * VS_PROF_SLOTS * 2;
+  g_prof.ev = new hipEvent_t[n];
+  for (int i = 0; i < n; ++i) VS_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
+  for (int i = 0; i < VS_PROF_SLOTS; ++i) g_prof.calls[i] = 0;
+  g_prof.max_calls = max_calls;
+  g_prof.on = true;
+  return 0;
+}
+
+int vs_profile_end(float* ms_total, int* calls) {
+  VS_REQUIRE(g_prof.on, "profile: not enabled");
+  g_prof.on = false;
+  int rc = 0;
+  for (int slot = 0; slot < VS_PROF_SLOTS; ++slot) {
+    double tot = 0;
+    for (int c = 0; c < g_prof.calls[slot]; ++c) {
+      const int idx = (c * VS_PROF_SLOTS + slot) * 2;
+      float ms = 0.f;
+      hipError_t e = hipEventSynchronize(g_prof.ev[idx + 1]);
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.ev[idx], g_prof.ev[idx + 1]);
+      if (e != hipSuccess) { vs_set_error("profile: %s", hipGetErrorString(e)); rc = -2; }
+      tot += ms;
+    }
+    if (ms_total) ms_total[slot] = (float)tot;
+    if (calls) calls[slot] = g_prof.calls[slot];
+  }
+  const int n = g_prof.max_calls * VS_PROF_SLOTS * 2;
+  for (int i = 0; i < n; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+  delete[] g_prof.ev;
+  g_prof.ev = nullptr;
+  g_prof.max_calls = 0;
+  return rc;
+}
+const char* vs_last_error(void) { return g_err; }
+
+int vs_workspace_layout(const vs_dims* dims, vs_ws_layout* out) {
+  VS_REQUIRE(out != nullptr, "layout out pointer is NULL");
+  memset(out, 0, sizeof(*out));
+  return layout(dims, out);
+}
+
+size_t vs_workspace_bytes(const vs_dims* dims) {
+  vs_ws_layout L;
+  memset(&L, 0, sizeof(L));
+  if (layout(dims, &L)) return 0;
+  return L.total_bytes;
+}
+
+int vs_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+               float eps, int C, float* scale, float* shift, void* stream) {
+  return vs_bn_fold_impl(gamma, beta, mean, var, conv_bias, eps, C, scale, shift, (hipStream_t)stream);
+}
+
+int vs_conv_first_fwd(const float* x, const float* w, const float* scale, const float* shift, float* out,
+                      int B, int T, int F, int act, void* stream) {
+  return vs_conv_first_fwd_impl(x, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);
+}
+
+int vs_conv64_pack(const float* w, float* packed, int KT, int KF, void* stream) {
+  return vs_conv64_pack_impl(w, packed, KT, KF, (hipStream_t)stream);
+}
+
+int vs_conv64_fwd(const float* in, const float* packed, const float* scale, const float* shift, float* out,
+                  int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
+  VS_REQUIRE(in != out, "conv64: in-place is not supported");
+  return vs_conv64_fwd_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, (hipStream_t)stream);
+}
+
+int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,
+                     int B, int T, int F, int act, void* stream) {
+  return vs_conv_last_fwd_impl(in, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);
+}
+
+int vs_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+               const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+               int a_relu, int act, void* stream) {
+  return vs_gemm_nt_impl(A, lda, W, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group, a_relu, act, (hipStream_t)stream);
+}
+
+int vs_lstm_pack(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, void* stream) {
+  return vs_lstm_pack_impl(w_hh_fwd, w_hh_bwd, packed, H, (hipStream_t)stream);
+}
+
+int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, float* out,
+                        int B, int T, int H, void* stream) {
+  return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, B, T, H, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 1: conv stack, models/voicesplit/model.py:68-74
+// ---------------------------------------------------------------------------------------------
+int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
+                      void* ws, size_t ws_bytes, float* feat, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  vs_ws_layout L;
+  if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  VS_REQUIRE(p && x, "conv_stack: NULL argument");
+  VS_REQUIRE(conv_act == VS_ACT_MISH || conv_act == VS_ACT_RELU, "conv_stack: conv_act must be MISH or RELU");
+  VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "conv_stack: unknown bn_mode %d", bn_mode);
+  if (!feat) feat = at<float>(ws, L.feat);
+  const int B = d->B, T = d->T, F = d->F;
+  float* act[2] = {at<float>(ws, L.act0), at<float>(ws, L.act1)};
+  float* scale = at<float>(ws, L.bn_scale);
+  float* shift = at<float>(ws, L.bn_shift);
+  double* stats = at<double>(ws, L.bn_stats);
+  const bool train = bn_mode == VS_BN_TRAIN;
+
+  for (int l = 0; l < 8; ++l) {
+    const vs_conv_layer& c = p->conv[l];
+    VS_REQUIRE(c.weight && c.bias && c.bn_weight && c.bn_bias && c.bn_running_mean && c.bn_running_var,
+               "conv_stack: layer %d has a NULL parameter", l + 1);
+  }
+  const int Cl[8] = {64, 64, 64, 64, 64, 64, 64, 8};
+  // Per-layer epilogue constants (slot l = scale/shift + 64*l).
+  //  eval : BatchNorm folded from the running statistics, activation fused into the conv.
+  //  train: the conv writes conv+bias (scale = 1, shift = bias, no activation); batch
+  //         statistics, normalisation and activation follow as a second pass which then
+  //         overwrites the layer's slot with the batch scale/shift.
+  const int layer_act = train ? VS_ACT_NONE : conv_act;
+  if (!train) {
+    for (int l = 0; l < 8; ++l) {
+      const vs_conv_layer& c = p->conv[l];
+      if (int rc = vs_bn_fold_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, c.bias, kBnEps, Cl[l],
+                                   scale + 64 * l, shift + 64 * l, stream)) return rc;
+    }
+  } else {
+    VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scale), 0x3f800000 /* 1.0f */, 8 * 64, stream));
+    for (int l = 0; l < 8; ++l)
+      VS_CHECK_HIP(hipMemcpyAsync(shift + 64 * l, p->conv[l].bias, sizeof(float) * Cl[l], hipMemcpyDeviceToDevice, stream));
+  }
+
+  int cur = 0;
+  // cnn1
+  {
+  ProfScope ps(VS_PROF_CNN1, stream);
+  if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, scale, shift, act[cur], B, T, F, layer_act, stream)) return rc;
+  if (train) {
+    if (int rc = vs_bn_train_impl(act[cur], B, 64, T * F, p->conv[0].bn_weight, p->conv[0].bn_bias, p->conv[0].bn_running_mean,
+                                  p->conv[0].bn_running_var, kBnEps, kBnMomentum, conv_act, stats, scale, shift, stream)) return rc;
+  }
+  }
+  // cnn2..cnn7
+  for (int i = 0; i < 6; ++i) {
+    const int l = i + 1;
+    float* packed = at<float>(ws, L.conv_packed[i]);
+    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, stream)) return rc;
+    ProfScope ps(VS_PROF_CNN2 + i, stream);
+    if (int rc = vs_conv64_fwd_impl(act[cur], packed, scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
+                                    kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
+    cur ^= 1;
+    if (train) {
+      if (int rc = vs_bn_train_impl(act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,
+                                    p->conv[l].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * l,
+                                    scale + 64 * l, shift + 64 * l, stream)) return rc;
+    }
+  }
+  // cnn8, written straight into the LSTM feature layout
+  ProfScope ps(VS_PROF_CNN8, stream);
+  if (int rc = vs_conv_last_fwd_impl(act[cur], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat, B, T, F, layer_act, stream)) return rc;
+  if (train) {
+    if (int rc = vs_bn_train_feat_impl(feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
+                                       p->conv[7].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * 7,
+                                       scale + 64 * 7, shift + 64 * 7, stream)) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 2: d-vector concat + BiLSTM, models/voicesplit/model.py:77-82
+// ---------------------------------------------------------------------------------------------
+int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
+                  void* ws, size_t ws_bytes, float* lstm_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  vs_ws_layout L;
+  if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  VS_REQUIRE(p && dvec, "bilstm: NULL argument");
+  if (!feat) feat = at<float>(ws, L.feat);
+  if (!lstm_out) lstm_out = at<float>(ws, L.lstm_out);
+  const int B = d->B, T = d->T, H = d->H, K = 8 * d->F, KE = K + d->E;
+  float* dvbias = at<float>(ws, L.dvbias);
+  float* xg = at<float>(ws, L.xg);
+  for (int dir = 0; dir < 2; ++dir) {
+    ProfScope ps(VS_PROF_LSTM_GEMM, stream);
+    VS_REQUIRE(p->w_ih[dir] && p->w_hh[dir] && p->b_ih[dir] && p->b_hh[dir], "bilstm: NULL LSTM parameter (dir %d)", dir);
+    // cat((x, dvec.repeat(T))) @ W_ih^T == x @ W_ih[:, :8F]^T + (dvec @ W_ih[:, 8F:]^T): the
+    // second term does not depend on t -> one [B][4H] row bias per utterance (+ b_ih + b_hh).
+    if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
+                                 p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+    if (int rc = vs_gemm_nt_impl(feat, K, p->w_ih[dir], KE, xg + (size_t)dir * 4 * H, 8 * H, B * T, 4 * H, K,
+                                 nullptr, nullptr, dvbias + (size_t)dir * 4 * H, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
+  }
+  float* packed = at<float>(ws, L.lstm_packed);
+  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
+  ProfScope ps(VS_PROF_LSTM_REC, stream);
+  return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, B, T, H, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 3: head, models/voicesplit/model.py:83-87
+// ---------------------------------------------------------------------------------------------
+int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, void* ws, size_t ws_bytes,
+                float* logits, float* mask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  vs_ws_layout L;
+  if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  VS_REQUIRE(p && p->fc1_w && p->fc1_b && p->fc2_w && p->fc2_b, "head: NULL parameter");
+  VS_REQUIRE(mask || logits, "head: no output requested");
+  if (!lstm_out) lstm_out = at<float>(ws, L.lstm_out);
+  float* h1 = at<float>(ws, L.fc1_out);
+  const int M = d->B * d->T;
+  ProfScope ps(VS_PROF_HEAD, stream);
+  // relu(lstm) -> fc1 -> relu
+  if (int rc = vs_gemm_nt_impl(lstm_out, 2 * d->H, p->fc1_w, 2 * d->H, h1, d->FC1, M, d->FC1, 2 * d->H,
+                               p->fc1_b, nullptr, nullptr, 0, 1, 1, VS_ACT_RELU, stream)) return rc;
+  // fc2 -> sigmoid
+  if (logits) {
+    if (int rc = vs_gemm_nt_impl(h1, d->FC1, p->fc2_w, d->FC1, logits, d->FC2, M, d->FC2, d->FC1,
+                                 p->fc2_b, nullptr, nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+  }
+  if (mask) {
+    if (int rc = vs_gemm_nt_impl(h1, d->FC1, p->fc2_w, d->FC1, mask, d->FC2, M, d->FC2, d->FC1,
+                                 p->fc2_b, nullptr, nullptr, 0, 1, 0, VS_ACT_SIGMOID, stream)) return rc;
+  }
+  return 0;
+}
+
+int vs_forward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
+               void* ws, size_t ws_bytes, float* mask, void* stream) {
+  VS_REQUIRE(mask != nullptr, "forward: mask is NULL");
+  if (int rc = vs_conv_stack_fwd(d, p, x, conv_act, bn_mode, ws, ws_bytes, nullptr, stream)) return rc;
+  if (int rc = vs_bilstm_fwd(d, p, nullptr, dvec, ws, ws_bytes, nullptr, stream)) return rc;
+  return vs_head_fwd(d, p, nullptr, ws, ws_bytes, nullptr, mask, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// The two bandwidth-bound ends of the conv stack and the BatchNorm fold.
+//
+//   cnn1: ZeroPad2d((3,3,0,0)) + Conv2d(1->64,(1,7)) + BN + act   models/voicesplit/model.py:17-19
+//   cnn8: Conv2d(64->8,(1,1)) + BN + act, written directly in the [B,T,8*F] layout that
+//         x.transpose(1,2).contiguous().view(B,T,-1) produces          models/voicesplit/model.py:51-52,72-74
+//
+// Both are ~3.5 FLOP/B: one thread per (t,f) pixel, lanes along f so every
+// channel plane is read/written in coalesced 256-byte wave rows; the per-channel weights are
+// wave-uniform and live in SGPRs.
+#include "vs_common.h"
+
+namespace {
+
+// scale = gamma / sqrt(var + eps);  shift = beta + (conv_bias - mean) * scale
+// so that  BN(conv + bias) = conv * scale + shift      (nn.BatchNorm2d eval, eps 1e-5)
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var,
+                               const float* __restrict__ conv_bias, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = gamma[c] / sqrtf(var[c] + eps);
+  float b = conv_bias ? conv_bias[c] : 0.f;
+  scale[c] = s;
+  shift[c] = beta[c] + (b - mean[c]) * s;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void conv_first_kernel(const float* __restrict__ x,      // [B][T][F]
+                       const float* __restrict__ w,      // [64][7]
+                       const float* __restrict__ scale, const float* __restrict__ shift,
+                       float* __restrict__ out,          // [B][64][T][F]
+                       int T, int F) {
+  const int plane = T * F;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= plane) return;
+  const int t = pix / F;
+  const int f = pix - t * F;
+  const float* row = x + (size_t)b * plane + (size_t)t * F;
+  float v[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int ff = f + k - 3;
+    v[k] = (ff >= 0 && ff < F) ? row[ff] : 0.f;
+  }
+  float* o = out + (size_t)b * 64 * plane + pix;
+#pragma unroll 4
+  for (int c = 0; c < 64; ++c) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a = fmaf(w[c * 7 + k], v[k], a);
+    o[(size_t)c * plane] = vs_act<ACT>(fmaf(a, scale[c], shift[c]));
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void conv_last_kernel(const float* __restrict__ in,      // [B][64][T][F]
+                      const float* __restrict__ w,       // [8][64]
+                      const float* __restrict__ scale, const float* __restrict__ shift,
+                      float* __restrict__ out,           // [B][T][8][F]
+                      int T, int F) {
+  const int plane = T * F;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= plane) return;
+  const int t = pix / F;
+  const int f = pix - t * F;
+  const float* src = in + (size_t)b * 64 * plane + pix;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < 64; ++c) {
+    const float v = src[(size_t)c * plane];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = fmaf(w[o * 64 + c], v, acc[o]);
+  }
+  float* dst = out + ((size_t)b * T + t) * 8 * F + f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) dst[(size_t)o * F] = vs_act<ACT>(fmaf(acc[o], scale[o], shift[o]));
+}
+
+
+// ---- train-mode BatchNorm (model.train(), train.py:84): batch statistics over (B,T,F) --------
+// stats[c] = {sum, sum of squares} in double; one block reduces a slab of one channel plane.
+__global__ __launch_bounds__(256)
+void bn_stats_kernel(const float* __restrict__ x, int C, int plane, int ld_batch /* = C*plane */,
+                     double* __restrict__ stats) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* src = x + (size_t)b * ld_batch + (size_t)c * plane;
+  float s = 0.f, q = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) {
+    const float v = src[i];
+    s += v;
+    q = fmaf(v, v, q);
+  }
+  double ds = s, dq = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ds += __shfl_down(ds, o, 64);
+    dq += __shfl_down(dq, o, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[2 * w] = ds; sh[2 * w + 1] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ds = sh[0] + sh[2] + sh[4] + sh[6];
+    dq = sh[1] + sh[3] + sh[5] + sh[7];
+    atomicAdd(&stats[2 * c], ds);
+    atomicAdd(&stats[2 * c + 1], dq);
+  }
+}
+
+// mean/var -> scale/shift for the apply pass, running buffers updated like nn.BatchNorm2d
+// (momentum 0.1, unbiased variance into running_var).
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, int C,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[2 * c] / count;
+  double var = stats[2 * c + 1] / count - mean * mean;
+  if (var < 0) var = 0;
+  const float sc = gamma[c] / sqrtf((float)var + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  const double unb = count > 1 ? var * (count / (count - 1)) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+}
+
+// y = act(x*scale[c] + shift[c]) in place over [B][C][plane]
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_apply_kernel(float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                     int C, int plane) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  float* p = x + ((size_t)b * C + c) * plane;
+  const float sc = scale[c], sh = shift[c];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256)
+    p[i] = vs_act<ACT>(fmaf(p[i], sc, sh));
+}
+
+// cnn8 keeps the [B][T][8][F] layout: channel stride F inside a frame, frame stride 8F
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_apply_feat_kernel(float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                          int F, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)((i / F) & 7);
+    x[i] = vs_act<ACT>(fmaf(x[i], scale[c], shift[c]));
+  }
+}
+
+__global__ __launch_bounds__(256)
+void bn_stats_feat_kernel(const float* __restrict__ x, int F, long long rows /* B*T*8 */, double* __restrict__ stats) {
+  // one block per group of rows; row r belongs to channel r & 7
+  __shared__ double sh[8][2];
+  if (threadIdx.x < 16) sh[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
+  __syncthreads();
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* p = x + r * F;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < F; i += 256) { const float v = p[i]; s += v; q = fmaf(v, v, q); }
+    double ds = s, dq = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_down(ds, o, 64); dq += __shfl_down(dq, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&sh[r & 7][0], ds);
+      atomicAdd(&sh[r & 7][1], dq);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(&stats[threadIdx.x], sh[threadIdx.x >> 1][threadIdx.x & 1]);
+}
+
+}  // namespace
+
+int vs_bn_fold_impl(const float* gamma, const float* beta, const float* mean, const float* var,
+                    const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t stream) {
+  VS_REQUIRE(C > 0, "bn_fold: C=%d", C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, gamma, beta, mean, var, conv_bias, eps, C, scale, shift);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_conv_first_fwd_impl(const float* x, const float* w, const float* scale, const float* shift, float* out,
+                           int B, int T, int F, int act, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "conv_first: bad shape B=%d T=%d F=%d", B, T, F);
+  VS_REQUIRE((long long)T * F < 2147483647LL / 64 && B <= 65535, "conv_first: shape too large");
+  dim3 grid((T * F + 255) / 256, B), block(256);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
+    default: VS_REQUIRE(false, "conv_first: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_conv_last_fwd_impl(const float* in, const float* w, const float* scale, const float* shift, float* out,
+                          int B, int T, int F, int act, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "conv_last: bad shape B=%d T=%d F=%d", B, T, F);
+  VS_REQUIRE((long long)T * F < 2147483647LL / 64 && B <= 65535, "conv_last: shape too large");
+  dim3 grid((T * F + 255) / 256, B), block(256);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(conv_last_kernel<VS_ACT_RELU>, grid, block, 0, stream, in, w, scale, shift, out, T, F); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(conv_last_kernel<VS_ACT_MISH>, grid, block, 0, stream, in, w, scale, shift, out, T, F); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(conv_last_kernel<VS_ACT_NONE>, grid, block, 0, stream, in, w, scale, shift, out, T, F); break;
+    default: VS_REQUIRE(false, "conv_last: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Train-mode BatchNorm over a raw conv output held as [B][C][T*F] (in place):
+// statistics -> scale/shift (+ running buffers) -> normalise + activation.
+int vs_bn_train_impl(float* x, int B, int C, int plane, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float eps, float momentum, int act,
+                     double* stats /* [C][2] */, float* scale, float* shift, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_train: bad shape B=%d C=%d plane=%d", B, C, plane);
+  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
+  int gx = (plane + 256 * 16 - 1) / (256 * 16);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, stream, x, C, plane, C * plane, stats);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)B * plane, gamma, beta,
+                     eps, momentum, C, running_mean, running_var, scale, shift);
+  dim3 grid(gx, C, B), block(256);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, scale, shift, C, plane); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, scale, shift, C, plane); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, scale, shift, C, plane); break;
+    default: VS_REQUIRE(false, "bn_train: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Same for cnn8's output, which already sits in the LSTM feature layout [B][T][8][F].
+int vs_bn_train_feat_impl(float* x, int B, int T, int F, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float eps, float momentum, int act,
+                          double* stats, float* scale, float* shift, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "bn_train_feat: bad shape");
+  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 16, stream));
+  const long long rows = (long long)B * T * 8;
+  const int gb = (int)(rows < 4096 ? rows : 4096);
+  hipLaunchKernelGGL(bn_stats_feat_kernel, dim3(gb), dim3(256), 0, stream, x, F, rows, stats);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, (double)B * T * F, gamma, beta,
+                     eps, momentum, 8, running_mean, running_var, scale, shift);
+  const long long total = rows * F;
+  const int ga = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_RELU>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_MISH>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_NONE>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
+    default: VS_REQUIRE(false, "bn_train_feat: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}

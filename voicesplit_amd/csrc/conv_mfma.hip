@@ -1,0 +1,264 @@
+// 64->64 channel "same" convolution with time dilation, fused BatchNorm(eval)+activation.
+//
+// Replaces, per layer, ZeroPad2d + Conv2d + BatchNorm2d + Mish/ReLU of
+//   models/voicesplit/model.py:21-23 (cnn2, 7x1) and :26-48 (cnn3..cnn7, 5x5, dilation (d,1))
+//   models/voicefilter/model.py:25-50 (same, ReLU).
+//
+// Formulation (im2col-free implicit GEMM on the fp32 matrix cores):
+//   out[co][t][f] = sum_{ci,kt,kf} W[co][ci][kt][kf] * in[ci][t+(kt-KT/2)*dil][f+kf-KF/2]
+//   M = co (64, two 32-row MFMA blocks), N = 32 consecutive f of one output row,
+//   K = ci pair per v_mfma_f32_32x32x2_f32 step, looped over taps and ci chunks.
+// A dilated layer is decomposed into `dil` residue classes of t (t = cls + dil*i): inside a
+// class it is an ordinary dense conv over rows i, so an LDS tile of R output rows needs only
+// R+KT-1 input rows whatever the dilation.
+//
+// Workgroup = 256 threads (4 waves, one per SIMD; two workgroups per CU so one computes while
+// the other stages/stores).  Tile = 64 co x (R = 4*P rows) x 32 f.  Wave w owns rows
+// w*P..w*P+P-1 for both co blocks: 2*P accumulators of 32x32 (16 VGPR each).
+// The ci dimension is walked in 8 chunks of 8 channels: the chunk's input window
+// [8][R+KT-1][32+KF-1] is staged global->VGPR->LDS with raw buffer loads whose out-of-range
+// offsets return 0 -- that zero fill outside the image IS the reference's ZeroPad2d; loads for
+// chunk c+1 are in flight while chunk c is multiplied.
+// B fragments (activations) are ds_read_b32 with compile-time offsets: lanes 0-31 read 32
+// consecutive f (conflict free), lanes 32-63 the next input channel.  A fragments (weights)
+// come pre-packed in fragment order (conv_pack_weights_kernel) as one coalesced dwordx4 per
+// lane per 4 K-steps (= one tap of one chunk) straight from L2/L1, prefetched one tap ahead.
+#include "vs_common.h"
+
+namespace {
+
+constexpr int kCo = 64;
+constexpr int kCi = 64;
+constexpr int kChunk = 8;               // input channels per LDS stage
+constexpr int kNChunk = kCi / kChunk;   // 8
+constexpr int kPairs = kChunk / 2;      // 4 MFMA K-steps per (chunk, tap) = one float4 of A
+constexpr unsigned kOob = 0x7FFFFFF0u;  // buffer offset guaranteed >= num_records -> load returns 0
+constexpr int kTileF = 32;
+
+// packed weight layout: [chunk][tap][cb(2)][lane(64)][4]; element j of the float4 is
+//   W[co = cb*32 + (lane&31)][ci = chunk*8 + 2*j + (lane>>5)][kt][kf]
+// plus one dummy tap block at the end so the one-tap-ahead prefetch never reads out of bounds.
+__global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int KT, int KF) {
+  const int NT = KT * KF;
+  const int total = kNChunk * NT * 2 * 64 * 4;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total + 512) return;
+  if (idx >= total) { wp[idx] = 0.f; return; }
+  int j = idx & 3;
+  int lane = (idx >> 2) & 63;
+  int cb = (idx >> 8) & 1;
+  int tg = idx >> 9;           // chunk*NT + tap
+  int chunk = tg / NT, tap = tg - chunk * NT;
+  int kt = tap / KF, kf = tap - kt * KF;
+  int co = cb * 32 + (lane & 31);
+  int ci = chunk * kChunk + 2 * j + (lane >> 5);
+  wp[idx] = w[((co * kCi + ci) * KT + kt) * KF + kf];
+}
+
+template <int KT, int KF, int P, int ACT>
+__global__ __launch_bounds__(256, 2)
+void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                        const float* __restrict__ scale, const float* __restrict__ shift,
+                        float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft) {
+  constexpr int R = 4 * P;
+  constexpr int ROWS = R + KT - 1;
+  constexpr int PITCH = kTileF + KF - 1;
+  constexpr int NELEM = kChunk * ROWS * PITCH;
+  constexpr int NPT = (NELEM + 255) / 256;
+  constexpr int NT = KT * KF;
+  __shared__ float sIn[NELEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int ft = bid % n_ft; bid /= n_ft;
+  const int rt = bid % n_rt; bid /= n_rt;
+  const int cls = bid % dil;
+  const int b = bid / dil;
+  const int n_c = (T - cls + dil - 1) / dil;   // rows of this residue class
+  const int i0 = rt * R;
+  if (i0 >= n_c) return;                       // uniform: nothing to do for this tile
+  const int f0 = ft * kTileF;
+  const size_t plane = (size_t)T * F;
+  const float* in_b = in + (size_t)b * kCi * plane;
+
+  // ---- staging: element e of the LDS window <-> (ci_l, rr, x); byte offset inside the
+  //      chunk's [8][T][F] slab, or kOob where the window leaves the image --------------------
+  unsigned voff[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int e = tid + 256 * i;
+    const int ci_l = e / (ROWS * PITCH);
+    const int rem = e - ci_l * (ROWS * PITCH);
+    const int rr = rem / PITCH;
+    const int x = rem - rr * PITCH;
+    const int iin = i0 - KT / 2 + rr;
+    const int f = f0 - KF / 2 + x;
+    const bool ok = (e < NELEM) && (iin >= 0) && (iin < n_c) && (f >= 0) && (f < F);
+    const int t = cls + dil * iin;
+    voff[i] = ok ? (unsigned)(((ci_l * T + t) * F + f) * 4) : kOob;
+  }
+  const unsigned slab_bytes = (unsigned)(kChunk * plane * sizeof(float));
+  float stage[NPT];
+  auto load_chunk = [&](int chunk) {
+    const float* src = in_b + (size_t)chunk * kChunk * plane;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, slab_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+      stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i], 0, 0));
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NELEM) sIn[e] = stage[i];
+    }
+  };
+
+  f32x16 acc[2][P];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][p][r] = 0.f;
+
+  const bool wave_active = (i0 + wave * P) < n_c;   // rows ascend: first row decides
+  const float4* wp4 = reinterpret_cast<const float4*>(wp) + lane;
+  // this lane's B-fragment base inside the window
+  const float* sB = sIn + (half * ROWS + wave * P) * PITCH + l31;
+
+  float4 a_cur[2], a_nxt[2];
+  a_cur[0] = wp4[0];
+  a_cur[1] = wp4[64];
+
+  load_chunk(0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < kNChunk; ++chunk) {
+    __syncthreads();            // previous chunk's window fully consumed
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < kNChunk) load_chunk(chunk + 1);   // in flight during the MFMA block below
+    if (wave_active) {
+#pragma unroll 1
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) {
+          const int tg = chunk * NT + kt * KF + kf;
+          const float4* nxt = wp4 + (size_t)(tg + 1) * 128;     // dummy block pads the very last
+          a_nxt[0] = nxt[0];
+          a_nxt[1] = nxt[64];
+#pragma unroll
+          for (int pr = 0; pr < kPairs; ++pr) {
+            float bfrag[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              bfrag[p] = sB[((2 * pr) * ROWS + p + kt) * PITCH + kf];
+            const float a0 = (pr == 0) ? a_cur[0].x : (pr == 1) ? a_cur[0].y : (pr == 2) ? a_cur[0].z : a_cur[0].w;
+            const float a1 = (pr == 0) ? a_cur[1].x : (pr == 1) ? a_cur[1].y : (pr == 2) ? a_cur[1].z : a_cur[1].w;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              acc[0][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bfrag[p], acc[0][p], 0, 0, 0);
+              acc[1][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bfrag[p], acc[1][p], 0, 0, 0);
+            }
+          }
+          a_cur[0] = a_nxt[0];
+          a_cur[1] = a_nxt[1];
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: y = act(acc*scale[co] + shift[co]) ; D layout: col = lane&31 (f),
+  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co within the 32-block) -------------------
+  if (!wave_active) return;
+  const int f = f0 + l31;
+  float* out_b = out + (size_t)b * kCo * plane;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float sc = scale[co], sh = shift[co];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = i0 + wave * P + p;
+        if (i < n_c && f < F) {
+          const int t = cls + dil * i;
+          out_b[(size_t)co * plane + (size_t)t * F + f] = vs_act<ACT>(fmaf(acc[cb][p][r], sc, sh));
+        }
+      }
+    }
+  }
+}
+
+template <int KT, int KF, int P>
+int launch_conv(const float* in, const float* wp, const float* scale, const float* shift, float* out,
+                int B, int T, int F, int dil, int act, hipStream_t stream) {
+  constexpr int R = 4 * P;
+  const int rows_max = (T + dil - 1) / dil;
+  const int n_rt = (rows_max + R - 1) / R;
+  const int n_ft = (F + kTileF - 1) / kTileF;
+  const long long nblk = (long long)B * dil * n_rt * n_ft;
+  VS_REQUIRE(nblk > 0 && nblk < 2147483647LL, "conv64: grid of %lld blocks out of range", nblk);
+  dim3 grid((unsigned)nblk), block(256);
+  switch (act) {
+    case VS_ACT_RELU:
+      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      break;
+    case VS_ACT_MISH:
+      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      break;
+    case VS_ACT_NONE:
+      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      break;
+    default:
+      VS_REQUIRE(false, "conv64: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// rows wasted by tiling each residue class with R-row tiles
+long long tile_rows(int T, int dil, int R) {
+  long long tot = 0;
+  for (int c = 0; c < dil && c < T; ++c) {
+    int n = (T - c + dil - 1) / dil;
+    tot += (long long)((n + R - 1) / R) * R;
+  }
+  return tot;
+}
+
+}  // namespace
+
+extern "C" size_t vs_conv64_packed_floats(int KT, int KF) { return (size_t)(kNChunk * KT * KF + 1) * 512; }
+
+int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, hipStream_t stream) {
+  VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64: unsupported kernel %dx%d", KT, KF);
+  const int total = (int)vs_conv64_packed_floats(KT, KF);
+  hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wp, KT, KF);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, const float* shift, float* out,
+                       int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
+  // pick the row-tile height (8 or 4 rows per residue class) that wastes fewer rows
+  const bool p2 = tile_rows(T, dil, 8) <= tile_rows(T, dil, 4);
+  if (KT == 7 && KF == 1) {
+    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, out, B, T, F, dil, act, stream)
+              : launch_conv<7, 1, 1>(in, wp, scale, shift, out, B, T, F, dil, act, stream);
+  }
+  if (KT == 5 && KF == 5) {
+    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, out, B, T, F, dil, act, stream)
+              : launch_conv<5, 5, 1>(in, wp, scale, shift, out, B, T, F, dil, act, stream);
+  }
+  VS_REQUIRE(false, "conv64: unsupported kernel %dx%d", KT, KF);
+  return -1;
+}

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the VoiceSplit MI355X (gfx950) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define VS_WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// activation codes shared with include/voicesplit_hip.h
+#define VS_ACT_RELU 0
+#define VS_ACT_MISH 1
+#define VS_ACT_NONE 2
+#define VS_ACT_SIGMOID 3
+
+// Mish, utils/generic_utils.py:395-399: x*tanh(softplus(x)), softplus threshold 20.
+// tanh(log(1+u)) = n/(n+2) with n = u(u+2), u = e^x: no cancellation for x << 0 and
+// exactly the reference's pass-through for x > 20 (softplus(x)=x, tanh(x)=1 in fp32).
+__device__ __forceinline__ float vs_mish(float x) {
+  float u = expf(fminf(x, 20.0f));
+  float n = u * (u + 2.0f);
+  float y = x * (n / (n + 2.0f));
+  return x > 20.0f ? x : y;
+}
+
+__device__ __forceinline__ float vs_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ocml tanhf: accurate near 0 (a (1-e)/(1+e) form cancels there)
+__device__ __forceinline__ float vs_tanh(float x) { return tanhf(x); }
+
+template <int ACT>
+__device__ __forceinline__ float vs_act(float v) {
+  if (ACT == VS_ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == VS_ACT_MISH) return vs_mish(v);
+  if (ACT == VS_ACT_SIGMOID) return vs_sigmoid(v);
+  return v;
+}
+
+__device__ __forceinline__ float vs_act_rt(float v, int act) {
+  switch (act) {
+    case VS_ACT_RELU: return fmaxf(v, 0.0f);
+    case VS_ACT_MISH: return vs_mish(v);
+    case VS_ACT_SIGMOID: return vs_sigmoid(v);
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side error plumbing: no exceptions cross the C ABI
+// ---------------------------------------------------------------------------
+void vs_set_error(const char* fmt, ...);
+
+#define VS_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      vs_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -2;                                                                  \
+    }                                                                             \
+  } while (0)
+
+#define VS_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      vs_set_error(__VA_ARGS__);     \
+      return -1;                     \
+    }                                \
+  } while (0)
+
+#define VS_LAUNCH_CHECK() VS_CHECK_HIP(hipGetLastError())

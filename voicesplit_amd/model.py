@@ -1,0 +1,108 @@
+"""``VoiceSplit`` / ``VoiceFilter`` behind the reference's own ``nn.Module`` surface.
+
+Drop-in for models/voicesplit/model.py:9-89 and models/voicefilter/model.py:11-90:
+
+* constructor ``Model(config)`` reading ``config.audio[config.audio['backend']]['num_freq']`` and
+  ``config.model['emb_dim'|'lstm_dim'|'fc1_dim'|'fc2_dim']``;
+* ``forward(x[B,T,num_freq], speaker_embedding[B,emb_dim]) -> mask[B,T,fc2_dim]``, called
+  positionally by train.py:94 and utils/generic_utils.py:495,545;
+* identical ``state_dict`` keys/shapes (``conv.{1,2,5,6,...,28,29}.*``, ``lstm.*``, ``fc1.*``,
+  ``fc2.*``) so reference checkpoints load with ``strict=True`` (train.py:46) and
+  ``set_init_dict`` (utils/generic_utils.py:647-679) matches by key and numel;
+* ``.train()`` / ``.eval()`` switch BatchNorm between batch and running statistics.
+
+The torch sub-modules below are *parameter containers only* -- they give the reference's default
+initialisation (same RNG consumption order as the upstream constructor) and key names.  Their
+``forward`` is never called: ``forward`` hands raw device pointers to ``vs_forward`` in
+``libvoicesplit_hip.so``.  Inputs on a CPU device raise; there is no fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# (cin, cout, (kt, kf), time dilation) -- models/voicesplit/model.py:15-52
+_CONV_TABLE = (
+    (1, 64, (1, 7), 1), (64, 64, (7, 1), 1), (64, 64, (5, 5), 1), (64, 64, (5, 5), 2),
+    (64, 64, (5, 5), 4), (64, 64, (5, 5), 8), (64, 64, (5, 5), 16), (64, 8, (1, 1), 1),
+)
+
+
+class _Slot(nn.Identity):
+    """Occupies the Sequential index of a ZeroPad2d / activation module of the reference."""
+
+
+class _MaskForward(torch.autograd.Function):
+    """Autograd node around the HIP forward.  The backward kernels (conv dgrad/wgrad, BPTT) are
+    the next row of the scope table; until they exist ``backward`` fails loudly
+    instead of silently detaching the graph."""
+
+    @staticmethod
+    def forward(ctx, module, x, dvec, *params):
+        return module._run(x, dvec)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            "voicesplit_amd: backward through the HIP mask-prediction path is not implemented yet "
+            "(forward-only build); run inference under torch.no_grad() or model.eval()")
+
+
+class _MaskNet(nn.Module):
+    conv_act = "mish"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.audio = self.config.audio[self.config.audio["backend"]]
+        layers = []
+        for i, (cin, cout, ks, dil) in enumerate(_CONV_TABLE):
+            if i < 7:
+                layers.append(_Slot())                       # ZeroPad2d slot
+            layers.append(nn.Conv2d(cin, cout, kernel_size=ks, dilation=(dil, 1)))
+            layers.append(nn.BatchNorm2d(cout))
+            layers.append(_Slot())                           # Mish / ReLU slot
+        self.conv = nn.Sequential(*layers)
+        self.lstm = nn.LSTM(8 * self.audio["num_freq"] + self.config.model["emb_dim"],
+                            self.config.model["lstm_dim"], batch_first=True, bidirectional=True)
+        self.fc1 = nn.Linear(2 * self.config.model["lstm_dim"], self.config.model["fc1_dim"])
+        self.fc2 = nn.Linear(self.config.model["fc1_dim"], self.config.model["fc2_dim"])
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _dims(self, B, T):
+        m = self.config.model
+        return ops.make_dims(B, T, self.audio["num_freq"], m["emb_dim"], m["lstm_dim"], m["fc1_dim"], m["fc2_dim"])
+
+    def _tensors(self):
+        sd = {k: v for k, v in self.named_parameters()}
+        sd.update({k: v for k, v in self.named_buffers()})
+        return sd
+
+    def _run(self, x, dvec):
+        x = x.contiguous()
+        dvec = dvec.contiguous()
+        dims = self._dims(x.shape[0], x.shape[1])
+        sd = {k: v.detach() for k, v in self._tensors().items()}
+        mask = ops.forward(sd, x.detach(), dvec.detach(), dims, self.conv_act, training=self.training)
+        if self.training:
+            with torch.no_grad():
+                for m in self.conv:
+                    if isinstance(m, nn.BatchNorm2d):
+                        m.num_batches_tracked += 1           # running_mean/var were updated in place by the library
+        return mask
+
+    def forward(self, x, speaker_embedding):
+        # x: [B, T, num_freq]; speaker_embedding: [B, emb_dim]  ->  mask [B, T, fc2_dim]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _MaskForward.apply(self, x, speaker_embedding, *self.parameters())
+        return self._run(x, speaker_embedding)
+
+
+class VoiceSplit(_MaskNet):
+    """models/voicesplit/model.py:9 -- Mish in the conv stack (utils/generic_utils.py:376-399)."""
+    conv_act = "mish"
+
+
+class VoiceFilter(_MaskNet):
+    """models/voicefilter/model.py:11 -- ReLU in the conv stack."""
+    conv_act = "relu"

@@ -1,0 +1,252 @@
+"""Thin torch-facing wrappers over the C ABI: torch supplies device buffers and the current HIP
+stream, every FLOP happens inside libvoicesplit_hip.so.
+
+Stage functions mirror the reference forward (models/voicesplit/model.py:66-89):
+``conv_stack`` (:68-74), ``bilstm`` (:77-82), ``head`` (:83-87), ``forward`` (all of it).
+The kernel-level functions (``conv64`` ...) exist for the unit tests.
+"""
+import ctypes
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, BN_EVAL, BN_TRAIN, VsDims, VsParams,
+                   VsWsLayout, check)
+
+ACT_CODES = {"relu": ACT_RELU, "mish": ACT_MISH, "none": ACT_NONE, "sigmoid": ACT_SIGMOID}
+
+# conv.{idx} of the reference nn.Sequential: (Conv2d index, BatchNorm2d index) for cnn1..cnn8
+CONV_INDEX = ((1, 2), (5, 6), (9, 10), (13, 14), (17, 18), (21, 22), (25, 26), (28, 29))
+
+
+def _dev_check(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.VoiceSplitHipError(
+            f"{name} is on {t.device}: this path only runs on an MI355X (HIP) device; there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_dims(B, T, F, E, H, FC1, FC2) -> VsDims:
+    return VsDims(int(B), int(T), int(F), int(E), int(H), int(FC1), int(FC2))
+
+
+def workspace_layout(dims: VsDims) -> VsWsLayout:
+    lay = VsWsLayout()
+    check(_lib.load().vs_workspace_layout(ctypes.byref(dims), ctypes.byref(lay)), "vs_workspace_layout")
+    return lay
+
+
+_WS_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def get_workspace(dims: VsDims, device) -> torch.Tensor:
+    """Caller-owned scratch (the library never allocates); cached per device and size."""
+    nbytes = _lib.load().vs_workspace_bytes(ctypes.byref(dims))
+    if nbytes == 0:
+        check(-1, "vs_workspace_bytes")
+    key = (torch.device(device).index, )
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _WS_CACHE.pop(key, None)   # drop the old buffer before allocating the larger one
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _WS_CACHE.clear()
+
+
+def ws_view(ws: torch.Tensor, offset: int, shape: Sequence[int], dtype=torch.float32) -> torch.Tensor:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    esz = torch.empty((), dtype=dtype).element_size()
+    return ws[offset:offset + n * esz].view(dtype).view(*shape)
+
+
+def pack_params(sd: Dict[str, torch.Tensor]) -> VsParams:
+    """state_dict (reference key names) -> vs_params of raw device pointers."""
+    p = VsParams()
+    for l, (ci, bi) in enumerate(CONV_INDEX):
+        names = {"weight": f"conv.{ci}.weight", "bias": f"conv.{ci}.bias",
+                 "bn_weight": f"conv.{bi}.weight", "bn_bias": f"conv.{bi}.bias",
+                 "bn_running_mean": f"conv.{bi}.running_mean", "bn_running_var": f"conv.{bi}.running_var"}
+        for field, key in names.items():
+            t = sd[key]
+            _dev_check(t, key)
+            setattr(p.conv[l], field, t.data_ptr())
+    for d, suffix in enumerate(("", "_reverse")):
+        for field, key in (("w_ih", "weight_ih_l0"), ("w_hh", "weight_hh_l0"),
+                           ("b_ih", "bias_ih_l0"), ("b_hh", "bias_hh_l0")):
+            t = sd[f"lstm.{key}{suffix}"]
+            _dev_check(t, f"lstm.{key}{suffix}")
+            getattr(p, field)[d] = t.data_ptr()
+    for field, key in (("fc1_w", "fc1.weight"), ("fc1_b", "fc1.bias"), ("fc2_w", "fc2.weight"), ("fc2_b", "fc2.bias")):
+        _dev_check(sd[key], key)
+        setattr(p, field, sd[key].data_ptr())
+    return p
+
+
+# ---------------------------------------------------------------------------------------------
+# whole path and stages
+# ---------------------------------------------------------------------------------------------
+
+def _check_inputs(x, dvec, dims: VsDims):
+    _dev_check(x, "x")
+    _dev_check(dvec, "speaker_embedding")
+    if x.dim() != 3 or x.shape[2] != dims.F:
+        raise ValueError(f"x must be [B, T, num_freq={dims.F}] (F contiguous), got {tuple(x.shape)}")
+    if dvec.dim() != 2 or dvec.shape[0] != x.shape[0] or dvec.shape[1] != dims.E:
+        raise ValueError(f"speaker_embedding must be [B={x.shape[0]}, emb_dim={dims.E}], got {tuple(dvec.shape)}")
+
+
+def forward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool = False,
+            workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mask = model(x, dvec): the whole reference forward in one C-ABI call."""
+    lib = _lib.load()
+    _check_inputs(x, dvec, dims)
+    params = pack_params(sd)
+    ws = workspace if workspace is not None else get_workspace(dims, x.device)
+    mask = torch.empty(dims.B, dims.T, dims.FC2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.vs_forward(ctypes.byref(dims), ctypes.byref(params), _p(x), _p(dvec), ACT_CODES[conv_act],
+                            BN_TRAIN if training else BN_EVAL, _p(ws), ws.numel(), _p(mask), _stream())
+    check(rc, "vs_forward")
+    return mask
+
+
+def conv_stack(sd, x, dims: VsDims, conv_act: str, training: bool = False, workspace=None) -> torch.Tensor:
+    lib = _lib.load()
+    _dev_check(x, "x")
+    params = pack_params(sd)
+    ws = workspace if workspace is not None else get_workspace(dims, x.device)
+    feat = torch.empty(dims.B, dims.T, 8 * dims.F, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.vs_conv_stack_fwd(ctypes.byref(dims), ctypes.byref(params), _p(x), ACT_CODES[conv_act],
+                                   BN_TRAIN if training else BN_EVAL, _p(ws), ws.numel(), _p(feat), _stream())
+    check(rc, "vs_conv_stack_fwd")
+    return feat
+
+
+def bilstm(sd, feat, dvec, dims: VsDims, workspace=None) -> torch.Tensor:
+    lib = _lib.load()
+    _dev_check(feat, "feat")
+    _dev_check(dvec, "speaker_embedding")
+    params = pack_params(sd)
+    ws = workspace if workspace is not None else get_workspace(dims, feat.device)
+    out = torch.empty(dims.B, dims.T, 2 * dims.H, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = lib.vs_bilstm_fwd(ctypes.byref(dims), ctypes.byref(params), _p(feat), _p(dvec), _p(ws), ws.numel(),
+                               _p(out), _stream())
+    check(rc, "vs_bilstm_fwd")
+    return out
+
+
+def head(sd, lstm_out, dims: VsDims, want_logits: bool = False, workspace=None):
+    lib = _lib.load()
+    _dev_check(lstm_out, "lstm_out")
+    params = pack_params(sd)
+    ws = workspace if workspace is not None else get_workspace(dims, lstm_out.device)
+    mask = torch.empty(dims.B, dims.T, dims.FC2, dtype=torch.float32, device=lstm_out.device)
+    logits = torch.empty_like(mask) if want_logits else None
+    with torch.cuda.device(lstm_out.device):
+        rc = lib.vs_head_fwd(ctypes.byref(dims), ctypes.byref(params), _p(lstm_out), _p(ws), ws.numel(),
+                             _p(logits), _p(mask), _stream())
+    check(rc, "vs_head_fwd")
+    return (mask, logits) if want_logits else mask
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel-level wrappers (unit tests)
+# ---------------------------------------------------------------------------------------------
+
+def bn_fold(gamma, beta, mean, var, conv_bias, eps=1e-5):
+    lib = _lib.load()
+    C = gamma.numel()
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(lib.vs_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), _p(conv_bias), eps, C, _p(scale), _p(shift), _stream()),
+          "vs_bn_fold")
+    return scale, shift
+
+
+def conv_first(x, w, scale, shift, act: str):
+    lib = _lib.load()
+    for n, t in (("x", x), ("w", w), ("scale", scale), ("shift", shift)):
+        _dev_check(t, n)
+    B, T, F = x.shape
+    out = torch.empty(B, 64, T, F, dtype=torch.float32, device=x.device)
+    check(lib.vs_conv_first_fwd(_p(x), _p(w), _p(scale), _p(shift), _p(out), B, T, F, ACT_CODES[act], _stream()),
+          "vs_conv_first_fwd")
+    return out
+
+
+def conv64(x, w, scale, shift, dil: int, act: str):
+    """x [B,64,T,F], w [64,64,KT,KF] -> [B,64,T,F] with 'same' zero padding and time dilation."""
+    lib = _lib.load()
+    for n, t in (("x", x), ("w", w), ("scale", scale), ("shift", shift)):
+        _dev_check(t, n)
+    B, C, T, F = x.shape
+    KT, KF = w.shape[2], w.shape[3]
+    packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=x.device)
+    check(lib.vs_conv64_pack(_p(w), _p(packed), KT, KF, _stream()), "vs_conv64_pack")
+    out = torch.empty_like(x)
+    check(lib.vs_conv64_fwd(_p(x), _p(packed), _p(scale), _p(shift), _p(out), B, T, F, KT, KF, dil,
+                            ACT_CODES[act], _stream()), "vs_conv64_fwd")
+    return out
+
+
+def conv_last(x, w, scale, shift, act: str):
+    lib = _lib.load()
+    for n, t in (("x", x), ("w", w), ("scale", scale), ("shift", shift)):
+        _dev_check(t, n)
+    B, C, T, F = x.shape
+    out = torch.empty(B, T, 8 * F, dtype=torch.float32, device=x.device)
+    check(lib.vs_conv_last_fwd(_p(x), _p(w), _p(scale), _p(shift), _p(out), B, T, F, ACT_CODES[act], _stream()),
+          "vs_conv_last_fwd")
+    return out
+
+
+def gemm_nt(A, W, bias1=None, bias2=None, rowbias=None, group: int = 1, a_relu: bool = False, act: str = "none",
+            K: Optional[int] = None):
+    """act(opA(A)[:, :K] @ W[:, :K]^T + biases); A [M,lda], W [N,ldw] row-major."""
+    lib = _lib.load()
+    _dev_check(A, "A")
+    _dev_check(W, "W")
+    M, lda = A.shape
+    N, ldw = W.shape
+    K = K if K is not None else min(lda, ldw)
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ldrb = rowbias.shape[1] if rowbias is not None else 0
+    check(lib.vs_gemm_nt(_p(A), lda, _p(W), ldw, _p(C), N, M, N, K, _p(bias1), _p(bias2), _p(rowbias), ldrb, group,
+                         int(a_relu), ACT_CODES[act], _stream()), "vs_gemm_nt")
+    return C
+
+
+def bilstm_recurrent(xg, w_hh_f, w_hh_b):
+    """xg [B,T,8H] (bias already added) -> [B,T,2H]."""
+    lib = _lib.load()
+    for n, t in (("xg", xg), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
+        _dev_check(t, n)
+    B, T, H8 = xg.shape
+    H = H8 // 8
+    packed = torch.empty(lib.vs_lstm_packed_floats(H), dtype=torch.float32, device=xg.device)
+    check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
+    state = torch.empty(lib.vs_lstm_state_floats(B, H), dtype=torch.float32, device=xg.device)
+    out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
+    check(lib.vs_bilstm_recurrent(_p(xg), _p(packed), _p(state), _p(out), B, T, H, _stream()), "vs_bilstm_recurrent")
+    return out
