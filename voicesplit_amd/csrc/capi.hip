@@ -296,8 +296,9 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
   const int B = d->B, T = d->T, H = d->H, K = 8 * d->F, KE = K + d->E;
   float* dvbias = at<float>(ws, L.dvbias);
   float* xg = at<float>(ws, L.xg);
+  {
+  ProfScope ps(VS_PROF_LSTM_GEMM, stream);
   for (int dir = 0; dir < 2; ++dir) {
-    ProfScope ps(VS_PROF_LSTM_GEMM, stream);
     VS_REQUIRE(p->w_ih[dir] && p->w_hh[dir] && p->b_ih[dir] && p->b_hh[dir], "bilstm: NULL LSTM parameter (dir %d)", dir);
     // cat((x, dvec.repeat(T))) @ W_ih^T == x @ W_ih[:, :8F]^T + (dvec @ W_ih[:, 8F:]^T): the
     // second term does not depend on t -> one [B][4H] row bias per utterance (+ b_ih + b_hh).
@@ -305,6 +306,7 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
                                  p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
     if (int rc = vs_gemm_nt_impl(feat, K, p->w_ih[dir], KE, xg + (size_t)dir * 4 * H, 8 * H, B * T, 4 * H, K,
                                  nullptr, nullptr, dvbias + (size_t)dir * 4 * H, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
+  }
   }
   float* packed = at<float>(ws, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;

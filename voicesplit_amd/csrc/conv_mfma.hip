@@ -23,6 +23,8 @@
 // consecutive f (conflict free), lanes 32-63 the next input channel.  A fragments (weights)
 // come pre-packed in fragment order (conv_pack_weights_kernel) as one coalesced dwordx4 per
 // lane per 4 K-steps (= one tap of one chunk) straight from L2/L1, prefetched one tap ahead.
+#include <stdlib.h>
+
 #include "vs_common.h"
 
 namespace {
@@ -55,7 +57,7 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __r
   wp[idx] = w[((co * kCi + ci) * KT + kt) * KF + kf];
 }
 
-template <int KT, int KF, int P, int ACT>
+template <int KT, int KF, int P, int ACT, int VAR>
 __global__ __launch_bounds__(256, 2)
 void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -66,7 +68,7 @@ void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ 
   constexpr int NELEM = kChunk * ROWS * PITCH;
   constexpr int NPT = (NELEM + 255) / 256;
   constexpr int NT = KT * KF;
-  __shared__ float sIn[NELEM];
+  __shared__ float sIn[NELEM + P * PITCH];     // + P rows: the one-tap-ahead B prefetch may overrun
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,7 +145,59 @@ void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ 
     store_chunk();
     __syncthreads();
     if (chunk + 1 < kNChunk) load_chunk(chunk + 1);   // in flight during the MFMA block below
-    if (wave_active) {
+    if (wave_active && VAR == 2) {
+      // software pipeline, one tap deep: while the 4*2P MFMAs of tap t run, the A fragment
+      // (global, L1/L2) and the 4*P B fragments (LDS) of tap t+1 are already in flight.
+      float b_cur[kPairs][P], b_nxt[kPairs][P];
+#pragma unroll
+      for (int pr = 0; pr < kPairs; ++pr)
+#pragma unroll
+        for (int p = 0; p < P; ++p) b_cur[pr][p] = sB[((2 * pr) * ROWS + p) * PITCH];
+#pragma unroll 1
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) {
+          const int tg = chunk * NT + kt * KF + kf;
+          // first K-step of this tap
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            acc[0][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0].x, b_cur[0][p], acc[0][p], 0, 0, 0);
+            acc[1][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1].x, b_cur[0][p], acc[1][p], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // prefetch tap t+1 (the tap after the chunk's last reads P rows past the window: the
+          // LDS array is padded for it and the values are discarded)
+          const float4* nxt = wp4 + (size_t)(tg + 1) * 128;
+          a_nxt[0] = nxt[0];
+          a_nxt[1] = nxt[64];
+          const int nkt = (kf + 1 < KF) ? 0 : 1;          // next tap: same row block or the next
+          const int nkf = (kf + 1 < KF) ? kf + 1 : 0;
+#pragma unroll
+          for (int pr = 0; pr < kPairs; ++pr)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              b_nxt[pr][p] = sB[((2 * pr) * ROWS + p + kt + nkt) * PITCH + nkf];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pr = 1; pr < kPairs; ++pr) {
+            const float a0 = (pr == 1) ? a_cur[0].y : (pr == 2) ? a_cur[0].z : a_cur[0].w;
+            const float a1 = (pr == 1) ? a_cur[1].y : (pr == 2) ? a_cur[1].z : a_cur[1].w;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              acc[0][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b_cur[pr][p], acc[0][p], 0, 0, 0);
+              acc[1][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b_cur[pr][p], acc[1][p], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          a_cur[0] = a_nxt[0];
+          a_cur[1] = a_nxt[1];
+#pragma unroll
+          for (int pr = 0; pr < kPairs; ++pr)
+#pragma unroll
+            for (int p = 0; p < P; ++p) b_cur[pr][p] = b_nxt[pr][p];
+        }
+      }
+    } else if (wave_active) {
 #pragma unroll 1
       for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -152,6 +206,7 @@ void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ 
           const float4* nxt = wp4 + (size_t)(tg + 1) * 128;     // dummy block pads the very last
           a_nxt[0] = nxt[0];
           a_nxt[1] = nxt[64];
+          if (VAR == 1) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch issued ahead of this tap's MFMAs
 #pragma unroll
           for (int pr = 0; pr < kPairs; ++pr) {
             float bfrag[P];
@@ -196,6 +251,12 @@ void conv64_mfma_kernel(const float* __restrict__ in, const float* __restrict__ 
   }
 }
 
+int conv_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VS_CONV_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <int KT, int KF, int P>
 int launch_conv(const float* in, const float* wp, const float* scale, const float* shift, float* out,
                 int B, int T, int F, int dil, int act, hipStream_t stream) {
@@ -208,13 +269,19 @@ int launch_conv(const float* in, const float* wp, const float* scale, const floa
   dim3 grid((unsigned)nblk), block(256);
   switch (act) {
     case VS_ACT_RELU:
-      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      if (conv_variant() == 2) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_RELU, 2>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else if (conv_variant() == 1) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_RELU, 1>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_RELU, 0>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
       break;
     case VS_ACT_MISH:
-      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      if (conv_variant() == 2) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_MISH, 2>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else if (conv_variant() == 1) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_MISH, 1>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_MISH, 0>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
       break;
     case VS_ACT_NONE:
-      hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      if (conv_variant() == 2) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_NONE, 2>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else if (conv_variant() == 1) hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_NONE, 1>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
+      else hipLaunchKernelGGL((conv64_mfma_kernel<KT, KF, P, VS_ACT_NONE, 0>), grid, block, 0, stream, in, wp, scale, shift, out, T, F, dil, n_rt, n_ft);
       break;
     default:
       VS_REQUIRE(false, "conv64: unknown activation %d", act);
