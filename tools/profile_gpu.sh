@@ -4,14 +4,15 @@
 # Usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/...
 set -u
 TAG=${1:-r01}
-OUT=$PWD/gpurun_out/prof_$TAG
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -f csv -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
-ONE="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o pmc -f csv -- $ONE > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1
