@@ -46,7 +46,7 @@ def test_workspace_layout_and_argument_errors():
     assert b"multiple of 8" in lib.vs_last_error()
     with pytest.raises(_lib.VoiceSplitHipError):
         ops.workspace_layout(bad)
-    assert lib.vs_conv64_packed_floats(5, 5) == (8 * 25 + 1) * 512
+    assert lib.vs_conv64_packed_floats(5, 5) == (8 * 25 + 4) * 512   # + 4 dummy taps for the prefetch overrun
     assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400
 
 
