@@ -1,0 +1,65 @@
+"""Batch sharding of the mask-prediction path across the GPUs of a node.
+
+Utterances are independent in the forward pass (eval-mode BN; the reference has no SyncBN and no
+multi-GPU code at all -- train.py:64-65, run_train.sh:1), so N GPUs run N contiguous slices of
+the batch with replicated weights and no data-path collective.  The helpers here are host logic
+only: slice arithmetic, and an optional all-gather for callers that want every rank to hold the
+full mask (embarrassingly-parallel inference does not need it).
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of `n_items` owned by `rank`; sizes differ by at most one and the
+    first `n_items % world` ranks get the extra item (ragged batches are allowed, including
+    ranks that own nothing when n_items < world)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    if n_items < 0:
+        raise ValueError("n_items must be >= 0")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def chunk_windows(n_frames: int, window: int = 301) -> int:
+    """BASELINE config 5: a long clip is cut into independent `window`-frame items (the last one
+    zero padded); returns how many batch items a clip of n_frames becomes."""
+    return max(1, -(-n_frames // window))
+
+
+def run_sharded(fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x: torch.Tensor,
+                dvec: torch.Tensor, rank: int, world: int, group=None, gather: bool = False
+                ) -> Optional[torch.Tensor]:
+    """Apply `fn(x_slice, dvec_slice) -> mask_slice` to this rank's utterances.
+
+    With gather=False returns the local slice (or None if the rank owns nothing).  With
+    gather=True every rank returns the full [B, T, F] mask via one all_gather of padded slices
+    (ranks may own different counts).
+    """
+    B = x.shape[0]
+    lo, hi = shard_range(B, rank, world)
+    local = fn(x[lo:hi].contiguous(), dvec[lo:hi].contiguous()) if hi > lo else None
+    if not gather or world == 1:
+        return local
+    import torch.distributed as dist
+    per = -(-B // world)                                   # padded slice length
+    shape = None
+    if local is not None:
+        shape = torch.tensor(list(local.shape[1:]), dtype=torch.int64, device=x.device)
+    else:
+        shape = torch.zeros(2, dtype=torch.int64, device=x.device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
+    tail = tuple(int(v) for v in shape.tolist())
+    buf = torch.zeros((per,) + tail, dtype=x.dtype, device=x.device)
+    if local is not None:
+        buf[: hi - lo] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    out = []
+    for r in range(world):
+        a, b = shard_range(B, r, world)
+        out.append(parts[r][: b - a])
+    return torch.cat(out, dim=0)
