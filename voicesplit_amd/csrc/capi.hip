@@ -15,6 +15,7 @@ int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*
 int vs_bn_train_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
 int vs_bn_train_feat_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
 int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
 int vs_bilstm_recurrent_impl(const float*, const float*, float*, float*, int, int, int, hipStream_t);
 
@@ -304,9 +305,10 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
     // second term does not depend on t -> one [B][4H] row bias per utterance (+ b_ih + b_hh).
     if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
                                  p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
-    if (int rc = vs_gemm_nt_impl(feat, K, p->w_ih[dir], KE, xg + (size_t)dir * 4 * H, 8 * H, B * T, 4 * H, K,
-                                 nullptr, nullptr, dvbias + (size_t)dir * 4 * H, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
   }
+  // both directions in one launch (N = 8H): twice the workgroups, half the tail quantisation
+  if (int rc = vs_gemm_nt2_impl(feat, K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
+                                nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
   }
   float* packed = at<float>(ws, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;

@@ -25,6 +25,7 @@ constexpr int PITCH = BK + 4;   // 36 floats = 144 B: 16-B aligned rows, conflic
 struct GemmArgs {
   const float* A; int lda;
   const float* W; int ldw;
+  const float* W_hi; int n_split;   // rows n >= n_split of the weight come from W_hi (two stacked matrices)
   float* C; int ldc;
   int M, N, K;
   const float* bias1;     // [N] or null
@@ -34,10 +35,11 @@ struct GemmArgs {
 };
 
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ base, int ld, int row, int nrows, int k, int K) {
+__device__ __forceinline__ float4 load4(const float* __restrict__ base, int ld, int row, int nrows, int k, int K,
+                                        const float* __restrict__ base_hi = nullptr, int split = 0x7fffffff) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row < nrows) {
-    const float* p = base + (size_t)row * ld + k;
+    const float* p = (row < split ? base + (size_t)row * ld : base_hi + (size_t)(row - split) * ld) + k;
     if (VEC) {
       if (k < K) v = *reinterpret_cast<const float4*>(p);
     } else {
@@ -78,7 +80,7 @@ void gemm_nt_kernel(GemmArgs g) {
       const int v = tid + 256 * i;
       const int row = v >> 3, c4 = (v & 7) * 4;
       ra[i] = load4<VEC>(g.A, g.lda, m0 + row, g.M, k0 + c4, g.K);
-      rw[i] = load4<VEC>(g.W, g.ldw, n0 + row, g.N, k0 + c4, g.K);
+      rw[i] = load4<VEC>(g.W, g.ldw, n0 + row, g.N, k0 + c4, g.K, g.W_hi, g.n_split);
       if (A_RELU) {
         ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
         ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
@@ -165,16 +167,33 @@ int launch_act(const GemmArgs& g, int act, hipStream_t stream) {
 
 }  // namespace
 
+int vs_gemm_nt2_impl(const float* A, int lda, const float* W, const float* W_hi, int n_split, int ldw,
+                     float* C, int ldc, int M, int N, int K,
+                     const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                     int a_relu, int act, hipStream_t stream);
+
 int vs_gemm_nt_impl(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                     const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
                     int a_relu, int act, hipStream_t stream) {
+  return vs_gemm_nt2_impl(A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
+                          a_relu, act, stream);
+}
+
+// Same GEMM with the weight given as two stacked row blocks (rows [0,n_split) from W, the rest
+// from W_hi, same leading dimension): the forward and reverse W_ih of the BiLSTM in one launch.
+int vs_gemm_nt2_impl(const float* A, int lda, const float* W, const float* W_hi, int n_split, int ldw,
+                     float* C, int ldc, int M, int N, int K,
+                     const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                     int a_relu, int act, hipStream_t stream) {
   VS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VS_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims lda=%d ldw=%d ldc=%d vs K=%d N=%d", lda, ldw, ldc, K, N);
   VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm: rowbias needs group>0 and ldrb>=N");
   VS_REQUIRE((M + BM - 1) / BM <= 65535, "gemm: M=%d too large", M);
-  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1};
+  VS_REQUIRE(n_split >= N || W_hi != nullptr, "gemm: W_hi is NULL but n_split=%d < N=%d", n_split, N);
+  GemmArgs g{A, lda, W, ldw, W_hi, n_split, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1};
   const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) &&
-                   ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+                   ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(W_hi) & 15) == 0);
   if (vec) return a_relu ? launch_act<true, true>(g, act, stream) : launch_act<true, false>(g, act, stream);
   return a_relu ? launch_act<false, true>(g, act, stream) : launch_act<false, false>(g, act, stream);
 }

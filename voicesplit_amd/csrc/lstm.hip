@@ -12,9 +12,9 @@
 // K reduction each lane holds i,f,g,o of the same (unit, batch) in its own accumulator
 // registers (D row = (r&3) + 8*(r>>2) + 4*(lane>>5): r>>2 = gate, (r&3)+4*(lane>>5) = unit) and
 // the gate math needs no cross-lane traffic.  The K = H reduction is split over the 4 waves and
-// combined through LDS.  W_hh is pre-packed in fragment order (one coalesced dwordx4 per lane
-// per 4 K-steps); h and c are kept transposed [dir][H][Bpad] so the B-operand reads and the
-// state updates are coalesced along batch.
+// combined through LDS.  W_hh and h are both kept in MFMA fragment order (one coalesced dwordx4
+// per lane per 4 K-steps) and every load of a step is issued before its first MFMA, so a step
+// costs one L2 round trip + 13 x 4 MFMAs per wave; c stays [dir][H][Bpad].
 #include "vs_common.h"
 
 namespace {
@@ -43,12 +43,21 @@ __global__ void lstm_pack_whh_kernel(const float* __restrict__ whh_f, const floa
 struct LstmStepArgs {
   const float* xg;      // [B][T][8H]
   const float* wp;      // packed W_hh
-  const float* h_prev;  // [2][H][Bpad]
-  float* h_next;        // [2][H][Bpad]
+  const float* h_prev;  // fragment order [2 dir][Bpad/32][H/8][64 lane][4]
+  float* h_next;        // same layout
   float* c;             // [2][H][Bpad]  (updated in place: each (unit,batch) has one owner)
   float* out;           // [B][T][2H]
   int B, T, H, Bpad, step;
 };
+
+// h is kept in MFMA B-fragment order so a K-quad is ONE coalesced dwordx4 per lane:
+//   hfrag[dir][bt][q][lane][j] = h[dir][k = 8q + 2j + (lane>>5)][b = 32*bt + (lane&31)]
+__device__ __forceinline__ size_t hfrag_index(int dir, int nbt, int bt, int hq, int k, int b31) {
+  const int q = k >> 3, j = (k & 7) >> 1, half = k & 1;
+  return ((((size_t)dir * nbt + bt) * hq + q) * 64 + half * 32 + b31) * 4 + j;
+}
+
+constexpr int kMaxQ = 13;   // K-quads per wave held in flight at once (H <= 416 in one pass)
 
 __global__ __launch_bounds__(256)
 void lstm_step_kernel(LstmStepArgs a) {
@@ -58,6 +67,7 @@ void lstm_step_kernel(LstmStepArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int HQ = a.H / 8;
+  const int NBT = a.Bpad / 32;
   const int jg = blockIdx.x % HQ;
   const int bt = blockIdx.x / HQ;
   const int dir = blockIdx.y;
@@ -65,7 +75,23 @@ void lstm_step_kernel(LstmStepArgs a) {
   const int b = bt * 32 + l31;
   const size_t hb = (size_t)dir * a.H * a.Bpad;
 
-  // wave 0 owns the epilogue: start its xg / c reads before the reduction loop
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // every load of this step is issued before the first MFMA: one L2 round trip, not 13
+  const float4* wq = reinterpret_cast<const float4*>(a.wp) + ((size_t)(dir * HQ + jg) * HQ) * 64 + lane;
+  const float4* hq = reinterpret_cast<const float4*>(a.h_prev) + (((size_t)dir * NBT + bt) * HQ) * 64 + lane;
+  const bool recur = a.step > 0;      // h_{-1} = 0: nothing to multiply at the first step
+  float4 w4[kMaxQ], h4[kMaxQ];
+#pragma unroll
+  for (int i = 0; i < kMaxQ; ++i) {
+    const int q = wave + 4 * i;
+    const bool ok = recur && q < HQ;
+    w4[i] = ok ? wq[(size_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    h4[i] = ok ? hq[(size_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // wave 0 owns the epilogue: its xg / c reads travel with the operand loads
   float xgv[16], cprev[4];
   if (wave == 0) {
     const bool ok = b < a.B;
@@ -75,24 +101,23 @@ void lstm_step_kernel(LstmStepArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) cprev[u] = a.c[hb + (size_t)(jg * 8 + 4 * half + u) * a.Bpad + b];
   }
-
-  f32x16 acc;
+  if (recur) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (a.step > 0) {   // h_{-1} = 0: nothing to multiply at the first step
-    const float4* wq = reinterpret_cast<const float4*>(a.wp) + ((size_t)(dir * HQ + jg) * HQ) * 64 + lane;
-    const float* hp = a.h_prev + hb + (size_t)half * a.Bpad + b;
-    for (int q = wave; q < HQ; q += 4) {
-      const float4 w4 = wq[(size_t)q * 64];
-      const float* hq = hp + (size_t)(8 * q) * a.Bpad;
-      const float h0 = hq[0];
-      const float h1 = hq[2 * (size_t)a.Bpad];
-      const float h2 = hq[4 * (size_t)a.Bpad];
-      const float h3 = hq[6 * (size_t)a.Bpad];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, h0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, h1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, h2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, h3, acc, 0, 0, 0);
+    for (int i = 0; i < kMaxQ; ++i) {
+      if (wave + 4 * i < HQ) {          // wave-uniform
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].x, h4[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].y, h4[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].z, h4[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].w, h4[i].w, acc, 0, 0, 0);
+      }
+    }
+    // hidden sizes beyond 4*kMaxQ*8 = 416: remaining quads, plain loop
+    for (int q = wave + 4 * kMaxQ; q < HQ; q += 4) {
+      const float4 w = wq[(size_t)q * 64], h = hq[(size_t)q * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h.w, acc, 0, 0, 0);
     }
   }
   if (wave > 0) {
@@ -115,9 +140,9 @@ void lstm_step_kernel(LstmStepArgs a) {
     const float go = vs_sigmoid(acc[12 + u] + xgv[12 + u]);
     const float cn = gf * cprev[u] + gi * gg;
     hv[u] = go * vs_tanh(cn);
-    const size_t si = hb + (size_t)(jg * 8 + 4 * half + u) * a.Bpad + b;
-    a.c[si] = cn;           // padded batch columns only ever hold garbage they produced themselves
-    a.h_next[si] = hv[u];
+    const int k = jg * 8 + 4 * half + u;
+    a.c[hb + (size_t)k * a.Bpad + b] = cn;   // padded batch columns only ever hold their own garbage
+    a.h_next[hfrag_index(dir, NBT, bt, HQ, k, l31)] = hv[u];
   }
   if (b < a.B) {
     float4* o = reinterpret_cast<float4*>(a.out + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
