@@ -15,9 +15,9 @@ echo "trace rc=$?"
 ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o pmc -f csv -- $ONE > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"
-timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma|conv_first|conv_last" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc_fetch rc=$?"
-timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -f csv -- $ONE > "$OUT/pmc_write.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma|conv_first|conv_last" --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -f csv -- $ONE > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "conv64_mfma" --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM -d "$OUT/pmc_lds" -o pmc -f csv -- $ONE > "$OUT/pmc_lds.log" 2>&1
 echo "pmc_lds rc=$?"
