@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 1
+#define VS_ABI_VERSION 2
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -156,6 +156,114 @@ size_t vs_lstm_state_floats(int B, int H);
 int vs_lstm_pack(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, void* stream);
 int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, float* out,
                         int B, int T, int H, void* stream);
+
+/* =============================================================================================
+ * Training: forward that keeps what backward needs + the backward pass itself.
+ * Replaces what autograd records/replays for `mask = model(x, emb)` ... `loss.backward()`
+ * (train.py:94-110) through models/voicesplit/model.py:66-89: every Conv2d / BatchNorm2d / Mish|ReLU
+ * / nn.LSTM / nn.Linear / sigmoid node of the reference graph.
+ * ============================================================================================= */
+
+/* d(loss)/d(parameter), same shapes as vs_params.  Every non-NULL pointer is OVERWRITTEN (the
+ * caller -- torch.autograd -- accumulates into .grad itself). */
+typedef struct vs_conv_layer_grad {
+  float* weight;              /* [Cout][Cin][KT][KF]                       */
+  float* bias;                /* [Cout]  (exactly 0 under batch-stat BN)   */
+  float* bn_weight;           /* [Cout]  d/d gamma                         */
+  float* bn_bias;             /* [Cout]  d/d beta                          */
+} vs_conv_layer_grad;
+
+typedef struct vs_grads {
+  vs_conv_layer_grad conv[8];
+  float* w_ih[2];             /* [4H][8F+E] */
+  float* w_hh[2];             /* [4H][H]    */
+  float* b_ih[2];             /* [4H]       */
+  float* b_hh[2];             /* [4H]       */
+  float* fc1_w; float* fc1_b; float* fc2_w; float* fc2_b;
+  float* dvec;                /* [B][E] d/d speaker embedding, may be NULL */
+} vs_grads;
+
+/* Byte offsets inside the caller-provided training tape.  vs_forward_train fills the "saved"
+ * part; vs_backward reads it and uses the rest as scratch.  The tape must not be touched between
+ * the two calls; one tape per in-flight forward. */
+typedef struct vs_tape_layout {
+  size_t total_bytes;
+  /* saved by the forward */
+  size_t z[7];                /* conv+bias outputs of cnn1..cnn7 before BatchNorm [B][64][T][F] */
+  size_t a[7];                /* act(BN(z)) = input of the next layer                           */
+  size_t z8;                  /* cnn8 conv+bias [B][T][8][F]                                    */
+  size_t feat;                /* act(BN(z8)) = LSTM features [B][T][8F]                         */
+  size_t bn_scale, bn_shift, bn_mean, bn_invstd;   /* [8][64] constants the forward used       */
+  size_t gates;               /* [B][T][8H]: gate pre-activations -> activated gates i,f,g,o ->
+                                 (backward) gradient wrt the gate pre-activations             */
+  size_t cstate;              /* [B][T][2H] cell states                                         */
+  size_t lstm_out;            /* [B][T][2H]                                                     */
+  size_t fc1_out;             /* relu(fc1) [B*T][FC1]                                           */
+  /* backward intermediates (kept for stage-level parity tests) */
+  size_t dlogits;             /* [B*T][FC2] */
+  size_t dfc1;                /* [B*T][FC1] gradient wrt fc1 pre-activation                     */
+  size_t dlstm_out;           /* [B*T][2H]                                                      */
+  size_t dsum;                /* [B][8H] sum over t of the gate gradients                       */
+  size_t dfeat;               /* [B][T][8F] gradient wrt feat, then wrt z8 (in place)           */
+  size_t grad0, grad1;        /* ping-pong [B][64][T][F] activation gradients                   */
+  /* scratch */
+  size_t dvbias, conv_packed[6], pack_tmp, lstm_packed, lstm_packed_t, lstm_state, lstm_bwd_state;
+  size_t consts;              /* ones[64], zeros[64] */
+  size_t bn_stats, bn_coef, first_acc, colsum_tmp, partials;
+} vs_tape_layout;
+
+int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);
+size_t vs_tape_bytes(const vs_dims* dims);
+
+/* Forward with the tape.  bn_mode VS_BN_TRAIN: batch statistics, running buffers updated
+ * (model.train(), train.py:84); VS_BN_EVAL: running statistics (fine-tuning with frozen BN). */
+int vs_forward_train(const vs_dims* dims, const vs_params* params, const float* x, const float* dvec,
+                     int conv_act, int bn_mode, void* tape, size_t tape_bytes, float* mask, void* stream);
+
+/* Backward: dmask [B][T][FC2] = d(loss)/d(mask) -> every gradient in `grads`.  `mask` is the
+ * tensor vs_forward_train returned; conv_act / bn_mode must match the forward call.  The
+ * gradient wrt the spectrogram x is not produced (the reference never asks for it: x is data). */
+int vs_backward(const vs_dims* dims, const vs_params* params, const float* x, const float* dvec,
+                int conv_act, int bn_mode, void* tape, size_t tape_bytes,
+                const float* mask, const float* dmask, const vs_grads* grads, void* stream);
+
+/* ---- backward kernels (unit-test surface) -------------------------------------------------- */
+/* data gradient of cnn2..cnn7 = vs_conv64_fwd with weights packed by this (transpose + tap flip) */
+int vs_conv64_pack_dgrad(const float* w, float* packed, int KT, int KF, void* stream);
+/* weight gradient of cnn2..cnn7: dz, in [B][64][T][F] -> dw [64][64][KT][KF]; partials scratch */
+size_t vs_conv64_wgrad_partial_floats(int KT, int KF);
+int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw,
+                    int B, int T, int F, int KT, int KF, int dil, void* stream);
+/* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
+ * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
+int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,
+                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                  float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream);
+/* cnn8 */
+int vs_conv_last_dgrad(const float* dz, const float* w, float* din, int B, int T, int F, void* stream);
+int vs_conv_last_wgrad_blocks(void);
+int vs_conv_last_wgrad(const float* dz, const float* in, float* partials /* [blocks][512] */, float* dw,
+                       int B, int T, int F, void* stream);
+/* cnn1: dw [64][7]; acc = 448 doubles of scratch */
+int vs_conv_first_wgrad(const float* dz, const float* x, double* acc, float* dw, int B, int T, int F, void* stream);
+/* general GEMM: layouts 0 = K contiguous (A[m][k], W[n][k]), 1 = K-major (A[k][m], W[k][n]);
+ * gate: C = gate[m][n] > 0 ? C : 0; w_shift/w_group: K-major W row k read from row k+w_shift,
+ * zero when (k % w_group)+w_shift leaves [0,w_group); splits > 1: split-K via partials [splits][M][N] */
+int vs_gemm(int layout_a, int layout_w, const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+            int M, int N, int K, const float* bias, const float* gate, int ldg, int a_relu, int w_relu, int act,
+            int accumulate, int w_shift, int w_group, int splits, float* partials, void* stream);
+/* BiLSTM recurrence that also saves the activated gates (may alias xg) and cell states */
+int vs_bilstm_recurrent_train(const float* xg, const float* packed_whh, float* state, float* out,
+                              float* gates_save, float* c_save, int B, int T, int H, void* stream);
+/* BPTT: gates (activated, from the call above) are overwritten with d/d(gate pre-activations) */
+size_t vs_lstm_packed_t_floats(int H);
+size_t vs_lstm_bwd_state_floats(int B, int H);
+int vs_lstm_pack_t(const float* w_hh_fwd, const float* w_hh_bwd, float* packed_t, int H, void* stream);
+int vs_bilstm_recurrent_bwd(const float* packed_t, float* state, float* gates, const float* c_all,
+                            const float* dout, int B, int T, int H, void* stream);
+int vs_sigmoid_bwd(const float* dmask, const float* mask, float* dlogits, long long n, void* stream);
+/* out[g][n] = sum over the g-th block of `rows` rows of X [groups*rows][ld] */
+int vs_colsum(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,5 +116,51 @@ def main():
               f"-> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+# gradient fixtures: name, model, dims, B, T, seed, training (BatchNorm mode), gain
+GRAD_CASES = [
+    ("vs_small_train_grads", "voicesplit",  SMALL, 4, 40, 13, True,  6.0),
+    ("vf_small_train_grads", "voicefilter", SMALL, 3, 35, 16, True,  6.0),
+    ("vs_small_evalbn_grads", "voicesplit", SMALL, 2, 50, 17, False, 6.0),   # frozen BatchNorm (model.eval())
+    ("vs_full_b1_grads",     "voicesplit",  R.default_dims(), 1, 301, 0, True, 8.0),
+]
+
+
+def main_grads():
+    """d(loss)/d(parameters) of the UPSTREAM modules for loss = (mask * w).sum(), the graph that
+    train.py:94-110 differentiates (with the audio-domain loss replaced by a fixed upstream
+    gradient w, see oracle/reference_backward.py)."""
+    from oracle import reference_backward as RB
+    VoiceSplit, VoiceFilter, _Mish, _load_config, AttrDict = import_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    for name, model_name, dims, B, T, seed, training, gain in GRAD_CASES:
+        sd = R.spread_logits(R.build_state_dict(dims, seed), gain)
+        x, dvec = R.synthetic_inputs(B, T, dims, seed)
+        w = RB.loss_weights(B, T, dims["fc2_dim"], seed)
+        cls = VoiceSplit if model_name == "voicesplit" else VoiceFilter
+        model = cls(make_config(AttrDict, dims))
+        model.load_state_dict(sd, strict=True)
+        model.train(training)
+        mask = model(x, dvec)
+        (mask * w).sum().backward()
+        out = {
+            "model": np.array(model_name), "B": B, "T": T, "seed": seed,
+            "training": training, "gain": gain,
+            "dims": np.array([dims[k] for k in ("num_freq", "emb_dim", "lstm_dim", "fc1_dim", "fc2_dim")]),
+            "sd_sha256": np.array(state_dict_digest(sd)),
+            "torch_version": np.array(torch.__version__),
+            "mask_sum": np.array(float(mask.detach().double().sum())),
+        }
+        for k, p in model.named_parameters():
+            out["grad/" + k] = RB.thin_grad(p.grad.detach()).numpy()
+            out["gabs/" + k] = np.array(float(p.grad.detach().abs().max()))
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez(path, **out)
+        print(f"{name}: {len(list(model.parameters()))} gradients -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--grads" in sys.argv:
+        main_grads()
+    else:
+        main()

@@ -1,0 +1,114 @@
+"""CPU oracle for the BACKWARD of the VoiceSplit / VoiceFilter mask-prediction path.
+
+TEST INFRASTRUCTURE ONLY (same rule as ``reference_forward.py``: nothing under
+``voicesplit_amd/`` may import this).
+
+The reference has no hand-written backward: ``train.py:94-110`` computes
+``mask = model(x, emb)``, a loss on ``mask``, and ``loss.backward()`` lets
+torch.autograd differentiate the graph that ``models/voicesplit/model.py:66-89``
+recorded.  This file restates exactly that: it runs the forward restatement
+(``reference_forward.forward``, same functional ops, nn.LSTM through
+``torch.func.functional_call`` so the graph reaches the state_dict tensors) with
+``requires_grad`` parameters and asks autograd for the gradients.
+
+Loss used for parity: ``loss = (mask * w).sum()`` with a fixed seeded ``w`` --
+i.e. an arbitrary upstream gradient ``d(loss)/d(mask) = w`` -- so every path of
+the backward graph is exercised independently of the reference's audio-domain
+losses (which sit outside the hot path).
+
+Pinning: ``oracle/make_golden.py --grads`` runs the UPSTREAM modules with the
+same ``w`` and commits (thinned) gradients under ``tests/golden/*_grads.npz``;
+``tests/test_oracle.py`` checks this file against them.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import reference_forward as R
+
+
+def loss_weights(B: int, T: int, F_out: int, seed: int, dtype=torch.float32) -> torch.Tensor:
+    """The fixed d(loss)/d(mask): randn [B,T,fc2_dim] from a dedicated generator."""
+    g = torch.Generator().manual_seed(seed + 4242)
+    return torch.randn(B, T, F_out, generator=g).to(dtype)
+
+
+def _bilstm_functional(xs, sd):
+    """nn.LSTM (models/voicesplit/model.py:57-61,82) with the graph attached to ``sd``."""
+    import torch.nn as nn
+    H = sd["lstm.weight_hh_l0"].shape[1]
+    m = nn.LSTM(xs.shape[2], H, batch_first=True, bidirectional=True).to(xs.dtype)
+    params = {k[len("lstm."):]: v for k, v in sd.items() if k.startswith("lstm.")}
+    y, _ = torch.func.functional_call(m, params, (xs,))
+    return y
+
+
+def forward_with_graph(sd, x, dvec, act: str, training: bool, lstm_impl: str = "aten"):
+    """reference_forward.forward without no_grad, returning the stage tensors (graph attached)."""
+    out = OrderedDict()
+    y = R.conv_stack(x, sd, act, training, out, None)
+    y = y.transpose(1, 2).contiguous()
+    y = y.view(y.size(0), y.size(1), -1)
+    out["feat"] = y
+    e = dvec.unsqueeze(1).repeat(1, y.size(1), 1)
+    y = torch.cat((y, e), dim=2)
+    y = _bilstm_functional(y, sd) if lstm_impl == "aten" else R.bilstm(y, sd)
+    out["lstm_out"] = y
+    y = torch.relu(y)
+    h = F.linear(y, sd["fc1.weight"], sd["fc1.bias"])
+    out["fc1_pre"] = h
+    y = torch.relu(h)
+    y = F.linear(y, sd["fc2.weight"], sd["fc2.bias"])
+    out["logits"] = y
+    out["mask"] = torch.sigmoid(y)
+    return out
+
+
+PARAM_SUFFIXES = ("weight", "bias")
+
+
+def trainable_keys(sd):
+    return [k for k in sd if sd[k].is_floating_point() and not ("running_" in k)]
+
+
+def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", training: bool = True,
+              dtype=torch.float32, lstm_impl: str = "aten", want_dvec: bool = False,
+              stages: Optional[dict] = None) -> "OrderedDict[str, torch.Tensor]":
+    """{state_dict key: d(loss)/d(param)} for loss = (mask * w).sum(); ``stages`` (optional dict)
+    receives d(loss)/d(stage) for feat, lstm_out, fc1_pre, logits and cnn1..cnn8 outputs."""
+    sd = OrderedDict((k, (v.detach().to(dtype).clone().requires_grad_(True)
+                          if (v.is_floating_point() and "running_" not in k) else
+                          (v.detach().to(dtype).clone() if v.is_floating_point() else v.clone())))
+                     for k, v in sd.items())
+    x = x.detach().to(dtype)
+    dvec = dvec.detach().to(dtype).clone().requires_grad_(want_dvec)
+    out = forward_with_graph(sd, x, dvec, act, training, lstm_impl)
+    if stages is not None:
+        for k in ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)):
+            out[k].retain_grad()
+    loss = (out["mask"] * w.to(dtype)).sum()
+    loss.backward()
+    grads = OrderedDict((k, v.grad.detach()) for k, v in sd.items() if v.requires_grad)
+    if want_dvec:
+        grads["speaker_embedding"] = dvec.grad.detach()
+    if stages is not None:
+        for k in ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)):
+            stages[k] = out[k].grad.detach()
+        stages["mask"] = out["mask"].detach()
+    return grads
+
+
+def thin_grad(g: torch.Tensor, limit: int = 20000):
+    """Fixture thinning: tensors above `limit` elements keep every stride-th element of the
+    flattened gradient (stride = the smallest odd number that brings it under the limit)."""
+    flat = g.reshape(-1)
+    n = flat.numel()
+    if n <= limit:
+        return flat
+    stride = (n + limit - 1) // limit
+    stride += 1 - stride % 2
+    return flat[::stride]

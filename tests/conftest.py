@@ -42,3 +42,13 @@ def load_golden(name):
 
 GOLDEN_CASES = ["vs_small_eval", "vf_small_eval", "vs_small_train", "vs_short_T", "vs_T1",
                 "vs_full_b1", "vf_full_b1"]
+
+GOLDEN_GRAD_CASES = ["vs_small_train_grads", "vf_small_train_grads", "vs_small_evalbn_grads", "vs_full_b1_grads"]
+
+
+def load_golden_grads(name):
+    """Gradient fixture made by `oracle/make_golden.py --grads` from the upstream modules."""
+    g = load_golden(name)
+    g["grads"] = {k[len("grad/"):]: g[k] for k in list(g) if k.startswith("grad/")}
+    g["gabs"] = {k[len("gabs/"):]: float(g[k]) for k in list(g) if k.startswith("gabs/")}
+    return g

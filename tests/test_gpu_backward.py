@@ -1,0 +1,412 @@
+"""GPU: the backward pass (vs_backward and every backward kernel) through the C ABI against
+(1) torch autograd in fp64 on the same seeded inputs (kernel level),
+(2) the backward oracle in fp64 and the committed upstream gradients (module level),
+(3) size-independent properties at BASELINE.json's B=64.
+Tolerance: 1e-4 of each gradient tensor's max magnitude at module level (the path's fp32
+contract), 3e-5 for single kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN_GRAD_CASES, load_golden_grads
+from oracle import reference_backward as RB
+from oracle import reference_forward as R
+
+pytestmark = pytest.mark.gpu
+KTOL = 3e-5
+MTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    ref = ref.detach().to(torch.float64).cpu()
+    got = got.detach().to(torch.float64).cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+CONV_BWD_CASES = [
+    # KT, KF, dil, B, T, F
+    (7, 1, 1, 2, 19, 37),
+    (5, 5, 1, 2, 19, 37),
+    (5, 5, 2, 1, 23, 70),
+    (5, 5, 4, 2, 21, 133),
+    (5, 5, 8, 1, 50, 64),
+    (5, 5, 16, 2, 40, 31),
+    (5, 5, 16, 1, 20, 37),     # T shorter than the dilation halo: some taps never see the image
+    (5, 5, 1, 1, 1, 5),
+    (7, 1, 1, 1, 8, 601),
+    (5, 5, 2, 3, 9, 601),
+]
+
+
+def _conv_ref(x, w, dil):
+    KT, KF = w.shape[2], w.shape[3]
+    return F.conv2d(F.pad(x, (KF // 2, KF // 2, dil * (KT // 2), dil * (KT // 2))), w, dilation=(dil, 1))
+
+
+@pytest.mark.parametrize("KT,KF,dil,B,T,Fq", CONV_BWD_CASES)
+def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(KT * 1000 + dil * 10 + B)
+    x = torch.randn(B, 64, T, Fq, generator=g)
+    w = torch.randn(64, 64, KT, KF, generator=g) * (1.0 / (64 * KT * KF) ** 0.5)
+    dz = torch.randn(B, 64, T, Fq, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    (_conv_ref(xd, wd, dil) * dz.double()).sum().backward()
+    d = dev()
+    dx = ops.conv64_dgrad(dz.to(d), w.to(d), dil)
+    dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil)
+    assert rel_err(dx, xd.grad) < KTOL
+    assert rel_err(dw, wd.grad) < KTOL
+
+
+def test_conv64_wgrad_one_hot_indices():
+    """dz one-hot at (b,co,t,f), input one-hot at (b,ci,t',f'): exactly one weight-gradient entry,
+    at (co, ci, kt, kf) with t' = t+(kt-2)*dil, f' = f+kf-2 -- catches transposed / flipped taps."""
+    from voicesplit_amd import ops
+    d = dev()
+    B, T, Fq, dil = 2, 14, 75, 2
+    for (b, co, t, f, ci, kt, kf) in [(0, 5, 6, 10, 11, 0, 4), (1, 63, 3, 70, 0, 4, 0), (1, 33, 7, 63, 62, 2, 3),
+                                      (0, 0, 13, 0, 40, 1, 2)]:
+        tp, fp = t + (kt - 2) * dil, f + kf - 2
+        assert 0 <= tp < T and 0 <= fp < Fq
+        dz = torch.zeros(B, 64, T, Fq)
+        x = torch.zeros(B, 64, T, Fq)
+        dz[b, co, t, f] = 1.0
+        x[b, ci, tp, fp] = 3.0
+        dw = ops.conv64_wgrad(dz.to(d), x.to(d), 5, 5, dil).cpu()
+        ref = torch.zeros(64, 64, 5, 5)
+        ref[co, ci, kt, kf] = 3.0
+        assert torch.equal(dw, ref), (b, co, t, f, ci, kt, kf, dw.nonzero().tolist())
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("layout", ["nchw", "feat"])
+def test_bn_act_backward(act, training, layout):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, T, Fq = 3, 11, 37
+    C = 64 if layout == "nchw" else 8
+    z = torch.randn(B, C, T, Fq, generator=g) * 1.5 + 0.3
+    da = torch.randn(B, C, T, Fq, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    rmean = torch.randn(C, generator=g) * 0.1
+    rvar = torch.rand(C, generator=g) + 0.5
+    zd = z.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    y = F.batch_norm(zd, rmean.double().clone(), rvar.double().clone(), gd, bd, training, 0.1, 1e-5)
+    (R.activation(y, act) * da.double()).sum().backward()
+    if training:
+        mean = z.double().mean(dim=(0, 2, 3))
+        var = z.double().var(dim=(0, 2, 3), unbiased=False)
+    else:
+        mean, var = rmean.double(), rvar.double()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mean * scale
+    d = dev()
+    if layout == "feat":      # [B][T][8][F]
+        zz, dd = z.permute(0, 2, 1, 3).contiguous(), da.permute(0, 2, 1, 3).contiguous()
+    else:
+        zz, dd = z, da
+    dz, dgamma, dbeta, dbias = ops.bn_act_bwd(dd.to(d).reshape(-1, Fq if layout == "feat" else T * Fq),
+                                              zz.to(d).reshape(-1, Fq if layout == "feat" else T * Fq), C, act, training,
+                                              scale.float().to(d), shift.float().to(d), mean.float().to(d), invstd.float().to(d))
+    dz = dz.reshape(zz.shape)
+    if layout == "feat":
+        dz = dz.permute(0, 2, 1, 3)
+    assert rel_err(dz, zd.grad) < KTOL
+    assert rel_err(dgamma, gd.grad) < KTOL
+    assert rel_err(dbeta, bd.grad) < KTOL
+    ref_dbias = zd.grad.sum(dim=(0, 2, 3))
+    assert (dbias.double().cpu() - ref_dbias).abs().max() < 1e-4 * zd.grad.abs().sum(dim=(0, 2, 3)).max()
+
+
+def test_conv_edge_layers_backward():
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, T, Fq = 2, 7, 83
+    d = dev()
+    # cnn8: 1x1, 64->8, output in [B][T][8][F]
+    a7 = torch.randn(B, 64, T, Fq, generator=g)
+    w8 = torch.randn(8, 64, 1, 1, generator=g) * 0.2
+    dz8 = torch.randn(B, T, 8, Fq, generator=g)
+    ad, wd = a7.double().requires_grad_(True), w8.double().requires_grad_(True)
+    (F.conv2d(ad, wd).transpose(1, 2) * dz8.double()).sum().backward()
+    assert rel_err(ops.conv_last_dgrad(dz8.to(d), w8.to(d), B, T, Fq), ad.grad) < KTOL
+    assert rel_err(ops.conv_last_wgrad(dz8.to(d), a7.to(d)), wd.grad) < KTOL
+    # cnn1: 1x7, 1->64
+    x = torch.rand(B, T, Fq, generator=g)
+    w1 = torch.randn(64, 1, 1, 7, generator=g)
+    dz1 = torch.randn(B, 64, T, Fq, generator=g)
+    w1d = w1.double().requires_grad_(True)
+    (F.conv2d(F.pad(x.double().unsqueeze(1), (3, 3, 0, 0)), w1d) * dz1.double()).sum().backward()
+    assert rel_err(ops.conv_first_wgrad(dz1.to(d), x.to(d)), w1d.grad) < KTOL
+
+
+GEMM_BWD_CASES = [
+    # la, lw, M, N, K, pad (extra leading-dim elements: 0 -> vector loads, 1 -> scalar path), splits
+    (0, 0, 70, 90, 200, 0, 1),
+    (0, 1, 301, 150, 77, 0, 1),
+    (0, 1, 130, 96, 64, 1, 1),
+    (1, 1, 96, 200, 301, 0, 1),
+    (1, 1, 37, 53, 1000, 0, 8),
+    (1, 1, 64, 40, 555, 1, 4),
+    (1, 0, 100, 60, 130, 0, 1),
+    (0, 0, 128, 128, 32, 0, 1),
+]
+
+
+@pytest.mark.parametrize("la,lw,M,N,K,pad,splits", GEMM_BWD_CASES)
+def test_gemm_layouts(la, lw, M, N, K, pad, splits):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    ref = A.double() @ W.double().t()
+    d = dev()
+
+    def store(mat, layout):     # [rows][K] logical -> device 2-D buffer in the requested layout, ld padded
+        m = mat.t().contiguous() if layout else mat
+        buf = torch.zeros(m.shape[0], m.shape[1] + pad)
+        buf[:, :m.shape[1]] = m
+        return buf.to(d)
+
+    got = ops.gemm(store(A, la), store(W, lw), M, N, K, layout_a=la, layout_w=lw, splits=splits)
+    assert rel_err(got, ref) < KTOL
+
+
+def test_gemm_epilogue_gate_accumulate_relu_and_shift():
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    d = dev()
+    M, N, K = 90, 70, 120
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    out = c0.clone().to(d)
+    ops.gemm(A.to(d), W.to(d), M, N, K, layout_a=0, layout_w=1, gate=gate.to(d), out=out, accumulate=True)
+    ref = c0.double() + (A.double() @ W.double()) * (gate > 0)
+    assert rel_err(out, ref) < KTOL
+    # relu on the K-major operand + bias + sigmoid
+    bias = torch.randn(N, generator=g)
+    got = ops.gemm(A.to(d), W.to(d), M, N, K, layout_a=0, layout_w=1, w_relu=True, bias=bias.to(d), act="sigmoid")
+    assert rel_err(got, torch.sigmoid(A.double() @ W.double().clamp_min(0) + bias.double())) < KTOL
+    # dW_hh pattern: sum_k A[k][m] * W[k + shift][n] inside groups of T rows
+    T, Bn, H4, H = 13, 3, 40, 24
+    Kk = T * Bn
+    G = torch.randn(Kk, H4, generator=g)
+    Hh = torch.randn(Kk, H, generator=g)
+    for shift in (-1, 1):
+        ref = torch.zeros(H4, H, dtype=torch.float64)
+        for k in range(Kk):
+            t = k % T
+            if 0 <= t + shift < T:
+                ref += torch.outer(G[k].double(), Hh[k + shift].double())
+        got = ops.gemm(G.to(d), Hh.to(d), H4, H, Kk, layout_a=1, layout_w=1, w_shift=shift, w_group=T, splits=4)
+        assert rel_err(got, ref) < KTOL
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 9, 24), (5, 17, 32), (33, 6, 40), (3, 12, 400)])
+def test_bilstm_train_forward_and_bptt(B, T, H):
+    """Saved gates / cell states of the training forward and the gate gradients of the BPTT kernel
+    against autograd through the explicit recurrence (fp64)."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T)
+    xg = torch.randn(B, T, 8 * H, generator=g)
+    whh = [torch.randn(4 * H, H, generator=g) * (1.5 / H ** 0.5) for _ in range(2)]
+    dout = torch.randn(B, T, 2 * H, generator=g)
+    xgd = xg.double().requires_grad_(True)
+    outs, gates_ref, c_ref = [], [], []
+    for dirn in range(2):
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
+        out = [None] * T
+        gs, cs = [None] * T, [None] * T
+        for t in (range(T - 1, -1, -1) if dirn else range(T)):
+            pre = xgd[:, t, dirn * 4 * H:(dirn + 1) * 4 * H] + h @ whh[dirn].double().t()
+            i, f, gg, o = pre.split(H, dim=1)
+            i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            out[t], gs[t], cs[t] = h, torch.cat((i, f, gg, o), 1), c
+        outs.append(torch.stack(out, 1))
+        gates_ref.append(torch.stack(gs, 1))
+        c_ref.append(torch.stack(cs, 1))
+    out_ref = torch.cat(outs, 2)
+    (out_ref * dout.double()).sum().backward()
+    d = dev()
+    out, gates, c = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d))
+    assert rel_err(out, out_ref) < KTOL
+    assert rel_err(gates, torch.cat(gates_ref, 2)) < KTOL
+    assert rel_err(c, torch.cat(c_ref, 2)) < KTOL
+    dxg = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d))
+    assert rel_err(dxg, xgd.grad) < KTOL
+
+
+def test_sigmoid_bwd_and_colsum():
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(1)
+    d = dev()
+    m = torch.rand(7, 13, 53, generator=g)
+    dm = torch.randn(7, 13, 53, generator=g)
+    assert rel_err(ops.sigmoid_bwd(dm.to(d), m.to(d)), dm.double() * m.double() * (1 - m.double())) < 1e-6
+    x = torch.randn(6 * 11, 301, generator=g)
+    assert rel_err(ops.colsum(x.to(d), 6, 11), x.double().reshape(6, 11, 301).sum(1)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# module level: model(x, emb) -> loss -> loss.backward()   (train.py:94-110)
+# ---------------------------------------------------------------------------------------------
+
+def _module(cls_name, dims_d, sd):
+    import voicesplit_amd as V
+    m = getattr(V, cls_name)(V.default_config(dims_d["num_freq"], dims_d["emb_dim"], dims_d["lstm_dim"],
+                                              dims_d["fc1_dim"], dims_d["fc2_dim"]))
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def _zero_bias_keys(training):
+    # conv biases in front of a batch-stat BatchNorm: the true gradient is exactly 0
+    return {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)} if training else set()
+
+
+@pytest.mark.parametrize("cls_name,act", [("VoiceSplit", "mish"), ("VoiceFilter", "relu")])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B,T", [(2, 45), (5, 17)])
+def test_module_backward_matches_fp64_oracle(cls_name, act, training, B, T):
+    from voicesplit_amd import ops
+    dims_d = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 21), 6.0)
+    x, dvec = R.synthetic_inputs(B, T, dims_d, 21)
+    w = RB.loss_weights(B, T, 53, 21)
+    stages = {}
+    ref = RB.gradients(sd, x, dvec, w, act=act, training=training, dtype=torch.float64, lstm_impl="loop",
+                       want_dvec=True, stages=stages)
+    m = _module(cls_name, dims_d, sd)
+    m.train(training)
+    emb = dvec.cuda().requires_grad_(True)
+    mask = m(x.cuda(), emb)
+    assert mask.requires_grad
+    assert rel_err(mask, stages["mask"]) < MTOL
+    # keep the tape alive past backward for the stage-level comparison
+    tape = mask.grad_fn.tape
+    (mask * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    dims = ops.make_dims(B, T, 53, 24, 32, 44, 53)
+    lay = ops.tape_layout(dims)
+    assert rel_err(ops.ws_view(tape, lay.dlogits, (B, T, 53)), stages["logits"]) < MTOL
+    assert rel_err(ops.ws_view(tape, lay.dfc1, (B, T, 44)), stages["fc1_pre"]) < MTOL
+    assert rel_err(ops.ws_view(tape, lay.dlstm_out, (B, T, 64)), stages["lstm_out"]) < MTOL
+    zero = _zero_bias_keys(training)
+    worst = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        if k in zero:
+            assert p.grad.abs().max().item() == 0.0
+            continue
+        worst[k] = rel_err(p.grad, ref[k])
+    bad = {k: v for k, v in worst.items() if v >= MTOL}
+    assert not bad, bad
+    assert rel_err(emb.grad, ref["speaker_embedding"]) < MTOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAD_CASES)
+def test_module_backward_matches_upstream_golden_gradients(name):
+    g = load_golden_grads(name)
+    d = g["dims"]
+    sd = R.spread_logits(R.build_state_dict(d, g["seed"]), g["gain"])
+    x, dvec = R.synthetic_inputs(g["B"], g["T"], d, g["seed"])
+    w = RB.loss_weights(g["B"], g["T"], d["fc2_dim"], g["seed"])
+    m = _module("VoiceSplit" if g["model"] == "voicesplit" else "VoiceFilter", d, sd)
+    m.train(g["training"])
+    mask = m(x.cuda(), dvec.cuda())
+    assert abs(float(mask.detach().double().sum()) - float(g["mask_sum"])) < 1e-4 * abs(float(g["mask_sum"]))
+    (mask * w.cuda()).sum().backward()
+    zero = _zero_bias_keys(g["training"])
+    bad = {}
+    for k, p in m.named_parameters():
+        if k in zero:
+            continue
+        got = RB.thin_grad(p.grad.detach().cpu()).double().numpy()
+        err = np.abs(got - g["grads"][k]).max() / max(g["gabs"][k], 1e-30)
+        if err >= MTOL:
+            bad[k] = err
+    assert not bad, bad
+
+
+def test_training_step_semantics():
+    """What train.py relies on around the call: the mask is an autograd tensor, BatchNorm running
+    statistics and num_batches_tracked move exactly once per forward, gradients accumulate into
+    .grad across two backward calls, x with requires_grad is refused loudly, a second backward
+    through the same graph is refused."""
+    dims_d = dict(num_freq=37, emb_dim=16, lstm_dim=24, fc1_dim=40, fc2_dim=37)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 2), 6.0)
+    m = _module("VoiceSplit", dims_d, sd).train()
+    x, dvec = R.synthetic_inputs(3, 21, dims_d, 2)
+    xc, dc = x.cuda(), dvec.cuda()
+    with torch.no_grad():
+        ref_mask = m(xc, dc)                       # inference-path kernels, batch-stat BN
+    rm1 = m.conv[2].running_mean.clone()
+    mask = m(xc, dc)                               # tape path
+    assert torch.allclose(mask, ref_mask, rtol=0, atol=2e-6)
+    assert int(m.conv[2].num_batches_tracked) == 2
+    assert not torch.equal(m.conv[2].running_mean, rm1)
+    mask.sum().backward()
+    g1 = m.fc2.weight.grad.clone()
+    with pytest.raises(RuntimeError):
+        mask.sum().backward()
+    m(xc, dc).sum().backward()
+    assert torch.allclose(m.fc2.weight.grad, 2 * g1, rtol=1e-4, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        m(xc.clone().requires_grad_(True), dc)
+    # an optimizer step runs on the produced gradients (train.py:34,111)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    before = m.fc1.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.fc1.weight.detach())
+
+
+def test_full_batch_backward_properties():
+    """BASELINE size (B=64, 301x601): finite gradients; with frozen BatchNorm utterances are
+    independent, so a loss that only touches utterance 5 must give the gradients of that utterance
+    run alone; scaling the upstream gradient by 2 scales every gradient by 2."""
+    import voicesplit_amd as V
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, 0), 8.0)
+    m = V.VoiceSplit(V.default_config()).eval()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x, dvec = R.synthetic_inputs(64, 301, dims_d, 0)
+    xc, dc = x.cuda(), dvec.cuda()
+    w = RB.loss_weights(1, 301, 601, 5).cuda()
+
+    def grads_of(xb, db, sel, scale):
+        m.zero_grad(set_to_none=True)
+        mask = m(xb, db)
+        (mask[sel] * w[0] * scale).sum().backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    big = grads_of(xc, dc, 5, 1.0)
+    one = grads_of(xc[5:6].contiguous(), dc[5:6].contiguous(), 0, 1.0)
+    twice = grads_of(xc, dc, 5, 2.0)
+    torch.cuda.synchronize()
+    bad = {}
+    for k in big:
+        assert torch.isfinite(big[k]).all(), k
+        sc = one[k].abs().max().clamp_min(1e-30)
+        e1 = ((big[k] - one[k]).abs().max() / sc).item()
+        e2 = ((twice[k] - 2 * big[k]).abs().max() / sc).item()
+        if e1 >= MTOL or e2 >= 1e-5:
+            bad[k] = (e1, e2)
+    assert not bad, bad

@@ -112,3 +112,62 @@ def test_dvec_fold_identity():
     full = torch.cat((x, d[:, None].repeat(1, 5, 1)), 2) @ W.t()
     fold = x @ W[:, :72].t() + (d @ W[:, 72:].t())[:, None]
     assert (full - fold).abs().max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# backward oracle (oracle/reference_backward.py)
+# ---------------------------------------------------------------------------------------------
+from conftest import GOLDEN_GRAD_CASES, load_golden_grads   # noqa: E402
+from oracle import reference_backward as RB                  # noqa: E402
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAD_CASES)
+def test_backward_oracle_reproduces_upstream_gradients(name):
+    """Same ops, same torch build as the fixture -> equal up to the summation order of the CPU
+    kernels (which depends on the thread count): 2e-6 of each gradient's max magnitude."""
+    g = load_golden_grads(name)
+    sd, x, dvec = case_tensors(g)
+    assert _digest(sd) == g["sd_sha256"]
+    act = "mish" if g["model"] == "voicesplit" else "relu"
+    w = RB.loss_weights(g["B"], g["T"], g["dims"]["fc2_dim"], g["seed"])
+    grads = RB.gradients(sd, x, dvec, w, act=act, training=g["training"])
+    assert sorted(grads) == sorted(g["grads"])
+    for k, ref in g["grads"].items():
+        got = RB.thin_grad(grads[k]).numpy()
+        assert got.shape == ref.shape, k
+        scale = max(g["gabs"][k], 1e-30)
+        # conv biases feeding a batch-stat BatchNorm have an exactly-zero true gradient: what
+        # autograd returns there is rounding noise (~1e-6 of the neighbouring gradients)
+        if g["training"] and k.startswith("conv.") and k.endswith(".bias") and int(k.split(".")[1]) in (1, 5, 9, 13, 17, 21, 25, 28):
+            continue
+        assert np.abs(got - ref).max() <= 2e-6 * scale + 1e-12, f"{name}:{k}"
+
+
+def test_backward_oracle_fp32_close_to_fp64_and_lstm_impls_agree():
+    dims = dict(num_freq=21, emb_dim=8, lstm_dim=16, fc1_dim=24, fc2_dim=21)
+    sd = R.spread_logits(R.build_state_dict(dims, 31), 4.0)
+    x, dvec = R.synthetic_inputs(2, 23, dims, 31)
+    w = RB.loss_weights(2, 23, 21, 31)
+    g32 = RB.gradients(sd, x, dvec, w, act="mish", training=True)
+    g64 = RB.gradients(sd, x, dvec, w, act="mish", training=True, dtype=torch.float64)
+    g64l = RB.gradients(sd, x, dvec, w, act="mish", training=True, dtype=torch.float64, lstm_impl="loop", want_dvec=True)
+    assert "speaker_embedding" in g64l
+    for k in g32:
+        scale = g64[k].abs().max().item()
+        if scale < 1e-9:
+            continue
+        assert (g64[k] - g64l[k]).abs().max().item() <= 1e-10 * scale, k
+        if not (k.startswith("conv.") and k.endswith(".bias")):
+            assert (g32[k].double() - g64[k]).abs().max().item() <= 2e-4 * scale, k
+
+
+def test_mish_gradient_closed_form():
+    # HIP: mish'(x) = t + x*(2/(n+2))*(1+t)*sigmoid(x), t = n/(n+2), n = e^x(e^x+2); 1 for x > 20
+    x = torch.linspace(-30, 30, 4001, dtype=torch.float64, requires_grad=True)
+    R.mish(x).sum().backward()
+    xd = x.detach()
+    u = torch.exp(torch.clamp(xd, max=20.0))
+    n = u * (u + 2)
+    t = n / (n + 2)
+    closed = torch.where(xd > 20, torch.ones_like(xd), t + xd * (2 / (n + 2)) * (1 + t) * (u / (1 + u)))
+    assert (closed - x.grad).abs().max() < 1e-12

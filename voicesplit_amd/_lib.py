@@ -6,7 +6,7 @@ loaded so that both resolve the same ``libamdhip64`` already mapped into the pro
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvoicesplit_hip.so")
@@ -15,7 +15,7 @@ ACT_RELU, ACT_MISH, ACT_NONE, ACT_SIGMOID = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN = 0, 1
 PROF_SLOTS = 11
 PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class VsDims(Structure):
@@ -44,6 +44,33 @@ class VsWsLayout(Structure):
     ]
 
 
+class VsConvLayerGrad(Structure):
+    _fields_ = [(n, c_void_p) for n in ("weight", "bias", "bn_weight", "bn_bias")]
+
+
+class VsGrads(Structure):
+    _fields_ = [
+        ("conv", VsConvLayerGrad * 8),
+        ("w_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_ih", c_void_p * 2), ("b_hh", c_void_p * 2),
+        ("fc1_w", c_void_p), ("fc1_b", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p),
+        ("dvec", c_void_p),
+    ]
+
+
+class VsTapeLayout(Structure):
+    _fields_ = [
+        ("total_bytes", c_size_t), ("z", c_size_t * 7), ("a", c_size_t * 7), ("z8", c_size_t), ("feat", c_size_t),
+        ("bn_scale", c_size_t), ("bn_shift", c_size_t), ("bn_mean", c_size_t), ("bn_invstd", c_size_t),
+        ("gates", c_size_t), ("cstate", c_size_t), ("lstm_out", c_size_t), ("fc1_out", c_size_t),
+        ("dlogits", c_size_t), ("dfc1", c_size_t), ("dlstm_out", c_size_t), ("dsum", c_size_t), ("dfeat", c_size_t),
+        ("grad0", c_size_t), ("grad1", c_size_t),
+        ("dvbias", c_size_t), ("conv_packed", c_size_t * 6), ("pack_tmp", c_size_t), ("lstm_packed", c_size_t),
+        ("lstm_packed_t", c_size_t), ("lstm_state", c_size_t), ("lstm_bwd_state", c_size_t), ("consts", c_size_t),
+        ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
+        ("partials", c_size_t),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/voicesplit_hip.h declares
 _P = c_void_p
 SIGNATURES = {
@@ -69,6 +96,29 @@ SIGNATURES = {
     "vs_lstm_state_floats": (c_size_t, [c_int, c_int]),
     "vs_lstm_pack": (c_int, [_P, _P, _P, c_int, _P]),
     "vs_bilstm_recurrent": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    # training
+    "vs_tape_layout_query": (c_int, [POINTER(VsDims), POINTER(VsTapeLayout)]),
+    "vs_tape_bytes": (c_size_t, [POINTER(VsDims)]),
+    "vs_forward_train": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_int, c_int, _P, c_size_t, _P, _P]),
+    "vs_backward": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_int, c_int, _P, c_size_t, _P, _P,
+                            POINTER(VsGrads), _P]),
+    "vs_conv64_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vs_conv64_wgrad_partial_floats": (c_size_t, [c_int, c_int]),
+    "vs_conv64_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_bn_act_bwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vs_conv_last_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_conv_last_wgrad_blocks": (c_int, []),
+    "vs_conv_last_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_conv_first_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_gemm": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vs_bilstm_recurrent_train": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_lstm_packed_t_floats": (c_size_t, [c_int]),
+    "vs_lstm_bwd_state_floats": (c_size_t, [c_int, c_int]),
+    "vs_lstm_pack_t": (c_int, [_P, _P, _P, c_int, _P]),
+    "vs_bilstm_recurrent_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_sigmoid_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),
+    "vs_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
 }
 
 _lib = None

@@ -4,20 +4,7 @@
 #include <string.h>
 
 #include "../../include/voicesplit_hip.h"
-#include "vs_common.h"
-
-// ---- implemented in the kernel files ----------------------------------------------------------
-int vs_conv64_pack_impl(const float*, float*, int, int, hipStream_t);
-int vs_conv64_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
-int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
-int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
-int vs_bn_train_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
-int vs_bn_train_feat_impl(float*, int, int, int, const float*, const float*, float*, float*, float, float, int, double*, float*, float*, hipStream_t);
-int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
-int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
-int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
-int vs_bilstm_recurrent_impl(const float*, const float*, float*, float*, int, int, int, hipStream_t);
+#include "vs_internal.h"
 
 // ---- error string --------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -109,6 +96,8 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
 
 }  // namespace
 
+int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
+
 extern "C" {
 
 int vs_abi_version(void) { return VS_ABI_VERSION; }
@@ -175,7 +164,7 @@ int vs_conv_first_fwd(const float* x, const float* w, const float* scale, const 
 }
 
 int vs_conv64_pack(const float* w, float* packed, int KT, int KF, void* stream) {
-  return vs_conv64_pack_impl(w, packed, KT, KF, (hipStream_t)stream);
+  return vs_conv64_pack_impl(w, packed, KT, KF, 0, (hipStream_t)stream);
 }
 
 int vs_conv64_fwd(const float* in, const float* packed, const float* scale, const float* shift, float* out,
@@ -201,7 +190,7 @@ int vs_lstm_pack(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, in
 
 int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, float* out,
                         int B, int T, int H, void* stream) {
-  return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, B, T, H, (hipStream_t)stream);
+  return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, nullptr, nullptr, B, T, H, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,32 +242,32 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   ProfScope ps(VS_PROF_CNN1, stream);
   if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, scale, shift, act[cur], B, T, F, layer_act, stream)) return rc;
   if (train) {
-    if (int rc = vs_bn_train_impl(act[cur], B, 64, T * F, p->conv[0].bn_weight, p->conv[0].bn_bias, p->conv[0].bn_running_mean,
-                                  p->conv[0].bn_running_var, kBnEps, kBnMomentum, conv_act, stats, scale, shift, stream)) return rc;
+    if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[0].bn_weight, p->conv[0].bn_bias, p->conv[0].bn_running_mean,
+                                  p->conv[0].bn_running_var, kBnEps, kBnMomentum, conv_act, stats, scale, shift, nullptr, nullptr, stream)) return rc;
   }
   }
   // cnn2..cnn7
   for (int i = 0; i < 6; ++i) {
     const int l = i + 1;
     float* packed = at<float>(ws, L.conv_packed[i]);
-    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, stream)) return rc;
+    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
     ProfScope ps(VS_PROF_CNN2 + i, stream);
     if (int rc = vs_conv64_fwd_impl(act[cur], packed, scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
                                     kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
     cur ^= 1;
     if (train) {
-      if (int rc = vs_bn_train_impl(act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,
+      if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,
                                     p->conv[l].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * l,
-                                    scale + 64 * l, shift + 64 * l, stream)) return rc;
+                                    scale + 64 * l, shift + 64 * l, nullptr, nullptr, stream)) return rc;
     }
   }
   // cnn8, written straight into the LSTM feature layout
   ProfScope ps(VS_PROF_CNN8, stream);
   if (int rc = vs_conv_last_fwd_impl(act[cur], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat, B, T, F, layer_act, stream)) return rc;
   if (train) {
-    if (int rc = vs_bn_train_feat_impl(feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
+    if (int rc = vs_bn_train_feat_impl(feat, feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
                                        p->conv[7].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * 7,
-                                       scale + 64 * 7, shift + 64 * 7, stream)) return rc;
+                                       scale + 64 * 7, shift + 64 * 7, nullptr, nullptr, stream)) return rc;
   }
   return 0;
 }
@@ -313,7 +302,7 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
   float* packed = at<float>(ws, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
   ProfScope ps(VS_PROF_LSTM_REC, stream);
-  return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, B, T, H, stream);
+  return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, nullptr, nullptr, B, T, H, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

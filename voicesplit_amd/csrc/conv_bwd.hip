@@ -1,0 +1,481 @@
+// Backward of the conv stack (the `.backward()` half of train.py:94-110 through
+// models/voicesplit/model.py:15-52): weight gradients of the 64->64 layers on the fp32 matrix
+// cores, BatchNorm+activation backward, and the two bandwidth-bound edge layers.
+//
+//   data gradient   dIn = conv(dZ, flip/transpose(W))  -> the FORWARD kernel (conv_mfma.hip) fed
+//                   with weights packed by conv_pack_weights_kernel(..., transpose_flip = 1)
+//   weight gradient dW[co][ci][kt][kf] = sum_{b,t,f} dZ[b][co][t][f] * In[b][ci][t+(kt-KT/2)*dil][f+kf-KF/2]
+//                   -> conv64_wgrad_kernel below: an implicit GEMM with M = co, N = ci, K = pixels
+//   BatchNorm+act   dZ = scale*(dY - mean(dY) - xhat*mean(dY*xhat)),  dY = dA * act'(Y)
+//                   (train: batch statistics; eval: dZ = scale*dY) -> two streaming passes
+//
+// conv64_wgrad_kernel.  Workgroup = 4 waves, fixed time tap kt, all KF frequency taps; it walks a
+// contiguous range of (utterance, frame, 64-bin segment) tiles and keeps its 64x64xKF partial
+// sums in accumulator registers the whole time (wave w owns the 32x32 block (co block w>>1,
+// ci block w&1) for every kf: 16*KF registers).  Per tile the dZ row segment [64 co][64 f] and
+// the input row segment [64 ci][64+KF-1 f] of frame t+(kt-KT/2)*dil are staged global -> VGPR ->
+// LDS (raw buffer loads, out-of-range offsets return 0 = ZeroPad2d; the loads of the next tile
+// are in flight during the MFMAs).  K runs over pixels: lane (row = lane&31, half = lane>>5)
+// reads the four pixels 8*kg+4*half+0..3 of its channel row with ONE ds_read_b128 (row pitch 68
+// floats: conflict-free for the b128 lane groups), and the KF shifted input windows are just
+// different registers of two such reads -- no data movement per tap.  Frames whose shifted input
+// row lies outside the image contribute nothing and are skipped (10 % of the rows at dil = 16).
+// The partial sums of the G workgroups of each kt go to a workspace and are summed in a fixed
+// order by conv64_wgrad_reduce_kernel (deterministic, no atomics).
+#include "vs_common.h"
+
+namespace {
+
+constexpr unsigned kOob = 0x7FFFFFF0u;
+constexpr int kNF = 64;    // output pixels (frequency bins) per tile
+constexpr int kPD = 68;    // LDS row pitch in floats: >= 64+4, == 4 (mod 64)
+
+struct WgradArgs {
+  const float* dz;   // [B][64][T][F]
+  const float* in;   // [B][64][T][F]
+  float* part;       // [G][KT][KF][64 co][64 ci]
+  int B, T, F, dil, KT, nseg, G;
+};
+
+template <int KF>
+__global__ __launch_bounds__(256, 2)
+void conv64_wgrad_kernel(WgradArgs g) {
+  constexpr int PADF = KF / 2;
+  __shared__ __attribute__((aligned(16))) float sD[64 * kPD];
+  __shared__ __attribute__((aligned(16))) float sA[64 * kPD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // block -> (kt, group): the KT workgroups of one group walk the same tiles at about the same
+  // time; bid % 8 is the XCD (observed placement, speed only), so keep them on one L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int kt = (bid >> 3) % g.KT;
+  const int grp = ((bid >> 3) / g.KT) * 8 + xcd;
+
+  const int off_t = (kt - g.KT / 2) * g.dil;
+  const int t_lo = off_t < 0 ? -off_t : 0;
+  const int t_hi = off_t > 0 ? g.T - off_t : g.T;
+  const int nvt = t_hi > t_lo ? t_hi - t_lo : 0;
+  const long long ntiles = (long long)g.B * nvt * g.nseg;
+  const long long per = (ntiles + g.G - 1) / g.G;
+  long long tile = (long long)grp * per;
+  long long tile_end = tile + per < ntiles ? tile + per : ntiles;
+
+  const size_t plane = (size_t)g.T * g.F;
+  const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
+
+  f32x16 acc[KF];
+#pragma unroll
+  for (int k = 0; k < KF; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  float sd[16], sa[16], sx = 0.f;
+  int nv_next = 0;
+  auto issue = [&](long long tl) {
+    const int seg = (int)(tl % g.nseg);
+    const long long bt = tl / g.nseg;
+    const int t = t_lo + (int)(bt % nvt);
+    const int b = (int)(bt / nvt);
+    const int f0 = seg * kNF;
+    nv_next = g.F - f0 < kNF ? g.F - f0 : kNF;
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.dz + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.in + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    const int fd = f0 + lane;
+    const unsigned vd = fd < g.F ? (unsigned)((t * g.F + fd) * 4) : kOob;
+    const int fa = f0 - PADF + lane;
+    const unsigned va = (fa >= 0 && fa < g.F) ? (unsigned)(((t + off_t) * g.F + fa) * 4) : kOob;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const unsigned so = (unsigned)(wave + 4 * i) * plane_bytes;     // channel plane, wave-uniform
+      sd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, vd, so, 0));
+      sa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, va, so, 0));
+    }
+    if (KF > 1) {   // the KF-1 halo columns 64..64+KF-2: one (channel, column) per thread
+      const int ch = tid >> 2, col = kNF + (tid & 3);
+      const int fx = f0 - PADF + col;
+      const unsigned vx = (fx >= 0 && fx < g.F) ? (unsigned)(ch * plane_bytes + ((t + off_t) * g.F + fx) * 4) : kOob;
+      sx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, vx, 0, 0));
+    }
+  };
+
+  const int cb = wave >> 1, nb = wave & 1;
+  const float* pd = sD + (cb * 32 + l31) * kPD + 4 * half;
+  const float* pa = sA + (nb * 32 + l31) * kPD + 4 * half;
+
+  if (tile < tile_end) issue(tile);
+  while (tile < tile_end) {
+    __syncthreads();          // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sD[(wave + 4 * i) * kPD + lane] = sd[i];
+      sA[(wave + 4 * i) * kPD + lane] = sa[i];
+    }
+    if (KF > 1) sA[(tid >> 2) * kPD + kNF + (tid & 3)] = sx;
+    const int nkg = (nv_next + 7) >> 3;
+    __syncthreads();
+    ++tile;
+    if (tile < tile_end) issue(tile);
+#pragma unroll
+    for (int kg = 0; kg < kNF / 8; ++kg) {
+      if (kg < nkg) {         // block-uniform
+        const float4 d4 = *reinterpret_cast<const float4*>(pd + 8 * kg);
+        float w[8];
+        {
+          const float4 w0 = *reinterpret_cast<const float4*>(pa + 8 * kg);
+          w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+        }
+        if (KF > 1) {
+          const float4 w1 = *reinterpret_cast<const float4*>(pa + 8 * kg + 4);
+          w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dv = j == 0 ? d4.x : j == 1 ? d4.y : j == 2 ? d4.z : d4.w;
+#pragma unroll
+          for (int kf = 0; kf < KF; ++kf)
+            acc[kf] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, w[j + kf], acc[kf], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial sums: D row = co (r&3)+8*(r>>2)+4*half, D col = ci = lane&31
+  float* out = g.part + ((size_t)grp * g.KT + kt) * KF * 4096;
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)kf * 4096 + co * 64 + nb * 32 + l31] = acc[kf][r];
+    }
+}
+
+// dW[co][ci][kt][kf] = sum_g part[g][kt][kf][co][ci]
+__global__ void conv64_wgrad_reduce_kernel(const float* __restrict__ part, int G, int NT, float* __restrict__ dw) {
+  const int total = NT * 4096;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int gq = 0; gq < G; ++gq) s += part[(size_t)gq * total + idx];
+  const int tap = idx >> 12, co = (idx >> 6) & 63, ci = idx & 63;
+  dw[((size_t)co * 64 + ci) * NT + tap] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm + activation backward.  The tensor is seen as rows [R][L] with channel = r % C:
+// NCHW activations R = B*C, L = T*F; the LSTM-feature layout of cnn8 R = B*T*8, L = F, C = 8.
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float act_grad(float y) {
+  if (ACT == VS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (ACT == VS_ACT_MISH) return vs_mish_grad(y);
+  return 1.f;
+}
+
+// pass 1: stats[c] += { sum dY, sum dY*xhat },  dY = dA * act'(z*scale+shift), xhat = (z-mean)*invstd
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_act_bwd_stats_kernel(const float* __restrict__ da, const float* __restrict__ z, int C, long long R, int L,
+                             const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                             double* __restrict__ stats) {
+  const int c = blockIdx.y;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const int e0 = blockIdx.x * 4096;
+  const int e1 = e0 + 4096 < L ? e0 + 4096 : L;
+  float s1 = 0.f, s2 = 0.f;
+  for (long long r = c + (long long)C * blockIdx.z; r < R; r += (long long)C * gridDim.z) {
+    const float* pz = z + r * L;
+    const float* pg = da + r * L;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+      const float zv = pz[e];
+      const float dy = pg[e] * act_grad<ACT>(fmaf(zv, sc, sh));
+      s1 += dy;
+      s2 = fmaf(dy, (zv - mu) * is, s2);
+    }
+  }
+  double d1 = s1, d2 = s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d1 += __shfl_down(d1, o, 64);
+    d2 += __shfl_down(d2, o, 64);
+  }
+  __shared__ double sh2[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh2[2 * w] = d1; sh2[2 * w + 1] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[2 * c], sh2[0] + sh2[2] + sh2[4] + sh2[6]);
+    atomicAdd(&stats[2 * c + 1], sh2[1] + sh2[3] + sh2[5] + sh2[7]);
+  }
+}
+
+// per channel: parameter gradients and the coefficients of pass 2,  dZ = cA*dY + cB*z + cC
+//   train: dZ = scale*(dY - s1/N - xhat*s2/N);   eval: dZ = scale*dY
+//   dgamma = s2, dbeta = s1, dbias(conv) = sum dZ = 0 (train) / scale*s1 (eval)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, double count, int train, int C,
+                                       const float* __restrict__ scale, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                                       float* __restrict__ coef /* [3][C] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double s1 = stats[2 * c], s2 = stats[2 * c + 1];
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  const double sc = scale[c];
+  if (train) {
+    const double k1 = s1 / count, k2 = s2 / count, is = invstd[c], mu = mean[c];
+    coef[c] = (float)sc;
+    coef[C + c] = (float)(-sc * k2 * is);
+    coef[2 * C + c] = (float)(-sc * k1 + sc * k2 * is * mu);
+    if (dbias) dbias[c] = 0.f;
+  } else {
+    coef[c] = (float)sc;
+    coef[C + c] = 0.f;
+    coef[2 * C + c] = 0.f;
+    if (dbias) dbias[c] = (float)(sc * s1);
+  }
+}
+
+// pass 2: dz = cA*(dA*act'(z*scale+shift)) + cB*z + cC     (dz may alias da)
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C, int L,
+                             const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ coef, float* dz, int gx) {
+  const long long r = blockIdx.x / gx;
+  const int c = (int)(r % C);
+  const float sc = scale[c], sh = shift[c], cA = coef[c], cB = coef[C + c], cC = coef[2 * C + c];
+  const float* pz = z + r * L;
+  const float* pg = da + r * L;
+  float* po = dz + r * L;
+  const int e0 = (int)(blockIdx.x % gx) * 4096;
+  const int e1 = e0 + 4096 < L ? e0 + 4096 : L;
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+    const float zv = pz[e];
+    const float dy = pg[e] * act_grad<ACT>(fmaf(zv, sc, sh));
+    po[e] = fmaf(cA, dy, fmaf(cB, zv, cC));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cnn8 (1x1, 64->8, output in the LSTM feature layout [B][T][8][F])
+// ---------------------------------------------------------------------------------------------
+// dIn[b][ci][t][f] = sum_o W[o][ci] * dZ[b][t][o][f]
+__global__ __launch_bounds__(256)
+void conv_last_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ din, int T, int F) {
+  const int plane = T * F;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= plane) return;
+  const int t = pix / F, f = pix - t * F;
+  const float* src = dz + ((size_t)b * T + t) * 8 * F + f;
+  float v[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) v[o] = src[(size_t)o * F];
+  float* dst = din + (size_t)b * 64 * plane + pix;
+#pragma unroll 4
+  for (int c = 0; c < 64; ++c) {
+    float a = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) a = fmaf(w[o * 64 + c], v[o], a);
+    dst[(size_t)c * plane] = a;
+  }
+}
+
+// part[blk][o][ci] = sum over this block's (b,t,64-bin segment) tiles of dZ[o][pix]*In[ci][pix]
+__global__ __launch_bounds__(256)
+void conv_last_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ in, float* __restrict__ part,
+                            int B, int T, int F, int nseg) {
+  __shared__ float sA[64 * 65];
+  __shared__ float sD[8 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ci = lane, og = w;
+  float acc0 = 0.f, acc1 = 0.f;
+  const long long ntiles = (long long)B * T * nseg;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int seg = (int)(tile % nseg);
+    const long long bt = tile / nseg;
+    const int f = seg * 64 + lane;
+    const bool ok = f < F;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ch = w + 4 * i;
+      const long long b = bt / T, t = bt % T;
+      sA[ch * 65 + lane] = ok ? in[((b * 64 + ch) * T + t) * F + f] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = w + 4 * i;
+      sD[o * 64 + lane] = ok ? dz[(bt * 8 + o) * F + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < 64; ++p) {
+      const float a = sA[ci * 65 + p];
+      acc0 = fmaf(a, sD[(2 * og) * 64 + p], acc0);
+      acc1 = fmaf(a, sD[(2 * og + 1) * 64 + p], acc1);
+    }
+  }
+  part[(size_t)blockIdx.x * 512 + (2 * og) * 64 + ci] = acc0;
+  part[(size_t)blockIdx.x * 512 + (2 * og + 1) * 64 + ci] = acc1;
+}
+
+// out[i] = sum_g part[g][i]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float s = 0.f;
+  for (int gq = 0; gq < G; ++gq) s += part[(size_t)gq * n + idx];
+  out[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cnn1 (1x7, 1->64): dW[c][k] = sum_{b,t,f} dZ[b][c][t][f] * x[b][t][f+k-3]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void conv_first_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, double* __restrict__ acc,
+                             int T, int F) {
+  const int plane = T * F;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* pz = dz + ((size_t)b * 64 + c) * plane;
+  const float* px = x + (size_t)b * plane;
+  float s[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) s[k] = 0.f;
+  const int e0 = blockIdx.x * 4096;
+  const int e1 = e0 + 4096 < plane ? e0 + 4096 : plane;
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int f = e % F;
+    const float v = pz[e];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int ff = f + k - 3;
+      const float xv = (ff >= 0 && ff < F) ? px[e + k - 3] : 0.f;
+      s[k] = fmaf(v, xv, s[k]);
+    }
+  }
+  __shared__ double red[4][7];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double d = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if (lane == 0) red[w][k] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    atomicAdd(&acc[c * 7 + k], red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
+}
+
+__global__ void cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------------
+
+extern "C" int vs_conv64_wgrad_groups(int KT) { return KT == 7 ? 72 : 104; }
+
+extern "C" size_t vs_conv64_wgrad_partial_floats(int KT, int KF) {
+  return (size_t)vs_conv64_wgrad_groups(KT) * KT * KF * 4096;
+}
+
+int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* dw,
+                         int B, int T, int F, int KT, int KF, int dil, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_wgrad: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad: unsupported kernel %dx%d", KT, KF);
+  VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad: T*F=%lld too large for 32-bit offsets", (long long)T * F);
+  const int G = vs_conv64_wgrad_groups(KT);
+  WgradArgs a{dz, in, part, B, T, F, dil, KT, (F + kNF - 1) / kNF, G};
+  dim3 grid(G * KT), block(256);
+  if (KF == 5) hipLaunchKernelGGL(conv64_wgrad_kernel<5>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(conv64_wgrad_kernel<1>, grid, block, 0, stream, a);
+  const int total = KT * KF * 4096;
+  hipLaunchKernelGGL(conv64_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// BatchNorm+activation backward over rows [R][L], channel = r % C (see above).
+//   stats [C][2] double scratch, coef [3][C] float scratch; dz may alias da.
+int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream) {
+  VS_REQUIRE(C > 0 && R > 0 && L > 0 && R % C == 0, "bn_act_bwd: bad shape C=%d R=%lld L=%d", C, R, L);
+  VS_REQUIRE(R <= 2147483647LL && C <= 65535, "bn_act_bwd: too many rows");
+  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
+  const int gx = (L + 4095) / 4096;
+  const long long rows_per_c = R / C;
+  int gz = (int)(rows_per_c < 512 ? rows_per_c : 512);
+  // keep the number of atomics per channel moderate when the rows are long
+  while ((long long)gx * gz > 4096 && gz > 1) gz = (gz + 1) / 2;
+  dim3 g1(gx, C, gz), block(256);
+  VS_REQUIRE(R * gx <= 2147483647LL, "bn_act_bwd: grid too large");
+  dim3 g2((unsigned)(R * gx));
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
+    default: VS_REQUIRE(false, "bn_act_bwd: unknown activation %d", act);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,
+                     scale, mean, invstd, dgamma, dbeta, dbias, coef);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
+    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && B <= 65535, "conv_last_dgrad: bad shape B=%d T=%d F=%d", B, T, F);
+  hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3((T * F + 255) / 256, B), dim3(256), 0, stream, dz, w, din, T, F);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vs_conv_last_wgrad_blocks(void) { return 1024; }
+
+int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part /* [1024][512] */, float* dw,
+                            int B, int T, int F, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "conv_last_wgrad: bad shape B=%d T=%d F=%d", B, T, F);
+  const int nblk = vs_conv_last_wgrad_blocks();
+  hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nblk), dim3(256), 0, stream, dz, in, part, B, T, F, (F + 63) / 64);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, stream, part, nblk, 512, dw);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_reduce_partials_impl(const float* part, int G, int n, float* out, hipStream_t stream) {
+  VS_REQUIRE(G > 0 && n > 0, "reduce_partials: bad shape G=%d n=%d", G, n);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part, G, n, out);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc /* [64][7] */, float* dw,
+                             int B, int T, int F, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && B <= 65535, "conv_first_wgrad: bad shape B=%d T=%d F=%d", B, T, F);
+  VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 448, stream));
+  hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3((T * F + 4095) / 4096, 64, B), dim3(256), 0, stream, dz, x, acc, T, F);
+  hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(2), dim3(256), 0, stream, acc, dw, 448);
+  VS_LAUNCH_CHECK();
+  return 0;
+}

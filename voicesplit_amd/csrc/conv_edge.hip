@@ -121,41 +121,62 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, int C,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mean = stats[2 * c] / count;
   double var = stats[2 * c + 1] / count - mean * mean;
   if (var < 0) var = 0;
-  const float sc = gamma[c] / sqrtf((float)var + eps);
+  const float is = 1.0f / sqrtf((float)var + eps);
+  const float sc = gamma[c] * is;
   scale[c] = sc;
   shift[c] = beta[c] - (float)mean * sc;
+  if (mean_out) mean_out[c] = (float)mean;          // saved for the backward pass
+  if (invstd_out) invstd_out[c] = is;
   const double unb = count > 1 ? var * (count / (count - 1)) : var;
   running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
 }
 
-// y = act(x*scale[c] + shift[c]) in place over [B][C][plane]
+// y = act(x*scale[c] + shift[c]) over [B][C][plane]; y may alias x (in place)
 template <int ACT>
 __global__ __launch_bounds__(256)
-void bn_apply_kernel(float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+void bn_apply_kernel(const float* x, float* y, const float* __restrict__ scale, const float* __restrict__ shift,
                      int C, int plane) {
   const int c = blockIdx.y, b = blockIdx.z;
-  float* p = x + ((size_t)b * C + c) * plane;
+  const float* p = x + ((size_t)b * C + c) * plane;
+  float* q = y + ((size_t)b * C + c) * plane;
   const float sc = scale[c], sh = shift[c];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256)
-    p[i] = vs_act<ACT>(fmaf(p[i], sc, sh));
+    q[i] = vs_act<ACT>(fmaf(p[i], sc, sh));
 }
 
 // cnn8 keeps the [B][T][8][F] layout: channel stride F inside a frame, frame stride 8F
 template <int ACT>
 __global__ __launch_bounds__(256)
-void bn_apply_feat_kernel(float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+void bn_apply_feat_kernel(const float* x, float* y, const float* __restrict__ scale, const float* __restrict__ shift,
                           int F, long long total) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)((i / F) & 7);
-    x[i] = vs_act<ACT>(fmaf(x[i], scale[c], shift[c]));
+    y[i] = vs_act<ACT>(fmaf(x[i], scale[c], shift[c]));
   }
+}
+
+// eval-mode BatchNorm applied to a raw conv output (bias already inside z): constants from the
+// running statistics, also kept as mean / invstd for the backward pass.
+__global__ void bn_eval_consts_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rmean[c] * sc;
+  mean_out[c] = rmean[c];
+  invstd_out[c] = is;
 }
 
 __global__ __launch_bounds__(256)
@@ -181,6 +202,9 @@ void bn_stats_feat_kernel(const float* __restrict__ x, int F, long long rows /* 
 }
 
 }  // namespace
+
+int vs_bn_apply_impl(const float*, float*, int, int, int, int, const float*, const float*, hipStream_t);
+int vs_bn_apply_feat_impl(const float*, float*, int, int, int, int, const float*, const float*, hipStream_t);
 
 int vs_bn_fold_impl(const float* gamma, const float* beta, const float* mean, const float* var,
                     const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t stream) {
@@ -220,48 +244,74 @@ int vs_conv_last_fwd_impl(const float* in, const float* w, const float* scale, c
   return 0;
 }
 
-// Train-mode BatchNorm over a raw conv output held as [B][C][T*F] (in place):
-// statistics -> scale/shift (+ running buffers) -> normalise + activation.
-int vs_bn_train_impl(float* x, int B, int C, int plane, const float* gamma, const float* beta,
+// Train-mode BatchNorm over a raw conv output x held as [B][C][T*F]:
+// statistics -> scale/shift (+ running buffers, + mean/invstd when requested) -> y = act(BN(x)).
+// y may alias x (in place, inference-only callers) or be a separate buffer (training keeps x).
+int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float eps, float momentum, int act,
-                     double* stats /* [C][2] */, float* scale, float* shift, hipStream_t stream) {
+                     double* stats /* [C][2] */, float* scale, float* shift, float* mean_out, float* invstd_out,
+                     hipStream_t stream) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_train: bad shape B=%d C=%d plane=%d", B, C, plane);
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
   int gx = (plane + 256 * 16 - 1) / (256 * 16);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, stream, x, C, plane, C * plane, stats);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)B * plane, gamma, beta,
-                     eps, momentum, C, running_mean, running_var, scale, shift);
+                     eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
+  return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, stream);
+}
+
+// y = act(x*scale[c] + shift[c]) over [B][C][plane]
+int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift,
+                     hipStream_t stream) {
+  VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_apply: bad shape B=%d C=%d plane=%d", B, C, plane);
+  int gx = (plane + 256 * 16 - 1) / (256 * 16);
+  if (gx < 1) gx = 1;
   dim3 grid(gx, C, B), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, scale, shift, C, plane); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, scale, shift, C, plane); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, scale, shift, C, plane); break;
-    default: VS_REQUIRE(false, "bn_train: unknown activation %d", act);
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
+    default: VS_REQUIRE(false, "bn_apply: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
   return 0;
 }
 
+int vs_bn_apply_feat_impl(const float* x, float* y, int B, int T, int F, int act, const float* scale, const float* shift,
+                          hipStream_t stream) {
+  const long long total = (long long)B * T * 8 * F;
+  const int ga = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_RELU>, dim3(ga), dim3(256), 0, stream, x, y, scale, shift, F, total); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_MISH>, dim3(ga), dim3(256), 0, stream, x, y, scale, shift, F, total); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_NONE>, dim3(ga), dim3(256), 0, stream, x, y, scale, shift, F, total); break;
+    default: VS_REQUIRE(false, "bn_apply_feat: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, int C,
+                           float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t stream) {
+  VS_REQUIRE(C > 0, "bn_eval_consts: C=%d", C);
+  hipLaunchKernelGGL(bn_eval_consts_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, gamma, beta, rmean, rvar, eps, C,
+                     scale, shift, mean_out, invstd_out);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 // Same for cnn8's output, which already sits in the LSTM feature layout [B][T][8][F].
-int vs_bn_train_feat_impl(float* x, int B, int T, int F, const float* gamma, const float* beta,
+int vs_bn_train_feat_impl(const float* x, float* y, int B, int T, int F, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float eps, float momentum, int act,
-                          double* stats, float* scale, float* shift, hipStream_t stream) {
+                          double* stats, float* scale, float* shift, float* mean_out, float* invstd_out,
+                          hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "bn_train_feat: bad shape");
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 16, stream));
   const long long rows = (long long)B * T * 8;
   const int gb = (int)(rows < 4096 ? rows : 4096);
   hipLaunchKernelGGL(bn_stats_feat_kernel, dim3(gb), dim3(256), 0, stream, x, F, rows, stats);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, (double)B * T * F, gamma, beta,
-                     eps, momentum, 8, running_mean, running_var, scale, shift);
-  const long long total = rows * F;
-  const int ga = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_RELU>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_MISH>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_NONE>, dim3(ga), dim3(256), 0, stream, x, scale, shift, F, total); break;
-    default: VS_REQUIRE(false, "bn_train_feat: unknown activation %d", act);
-  }
-  VS_LAUNCH_CHECK();
-  return 0;
+                     eps, momentum, 8, running_mean, running_var, scale, shift, mean_out, invstd_out);
+  return vs_bn_apply_feat_impl(x, y, B, T, F, act, scale, shift, stream);
 }

@@ -50,7 +50,9 @@ constexpr int kPadTaps = 4;             // dummy tap blocks behind the packed we
 // packed weight layout: [chunk][tap][cb(2)][lane(64)][4]; element j of the float4 is
 //   W[co = cb*32 + (lane&31)][ci = chunk*8 + 4*(lane>>5) + j][kt][kf]
 // i.e. MFMA K-step j multiplies channels (j, 4+j) of the chunk; kPadTaps zero blocks follow.
-__global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int KT, int KF) {
+// transpose_flip = 1 packs the data-gradient weights W'[co'][ci'][kt][kf] = W[ci'][co'][KT-1-kt][KF-1-kf]:
+// with them the same forward kernel computes dIn = conv^T(dOut) ("same" padding is symmetric).
+__global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int KT, int KF, int transpose_flip) {
   const int NT = KT * KF;
   const int total = kNChunk * NT * 2 * 64 * 4;
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +66,8 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __r
   int kt = tap / KF, kf = tap - kt * KF;
   int co = cb * 32 + (lane & 31);
   int ci = chunk * kChunk + 4 * (lane >> 5) + j;
-  wp[idx] = w[((co * kCi + ci) * KT + kt) * KF + kf];
+  wp[idx] = transpose_flip ? w[((ci * kCi + co) * KT + (KT - 1 - kt)) * KF + (KF - 1 - kf)]
+                           : w[((co * kCi + ci) * KT + kt) * KF + kf];
 }
 
 template <int KT, int KF, int P, int ACT>
@@ -260,10 +263,10 @@ long long tile_rows(int T, int dil, int R) {
 
 extern "C" size_t vs_conv64_packed_floats(int KT, int KF) { return (size_t)(kNChunk * KT * KF + kPadTaps) * 512; }
 
-int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, hipStream_t stream) {
+int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t stream) {
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64: unsupported kernel %dx%d", KT, KF);
   const int total = (int)vs_conv64_packed_floats(KT, KF);
-  hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wp, KT, KF);
+  hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wp, KT, KF, transpose_flip);
   VS_LAUNCH_CHECK();
   return 0;
 }

@@ -1,62 +1,75 @@
-// fp32 "NT" GEMM on the f32 matrix cores with fused prologue/epilogue:
+// fp32 GEMM on the f32 matrix cores with fused prologue/epilogue, for every dense contraction of
+// the path that is not a convolution:
 //
-//   C[m][n] = act( sum_k opA(A[m][k]) * W[n][k] + bias1[n] + bias2[n] + rowbias[m / group][n] )
+//   C[m][n] (+)= act( sum_k opA(A)(m,k) * opW(W)(n,k) + bias1[n] + bias2[n] + rowbias[m/group][n] ) * (gate[m][n] > 0)
 //
-// Both operands are K-contiguous (activations [rows][features], nn.Linear / nn.LSTM weights
-// [out][in]), which is exactly how the reference stores them, so no transposes are needed.
-// Used for
-//   * the LSTM input projection x @ W_ih^T for both directions (models/voicesplit/model.py:82),
-//     with the d-vector columns of W_ih folded into a per-utterance row bias
-//     (models/voicesplit/model.py:77-81: repeat+cat of the speaker embedding);
-//   * the d-vector fold itself  dvec @ W_ih[:, 8F:]^T + b_ih + b_hh;
-//   * the head: relu -> fc1 -> relu -> fc2 -> sigmoid (models/voicesplit/model.py:83-87).
+// Each operand is either K-contiguous ("row" layout: A[m][k], W[n][k] -- activations
+// [rows][features] and nn.Linear / nn.LSTM weights [out][in], exactly how the reference stores
+// them) or K-major ("col" layout: A[k][m], W[k][n]), so the forward products (NT), the data
+// gradients (NN: dX = dY @ W) and the weight gradients (TN: dW = dY^T @ X) all run without a
+// transpose pass:
+//   forward   * LSTM input projection x @ W_ih^T, both directions   models/voicesplit/model.py:82
+//             * d-vector fold dvec @ W_ih[:, 8F:]^T + b_ih + b_hh   models/voicesplit/model.py:77-81
+//             * head relu -> fc1 -> relu -> fc2 -> sigmoid          models/voicesplit/model.py:83-87
+//   backward  * dX  = dY @ W          (NN)   gate = relu mask of the layer input
+//             * dW  = dY^T @ X        (TN)   split-K for the small fc / W_hh outputs
+//             * dW_hh = sum_t dgates_t^T h_{t-1}: TN with the X rows shifted by one frame inside
+//               each utterance (w_shift / w_group)
 //
 // Tile 128x128x32, 256 threads = 2x2 waves, each wave 64x64 = 2x2 accumulators of
-// v_mfma_f32_32x32x2_f32.  Global -> VGPR (float4, next K tile prefetched during the MFMAs)
-// -> LDS rows padded to 36 floats so the ds_read_b128 fragment reads (lane = row, 4 consecutive
-// k per lane half) are bank-conflict free; one b128 read feeds four K-steps.
+// v_mfma_f32_32x32x2_f32.  Global -> VGPR (float4, next K tile prefetched during the MFMAs) ->
+// LDS.  Row-layout operands sit in LDS as [row][36]: the fragment read (lane = row, 4 consecutive
+// k per lane half) is one conflict-free ds_read_b128 feeding four K-steps.  Col-layout operands
+// stay K-major in LDS ([k][132]) and are read with ds_read_b32 (lanes = 32 consecutive rows:
+// conflict-free); the k -> (K-step, lane half) mapping is the same for both so they can be mixed.
 #include "vs_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PITCH = BK + 4;   // 36 floats = 144 B: 16-B aligned rows, conflict-free b128 reads
+constexpr int PITCH = BK + 4;    // row layout: 36 floats = 144 B rows, conflict-free b128 reads
+constexpr int PITCH_T = BM + 4;  // col layout: 132 floats = 528 B rows (16-B aligned)
+constexpr int LDS_FLOATS = BM * PITCH;   // 4608 >= BK * PITCH_T = 4224
 
 struct GemmArgs {
   const float* A; int lda;
   const float* W; int ldw;
-  const float* W_hi; int n_split;   // rows n >= n_split of the weight come from W_hi (two stacked matrices)
+  const float* W_hi; int n_split;   // row layout W only: rows n >= n_split come from W_hi
   float* C; int ldc;
   int M, N, K;
   const float* bias1;     // [N] or null
   const float* bias2;     // [N] or null
   const float* rowbias;   // [ceil(M/group)][ldrb] or null
   int ldrb, group;
+  const float* gate; int ldg;   // epilogue mask: C = gate[m][n] > 0 ? C : 0
+  int a_relu, w_relu, act, accumulate;
+  int w_shift, w_group;   // col layout W only: row k is read from row k + w_shift, zero when
+                          // (k % w_group) + w_shift falls outside [0, w_group)
+  int k_chunk;            // split-K: blockIdx.z covers k in [z*k_chunk, (z+1)*k_chunk)
+  long long c_split_stride;
 };
 
+// 4 consecutive elements p[i..i+3] of a row of n valid elements, zero beyond
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ base, int ld, int row, int nrows, int k, int K,
-                                        const float* __restrict__ base_hi = nullptr, int split = 0x7fffffff) {
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int i, int n) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < nrows) {
-    const float* p = (row < split ? base + (size_t)row * ld : base_hi + (size_t)(row - split) * ld) + k;
-    if (VEC) {
-      if (k < K) v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (k + 0 < K) v.x = p[0];
-      if (k + 1 < K) v.y = p[1];
-      if (k + 2 < K) v.z = p[2];
-      if (k + 3 < K) v.w = p[3];
-    }
-  }
+  if (VEC && i + 3 < n) return *reinterpret_cast<const float4*>(p + i);
+  if (i + 0 < n) v.x = p[i + 0];
+  if (i + 1 < n) v.y = p[i + 1];
+  if (i + 2 < n) v.z = p[i + 2];
+  if (i + 3 < n) v.w = p[i + 3];
   return v;
 }
 
-template <bool VEC, bool A_RELU, int ACT>
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+template <int LA, int LB, bool VEC>
 __global__ __launch_bounds__(256, 2)
-void gemm_nt_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float sA[BM * PITCH];
-  __shared__ __attribute__((aligned(16))) float sW[BN * PITCH];
+void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sW[LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,6 +77,9 @@ void gemm_nt_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = blockIdx.z * g.k_chunk;
+  const int ke = kb + g.k_chunk < g.K ? kb + g.k_chunk : g.K;
+  float* Cz = g.C + (long long)blockIdx.z * g.c_split_stride;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -78,54 +94,78 @@ void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
-      const int row = v >> 3, c4 = (v & 7) * 4;
-      ra[i] = load4<VEC>(g.A, g.lda, m0 + row, g.M, k0 + c4, g.K);
-      rw[i] = load4<VEC>(g.W, g.ldw, n0 + row, g.N, k0 + c4, g.K, g.W_hi, g.n_split);
-      if (A_RELU) {
-        ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
-        ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+      if (LA == 0) {
+        const int row = m0 + (v >> 3), c4 = k0 + (v & 7) * 4;
+        ra[i] = row < g.M ? load4<VEC>(g.A + (size_t)row * g.lda, c4, ke) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int k = k0 + (v >> 5), c4 = m0 + (v & 31) * 4;
+        ra[i] = k < ke ? load4<VEC>(g.A + (size_t)k * g.lda, c4, g.M) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      if (g.a_relu) ra[i] = relu4(ra[i]);
+      if (LB == 0) {
+        const int row = n0 + (v >> 3), c4 = k0 + (v & 7) * 4;
+        const float* p = row < g.n_split ? g.W + (size_t)row * g.ldw : g.W_hi + (size_t)(row - g.n_split) * g.ldw;
+        rw[i] = row < g.N ? load4<VEC>(p, c4, ke) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int k = k0 + (v >> 5), c4 = n0 + (v & 31) * 4;
+        bool ok = k < ke;
+        if (g.w_group > 0) {
+          const int pos = k % g.w_group + g.w_shift;
+          ok = ok && pos >= 0 && pos < g.w_group;
+        }
+        rw[i] = ok ? load4<VEC>(g.W + ((long long)k + g.w_shift) * g.ldw, c4, g.N) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (g.w_relu) rw[i] = relu4(rw[i]);
     }
   };
   auto sstore = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
-      const int row = v >> 3, c4 = (v & 7) * 4;
-      *reinterpret_cast<float4*>(&sA[row * PITCH + c4]) = ra[i];
-      *reinterpret_cast<float4*>(&sW[row * PITCH + c4]) = rw[i];
+      if (LA == 0) *reinterpret_cast<float4*>(&sA[(v >> 3) * PITCH + (v & 7) * 4]) = ra[i];
+      else *reinterpret_cast<float4*>(&sA[(v >> 5) * PITCH_T + (v & 31) * 4]) = ra[i];
+      if (LB == 0) *reinterpret_cast<float4*>(&sW[(v >> 3) * PITCH + (v & 7) * 4]) = rw[i];
+      else *reinterpret_cast<float4*>(&sW[(v >> 5) * PITCH_T + (v & 31) * 4]) = rw[i];
     }
   };
 
-  const float* fa = sA + (wm * 64 + l31) * PITCH + half * 4;
-  const float* fw = sW + (wn * 64 + l31) * PITCH + half * 4;
+  // fragment bases: K-step j of k-quad kq multiplies k = 8*kq + 4*half + j in both layouts
+  const float* fa = LA == 0 ? sA + (wm * 64 + l31) * PITCH + half * 4 : sA + (half * 4) * PITCH_T + wm * 64 + l31;
+  const float* fw = LB == 0 ? sW + (wn * 64 + l31) * PITCH + half * 4 : sW + (half * 4) * PITCH_T + wn * 64 + l31;
 
-  gload(0);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
+  if (kb < ke) gload(kb);
+  for (int k0 = kb; k0 < ke; k0 += BK) {
     __syncthreads();
     sstore();
     __syncthreads();
-    if (k0 + BK < g.K) gload(k0 + BK);
+    if (k0 + BK < ke) gload(k0 + BK);
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
-      float4 a4[2], b4[2];
+      float a4[2][4], b4[2][4];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
-        a4[x] = *reinterpret_cast<const float4*>(fa + x * 32 * PITCH + kq * 8);
-        b4[x] = *reinterpret_cast<const float4*>(fw + x * 32 * PITCH + kq * 8);
-      }
+        if (LA == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(fa + x * 32 * PITCH + kq * 8);
+          a4[x][0] = t.x; a4[x][1] = t.y; a4[x][2] = t.z; a4[x][3] = t.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; ++j) a4[x][j] = fa[(kq * 8 + j) * PITCH_T + x * 32];
+        }
+        if (LB == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(fw + x * 32 * PITCH + kq * 8);
+          b4[x][0] = t.x; b4[x][1] = t.y; b4[x][2] = t.z; b4[x][3] = t.w;
+        } else {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          const float av = j == 0 ? a4[mb].x : j == 1 ? a4[mb].y : j == 2 ? a4[mb].z : a4[mb].w;
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const float bv = j == 0 ? b4[nb].x : j == 1 ? b4[nb].y : j == 2 ? b4[nb].z : b4[nb].w;
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mb][nb], 0, 0, 0);
-          }
+          for (int j = 0; j < 4; ++j) b4[x][j] = fw[(kq * 8 + j) * PITCH_T + x * 32];
         }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mb][j], b4[nb][j], acc[mb][nb], 0, 0, 0);
     }
   }
 
@@ -145,55 +185,91 @@ void gemm_nt_kernel(GemmArgs g) {
         if (m < g.M) {
           float v = acc[mb][nb][r] + bcol;
           if (g.rowbias) v += g.rowbias[(size_t)(m / g.group) * g.ldrb + n];
-          g.C[(size_t)m * g.ldc + n] = vs_act<ACT>(v);
+          v = vs_act_rt(v, g.act);
+          if (g.gate) v = g.gate[(size_t)m * g.ldg + n] > 0.f ? v : 0.f;
+          float* c = Cz + (size_t)m * g.ldc + n;
+          if (g.accumulate) v += *c;
+          *c = v;
         }
       }
     }
   }
 }
 
-template <bool VEC, bool A_RELU>
-int launch_act(const GemmArgs& g, int act, hipStream_t stream) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), block(256);
-  switch (act) {
-    case VS_ACT_NONE: hipLaunchKernelGGL((gemm_nt_kernel<VEC, A_RELU, VS_ACT_NONE>), grid, block, 0, stream, g); break;
-    case VS_ACT_RELU: hipLaunchKernelGGL((gemm_nt_kernel<VEC, A_RELU, VS_ACT_RELU>), grid, block, 0, stream, g); break;
-    case VS_ACT_SIGMOID: hipLaunchKernelGGL((gemm_nt_kernel<VEC, A_RELU, VS_ACT_SIGMOID>), grid, block, 0, stream, g); break;
-    default: VS_REQUIRE(false, "gemm: unsupported activation %d", act);
+template <int LA, int LB>
+void launch_layout(const GemmArgs& g, bool vec, dim3 grid, hipStream_t stream) {
+  if (vec) hipLaunchKernelGGL((gemm_kernel<LA, LB, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<LA, LB, false>), grid, dim3(256), 0, stream, g);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, long long n, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float s = 0.f;
+  for (int q = 0; q < S; ++q) s += part[(long long)q * n + idx];
+  out[idx] = s;
+}
+
+}  // namespace
+
+// General entry.  layout_a / layout_w: 0 = K contiguous (A[m][k], W[n][k]); 1 = K-major
+// (A[k][m], W[k][n]).  splits > 1: split-K through `partials` ([splits][M][N] floats), summed in
+// a fixed order into C (which must then be dense, ldc == N, and take no epilogue terms).
+int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                         int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                         const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                         int w_shift, int w_group, int splits, float* partials, hipStream_t stream) {
+  VS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  VS_REQUIRE((layout_a == 0 || layout_a == 1) && (layout_w == 0 || layout_w == 1), "gemm: bad layout");
+  VS_REQUIRE(lda >= (layout_a ? M : K) && ldw >= (layout_w ? N : K) && ldc >= N,
+             "gemm: leading dims lda=%d ldw=%d ldc=%d vs M=%d N=%d K=%d", lda, ldw, ldc, M, N, K);
+  VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm: rowbias needs group>0 and ldrb>=N");
+  VS_REQUIRE(!gate || ldg >= N, "gemm: gate needs ldg>=N");
+  VS_REQUIRE((M + BM - 1) / BM <= 65535, "gemm: M=%d too large", M);
+  VS_REQUIRE(act == VS_ACT_NONE || act == VS_ACT_RELU || act == VS_ACT_SIGMOID, "gemm: unsupported activation %d", act);
+  VS_REQUIRE(layout_w == 0 || (W_hi == nullptr || n_split >= N), "gemm: stacked W needs the K-contiguous layout");
+  VS_REQUIRE(n_split >= N || W_hi != nullptr, "gemm: W_hi is NULL but n_split=%d < N=%d", n_split, N);
+  VS_REQUIRE(w_group == 0 || layout_w == 1, "gemm: w_shift/w_group need the K-major W layout");
+  if (splits < 1) splits = 1;
+  int k_chunk = K;
+  if (splits > 1) {
+    VS_REQUIRE(partials != nullptr && ldc == N && !bias1 && !bias2 && !rowbias && !gate && act == VS_ACT_NONE && !accumulate,
+               "gemm: split-K needs a partial buffer, a dense C and no epilogue terms");
+    k_chunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (K + k_chunk - 1) / k_chunk;
+  }
+  GemmArgs g{A, lda, W, ldw, W_hi, n_split, splits > 1 ? partials : C, ldc, M, N, K, bias1, bias2, rowbias, ldrb,
+             group > 0 ? group : 1, gate, ldg, a_relu, w_relu, act, accumulate, w_shift, w_group, k_chunk,
+             (long long)M * N};
+  const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+  if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream);
+  else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream);
+  else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream);
+  else launch_layout<1, 1>(g, vec, grid, stream);
+  if (splits > 1) {
+    const long long n = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partials, splits, n, C);
   }
   VS_LAUNCH_CHECK();
   return 0;
 }
 
-}  // namespace
-
+// C = act(opA(A) @ W^T + biases): both operands K-contiguous (the forward products).
 int vs_gemm_nt2_impl(const float* A, int lda, const float* W, const float* W_hi, int n_split, int ldw,
                      float* C, int ldc, int M, int N, int K,
                      const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
-                     int a_relu, int act, hipStream_t stream);
+                     int a_relu, int act, hipStream_t stream) {
+  return vs_gemm_general_impl(0, 0, A, lda, W, W_hi, n_split, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
+                              nullptr, 0, a_relu, 0, act, 0, 0, 0, 1, nullptr, stream);
+}
 
 int vs_gemm_nt_impl(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                     const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
                     int a_relu, int act, hipStream_t stream) {
   return vs_gemm_nt2_impl(A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
                           a_relu, act, stream);
-}
-
-// Same GEMM with the weight given as two stacked row blocks (rows [0,n_split) from W, the rest
-// from W_hi, same leading dimension): the forward and reverse W_ih of the BiLSTM in one launch.
-int vs_gemm_nt2_impl(const float* A, int lda, const float* W, const float* W_hi, int n_split, int ldw,
-                     float* C, int ldc, int M, int N, int K,
-                     const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
-                     int a_relu, int act, hipStream_t stream) {
-  VS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
-  VS_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dims lda=%d ldw=%d ldc=%d vs K=%d N=%d", lda, ldw, ldc, K, N);
-  VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm: rowbias needs group>0 and ldrb>=N");
-  VS_REQUIRE((M + BM - 1) / BM <= 65535, "gemm: M=%d too large", M);
-  VS_REQUIRE(n_split >= N || W_hi != nullptr, "gemm: W_hi is NULL but n_split=%d < N=%d", n_split, N);
-  GemmArgs g{A, lda, W, ldw, W_hi, n_split, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1};
-  const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) &&
-                   ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(W_hi) & 15) == 0);
-  if (vec) return a_relu ? launch_act<true, true>(g, act, stream) : launch_act<true, false>(g, act, stream);
-  return a_relu ? launch_act<false, true>(g, act, stream) : launch_act<false, false>(g, act, stream);
 }

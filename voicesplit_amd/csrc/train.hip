@@ -1,0 +1,367 @@
+// Training orchestration: vs_forward_train (forward that keeps the tape) and vs_backward, plus
+// the extern "C" unit-test surface of the backward kernels.  Which kernel runs on which buffer,
+// in which order -- no arithmetic lives here.
+//
+// Reference graph being differentiated: models/voicesplit/model.py:66-89 (forward) as driven by
+// train.py:94-110 (mask -> loss -> loss.backward()).
+#include <string.h>
+
+#include "../../include/voicesplit_hip.h"
+#include "vs_internal.h"
+
+int vs_check_dims_impl(const vs_dims* d);   // capi.hip
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+constexpr float kBnMomentum = 0.1f;
+struct Spec { int kt, kf, dil; };
+constexpr Spec kMid[6] = {{7, 1, 1}, {5, 5, 1}, {5, 5, 2}, {5, 5, 4}, {5, 5, 8}, {5, 5, 16}};
+constexpr int kSplitK = 16;    // split-K factor of the small weight-gradient GEMMs (fc1, fc2, W_hh)
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+template <typename T>
+inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+inline size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+int tape_layout(const vs_dims* d, vs_tape_layout* L) {
+  if (int rc = vs_check_dims_impl(d)) return rc;
+  memset(L, 0, sizeof(*L));
+  const size_t B = d->B, T = d->T, F = d->F, H = d->H, M = B * T;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  const size_t act = B * 64 * T * F * 4;
+  for (int l = 0; l < 7; ++l) { L->z[l] = take(act); L->a[l] = take(act); }
+  L->z8 = take(M * 8 * F * 4);
+  L->feat = take(M * 8 * F * 4);
+  L->bn_scale = take(8 * 64 * 4);
+  L->bn_shift = take(8 * 64 * 4);
+  L->bn_mean = take(8 * 64 * 4);
+  L->bn_invstd = take(8 * 64 * 4);
+  L->gates = take(M * 8 * H * 4);
+  L->cstate = take(M * 2 * H * 4);
+  L->lstm_out = take(M * 2 * H * 4);
+  L->fc1_out = take(M * (size_t)d->FC1 * 4);
+  L->dlogits = take(M * (size_t)d->FC2 * 4);
+  L->dfc1 = take(M * (size_t)d->FC1 * 4);
+  L->dlstm_out = take(M * 2 * H * 4);
+  L->dsum = take(B * 8 * H * 4);
+  L->dfeat = take(M * 8 * F * 4);
+  L->grad0 = take(act);
+  L->grad1 = take(act);
+  L->dvbias = take(B * 8 * H * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
+  L->pack_tmp = take(vs_conv64_packed_floats(5, 5) * 4);
+  L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
+  L->lstm_packed_t = take(vs_lstm_packed_t_floats(d->H) * 4);
+  L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
+  L->lstm_bwd_state = take(vs_lstm_bwd_state_floats(d->B, d->H) * 4);
+  L->consts = take(128 * 4);
+  L->bn_stats = take(64 * 2 * 8);
+  L->bn_coef = take(3 * 64 * 4);
+  L->first_acc = take(448 * 8);
+  L->colsum_tmp = take(B * max3(8 * H, d->FC1, d->FC2) * 4);
+  // one scratch region, reused by the stream-ordered consumers: conv wgrad partial sums,
+  // cnn8 wgrad partials, split-K partials of the fc / W_hh weight gradients
+  size_t part = vs_conv64_wgrad_partial_floats(5, 5);
+  part = max3(part, vs_conv64_wgrad_partial_floats(7, 1), (size_t)vs_conv_last_wgrad_blocks() * 512);
+  part = max3(part, (size_t)kSplitK * d->FC2 * d->FC1, (size_t)kSplitK * d->FC1 * 2 * H);
+  part = max3(part, (size_t)kSplitK * 4 * H * H, 0);
+  L->partials = take(part * 4);
+  L->total_bytes = off;
+  return 0;
+}
+
+int check_tape(const vs_dims* d, void* tape, size_t bytes, vs_tape_layout* L) {
+  if (int rc = tape_layout(d, L)) return rc;
+  VS_REQUIRE(tape != nullptr, "tape is NULL");
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(tape) & 255) == 0, "tape must be 256-byte aligned");
+  VS_REQUIRE(bytes >= L->total_bytes, "tape too small: %zu < %zu bytes", bytes, L->total_bytes);
+  return 0;
+}
+
+int check_params(const vs_params* p) {
+  VS_REQUIRE(p != nullptr, "params is NULL");
+  for (int l = 0; l < 8; ++l) {
+    const vs_conv_layer& c = p->conv[l];
+    VS_REQUIRE(c.weight && c.bias && c.bn_weight && c.bn_bias && c.bn_running_mean && c.bn_running_var,
+               "conv layer %d has a NULL parameter", l + 1);
+  }
+  for (int dir = 0; dir < 2; ++dir)
+    VS_REQUIRE(p->w_ih[dir] && p->w_hh[dir] && p->b_ih[dir] && p->b_hh[dir], "NULL LSTM parameter (dir %d)", dir);
+  VS_REQUIRE(p->fc1_w && p->fc1_b && p->fc2_w && p->fc2_b, "NULL head parameter");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out) {
+  VS_REQUIRE(out != nullptr, "tape layout out pointer is NULL");
+  return tape_layout(dims, out);
+}
+
+size_t vs_tape_bytes(const vs_dims* dims) {
+  vs_tape_layout L;
+  if (tape_layout(dims, &L)) return 0;
+  return L.total_bytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward with tape
+// ---------------------------------------------------------------------------------------------
+int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
+                     void* tape, size_t tape_bytes, float* mask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  vs_tape_layout L;
+  if (int rc = check_tape(d, tape, tape_bytes, &L)) return rc;
+  if (int rc = check_params(p)) return rc;
+  VS_REQUIRE(x && dvec && mask, "forward_train: NULL argument");
+  VS_REQUIRE(conv_act == VS_ACT_MISH || conv_act == VS_ACT_RELU, "forward_train: conv_act must be MISH or RELU");
+  VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "forward_train: unknown bn_mode %d", bn_mode);
+  const int B = d->B, T = d->T, F = d->F, H = d->H;
+  const bool train = bn_mode == VS_BN_TRAIN;
+  float* ones = at<float>(tape, L.consts);
+  float* scale = at<float>(tape, L.bn_scale);
+  float* shift = at<float>(tape, L.bn_shift);
+  float* mean = at<float>(tape, L.bn_mean);
+  float* invstd = at<float>(tape, L.bn_invstd);
+  double* stats = at<double>(tape, L.bn_stats);
+  VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000 /* 1.0f */, 64, stream));
+  VS_CHECK_HIP(hipMemsetAsync(ones + 64, 0, 64 * sizeof(float), stream));
+
+  // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
+  auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout) -> int {
+    const vs_conv_layer& c = p->conv[l];
+    float *sc = scale + 64 * l, *sh = shift + 64 * l, *mu = mean + 64 * l, *is = invstd + 64 * l;
+    if (train) {
+      return feat_layout
+                 ? vs_bn_train_feat_impl(z, a, B, T, F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
+                                         kBnMomentum, conv_act, stats, sc, sh, mu, is, stream)
+                 : vs_bn_train_impl(z, a, B, C, T * F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
+                                    kBnMomentum, conv_act, stats, sc, sh, mu, is, stream);
+    }
+    if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, C, sc, sh, mu, is, stream)) return rc;
+    return feat_layout ? vs_bn_apply_feat_impl(z, a, B, T, F, conv_act, sc, sh, stream)
+                       : vs_bn_apply_impl(z, a, B, C, T * F, conv_act, sc, sh, stream);
+  };
+
+  if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, stream)) return rc;
+  if (int rc = bn(0, at<float>(tape, L.z[0]), at<float>(tape, L.a[0]), 64, false)) return rc;
+  for (int i = 0; i < 6; ++i) {
+    const int l = i + 1;
+    float* packed = at<float>(tape, L.conv_packed[i]);
+    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+    if (int rc = vs_conv64_fwd_impl(at<float>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<float>(tape, L.z[l]), B, T, F,
+                                    kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false)) return rc;
+  }
+  if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
+  if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
+
+  // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
+  const int K = 8 * F, KE = K + d->E;
+  float* dvbias = at<float>(tape, L.dvbias);
+  float* xg = at<float>(tape, L.gates);
+  for (int dir = 0; dir < 2; ++dir) {
+    if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
+                                 p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+  }
+  if (int rc = vs_gemm_nt2_impl(at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
+                                nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
+  float* packed = at<float>(tape, L.lstm_packed);
+  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
+  if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
+                                        at<float>(tape, L.cstate), B, T, H, stream)) return rc;
+
+  // head
+  const int M = B * T;
+  float* h1 = at<float>(tape, L.fc1_out);
+  if (int rc = vs_gemm_nt_impl(at<float>(tape, L.lstm_out), 2 * H, p->fc1_w, 2 * H, h1, d->FC1, M, d->FC1, 2 * H,
+                               p->fc1_b, nullptr, nullptr, 0, 1, 1, VS_ACT_RELU, stream)) return rc;
+  return vs_gemm_nt_impl(h1, d->FC1, p->fc2_w, d->FC1, mask, d->FC2, M, d->FC2, d->FC1,
+                         p->fc2_b, nullptr, nullptr, 0, 1, 0, VS_ACT_SIGMOID, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
+                void* tape, size_t tape_bytes, const float* mask, const float* dmask, const vs_grads* g, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  vs_tape_layout L;
+  if (int rc = check_tape(d, tape, tape_bytes, &L)) return rc;
+  if (int rc = check_params(p)) return rc;
+  VS_REQUIRE(x && dvec && mask && dmask && g, "backward: NULL argument");
+  VS_REQUIRE(conv_act == VS_ACT_MISH || conv_act == VS_ACT_RELU, "backward: conv_act must be MISH or RELU");
+  VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "backward: unknown bn_mode %d", bn_mode);
+  for (int l = 0; l < 8; ++l)
+    VS_REQUIRE(g->conv[l].weight && g->conv[l].bias && g->conv[l].bn_weight && g->conv[l].bn_bias,
+               "backward: conv layer %d has a NULL gradient pointer", l + 1);
+  for (int dir = 0; dir < 2; ++dir)
+    VS_REQUIRE(g->w_ih[dir] && g->w_hh[dir] && g->b_ih[dir] && g->b_hh[dir], "backward: NULL LSTM gradient pointer (dir %d)", dir);
+  VS_REQUIRE(g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b, "backward: NULL head gradient pointer");
+
+  const int B = d->B, T = d->T, F = d->F, H = d->H, E = d->E, FC1 = d->FC1, FC2 = d->FC2;
+  const int M = B * T, K8 = 8 * F, KE = K8 + E;
+  const int train = bn_mode == VS_BN_TRAIN;
+  float* part = at<float>(tape, L.partials);
+  float* tmp = at<float>(tape, L.colsum_tmp);
+  float* ones = at<float>(tape, L.consts);
+  float* zeros = ones + 64;
+
+  // ---- head: sigmoid, fc2, relu, fc1, relu (models/voicesplit/model.py:83-87 backwards) ----
+  float* dlogits = at<float>(tape, L.dlogits);
+  float* h1 = at<float>(tape, L.fc1_out);
+  float* dfc1 = at<float>(tape, L.dfc1);
+  float* lstm_out = at<float>(tape, L.lstm_out);
+  float* dlstm = at<float>(tape, L.dlstm_out);
+  if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
+  if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp, FC2, stream)) return rc;
+  if (int rc = vs_colsum_impl(tmp, FC2, 1, B, FC2, g->fc2_b, FC2, stream)) return rc;
+  // dW2 = dlogits^T @ h1
+  if (int rc = vs_gemm_general_impl(1, 1, dlogits, FC2, h1, nullptr, 0x7fffffff, FC1, g->fc2_w, FC1, FC2, FC1, M,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, kSplitK, part, stream)) return rc;
+  // dfc1 = (dlogits @ W2) * (h1 > 0)
+  if (int rc = vs_gemm_general_impl(0, 1, dlogits, FC2, p->fc2_w, nullptr, 0x7fffffff, FC1, dfc1, FC1, M, FC1, FC2,
+                                    nullptr, nullptr, nullptr, 0, 1, h1, FC1, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  if (int rc = vs_colsum_impl(dfc1, FC1, B, T, FC1, tmp, FC1, stream)) return rc;
+  if (int rc = vs_colsum_impl(tmp, FC1, 1, B, FC1, g->fc1_b, FC1, stream)) return rc;
+  // dW1 = dfc1^T @ relu(lstm_out)
+  if (int rc = vs_gemm_general_impl(1, 1, dfc1, FC1, lstm_out, nullptr, 0x7fffffff, 2 * H, g->fc1_w, 2 * H, FC1, 2 * H, M,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 1, VS_ACT_NONE, 0, 0, 0, kSplitK, part, stream)) return rc;
+  // dlstm_out = (dfc1 @ W1) * (lstm_out > 0)
+  if (int rc = vs_gemm_general_impl(0, 1, dfc1, FC1, p->fc1_w, nullptr, 0x7fffffff, 2 * H, dlstm, 2 * H, M, 2 * H, FC1,
+                                    nullptr, nullptr, nullptr, 0, 1, lstm_out, 2 * H, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+
+  // ---- BiLSTM: BPTT, then the batched weight / input gradients ------------------------------
+  float* dxg = at<float>(tape, L.gates);
+  float* wpt = at<float>(tape, L.lstm_packed_t);
+  if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream)) return rc;
+  if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
+                                            B, T, H, stream)) return rc;
+  float* dsum = at<float>(tape, L.dsum);
+  if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
+  if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
+  float* feat = at<float>(tape, L.feat);
+  float* dfeat = at<float>(tape, L.dfeat);
+  for (int dir = 0; dir < 2; ++dir) {
+    VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
+    VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
+    const float* dxg_d = dxg + (size_t)dir * 4 * H;
+    // dW_ih[:, :8F] = dxg_d^T @ feat
+    if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    // dW_ih[:, 8F:] = (sum_t dxg_d)^T @ dvec    (the repeated d-vector columns, model.py:77-81)
+    if (int rc = vs_gemm_general_impl(1, 1, dsum + (size_t)dir * 4 * H, 8 * H, dvec, nullptr, 0x7fffffff, E, g->w_ih[dir] + K8, KE,
+                                      4 * H, E, B, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    // dW_hh = sum_t dgates_t^T h_{t-1}: the lstm_out rows shifted by one frame inside each utterance
+    if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, lstm_out + (size_t)dir * H, nullptr, 0x7fffffff, 2 * H, g->w_hh[dir], H,
+                                      4 * H, H, M, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0,
+                                      dir ? 1 : -1, T, kSplitK, part, stream)) return rc;
+    // dfeat (+)= dxg_d @ W_ih[:, :8F]
+    if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+    if (g->dvec) {
+      if (int rc = vs_gemm_general_impl(0, 1, dsum + (size_t)dir * 4 * H, 8 * H, p->w_ih[dir] + K8, nullptr, 0x7fffffff, KE, g->dvec, E,
+                                        B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+    }
+  }
+
+  // ---- conv stack, cnn8 .. cnn1 (models/voicesplit/model.py:15-52 backwards) ------------------
+  float* scale = at<float>(tape, L.bn_scale);
+  float* shift = at<float>(tape, L.bn_shift);
+  float* mean = at<float>(tape, L.bn_mean);
+  float* invstd = at<float>(tape, L.bn_invstd);
+  double* stats = at<double>(tape, L.bn_stats);
+  float* coef = at<float>(tape, L.bn_coef);
+  auto bn_bwd = [&](int l, const float* da, const float* z, float* dz, int C, long long R, int Lrow) -> int {
+    return vs_bn_act_bwd_impl(da, z, dz, C, R, Lrow, conv_act, train, scale + 64 * l, shift + 64 * l, mean + 64 * l,
+                              invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias, stats, coef, stream);
+  };
+  // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
+  if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
+  if (int rc = vs_conv_last_wgrad_impl(dfeat, at<float>(tape, L.a[6]), part, g->conv[7].weight, B, T, F, stream)) return rc;
+  float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
+  int cur = 0;
+  if (int rc = vs_conv_last_dgrad_impl(dfeat, p->conv[7].weight, gbuf[cur], B, T, F, stream)) return rc;
+  float* pack_tmp = at<float>(tape, L.pack_tmp);
+  for (int i = 5; i >= 0; --i) {
+    const int l = i + 1;   // cnn(l+1), conv index l
+    if (int rc = bn_bwd(l, gbuf[cur], at<float>(tape, L.z[l]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
+    if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
+                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, pack_tmp, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
+    if (int rc = vs_conv64_fwd_impl(gbuf[cur], pack_tmp, ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf,
+                                    kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    cur ^= 1;
+  }
+  if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
+  return vs_conv_first_wgrad_impl(gbuf[cur], x, at<double>(tape, L.first_acc), g->conv[0].weight, B, T, F, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-test surface
+// ---------------------------------------------------------------------------------------------
+int vs_conv64_pack_dgrad(const float* w, float* packed, int KT, int KF, void* stream) {
+  return vs_conv64_pack_impl(w, packed, KT, KF, 1, (hipStream_t)stream);
+}
+
+int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw, int B, int T, int F, int KT, int KF,
+                    int dil, void* stream) {
+  VS_REQUIRE(dz && in && partials && dw, "conv64_wgrad: NULL argument");
+  return vs_conv64_wgrad_impl(dz, in, partials, dw, B, T, F, KT, KF, dil, (hipStream_t)stream);
+}
+
+int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,
+                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                  float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream) {
+  VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef, "bn_act_bwd: NULL argument");
+  return vs_bn_act_bwd_impl(da, z, dz, C, R, L, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
+                            stats, coef, (hipStream_t)stream);
+}
+
+int vs_conv_last_dgrad(const float* dz, const float* w, float* din, int B, int T, int F, void* stream) {
+  return vs_conv_last_dgrad_impl(dz, w, din, B, T, F, (hipStream_t)stream);
+}
+
+int vs_conv_last_wgrad(const float* dz, const float* in, float* partials, float* dw, int B, int T, int F, void* stream) {
+  return vs_conv_last_wgrad_impl(dz, in, partials, dw, B, T, F, (hipStream_t)stream);
+}
+
+int vs_conv_first_wgrad(const float* dz, const float* x, double* acc, float* dw, int B, int T, int F, void* stream) {
+  return vs_conv_first_wgrad_impl(dz, x, acc, dw, B, T, F, (hipStream_t)stream);
+}
+
+int vs_gemm(int layout_a, int layout_w, const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+            int M, int N, int K, const float* bias, const float* gate, int ldg, int a_relu, int w_relu, int act,
+            int accumulate, int w_shift, int w_group, int splits, float* partials, void* stream) {
+  VS_REQUIRE(A && W && C, "gemm: NULL argument");
+  return vs_gemm_general_impl(layout_a, layout_w, A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1,
+                              gate, ldg, a_relu, w_relu, act, accumulate, w_shift, w_group, splits, partials, (hipStream_t)stream);
+}
+
+int vs_bilstm_recurrent_train(const float* xg, const float* packed_whh, float* state, float* out, float* gates_save,
+                              float* c_save, int B, int T, int H, void* stream) {
+  return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, gates_save, c_save, B, T, H, (hipStream_t)stream);
+}
+
+int vs_lstm_pack_t(const float* w_hh_fwd, const float* w_hh_bwd, float* packed_t, int H, void* stream) {
+  return vs_lstm_pack_t_impl(w_hh_fwd, w_hh_bwd, packed_t, H, (hipStream_t)stream);
+}
+
+int vs_bilstm_recurrent_bwd(const float* packed_t, float* state, float* gates, const float* c_all, const float* dout,
+                            int B, int T, int H, void* stream) {
+  return vs_bilstm_bwd_recurrent_impl(packed_t, state, gates, c_all, dout, B, T, H, (hipStream_t)stream);
+}
+
+int vs_sigmoid_bwd(const float* dmask, const float* mask, float* dlogits, long long n, void* stream) {
+  return vs_sigmoid_bwd_impl(dmask, mask, dlogits, n, (hipStream_t)stream);
+}
+
+int vs_colsum(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, void* stream) {
+  return vs_colsum_impl(x, ld, groups, rows, N, out, ldo, (hipStream_t)stream);
+}
+
+}  // extern "C"

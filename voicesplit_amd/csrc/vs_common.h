@@ -25,6 +25,19 @@ __device__ __forceinline__ float vs_mish(float x) {
   return x > 20.0f ? x : y;
 }
 
+// d/dx Mish = tanh(sp) + x*(1 - tanh(sp)^2)*sigmoid(x); what autograd gives for
+// utils/generic_utils.py:399 (softplus' = sigmoid below the threshold, 1 above, where tanh' = 0).
+// 1 - tanh(sp) = 2/(n+2) exactly, so (1 - tanh^2) = (2/(n+2))*(1+tanh) has no cancellation.
+__device__ __forceinline__ float vs_mish_grad(float x) {
+  float u = expf(fminf(x, 20.0f));
+  float n = u * (u + 2.0f);
+  float inv = 1.0f / (n + 2.0f);
+  float tsp = n * inv;
+  float sig = u / (1.0f + u);
+  float g = tsp + x * (2.0f * inv) * (1.0f + tsp) * sig;
+  return x > 20.0f ? 1.0f : g;
+}
+
 __device__ __forceinline__ float vs_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ocml tanhf: accurate near 0 (a (1-e)/(1+e) form cancels there)

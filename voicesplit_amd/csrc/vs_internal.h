@@ -1,0 +1,50 @@
+// Prototypes of the per-kernel host launchers shared by capi.hip (inference orchestration) and
+// train.hip (training forward + backward orchestration).  Internal to libvoicesplit_hip.so.
+#pragma once
+#include "vs_common.h"
+
+// conv_mfma.hip
+int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t);
+int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, const float* shift, float* out,
+                       int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
+// conv_edge.hip
+int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
+int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
+                     float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
+int vs_bn_train_feat_impl(const float* x, float* y, int B, int T, int F, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
+                          float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
+int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift, hipStream_t);
+int vs_bn_apply_feat_impl(const float* x, float* y, int B, int T, int F, int act, const float* scale, const float* shift, hipStream_t);
+int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, int C,
+                           float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
+// conv_bwd.hip
+int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
+int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);
+int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t);
+int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, hipStream_t);
+int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc, float* dw, int B, int T, int F, hipStream_t);
+int vs_reduce_partials_impl(const float* part, int G, int n, float* out, hipStream_t);
+// gemm_mfma.hip
+int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                         int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                         const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                         int w_shift, int w_group, int splits, float* partials, hipStream_t);
+int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+// lstm.hip
+int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
+int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,
+                             int B, int T, int H, hipStream_t);
+int vs_lstm_pack_t_impl(const float*, const float*, float*, int, hipStream_t);
+int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
+                                 int B, int T, int H, hipStream_t);
+// reduce.hip
+int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, long long n, hipStream_t);
+int vs_colsum_impl(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, hipStream_t);

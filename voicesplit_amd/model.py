@@ -33,19 +33,43 @@ class _Slot(nn.Identity):
 
 
 class _MaskForward(torch.autograd.Function):
-    """Autograd node around the HIP forward.  The backward kernels (conv dgrad/wgrad, BPTT) are
-    the next row of the scope table; until they exist ``backward`` fails loudly
-    instead of silently detaching the graph."""
+    """Autograd node around the HIP path: ``forward`` = vs_forward_train (keeps the tape of saved
+    activations), ``backward`` = vs_backward.  Replaces the graph autograd would record through
+    models/voicesplit/model.py:66-89 when train.py:110 calls ``loss.backward()``."""
 
     @staticmethod
     def forward(ctx, module, x, dvec, *params):
-        return module._run(x, dvec)
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError(
+                "voicesplit_amd: the gradient wrt the input spectrogram is not produced (the reference "
+                "never asks for it: x is data, train.py:85-94); detach x")
+        x = x.detach().contiguous()
+        dvec_c = dvec.detach().contiguous()
+        dims = module._dims(x.shape[0], x.shape[1])
+        sd = {k: v.detach() for k, v in module._tensors().items()}
+        tape = ops.new_tape(dims, x.device)
+        mask = ops.forward_train(sd, x, dvec_c, dims, module.conv_act, module.training, tape)
+        module._bump_bn_counters()
+        ctx.module, ctx.dims, ctx.tape = module, dims, tape
+        ctx.training = module.training
+        ctx.names = [n for n, _ in module.named_parameters()]
+        ctx.save_for_backward(x, dvec_c, mask)
+        return mask
 
     @staticmethod
-    def backward(ctx, grad):
-        raise NotImplementedError(
-            "voicesplit_amd: backward through the HIP mask-prediction path is not implemented yet "
-            "(forward-only build); run inference under torch.no_grad() or model.eval()")
+    def backward(ctx, grad_mask):
+        x, dvec, mask = ctx.saved_tensors
+        module = ctx.module
+        if ctx.tape is None:
+            raise RuntimeError("voicesplit_amd: backward called twice on the same forward (the tape was released)")
+        sd = {k: v.detach() for k, v in module._tensors().items()}
+        grads = ops.backward(sd, x, dvec, ctx.dims, module.conv_act, ctx.training, ctx.tape, mask,
+                             grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2])
+        ctx.tape = None                                      # 49 GB at B=64: release it now
+        out = [None, None, grads.get("speaker_embedding")]
+        for i, name in enumerate(ctx.names):
+            out.append(grads[name] if ctx.needs_input_grad[3 + i] else None)
+        return tuple(out)
 
 
 class _MaskNet(nn.Module):
@@ -84,16 +108,19 @@ class _MaskNet(nn.Module):
         dims = self._dims(x.shape[0], x.shape[1])
         sd = {k: v.detach() for k, v in self._tensors().items()}
         mask = ops.forward(sd, x.detach(), dvec.detach(), dims, self.conv_act, training=self.training)
+        self._bump_bn_counters()
+        return mask
+
+    def _bump_bn_counters(self):
         if self.training:
             with torch.no_grad():
                 for m in self.conv:
                     if isinstance(m, nn.BatchNorm2d):
                         m.num_batches_tracked += 1           # running_mean/var were updated in place by the library
-        return mask
 
     def forward(self, x, speaker_embedding):
         # x: [B, T, num_freq]; speaker_embedding: [B, emb_dim]  ->  mask [B, T, fc2_dim]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (speaker_embedding.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _MaskForward.apply(self, x, speaker_embedding, *self.parameters())
         return self._run(x, speaker_embedding)
 

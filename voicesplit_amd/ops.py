@@ -250,3 +250,222 @@ def bilstm_recurrent(xg, w_hh_f, w_hh_b):
     out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
     check(lib.vs_bilstm_recurrent(_p(xg), _p(packed), _p(state), _p(out), B, T, H, _stream()), "vs_bilstm_recurrent")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training: forward with tape, backward (train.py:94-110 through models/voicesplit/model.py:66-89)
+# ---------------------------------------------------------------------------------------------
+
+# vs_grads field <- state_dict key, in the order model.parameters() yields them is NOT assumed:
+# gradients are returned as a dict keyed like the state_dict.
+def tape_layout(dims: VsDims) -> "_lib.VsTapeLayout":
+    lay = _lib.VsTapeLayout()
+    check(_lib.load().vs_tape_layout_query(ctypes.byref(dims), ctypes.byref(lay)), "vs_tape_layout_query")
+    return lay
+
+
+def new_tape(dims: VsDims, device) -> torch.Tensor:
+    """Caller-owned training tape (saved activations + backward scratch).  Allocated per forward
+    from torch's caching allocator, so steady-state training does no hipMalloc."""
+    nbytes = _lib.load().vs_tape_bytes(ctypes.byref(dims))
+    if nbytes == 0:
+        check(-1, "vs_tape_bytes")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def forward_train(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _check_inputs(x, dvec, dims)
+    params = pack_params(sd)
+    mask = torch.empty(dims.B, dims.T, dims.FC2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.vs_forward_train(ctypes.byref(dims), ctypes.byref(params), _p(x), _p(dvec), ACT_CODES[conv_act],
+                                  BN_TRAIN if training else BN_EVAL, _p(tape), tape.numel(), _p(mask), _stream())
+    check(rc, "vs_forward_train")
+    return mask
+
+
+GRAD_KEYS_CONV = (("weight", "weight"), ("bias", "bias"))
+GRAD_KEYS_BN = (("bn_weight", "weight"), ("bn_bias", "bias"))
+
+
+def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor, mask, dmask,
+             want_dvec: bool = False) -> Dict[str, torch.Tensor]:
+    """d(loss)/d(parameters) for dmask = d(loss)/d(mask); returns {state_dict key: gradient}
+    (+ 'speaker_embedding' when want_dvec)."""
+    lib = _lib.load()
+    _dev_check(dmask, "grad_mask")
+    _dev_check(mask, "mask")
+    params = pack_params(sd)
+    grads = _lib.VsGrads()
+    out: Dict[str, torch.Tensor] = {}
+
+    def alloc(key):
+        t = torch.empty_like(sd[key])
+        out[key] = t
+        return t.data_ptr()
+
+    for l, (ci, bi) in enumerate(CONV_INDEX):
+        for field, name in GRAD_KEYS_CONV:
+            setattr(grads.conv[l], field, alloc(f"conv.{ci}.{name}"))
+        for field, name in GRAD_KEYS_BN:
+            setattr(grads.conv[l], field, alloc(f"conv.{bi}.{name}"))
+    for d, suffix in enumerate(("", "_reverse")):
+        for field, key in (("w_ih", "weight_ih_l0"), ("w_hh", "weight_hh_l0"),
+                           ("b_ih", "bias_ih_l0"), ("b_hh", "bias_hh_l0")):
+            getattr(grads, field)[d] = alloc(f"lstm.{key}{suffix}")
+    for field, key in (("fc1_w", "fc1.weight"), ("fc1_b", "fc1.bias"), ("fc2_w", "fc2.weight"), ("fc2_b", "fc2.bias")):
+        setattr(grads, field, alloc(key))
+    if want_dvec:
+        out["speaker_embedding"] = torch.empty_like(dvec)
+        grads.dvec = out["speaker_embedding"].data_ptr()
+    with torch.cuda.device(x.device):
+        rc = lib.vs_backward(ctypes.byref(dims), ctypes.byref(params), _p(x), _p(dvec), ACT_CODES[conv_act],
+                             BN_TRAIN if training else BN_EVAL, _p(tape), tape.numel(), _p(mask), _p(dmask),
+                             ctypes.byref(grads), _stream())
+    check(rc, "vs_backward")
+    return out
+
+
+# ---- backward kernels (unit tests) -------------------------------------------------------------
+
+def conv64_dgrad(dz, w, dil: int):
+    """dIn [B,64,T,F] = conv^T(dz, w): the forward kernel with transposed + tap-flipped weights."""
+    lib = _lib.load()
+    _dev_check(dz, "dz")
+    _dev_check(w, "w")
+    B, C, T, F = dz.shape
+    KT, KF = w.shape[2], w.shape[3]
+    packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=dz.device)
+    check(lib.vs_conv64_pack_dgrad(_p(w), _p(packed), KT, KF, _stream()), "vs_conv64_pack_dgrad")
+    ones, zeros = torch.ones(64, device=dz.device), torch.zeros(64, device=dz.device)
+    out = torch.empty_like(dz)
+    check(lib.vs_conv64_fwd(_p(dz), _p(packed), _p(ones), _p(zeros), _p(out), B, T, F, KT, KF, dil,
+                            ACT_NONE, _stream()), "vs_conv64_fwd(dgrad)")
+    return out
+
+
+def conv64_wgrad(dz, x, KT: int, KF: int, dil: int):
+    lib = _lib.load()
+    _dev_check(dz, "dz")
+    _dev_check(x, "x")
+    B, C, T, F = dz.shape
+    part = torch.empty(lib.vs_conv64_wgrad_partial_floats(KT, KF), dtype=torch.float32, device=dz.device)
+    dw = torch.empty(64, 64, KT, KF, dtype=torch.float32, device=dz.device)
+    check(lib.vs_conv64_wgrad(_p(dz), _p(x), _p(part), _p(dw), B, T, F, KT, KF, dil, _stream()), "vs_conv64_wgrad")
+    return dw
+
+
+def bn_act_bwd(da, z, C: int, act: str, training: bool, scale, shift, mean, invstd):
+    """rows [R][L] view of da/z (channel = r % C) -> dz, dgamma, dbeta, dbias."""
+    lib = _lib.load()
+    for n, t in (("da", da), ("z", z), ("scale", scale), ("shift", shift), ("mean", mean), ("invstd", invstd)):
+        _dev_check(t, n)
+    L = da.shape[-1]
+    R = da.numel() // L
+    dev = da.device
+    dz = torch.empty_like(da)
+    dgamma, dbeta, dbias = (torch.empty(C, device=dev) for _ in range(3))
+    stats = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    coef = torch.empty(3 * C, device=dev)
+    check(lib.vs_bn_act_bwd(_p(da), _p(z), _p(dz), C, R, L, ACT_CODES[act], BN_TRAIN if training else BN_EVAL,
+                            _p(scale), _p(shift), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(dbias),
+                            _p(stats), _p(coef), _stream()), "vs_bn_act_bwd")
+    return dz, dgamma, dbeta, dbias
+
+
+def conv_last_dgrad(dz8, w, B, T, F):
+    lib = _lib.load()
+    _dev_check(dz8, "dz8")
+    _dev_check(w, "w")
+    out = torch.empty(B, 64, T, F, dtype=torch.float32, device=dz8.device)
+    check(lib.vs_conv_last_dgrad(_p(dz8), _p(w), _p(out), B, T, F, _stream()), "vs_conv_last_dgrad")
+    return out
+
+
+def conv_last_wgrad(dz8, a7):
+    lib = _lib.load()
+    _dev_check(dz8, "dz8")
+    _dev_check(a7, "a7")
+    B, C, T, F = a7.shape
+    part = torch.empty(lib.vs_conv_last_wgrad_blocks() * 512, dtype=torch.float32, device=a7.device)
+    dw = torch.empty(8, 64, 1, 1, dtype=torch.float32, device=a7.device)
+    check(lib.vs_conv_last_wgrad(_p(dz8), _p(a7), _p(part), _p(dw), B, T, F, _stream()), "vs_conv_last_wgrad")
+    return dw
+
+
+def conv_first_wgrad(dz1, x):
+    lib = _lib.load()
+    _dev_check(dz1, "dz1")
+    _dev_check(x, "x")
+    B, T, F = x.shape
+    acc = torch.empty(448, dtype=torch.float64, device=x.device)
+    dw = torch.empty(64, 1, 1, 7, dtype=torch.float32, device=x.device)
+    check(lib.vs_conv_first_wgrad(_p(dz1), _p(x), _p(acc), _p(dw), B, T, F, _stream()), "vs_conv_first_wgrad")
+    return dw
+
+
+def gemm(A, W, M: int, N: int, K: int, layout_a: int = 0, layout_w: int = 0, bias=None, gate=None,
+         a_relu=False, w_relu=False, act="none", out=None, accumulate=False, w_shift=0, w_group=0, splits=1):
+    """General GEMM (see vs_gemm in the header); A/W are 2-D row-major views with their own ld."""
+    lib = _lib.load()
+    _dev_check(A, "A")
+    _dev_check(W, "W")
+    C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    part = torch.empty(splits * M * N, dtype=torch.float32, device=A.device) if splits > 1 else None
+    check(lib.vs_gemm(layout_a, layout_w, _p(A), A.shape[1], _p(W), W.shape[1], _p(C), C.shape[1], M, N, K,
+                      _p(bias), _p(gate), gate.shape[1] if gate is not None else 0, int(a_relu), int(w_relu),
+                      ACT_CODES[act], int(accumulate), w_shift, w_group, splits, _p(part), _stream()), "vs_gemm")
+    return C
+
+
+def bilstm_recurrent_train(xg, w_hh_f, w_hh_b):
+    """xg [B,T,8H] -> (out [B,T,2H], gates [B,T,8H] activated, c [B,T,2H])."""
+    lib = _lib.load()
+    for n, t in (("xg", xg), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
+        _dev_check(t, n)
+    B, T, H8 = xg.shape
+    H = H8 // 8
+    packed = torch.empty(lib.vs_lstm_packed_floats(H), dtype=torch.float32, device=xg.device)
+    check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
+    state = torch.empty(lib.vs_lstm_state_floats(B, H), dtype=torch.float32, device=xg.device)
+    out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
+    gates = xg.clone()
+    c = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
+    check(lib.vs_bilstm_recurrent_train(_p(gates), _p(packed), _p(state), _p(out), _p(gates), _p(c), B, T, H, _stream()),
+          "vs_bilstm_recurrent_train")
+    return out, gates, c
+
+
+def bilstm_recurrent_bwd(gates, c, dout, w_hh_f, w_hh_b):
+    """BPTT: returns d(loss)/d(xg) [B,T,8H] (gates is not modified: works on a copy)."""
+    lib = _lib.load()
+    for n, t in (("gates", gates), ("c", c), ("dout", dout), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
+        _dev_check(t, n)
+    B, T, H8 = gates.shape
+    H = H8 // 8
+    packed_t = torch.empty(lib.vs_lstm_packed_t_floats(H), dtype=torch.float32, device=gates.device)
+    check(lib.vs_lstm_pack_t(_p(w_hh_f), _p(w_hh_b), _p(packed_t), H, _stream()), "vs_lstm_pack_t")
+    state = torch.empty(lib.vs_lstm_bwd_state_floats(B, H), dtype=torch.float32, device=gates.device)
+    dxg = gates.clone()
+    check(lib.vs_bilstm_recurrent_bwd(_p(packed_t), _p(state), _p(dxg), _p(c), _p(dout), B, T, H, _stream()),
+          "vs_bilstm_recurrent_bwd")
+    return dxg
+
+
+def sigmoid_bwd(dmask, mask):
+    lib = _lib.load()
+    _dev_check(dmask, "dmask")
+    _dev_check(mask, "mask")
+    out = torch.empty_like(mask)
+    check(lib.vs_sigmoid_bwd(_p(dmask), _p(mask), _p(out), mask.numel(), _stream()), "vs_sigmoid_bwd")
+    return out
+
+
+def colsum(x, groups: int, rows: int):
+    lib = _lib.load()
+    _dev_check(x, "x")
+    N = x.shape[-1]
+    out = torch.empty(groups, N, dtype=torch.float32, device=x.device)
+    check(lib.vs_colsum(_p(x), N, groups, rows, N, _p(out), N, _stream()), "vs_colsum")
+    return out
