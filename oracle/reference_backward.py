@@ -50,7 +50,9 @@ def _bilstm_functional(xs, sd):
 def forward_with_graph(sd, x, dvec, act: str, training: bool, lstm_impl: str = "aten"):
     """reference_forward.forward without no_grad, returning the stage tensors (graph attached)."""
     out = OrderedDict()
-    y = R.conv_stack(x, sd, act, training, out, None)
+    pre = {}
+    y = R.conv_stack(x, sd, act, training, out, None, pre)
+    out.update(pre)                                      # z1..z8: conv+bias before BatchNorm
     y = y.transpose(1, 2).contiguous()
     y = y.view(y.size(0), y.size(1), -1)
     out["feat"] = y
@@ -79,7 +81,8 @@ def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", traini
               dtype=torch.float32, lstm_impl: str = "aten", want_dvec: bool = False,
               stages: Optional[dict] = None) -> "OrderedDict[str, torch.Tensor]":
     """{state_dict key: d(loss)/d(param)} for loss = (mask * w).sum(); ``stages`` (optional dict)
-    receives d(loss)/d(stage) for feat, lstm_out, fc1_pre, logits and cnn1..cnn8 outputs."""
+    receives d(loss)/d(stage) for feat, lstm_out, fc1_pre, logits, the cnn1..cnn8 outputs and the
+    pre-BatchNorm conv outputs z1..z8, plus the stage values under "val/<stage>"."""
     sd = OrderedDict((k, (v.detach().to(dtype).clone().requires_grad_(True)
                           if (v.is_floating_point() and "running_" not in k) else
                           (v.detach().to(dtype).clone() if v.is_floating_point() else v.clone())))
@@ -87,8 +90,10 @@ def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", traini
     x = x.detach().to(dtype)
     dvec = dvec.detach().to(dtype).clone().requires_grad_(want_dvec)
     out = forward_with_graph(sd, x, dvec, act, training, lstm_impl)
+    keys = ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)) + \
+        tuple(f"z{i}" for i in range(1, 9))
     if stages is not None:
-        for k in ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)):
+        for k in keys:
             out[k].retain_grad()
     loss = (out["mask"] * w.to(dtype)).sum()
     loss.backward()
@@ -96,8 +101,9 @@ def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", traini
     if want_dvec:
         grads["speaker_embedding"] = dvec.grad.detach()
     if stages is not None:
-        for k in ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)):
-            stages[k] = out[k].grad.detach()
+        for k in keys:
+            stages[k] = out[k].grad.detach()             # d(loss)/d(stage)
+            stages["val/" + k] = out[k].detach()         # the stage tensor itself
         stages["mask"] = out["mask"].detach()
     return grads
 

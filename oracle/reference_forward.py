@@ -87,13 +87,15 @@ def activation(x: torch.Tensor, act: str) -> torch.Tensor:
 
 
 def conv_layer(x, sd, spec: ConvSpec, act: str, training: bool,
-               bn_out: Optional[dict] = None) -> torch.Tensor:
+               bn_out: Optional[dict] = None, pre: Optional[dict] = None, name: str = "") -> torch.Tensor:
     """ZeroPad2d -> Conv2d -> BatchNorm2d -> activation for one table row."""
     w = sd[f"conv.{spec.conv_idx}.weight"]
     b = sd[f"conv.{spec.conv_idx}.bias"]
     pf, pt = spec.kf // 2, spec.dil_t * (spec.kt // 2)
     x = F.pad(x, (pf, pf, pt, pt))
     x = F.conv2d(x, w, b, dilation=(spec.dil_t, 1))
+    if pre is not None:          # conv+bias output before BatchNorm (what the HIP tape keeps as z)
+        pre[name] = x
     p = f"conv.{spec.bn_idx}."
     # nn.BatchNorm2d == F.batch_norm: eval -> running stats; train
     # (train.py:84 model.train()) -> batch statistics over (B,T,F), running
@@ -109,11 +111,11 @@ def conv_layer(x, sd, spec: ConvSpec, act: str, training: bool,
 
 
 def conv_stack(x, sd, act: str, training: bool = False, taps: Optional[dict] = None,
-               bn_out: Optional[dict] = None) -> torch.Tensor:
+               bn_out: Optional[dict] = None, pre: Optional[dict] = None) -> torch.Tensor:
     """[B,T,F] -> [B,8,T,F]  (models/voicesplit/model.py:68-70)."""
     x = x.unsqueeze(1)
     for i, spec in enumerate(CONV_TABLE):
-        x = conv_layer(x, sd, spec, act, training, bn_out)
+        x = conv_layer(x, sd, spec, act, training, bn_out, pre, f"z{i + 1}")
         if taps is not None:
             taps[f"cnn{i + 1}"] = x
     return x

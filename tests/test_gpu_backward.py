@@ -316,6 +316,7 @@ def test_module_backward_matches_fp64_oracle(cls_name, act, training, B, T):
             assert p.grad.abs().max().item() == 0.0
             continue
         worst[k] = rel_err(p.grad, ref[k])
+    _dump(f"oracle64_{cls_name}_{training}_{B}_{T}", worst)
     bad = {k: v for k, v in worst.items() if v >= MTOL}
     assert not bad, bad
     assert rel_err(emb.grad, ref["speaker_embedding"]) < MTOL
@@ -334,14 +335,16 @@ def test_module_backward_matches_upstream_golden_gradients(name):
     assert abs(float(mask.detach().double().sum()) - float(g["mask_sum"])) < 1e-4 * abs(float(g["mask_sum"]))
     (mask * w.cuda()).sum().backward()
     zero = _zero_bias_keys(g["training"])
-    bad = {}
+    bad, table = {}, {}
     for k, p in m.named_parameters():
         if k in zero:
             continue
         got = RB.thin_grad(p.grad.detach().cpu()).double().numpy()
         err = np.abs(got - g["grads"][k]).max() / max(g["gabs"][k], 1e-30)
+        table[k] = float(err)
         if err >= MTOL:
             bad[k] = err
+    _dump(name, table)
     assert not bad, bad
 
 
@@ -409,4 +412,62 @@ def test_full_batch_backward_properties():
         e2 = ((twice[k] - 2 * big[k]).abs().max() / sc).item()
         if e1 >= MTOL or e2 >= 1e-5:
             bad[k] = (e1, e2)
+    assert not bad, bad
+
+
+def _dump(name, table):
+    """Keep the per-tensor error table of the big cases (merged back from the GPU box)."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"errors_{name}.json"), "w") as f:
+            json.dump(table, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_full_size_layerwise_backward_vs_fp64_oracle():
+    """One full-size utterance (301x601, Mish, batch-stat BN): every conv-stack backward kernel
+    fed with the fp64 oracle's own tensors (cast to fp32) and compared with the oracle's result,
+    layer by layer -- long reductions (181k pixels) and the real dilation/size combinations."""
+    from voicesplit_amd import ops
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, 0), 8.0)
+    x, dvec = R.synthetic_inputs(1, 301, dims_d, 0)
+    w = RB.loss_weights(1, 301, 601, 0)
+    st = {}
+    ref = RB.gradients(sd, x, dvec, w, act="mish", training=True, dtype=torch.float64, stages=st)
+    d = dev()
+    f32 = lambda t: t.float().contiguous().to(d)
+    table = {}
+    T, Fq = 301, 601
+    for l, spec in enumerate(R.CONV_TABLE):
+        if l == 0 or l == 7:
+            continue
+        z, da, dz = st[f"val/z{l + 1}"], st[f"cnn{l + 1}"], st[f"z{l + 1}"]
+        a_in = st[f"val/cnn{l}"]
+        mean = z.mean(dim=(0, 2, 3))
+        invstd = 1.0 / torch.sqrt(z.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+        gamma, beta = sd[f"conv.{spec.bn_idx}.weight"].double(), sd[f"conv.{spec.bn_idx}.bias"].double()
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        gdz, dgamma, dbeta, _ = ops.bn_act_bwd(f32(da).reshape(64, T * Fq), f32(z).reshape(64, T * Fq), 64, "mish", True,
+                                               f32(scale), f32(shift), f32(mean), f32(invstd))
+        table[f"cnn{l + 1}.bn_dz"] = rel_err(gdz.reshape(1, 64, T, Fq), dz)
+        table[f"cnn{l + 1}.dgamma"] = rel_err(dgamma, ref[f"conv.{spec.bn_idx}.weight"])
+        table[f"cnn{l + 1}.dbeta"] = rel_err(dbeta, ref[f"conv.{spec.bn_idx}.bias"])
+        dw = ops.conv64_wgrad(f32(dz), f32(a_in), spec.kt, spec.kf, spec.dil_t)
+        table[f"cnn{l + 1}.wgrad"] = rel_err(dw, ref[f"conv.{spec.conv_idx}.weight"])
+        din = ops.conv64_dgrad(f32(dz), f32(sd[f"conv.{spec.conv_idx}.weight"]), spec.dil_t)
+        table[f"cnn{l + 1}.dgrad"] = rel_err(din, st[f"cnn{l}"])
+        # and the forward kernel on every pixel of the full-size layer (the golden fixtures only
+        # keep a strided subset of cnn8): y = (conv + bias)*scale + shift
+        bias = sd[f"conv.{spec.conv_idx}.bias"].double()
+        out = ops.conv64(f32(a_in), f32(sd[f"conv.{spec.conv_idx}.weight"]), f32(scale), f32(shift + bias * scale),
+                         spec.dil_t, "mish")
+        table[f"cnn{l + 1}.fwd"] = rel_err(out, st[f"val/cnn{l + 1}"])
+    _dump("layerwise_full", table)
+    bad = {k: v for k, v in table.items() if v >= KTOL}
     assert not bad, bad

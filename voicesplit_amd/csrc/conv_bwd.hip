@@ -38,7 +38,7 @@ struct WgradArgs {
 };
 
 template <int KF>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, KF == 1 ? 4 : 3)
 void conv64_wgrad_kernel(WgradArgs g) {
   constexpr int PADF = KF / 2;
   __shared__ __attribute__((aligned(16))) float sD[64 * kPD];
@@ -60,10 +60,10 @@ void conv64_wgrad_kernel(WgradArgs g) {
   const int t_lo = off_t < 0 ? -off_t : 0;
   const int t_hi = off_t > 0 ? g.T - off_t : g.T;
   const int nvt = t_hi > t_lo ? t_hi - t_lo : 0;
-  const long long ntiles = (long long)g.B * nvt * g.nseg;
-  const long long per = (ntiles + g.G - 1) / g.G;
-  long long tile = (long long)grp * per;
-  long long tile_end = tile + per < ntiles ? tile + per : ntiles;
+  const int ntiles = g.B * nvt * g.nseg;          // < 2^31, checked by the launcher
+  const int per = (ntiles + g.G - 1) / g.G;
+  int tile = grp * per;
+  const int tile_end = tile + per < ntiles ? tile + per : ntiles;
 
   const size_t plane = (size_t)g.T * g.F;
   const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
@@ -76,11 +76,11 @@ void conv64_wgrad_kernel(WgradArgs g) {
 
   float sd[16], sa[16], sx = 0.f;
   int nv_next = 0;
-  auto issue = [&](long long tl) {
-    const int seg = (int)(tl % g.nseg);
-    const long long bt = tl / g.nseg;
-    const int t = t_lo + (int)(bt % nvt);
-    const int b = (int)(bt / nvt);
+  auto issue = [&](int tl) {
+    const int bt = tl / g.nseg;
+    const int seg = tl - bt * g.nseg;
+    const int b = bt / nvt;
+    const int t = t_lo + (bt - b * nvt);
     const int f0 = seg * kNF;
     nv_next = g.F - f0 < kNF ? g.F - f0 : kNF;
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
@@ -389,7 +389,10 @@ __global__ void cvt_f64_f32_kernel(const double* __restrict__ src, float* __rest
 
 // ---- host side --------------------------------------------------------------------------------
 
-extern "C" int vs_conv64_wgrad_groups(int KT) { return KT == 7 ? 72 : 104; }
+// Persistent grid = one resident round: KT * groups <= 256 CUs x workgroups per CU (3 for the
+// 5x5 kernel at <= 168 VGPRs, 4 for the 7x1 one), groups a multiple of 8 (XCD mapping).  A grid
+// even slightly above the resident capacity would run a second, nearly empty round.
+extern "C" int vs_conv64_wgrad_groups(int KT) { return KT == 7 ? 144 : 152; }
 
 extern "C" size_t vs_conv64_wgrad_partial_floats(int KT, int KF) {
   return (size_t)vs_conv64_wgrad_groups(KT) * KT * KF * 4096;
@@ -400,6 +403,7 @@ int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* d
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_wgrad: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad: unsupported kernel %dx%d", KT, KF);
   VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad: T*F=%lld too large for 32-bit offsets", (long long)T * F);
+  VS_REQUIRE((long long)B * T * ((F + kNF - 1) / kNF) < 2147483647LL, "conv64_wgrad: too many tiles");
   const int G = vs_conv64_wgrad_groups(KT);
   WgradArgs a{dz, in, part, B, T, F, dil, KT, (F + kNF - 1) / kNF, G};
   dim3 grid(G * KT), block(256);
