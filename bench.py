@@ -1,18 +1,24 @@
 #!/usr/bin/env python
-"""Throughput of the hot path on MI355X: utterances/s of the VoiceSplit mask-prediction forward.
+"""Throughput of the hot path on MI355X: utterances/s of the VoiceSplit mask-prediction path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--model voicesplit]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--mode train|forward]
 
-Workload (BASELINE.json configs[1]): B=64 synthetic [64,301,601] spectrograms + 256-d d-vectors
-per GPU, fp32, forward only, eval-mode BatchNorm, random-init weights of the reference
-architecture.  A "step" is one forward pass over one batch already resident in HBM.
-N>1 (launched by torch.distributed.run, one rank per GPU): the batch dimension shards across
-ranks -- every rank runs its own 64 utterances, no data-path collective; the
-only collectives are the timing barrier and the MAX reduction of the elapsed time.
+Workload (BASELINE.json metric "utterances/sec (3 s clips, B=64) fwd+bwd"): B=64 synthetic
+[64,301,601] spectrograms + 256-d d-vectors per GPU, fp32, random-init weights of the reference
+architecture, batch-statistics BatchNorm (model.train(), train.py:84).  A "step" is what one
+iteration of train.py:85-111 does with the model: forward (with the tape), backward from a
+fixed upstream gradient d(loss)/d(mask) (the audio-domain loss itself sits outside the hot path),
+the gradient exchange (one flat-bucket all-reduce, a no-op at N=1) and the Adam update.  Inputs
+are resident in HBM before the timed region.  --mode forward times BASELINE configs[1]
+(forward only, eval-mode BatchNorm) instead.
+N>1 (launched by torch.distributed.run, one rank per GPU): data parallel, 64 utterances per rank
+("weak" scaling), one RCCL all-reduce of the 75.5 MB gradient bucket per step over xGMI.
 
 Rank 0 prints ONE JSON line with the whole-job utterances/s plus
-  roofline     -- the five 5x5 dilated conv launches (89 % of the FLOPs): algorithmic FLOPs per
-                  launch / mean launch time from HIP events recorded inside the timed region
+  roofline     -- the dominant kernel, conv64_mfma_kernel<5,5> (cnn3..cnn7 forward and their data
+                  gradients: 10 launches per training step): algorithmic FLOPs per launch / mean
+                  launch time from HIP events recorded inside the timed region; the weight-
+                  gradient kernel is reported next to it
   cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores.
 """
 import argparse
@@ -63,25 +69,36 @@ def _pick_threads():
     return best[0] or 1, avail
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle forward (reference restatement, torch CPU ops, nn.LSTM) on the host cores."""
+def cpu_baseline(mode, seconds_budget=20.0):
+    """Oracle (reference restatement, torch CPU ops, nn.LSTM) on the host cores: forward, or
+    forward + autograd backward from the same fixed upstream gradient."""
+    from oracle import reference_backward as RB
     from oracle import reference_forward as R
     threads, avail = _pick_threads()
     torch.set_num_threads(threads)
     dims = R.default_dims()
     sd = R.build_state_dict(dims, 0)
     x, dvec = R.synthetic_inputs(1, T_FRAMES, dims, 0)
-    with torch.no_grad():
-        R.forward(sd, x, dvec, act="mish")                     # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            R.forward(sd, x, dvec, act="mish")
-            n += 1
-            el = time.perf_counter() - t0
-            if el > seconds_budget or n >= 30:
-                break
+    w = RB.loss_weights(1, T_FRAMES, dims["fc2_dim"], 0)
+
+    def once():
+        if mode == "train":
+            RB.gradients(sd, x, dvec, w, act="mish", training=True)
+        else:
+            with torch.no_grad():
+                R.forward(sd, x, dvec, act="mish")
+
+    once()                                                     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        once()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 30:
+            break
+    what = "forward + autograd backward" if mode == "train" else "forward"
     return {"value": round(n / el, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
-            "sample": f"{n} forward passes of one [1,301,601] utterance (B=1, fp32, eval), "
+            "sample": f"{n} x {what} of one [1,301,601] utterance (B=1, fp32), "
                       f"{el:.1f} s, torch {torch.__version__} CPU ops, {threads} threads "
                       f"(fastest of a 4..256 sweep; {avail} logical cores visible)"}
 
@@ -92,6 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -112,13 +130,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import voicesplit_amd as V
-    from voicesplit_amd import _lib, ops
+    from voicesplit_amd import _lib
+    from voicesplit_amd.sharding import GradientBucket
     lib = _lib.load()
 
     B = args.batch
+    train = args.mode == "train"
     torch.manual_seed(0)
     cls = V.VoiceSplit if args.model == "voicesplit" else V.VoiceFilter
-    model = cls(V.default_config()).eval()
+    model = cls(V.default_config())
+    model.train(train)
     with torch.no_grad():                                           # non-trivial BN statistics
         g = torch.Generator().manual_seed(1000)
         for m in model.conv:
@@ -132,10 +153,24 @@ def main():
     spec = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)      # resident in HBM before timing
     dvec = torch.randn(B, EMB, generator=g)
     dvec = (dvec / dvec.norm(dim=1, keepdim=True)).to(dev)
+    # d(loss)/d(mask) of a mean-over-batch loss; stands in for train.py:95-108 (mask -> iSTFT -> SI-SNR)
+    dmask = (torch.randn(B, T_FRAMES, N_FREQ, generator=g) / B).to(dev)
 
-    def step():
-        with torch.no_grad():
-            return model(spec, dvec)
+    if train:
+        bucket = GradientBucket(model.parameters()).attach()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)          # train.py:34
+
+        def step():
+            bucket.zero()
+            mask = model(spec, dvec)
+            mask.backward(dmask)
+            bucket.all_reduce(world)                                 # the one exchange step
+            opt.step()
+            return mask
+    else:
+        def step():
+            with torch.no_grad():
+                return model(spec, dvec)
 
     for _ in range(args.warmup):
         out = step()
@@ -158,38 +193,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
+    if train:
+        assert torch.isfinite(bucket.flat).all()
 
     if rank == 0:
         ms = (ctypes.c_float * _lib.PROF_SLOTS)()
         calls = (ctypes.c_int * _lib.PROF_SLOTS)()
         _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
-        stage_ms = {n: (ms[i] / calls[i] if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
-        # dominant kernel: conv64_mfma_kernel<5,5,...>, five launches per forward (cnn3..cnn7)
-        conv_ms = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
-        mean_launch_ms = sum(conv_ms) / 5.0
+        # per training step: total ms of each slot / steps (a slot may be entered once per layer)
+        stage_ms = {n: (ms[i] / args.steps if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
+        # dominant kernel: conv64_mfma_kernel<5,5>: cnn3..cnn7 forward (+ their data gradients in training)
+        launches = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
+        if train:
+            launches += [stage_ms[f"dgrad_cnn{i}"] for i in range(3, 8)]
+        mean_launch_ms = sum(launches) / len(launches)
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # GFLOP / ms == TFLOP/s
         value = world * B * args.steps / elapsed
+        roof = {"bound": "mfma",
+                "kernel": "conv64_mfma_kernel<5,5> (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
+                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
+                "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
+        if train:
+            wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
+            wg_mean = sum(wg) / 5.0
+            roof["second_kernel"] = {"kernel": "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, incl. its reduce)",
+                                     "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "unit": "TFLOP/s",
+                                     "frac": round(B * GFLOP_CONV5X5 / wg_mean / PEAK_FP32_MFMA_TFLOPS, 4),
+                                     "launch_ms": [round(v, 3) for v in wg]}
         line = {
-            "metric": "utterances/sec (3 s clips, B=64/GPU) forward, fp32",
+            "metric": "utterances/sec (3 s clips, B=64/GPU) fwd+bwd, fp32" if train
+                      else "utterances/sec (3 s clips, B=64/GPU) forward, fp32",
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
-                                   f"{args.model} forward-only, eval BN, random-init weights",
-                       "batch_per_gpu": B, "frames": T_FRAMES, "num_freq": N_FREQ,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv64_mfma_kernel<5,5> (cnn3..cnn7)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "launch_ms": [round(v, 3) for v in conv_ms],
-                         "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)},
+            "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
+                                    "training step = forward (batch-stat BN) + backward + gradient all-reduce + Adam, "
+                                    "fixed upstream gradient on the mask, random-init weights") if train else
+                                   (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
+                                    f"{args.model} forward-only, eval BN, random-init weights"),
+                       "batch_per_gpu": B, "global_batch": B * world, "frames": T_FRAMES, "num_freq": N_FREQ,
+                       "parallelism": (f"dp{world}: one flat 75.5 MB fp32 gradient all-reduce per step" if train else
+                                       f"batch-sharded x{world}, no data-path collective")},
+            "roofline": roof,
             "stage_ms": {k: (round(v, 3) if v is not None else None) for k, v in stage_ms.items()},
-            "whole_forward_tflops": round(value / world * GFLOP_FWD_TOTAL / 1e3, 2),
+            "model_tflops": round(value / world * GFLOP_FWD_TOTAL * (3 if train else 1) / 1e3, 2),
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.mode)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -97,7 +97,11 @@ int vs_abi_version(void);
 const char* vs_last_error(void);
 
 /* Opt-in per-stage GPU timing (HIP events on the caller's stream, no synchronisation while
- * enabled).  Slots: cnn1..cnn8 (0-7), LSTM input GEMMs (8), LSTM recurrence (9), head (10).
+ * enabled).  Forward slots: cnn1..cnn8 conv kernels (0-7), LSTM input GEMMs (8), LSTM recurrence
+ * (9), head (10), training-forward BatchNorm passes (11).  Backward slots: head (12), BPTT (13),
+ * LSTM weight/input-gradient GEMMs (14), BatchNorm+activation backward (15), weight gradient of
+ * cnn2..cnn7 (16-21), data gradient of cnn2..cnn7 (22-27), cnn1/cnn8 kernels (28).  A slot may be
+ * entered several times per step; vs_profile_end returns the summed time and the entry count.
  * Instrumentation for bench.py only: process-global, not thread safe. */
 #define VS_PROF_CNN1 0
 #define VS_PROF_CNN2 1      /* cnn2..cnn7 = 1..6 */
@@ -105,7 +109,15 @@ const char* vs_last_error(void);
 #define VS_PROF_LSTM_GEMM 8
 #define VS_PROF_LSTM_REC 9
 #define VS_PROF_HEAD 10
-#define VS_PROF_SLOTS 11
+#define VS_PROF_FWD_BN 11
+#define VS_PROF_BWD_HEAD 12
+#define VS_PROF_BWD_LSTM_REC 13
+#define VS_PROF_BWD_LSTM_GEMM 14
+#define VS_PROF_BWD_BN 15
+#define VS_PROF_BWD_WGRAD 16   /* cnn2..cnn7 = 16..21 */
+#define VS_PROF_BWD_DGRAD 22   /* cnn2..cnn7 = 22..27 */
+#define VS_PROF_BWD_EDGE 28
+#define VS_PROF_SLOTS 29
 int vs_profile_begin(int max_calls);
 int vs_profile_end(float* ms_total /* [VS_PROF_SLOTS] */, int* calls /* [VS_PROF_SLOTS] */);
 

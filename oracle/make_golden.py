@@ -121,7 +121,7 @@ GRAD_CASES = [
     ("vs_small_train_grads", "voicesplit",  SMALL, 4, 40, 13, True,  6.0),
     ("vf_small_train_grads", "voicefilter", SMALL, 3, 35, 16, True,  6.0),
     ("vs_small_evalbn_grads", "voicesplit", SMALL, 2, 50, 17, False, 6.0),   # frozen BatchNorm (model.eval())
-    ("vs_full_b1_grads",     "voicesplit",  R.default_dims(), 1, 301, 0, True, 8.0),
+    ("vs_full_b1_grads",     "voicesplit",  R.default_dims(), 1, 301, 1, True, 8.0),
 ]
 
 
@@ -154,6 +154,18 @@ def main_grads():
         for k, p in model.named_parameters():
             out["grad/" + k] = RB.thin_grad(p.grad.detach()).numpy()
             out["gabs/" + k] = np.array(float(p.grad.detach().abs().max()))
+        # ReLU kinks: elements of a ReLU input within 5e-5 (relative) of zero.  An implementation
+        # whose forward lands on the other side of one of them differentiates a different branch;
+        # the GPU test checks the signs here first (oracle/reference_backward.relu_gates).
+        act = "mish" if model_name == "voicesplit" else "relu"
+        with torch.no_grad():
+            stages = RB.forward_with_graph(sd, x, dvec, act, training)
+        assert (stages["mask"] - mask.detach()).abs().max() < 2e-5, "oracle forward differs from upstream"
+        for nm in RB.relu_inputs(act):
+            v = stages[nm].reshape(-1)
+            idx = (v.abs() < 5e-5 * v.abs().max()).nonzero().reshape(-1)
+            out["fragile_idx/" + nm] = idx.numpy()
+            out["fragile_val/" + nm] = v[idx].numpy()
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez(path, **out)
         print(f"{name}: {len(list(model.parameters()))} gradients -> {os.path.getsize(path) / 1e3:.0f} kB")

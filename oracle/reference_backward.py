@@ -47,23 +47,30 @@ def _bilstm_functional(xs, sd):
     return y
 
 
-def forward_with_graph(sd, x, dvec, act: str, training: bool, lstm_impl: str = "aten"):
-    """reference_forward.forward without no_grad, returning the stage tensors (graph attached)."""
+def _relu(v, gates, name):
+    if gates is not None and name in gates:
+        return v * gates[name].to(v.dtype)
+    return torch.relu(v)
+
+
+def forward_with_graph(sd, x, dvec, act: str, training: bool, lstm_impl: str = "aten", gates: Optional[dict] = None):
+    """reference_forward.forward without no_grad, returning the stage tensors (graph attached).
+    ``gates`` (see ``relu_gates``) pins every ReLU to a given branch."""
     out = OrderedDict()
     pre = {}
-    y = R.conv_stack(x, sd, act, training, out, None, pre)
+    y = R.conv_stack(x, sd, act, training, out, None, pre, gates)
     out.update(pre)                                      # z1..z8: conv+bias before BatchNorm
     y = y.transpose(1, 2).contiguous()
     y = y.view(y.size(0), y.size(1), -1)
     out["feat"] = y
     e = dvec.unsqueeze(1).repeat(1, y.size(1), 1)
     y = torch.cat((y, e), dim=2)
-    y = _bilstm_functional(y, sd) if lstm_impl == "aten" else R.bilstm(y, sd)
+    y = _bilstm_functional(y, sd) if lstm_impl == "aten" else R.bilstm(y, sd, out)   # "loop": also xg, xg_reverse
     out["lstm_out"] = y
-    y = torch.relu(y)
+    y = _relu(y, gates, "lstm_out")
     h = F.linear(y, sd["fc1.weight"], sd["fc1.bias"])
     out["fc1_pre"] = h
-    y = torch.relu(h)
+    y = _relu(h, gates, "fc1_pre")
     y = F.linear(y, sd["fc2.weight"], sd["fc2.bias"])
     out["logits"] = y
     out["mask"] = torch.sigmoid(y)
@@ -77,9 +84,36 @@ def trainable_keys(sd):
     return [k for k in sd if sd[k].is_floating_point() and not ("running_" in k)]
 
 
+def relu_inputs(act: str):
+    """Names of the tensors that feed a ReLU: the kinks of the differentiated function
+    (models/voicesplit/model.py:83,85; VoiceFilter also after every BatchNorm2d)."""
+    return ("lstm_out", "fc1_pre") + (tuple(f"y{i}" for i in range(1, 9)) if act == "relu" else ())
+
+
+def relu_gates(ref_inputs: Dict[str, torch.Tensor], other_positive: Dict[str, torch.Tensor], margin: float = 1e-4):
+    """Branch-consistent ReLU decisions for a gradient parity test.
+
+    d(relu)/dx jumps at 0, so two implementations whose forward values differ by rounding may sit
+    on different sides of a kink for the handful of elements with |x| ~ 1e-7; their gradients then
+    differ by O(1) contributions and parity is undefined.  For elements of the oracle's ReLU input
+    within ``margin`` (relative to the tensor's max) of zero the gate is therefore taken from the
+    implementation under test (``other_positive[name]`` = "its value was > 0"); everywhere else it
+    is the oracle's own sign.  Returns (gates, n_overridden, n_total)."""
+    gates, n_over, n_tot = {}, 0, 0
+    for name, v in ref_inputs.items():
+        v = v.detach()
+        near = v.abs() < margin * v.abs().max()
+        mine = v > 0
+        theirs = other_positive[name].to(mine.device).reshape(mine.shape)
+        gates[name] = torch.where(near, theirs, mine)
+        n_over += int((near & (theirs != mine)).sum())
+        n_tot += v.numel()
+    return gates, n_over, n_tot
+
+
 def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", training: bool = True,
               dtype=torch.float32, lstm_impl: str = "aten", want_dvec: bool = False,
-              stages: Optional[dict] = None) -> "OrderedDict[str, torch.Tensor]":
+              stages: Optional[dict] = None, gates: Optional[dict] = None) -> "OrderedDict[str, torch.Tensor]":
     """{state_dict key: d(loss)/d(param)} for loss = (mask * w).sum(); ``stages`` (optional dict)
     receives d(loss)/d(stage) for feat, lstm_out, fc1_pre, logits, the cnn1..cnn8 outputs and the
     pre-BatchNorm conv outputs z1..z8, plus the stage values under "val/<stage>"."""
@@ -89,9 +123,10 @@ def gradients(sd: Dict[str, torch.Tensor], x, dvec, w, act: str = "mish", traini
                      for k, v in sd.items())
     x = x.detach().to(dtype)
     dvec = dvec.detach().to(dtype).clone().requires_grad_(want_dvec)
-    out = forward_with_graph(sd, x, dvec, act, training, lstm_impl)
+    out = forward_with_graph(sd, x, dvec, act, training, lstm_impl, gates)
     keys = ("feat", "lstm_out", "fc1_pre", "logits") + tuple(f"cnn{i}" for i in range(1, 9)) + \
-        tuple(f"z{i}" for i in range(1, 9))
+        tuple(f"z{i}" for i in range(1, 9)) + tuple(f"y{i}" for i in range(1, 9)) + \
+        (("xg", "xg_reverse") if lstm_impl == "loop" else ())
     if stages is not None:
         for k in keys:
             out[k].retain_grad()

@@ -87,7 +87,8 @@ def activation(x: torch.Tensor, act: str) -> torch.Tensor:
 
 
 def conv_layer(x, sd, spec: ConvSpec, act: str, training: bool,
-               bn_out: Optional[dict] = None, pre: Optional[dict] = None, name: str = "") -> torch.Tensor:
+               bn_out: Optional[dict] = None, pre: Optional[dict] = None, name: str = "",
+               gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ZeroPad2d -> Conv2d -> BatchNorm2d -> activation for one table row."""
     w = sd[f"conv.{spec.conv_idx}.weight"]
     b = sd[f"conv.{spec.conv_idx}.bias"]
@@ -107,21 +108,29 @@ def conv_layer(x, sd, spec: ConvSpec, act: str, training: bool,
         bn_out[p + "running_mean"] = rm
         bn_out[p + "running_var"] = rv
         bn_out[p + "num_batches_tracked"] = sd[p + "num_batches_tracked"] + 1
+    if pre is not None:          # BatchNorm output = activation input (where a ReLU has its kink)
+        pre["y" + name[1:]] = x
+    if gate is not None and act == "relu":
+        # branch-consistent ReLU for gradient parity tests: the caller fixes which side of the
+        # kink every element is on (see reference_backward.relu_gates)
+        return x * gate.to(x.dtype)
     return activation(x, act)
 
 
 def conv_stack(x, sd, act: str, training: bool = False, taps: Optional[dict] = None,
-               bn_out: Optional[dict] = None, pre: Optional[dict] = None) -> torch.Tensor:
+               bn_out: Optional[dict] = None, pre: Optional[dict] = None,
+               gates: Optional[dict] = None) -> torch.Tensor:
     """[B,T,F] -> [B,8,T,F]  (models/voicesplit/model.py:68-70)."""
     x = x.unsqueeze(1)
     for i, spec in enumerate(CONV_TABLE):
-        x = conv_layer(x, sd, spec, act, training, bn_out, pre, f"z{i + 1}")
+        x = conv_layer(x, sd, spec, act, training, bn_out, pre, f"z{i + 1}",
+                       None if gates is None else gates.get(f"y{i + 1}"))
         if taps is not None:
             taps[f"cnn{i + 1}"] = x
     return x
 
 
-def lstm_direction(xs, w_ih, w_hh, b_ih, b_hh, reverse: bool) -> torch.Tensor:
+def lstm_direction(xs, w_ih, w_hh, b_ih, b_hh, reverse: bool, taps: Optional[dict] = None) -> torch.Tensor:
     """One direction of nn.LSTM(batch_first=True), zero initial state.
 
     Gate order in the stacked weights is i, f, g, o;
@@ -132,6 +141,8 @@ def lstm_direction(xs, w_ih, w_hh, b_ih, b_hh, reverse: bool) -> torch.Tensor:
     h = xs.new_zeros(B, H)
     c = xs.new_zeros(B, H)
     xg = xs @ w_ih.t() + (b_ih + b_hh)          # [B,T,4H]
+    if taps is not None:                        # gate pre-activation inputs (what the HIP path calls xg)
+        taps["xg_reverse" if reverse else "xg"] = xg
     out = xs.new_empty(B, T, H)
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
@@ -157,12 +168,12 @@ def bilstm_aten(xs, sd) -> torch.Tensor:
     return y
 
 
-def bilstm(xs, sd) -> torch.Tensor:
+def bilstm(xs, sd, taps: Optional[dict] = None) -> torch.Tensor:
     """models/voicesplit/model.py:57-61,82 -> [B,T,2H] = cat(fwd, bwd)."""
     f = lstm_direction(xs, sd["lstm.weight_ih_l0"], sd["lstm.weight_hh_l0"],
-                       sd["lstm.bias_ih_l0"], sd["lstm.bias_hh_l0"], False)
+                       sd["lstm.bias_ih_l0"], sd["lstm.bias_hh_l0"], False, taps)
     b = lstm_direction(xs, sd["lstm.weight_ih_l0_reverse"], sd["lstm.weight_hh_l0_reverse"],
-                       sd["lstm.bias_ih_l0_reverse"], sd["lstm.bias_hh_l0_reverse"], True)
+                       sd["lstm.bias_ih_l0_reverse"], sd["lstm.bias_hh_l0_reverse"], True, taps)
     return torch.cat((f, b), dim=2)
 
 

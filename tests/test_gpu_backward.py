@@ -216,7 +216,7 @@ def test_gemm_epilogue_gate_accumulate_relu_and_shift():
         assert rel_err(got, ref) < KTOL
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 9, 24), (5, 17, 32), (33, 6, 40), (3, 12, 400)])
+@pytest.mark.parametrize("B,T,H", [(2, 9, 24), (5, 17, 32), (33, 6, 40), (3, 12, 400), (2, 301, 40), (1, 301, 400)])
 def test_bilstm_train_forward_and_bptt(B, T, H):
     """Saved gates / cell states of the training forward and the gate gradients of the BPTT kernel
     against autograd through the explicit recurrence (fp64)."""
@@ -250,7 +250,9 @@ def test_bilstm_train_forward_and_bptt(B, T, H):
     assert rel_err(gates, torch.cat(gates_ref, 2)) < KTOL
     assert rel_err(c, torch.cat(c_ref, 2)) < KTOL
     dxg = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d))
-    assert rel_err(dxg, xgd.grad) < KTOL
+    err_t = (dxg.double().cpu() - xgd.grad).abs().amax(dim=(0, 2)) / xgd.grad.abs().max()
+    worst = torch.topk(err_t, min(5, T))
+    assert rel_err(dxg, xgd.grad) < KTOL, (worst.indices.tolist(), worst.values.tolist())
 
 
 def test_sigmoid_bwd_and_colsum():
@@ -276,6 +278,33 @@ def _module(cls_name, dims_d, sd):
     return m.cuda()
 
 
+def _our_relu_signs(tape, dims, act, B, T):
+    """'was the ReLU input positive' for every ReLU of the path, read from the HIP tape."""
+    from voicesplit_amd import ops
+    lay = ops.tape_layout(dims)
+    Fq, H = dims.F, dims.H
+    pos = {"lstm_out": ops.ws_view(tape, lay.lstm_out, (B, T, 2 * H)).cpu() > 0,
+           "fc1_pre": ops.ws_view(tape, lay.fc1_out, (B, T, dims.FC1)).cpu() > 0}      # relu(fc1) > 0 <=> fc1 > 0
+    if act == "relu":
+        for l in range(7):
+            pos[f"y{l + 1}"] = ops.ws_view(tape, lay.a[l], (B, 64, T, Fq)).cpu() > 0
+        pos["y8"] = ops.ws_view(tape, lay.feat, (B, T, 8, Fq)).cpu().permute(0, 2, 1, 3) > 0
+    return pos
+
+
+def _branch_consistent_oracle(sd, x, dvec, w, act, training, tape, dims, **kw):
+    """fp64 oracle gradients with every ReLU pinned to the branch the HIP forward took for the
+    (few) elements within 1e-4 of a kink -- see oracle/reference_backward.relu_gates."""
+    B, T = x.shape[0], x.shape[1]
+    sd64 = R.cast_state_dict(sd, torch.float64)
+    with torch.no_grad():
+        fw = RB.forward_with_graph(sd64, x.double(), dvec.double(), act, training, kw.get("lstm_impl", "aten"))
+    ref_in = {k: fw[k] for k in RB.relu_inputs(act)}
+    gates, n_over, n_tot = RB.relu_gates(ref_in, _our_relu_signs(tape, dims, act, B, T))
+    assert n_over <= 5 + 2e-5 * n_tot, f"{n_over} of {n_tot} ReLU decisions differ from the oracle's"
+    return RB.gradients(sd, x, dvec, w, act=act, training=training, dtype=torch.float64, gates=gates, **kw)
+
+
 def _zero_bias_keys(training):
     # conv biases in front of a batch-stat BatchNorm: the true gradient is exactly 0
     return {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)} if training else set()
@@ -290,21 +319,21 @@ def test_module_backward_matches_fp64_oracle(cls_name, act, training, B, T):
     sd = R.spread_logits(R.build_state_dict(dims_d, 21), 6.0)
     x, dvec = R.synthetic_inputs(B, T, dims_d, 21)
     w = RB.loss_weights(B, T, 53, 21)
-    stages = {}
-    ref = RB.gradients(sd, x, dvec, w, act=act, training=training, dtype=torch.float64, lstm_impl="loop",
-                       want_dvec=True, stages=stages)
     m = _module(cls_name, dims_d, sd)
     m.train(training)
     emb = dvec.cuda().requires_grad_(True)
     mask = m(x.cuda(), emb)
     assert mask.requires_grad
-    assert rel_err(mask, stages["mask"]) < MTOL
     # keep the tape alive past backward for the stage-level comparison
     tape = mask.grad_fn.tape
     (mask * w.cuda()).sum().backward()
     torch.cuda.synchronize()
     dims = ops.make_dims(B, T, 53, 24, 32, 44, 53)
     lay = ops.tape_layout(dims)
+    stages = {}
+    ref = _branch_consistent_oracle(sd, x, dvec, w, act, training, tape, dims, lstm_impl="loop", want_dvec=True,
+                                    stages=stages)
+    assert rel_err(mask, stages["mask"]) < MTOL
     assert rel_err(ops.ws_view(tape, lay.dlogits, (B, T, 53)), stages["logits"]) < MTOL
     assert rel_err(ops.ws_view(tape, lay.dfc1, (B, T, 44)), stages["fc1_pre"]) < MTOL
     assert rel_err(ops.ws_view(tape, lay.dlstm_out, (B, T, 64)), stages["lstm_out"]) < MTOL
@@ -333,7 +362,25 @@ def test_module_backward_matches_upstream_golden_gradients(name):
     m.train(g["training"])
     mask = m(x.cuda(), dvec.cuda())
     assert abs(float(mask.detach().double().sum()) - float(g["mask_sum"])) < 1e-4 * abs(float(g["mask_sum"]))
+    tape = mask.grad_fn.tape
     (mask * w.cuda()).sum().backward()
+    # ReLU kinks: the fixture lists the upstream ReLU inputs within 5e-5 of zero.  If the HIP forward
+    # sits on the other side of one of them it differentiates a different (equally valid) branch
+    # and elementwise parity with THIS fixture is undefined; the branch-consistent fp64 oracle
+    # tests above/below are the check in that case.
+    from voicesplit_amd import ops
+    dims = ops.make_dims(g["B"], g["T"], d["num_freq"], d["emb_dim"], d["lstm_dim"], d["fc1_dim"], d["fc2_dim"])
+    act = "mish" if g["model"] == "voicesplit" else "relu"
+    signs = _our_relu_signs(tape, dims, act, g["B"], g["T"])
+    flipped = []
+    for nm in RB.relu_inputs(act):
+        idx = torch.from_numpy(g["fragile_idx/" + nm]).long()
+        if idx.numel():
+            ours = signs[nm].reshape(-1)[idx]
+            theirs = torch.from_numpy(g["fragile_val/" + nm]) > 0
+            flipped += [(nm, int(i), float(v)) for i, v, o, t in zip(idx, g["fragile_val/" + nm], ours, theirs) if bool(o) != bool(t)]
+    if flipped:
+        pytest.skip(f"HIP forward is on the other side of {len(flipped)} ReLU kink(s) of this fixture: {flipped[:4]}")
     zero = _zero_bias_keys(g["training"])
     bad, table = {}, {}
     for k, p in m.named_parameters():
@@ -471,3 +518,45 @@ def test_full_size_layerwise_backward_vs_fp64_oracle():
     _dump("layerwise_full", table)
     bad = {k: v for k, v in table.items() if v >= KTOL}
     assert not bad, bad
+
+
+def test_full_size_module_gradients_vs_fp64_oracle():
+    """Full-size utterance (301x601, H=400) through the module: every parameter gradient and the
+    gradients the tape keeps (gate pre-activations per direction and frame, lstm output, fc1,
+    logits, cnn8) against the branch-consistent fp64 oracle."""
+    from voicesplit_amd import ops
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, 0), 8.0)
+    x, dvec = R.synthetic_inputs(1, 301, dims_d, 0)
+    w = RB.loss_weights(1, 301, 601, 0)
+    m = _module("VoiceSplit", dims_d, sd).train()
+    mask = m(x.cuda(), dvec.cuda())
+    tape = mask.grad_fn.tape
+    (mask * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    dims = ops.make_dims(1, 301, 601, 256, 400, 600, 601)
+    lay = ops.tape_layout(dims)
+    st = {}
+    ref = _branch_consistent_oracle(sd, x, dvec, w, "mish", True, tape, dims, lstm_impl="loop", stages=st)
+    table = {}
+    zero = _zero_bias_keys(True)
+    for k, p in m.named_parameters():
+        if k not in zero:
+            table["grad/" + k] = rel_err(p.grad, ref[k])
+    table["mask"] = rel_err(mask, st["mask"])
+    table["dlogits"] = rel_err(ops.ws_view(tape, lay.dlogits, (1, 301, 601)), st["logits"])
+    table["dfc1"] = rel_err(ops.ws_view(tape, lay.dfc1, (1, 301, 600)), st["fc1_pre"])
+    table["dlstm_out"] = rel_err(ops.ws_view(tape, lay.dlstm_out, (1, 301, 800)), st["lstm_out"])
+    table["lstm_out_fwd_err"] = rel_err(ops.ws_view(tape, lay.lstm_out, (1, 301, 800)), st["val/lstm_out"])
+    dxg = ops.ws_view(tape, lay.gates, (1, 301, 3200)).double().cpu()
+    for name, sl in (("xg", slice(0, 1600)), ("xg_reverse", slice(1600, 3200))):
+        ref = st[name]
+        err_t = (dxg[:, :, sl] - ref).abs().amax(dim=(0, 2)) / ref.abs().max()
+        worst = torch.topk(err_t, 5)
+        table["d" + name] = float(err_t.max())
+        table["d" + name + "_worst_t"] = worst.indices.tolist()
+        table["d" + name + "_worst_err"] = [float(v) for v in worst.values]
+    table["dfeat->dz8 (cnn8)"] = rel_err(ops.ws_view(tape, lay.dfeat, (1, 301, 8, 601)).permute(0, 2, 1, 3), st["z8"])
+    _dump("stages_full", table)
+    bad = {k: v for k, v in table.items() if isinstance(v, float) and v >= MTOL}
+    assert not bad, (bad, table)

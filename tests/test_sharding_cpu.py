@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from voicesplit_amd.sharding import chunk_windows, run_sharded, shard_range
+from voicesplit_amd.sharding import GradientBucket, chunk_windows, run_sharded, shard_range, sync_buffers
 
 
 def test_shard_range_partitions_exactly():
@@ -61,6 +61,63 @@ def test_world2_gloo_sharded_equals_unsharded(B):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+# ---- data-parallel training exchange step ------------------------------------------------------
+
+def _toy():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    m = _toy().eval()                      # frozen BN: the global-batch gradient is the mean of the shard gradients
+    bucket = GradientBucket(m.parameters()).attach()
+    lo, hi = shard_range(8, rank, world)
+    loss = ((m(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+    loss.backward()
+    flat = bucket.all_reduce(world).clone()
+    ref = _toy().eval()
+    ((ref(x) - y) ** 2).mean().backward()
+    ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    ok = torch.allclose(flat, ref_flat, rtol=1e-5, atol=1e-7)
+    ok = ok and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    # identical optimizer step on every rank -> identical weights
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    opt.step()
+    w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    ok = ok and all(torch.equal(ws[0], t) for t in ws)
+    # running statistics follow rank 0
+    m[1].running_mean.fill_(float(rank + 1))
+    sync_buffers(m)
+    ok = ok and float(m[1].running_mean[0]) == 1.0
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_gradient_bucket_allreduce():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)

@@ -1,6 +1,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -q -k "full_size_layerwise or golden_gradients or fp64_oracle" 2>&1 | tail -40 > gpurun_out/t_bwd.log
-timeout 300 python tools/train_step_timing.py --steps 2 --warmup 1 > gpurun_out/train_timing.log 2>&1
-cat gpurun_out/t_bwd.log | tail -30; cat gpurun_out/train_timing.log; cat gpurun_out/errors_layerwise_full.json
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/t_all.log
+grep -E "^E  |passed|failed|SKIP|skipped" gpurun_out/t_all.log | cut -c1-700
+timeout 600 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_train.json 2> gpurun_out/bench_train.err; tail -3 gpurun_out/bench_train.err; cat gpurun_out/bench_train.json
+timeout 300 python bench.py --mode forward --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/bench_fwd.json 2> gpurun_out/bench_fwd.err; tail -3 gpurun_out/bench_fwd.err; cat gpurun_out/bench_fwd.json

@@ -13,8 +13,11 @@ LIB_PATH = os.path.join(_HERE, "libvoicesplit_hip.so")
 
 ACT_RELU, ACT_MISH, ACT_NONE, ACT_SIGMOID = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN = 0, 1
-PROF_SLOTS = 11
-PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head")
+PROF_SLOTS = 29
+PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head",
+              "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
+              "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
+              "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
 ABI_VERSION = 2
 
 

@@ -30,16 +30,17 @@ struct Prof {
   hipEvent_t* ev = nullptr;   // [max_calls][VS_PROF_SLOTS][2]
 } g_prof;
 
-struct ProfScope {
-  hipStream_t s; int slot; int idx;
-  ProfScope(int slot_, hipStream_t s_) : s(s_), slot(slot_), idx(-1) {
-    if (!g_prof.on || g_prof.calls[slot] >= g_prof.max_calls) return;
-    idx = (g_prof.calls[slot]++ * VS_PROF_SLOTS + slot) * 2;
-    (void)hipEventRecord(g_prof.ev[idx], s);
-  }
-  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.ev[idx + 1], s); }
-};
 }  // namespace
+
+// a slot may be entered several times per step (e.g. one BatchNorm scope per layer): every entry
+// gets its own event pair, `calls` counts entries
+VsProfScope::VsProfScope(int slot, hipStream_t s_) : s(s_), idx(-1) {
+  if (!g_prof.on || g_prof.calls[slot] >= g_prof.max_calls) return;
+  idx = (g_prof.calls[slot]++ * VS_PROF_SLOTS + slot) * 2;
+  (void)hipEventRecord(g_prof.ev[idx], s);
+}
+VsProfScope::~VsProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof.ev[idx + 1], s); }
+typedef VsProfScope ProfScope;
 
 namespace {
 
@@ -105,6 +106,7 @@ int vs_abi_version(void) { return VS_ABI_VERSION; }
 int vs_profile_begin(int max_calls) {
   VS_REQUIRE(!g_prof.on, "profile: already enabled");
   VS_REQUIRE(max_calls > 0 && max_calls <= 4096, "profile: max_calls=%d out of range", max_calls);
+  max_calls *= 8;   // slots entered once per layer (BatchNorm passes) use up to 8 entries per step
   const int n = max_calls * VS_PROF_SLOTS * 2;
   g_prof.ev = new hipEvent_t[n];
   for (int i = 0; i < n; ++i) VS_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));

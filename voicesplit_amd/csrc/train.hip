@@ -133,6 +133,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
 
   // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
   auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout) -> int {
+    VsProfScope ps(VS_PROF_FWD_BN, stream);
     const vs_conv_layer& c = p->conv[l];
     float *sc = scale + 64 * l, *sh = shift + 64 * l, *mu = mean + 64 * l, *is = invstd + 64 * l;
     if (train) {
@@ -147,35 +148,51 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
                        : vs_bn_apply_impl(z, a, B, C, T * F, conv_act, sc, sh, stream);
   };
 
-  if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_CNN1, stream);
+    if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, stream)) return rc;
+  }
   if (int rc = bn(0, at<float>(tape, L.z[0]), at<float>(tape, L.a[0]), 64, false)) return rc;
   for (int i = 0; i < 6; ++i) {
     const int l = i + 1;
     float* packed = at<float>(tape, L.conv_packed[i]);
     if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
-    if (int rc = vs_conv64_fwd_impl(at<float>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<float>(tape, L.z[l]), B, T, F,
-                                    kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    {
+      VsProfScope ps(VS_PROF_CNN2 + i, stream);
+      if (int rc = vs_conv64_fwd_impl(at<float>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<float>(tape, L.z[l]), B, T, F,
+                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    }
     if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false)) return rc;
   }
-  if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_CNN8, stream);
+    if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
+  }
   if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
 
   // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
   const int K = 8 * F, KE = K + d->E;
   float* dvbias = at<float>(tape, L.dvbias);
   float* xg = at<float>(tape, L.gates);
-  for (int dir = 0; dir < 2; ++dir) {
-    if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
-                                 p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_LSTM_GEMM, stream);
+    for (int dir = 0; dir < 2; ++dir) {
+      if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
+                                   p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+    }
+    if (int rc = vs_gemm_nt2_impl(at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
+                                  nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
   }
-  if (int rc = vs_gemm_nt2_impl(at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
-                                nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
-  if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
-                                        at<float>(tape, L.cstate), B, T, H, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_LSTM_REC, stream);
+    if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
+                                          at<float>(tape, L.cstate), B, T, H, stream)) return rc;
+  }
 
   // head
+  VsProfScope ps_head(VS_PROF_HEAD, stream);
   const int M = B * T;
   float* h1 = at<float>(tape, L.fc1_out);
   if (int rc = vs_gemm_nt_impl(at<float>(tape, L.lstm_out), 2 * H, p->fc1_w, 2 * H, h1, d->FC1, M, d->FC1, 2 * H,
@@ -217,6 +234,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* dfc1 = at<float>(tape, L.dfc1);
   float* lstm_out = at<float>(tape, L.lstm_out);
   float* dlstm = at<float>(tape, L.dlstm_out);
+  {
+  VsProfScope ps(VS_PROF_BWD_HEAD, stream);
   if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp, FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(tmp, FC2, 1, B, FC2, g->fc2_b, FC2, stream)) return rc;
@@ -234,18 +253,24 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // dlstm_out = (dfc1 @ W1) * (lstm_out > 0)
   if (int rc = vs_gemm_general_impl(0, 1, dfc1, FC1, p->fc1_w, nullptr, 0x7fffffff, 2 * H, dlstm, 2 * H, M, 2 * H, FC1,
                                     nullptr, nullptr, nullptr, 0, 1, lstm_out, 2 * H, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  }
 
   // ---- BiLSTM: BPTT, then the batched weight / input gradients ------------------------------
   float* dxg = at<float>(tape, L.gates);
   float* wpt = at<float>(tape, L.lstm_packed_t);
   if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream)) return rc;
-  if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
-                                            B, T, H, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_BWD_LSTM_REC, stream);
+    if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
+                                              B, T, H, stream)) return rc;
+  }
   float* dsum = at<float>(tape, L.dsum);
-  if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
-  if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
   float* feat = at<float>(tape, L.feat);
   float* dfeat = at<float>(tape, L.dfeat);
+  {
+  VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+  if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
+  if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
   for (int dir = 0; dir < 2; ++dir) {
     VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
     VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
@@ -269,6 +294,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     }
   }
 
+  }
+
   // ---- conv stack, cnn8 .. cnn1 (models/voicesplit/model.py:15-52 backwards) ------------------
   float* scale = at<float>(tape, L.bn_scale);
   float* shift = at<float>(tape, L.bn_shift);
@@ -277,27 +304,38 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   double* stats = at<double>(tape, L.bn_stats);
   float* coef = at<float>(tape, L.bn_coef);
   auto bn_bwd = [&](int l, const float* da, const float* z, float* dz, int C, long long R, int Lrow) -> int {
+    VsProfScope ps(VS_PROF_BWD_BN, stream);
     return vs_bn_act_bwd_impl(da, z, dz, C, R, Lrow, conv_act, train, scale + 64 * l, shift + 64 * l, mean + 64 * l,
                               invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias, stats, coef, stream);
   };
   // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
   if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
-  if (int rc = vs_conv_last_wgrad_impl(dfeat, at<float>(tape, L.a[6]), part, g->conv[7].weight, B, T, F, stream)) return rc;
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;
-  if (int rc = vs_conv_last_dgrad_impl(dfeat, p->conv[7].weight, gbuf[cur], B, T, F, stream)) return rc;
+  {
+    VsProfScope ps(VS_PROF_BWD_EDGE, stream);
+    if (int rc = vs_conv_last_wgrad_impl(dfeat, at<float>(tape, L.a[6]), part, g->conv[7].weight, B, T, F, stream)) return rc;
+    if (int rc = vs_conv_last_dgrad_impl(dfeat, p->conv[7].weight, gbuf[cur], B, T, F, stream)) return rc;
+  }
   float* pack_tmp = at<float>(tape, L.pack_tmp);
   for (int i = 5; i >= 0; --i) {
     const int l = i + 1;   // cnn(l+1), conv index l
     if (int rc = bn_bwd(l, gbuf[cur], at<float>(tape, L.z[l]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
-    if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
-                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+    {
+      VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
+      if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
+                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+    }
     if (int rc = vs_conv64_pack_impl(p->conv[l].weight, pack_tmp, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
-    if (int rc = vs_conv64_fwd_impl(gbuf[cur], pack_tmp, ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf,
-                                    kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    {
+      VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
+      if (int rc = vs_conv64_fwd_impl(gbuf[cur], pack_tmp, ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf,
+                                      kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+    }
     cur ^= 1;
   }
   if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
+  VsProfScope ps(VS_PROF_BWD_EDGE, stream);
   return vs_conv_first_wgrad_impl(gbuf[cur], x, at<double>(tape, L.first_acc), g->conv[0].weight, B, T, F, stream);
 }
 

@@ -3,6 +3,13 @@
 #pragma once
 #include "vs_common.h"
 
+// capi.hip: opt-in per-stage timing scope (see vs_profile_begin in the public header)
+struct VsProfScope {
+  hipStream_t s; int idx;
+  VsProfScope(int slot, hipStream_t s);
+  ~VsProfScope();
+};
+
 // conv_mfma.hip
 int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, const float* shift, float* out,

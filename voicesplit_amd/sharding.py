@@ -63,3 +63,65 @@ def run_sharded(fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x: tor
         a, b = shard_range(B, r, world)
         out.append(parts[r][: b - a])
     return torch.cat(out, dim=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training: the one exchange step of the path (BASELINE config 4)
+# ---------------------------------------------------------------------------------------------
+
+class GradientBucket:
+    """One flat fp32 bucket for every parameter gradient (18 876 001 floats = 75.5 MB at the
+    default config) and a single sum-all-reduce over it per step -- RCCL over xGMI on the GPUs
+    (backend "nccl"), gloo in the CPU tests.  One large collective instead of per-tensor ones:
+    xGMI rings are per-link bound, so 44 small all-reduces would be latency dominated.
+
+    Convention: gradients are averaged over ranks, so N ranks with local batch b and a
+    mean-over-batch loss reproduce one process with batch N*b (utils/generic_utils.py:473 takes
+    the mean over the batch).  BatchNorm statistics stay per replica exactly as in the reference
+    (no SyncBN); ``sync_buffers`` broadcasts rank 0's running statistics when a checkpoint is cut.
+    """
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.numel = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.views = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def attach(self):
+        """Make every ``p.grad`` a view into the bucket, so backward accumulates straight into it
+        and no gather/scatter copy is needed around the all-reduce."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self
+
+    def all_reduce(self, world: int):
+        """Sum over ranks, then divide by `world` (call after backward has finished: the
+        collective must not be co-scheduled with the persistent LSTM kernels)."""
+        import torch.distributed as dist
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():        # someone re-created .grad: copy in
+                v.copy_(p.grad)
+                p.grad = v
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(world)
+        return self.flat
+
+    def zero(self):
+        self.flat.zero_()
+
+
+def sync_buffers(module: torch.nn.Module, src: int = 0, group=None):
+    """Broadcast rank `src`'s BatchNorm running statistics / counters (DDP's default policy)."""
+    import torch.distributed as dist
+    for b in module.buffers():
+        dist.broadcast(b, src=src, group=group)
