@@ -43,11 +43,42 @@ def main():
         if it >= args.warmup:
             fwd += ev[0].elapsed_time(ev[1])
             bwd += ev[1].elapsed_time(ev[2])
+    # host-side view of one bench.py-style step: wall clock with a synchronize after each phase
+    from voicesplit_amd.sharding import GradientBucket
+    bucket = GradientBucket(m.parameters()).attach()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    phases = {}
+
+    def lap(name, t0):
+        torch.cuda.synchronize()
+        phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
+    for it in range(3):
+        if it == 1:
+            phases = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bucket.zero(); t0 = lap("bucket_zero", t0)
+        mask = m(x, d); t0 = lap("forward", t0)
+        mask.backward(w); t0 = lap("backward", t0)
+        bucket.all_reduce(1); t0 = lap("bucket_allreduce", t0)
+        opt.step(); t0 = lap("adam", t0)
+    phases = {k: round(v / 2, 2) for k, v in phases.items()}
+    t0 = time.perf_counter()
+    for it in range(2):
+        bucket.zero()
+        mask = m(x, d)
+        mask.backward(w)
+        bucket.all_reduce(1)
+        opt.step()
+    torch.cuda.synchronize()
+    phases["unsynced_step_wall"] = round((time.perf_counter() - t0) * 1e3 / 2, 2)
     n = args.steps
     ok = all(torch.isfinite(p.grad).all().item() for p in m.parameters())
     print(json.dumps({"batch": args.batch, "fwd_train_ms": round(fwd / n, 3), "bwd_ms": round(bwd / n, 3),
                       "utt_per_s_fwd_bwd": round(args.batch / ((fwd + bwd) / n / 1e3), 2), "finite": ok,
-                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}), flush=True)
+                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "host_phases_ms": phases}), flush=True)
 
 
 if __name__ == "__main__":

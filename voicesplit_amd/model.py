@@ -65,7 +65,8 @@ class _MaskForward(torch.autograd.Function):
         sd = {k: v.detach() for k, v in module._tensors().items()}
         grads = ops.backward(sd, x, dvec, ctx.dims, module.conv_act, ctx.training, ctx.tape, mask,
                              grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2])
-        ctx.tape = None                                      # 49 GB at B=64: release it now
+        ops.recycle_tape(ctx.tape)                           # 49 GB at B=64: back to the pool for the next forward
+        ctx.tape = None
         out = [None, None, grads.get("speaker_embedding")]
         for i, name in enumerate(ctx.names):
             out.append(grads[name] if ctx.needs_input_grad[3 + i] else None)

@@ -69,6 +69,7 @@ def get_workspace(dims: VsDims, device) -> torch.Tensor:
 
 def release_workspaces():
     _WS_CACHE.clear()
+    _TAPE_POOL.clear()
 
 
 def ws_view(ws: torch.Tensor, offset: int, shape: Sequence[int], dtype=torch.float32) -> torch.Tensor:
@@ -264,13 +265,31 @@ def tape_layout(dims: VsDims) -> "_lib.VsTapeLayout":
     return lay
 
 
+_TAPE_POOL: Dict[tuple, list] = {}
+
+
 def new_tape(dims: VsDims, device) -> torch.Tensor:
-    """Caller-owned training tape (saved activations + backward scratch).  Allocated per forward
-    from torch's caching allocator, so steady-state training does no hipMalloc."""
+    """Caller-owned training tape (saved activations + backward scratch, 49 GB at B=64).  Tapes
+    are recycled through a small pool: a forward takes one, its backward hands it back
+    (``recycle_tape``), so steady-state training touches no allocator at all; a second forward
+    before the first backward simply gets a second tape."""
     nbytes = _lib.load().vs_tape_bytes(ctypes.byref(dims))
     if nbytes == 0:
         check(-1, "vs_tape_bytes")
+    key = (torch.device(device).index, nbytes)
+    free = _TAPE_POOL.get(key)
+    if free:
+        return free.pop()
+    for k in [k for k in _TAPE_POOL if k[0] == key[0]]:     # other sizes on this device: let go
+        _TAPE_POOL.pop(k)
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def recycle_tape(tape: torch.Tensor):
+    key = (tape.device.index, tape.numel())
+    pool = _TAPE_POOL.setdefault(key, [])
+    if len(pool) < 2:
+        pool.append(tape)
 
 
 def forward_train(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor) -> torch.Tensor:
