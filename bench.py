@@ -38,6 +38,7 @@ T_FRAMES, N_FREQ, EMB = 301, 601, 256
 GFLOP_CONV5X5 = 2 * 64 * 64 * 25 * T_FRAMES * N_FREQ / 1e9       # 37.05 per layer per utterance
 GFLOP_FWD_TOTAL = 206.995
 PEAK_FP32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md chip table
+PEAK_F16_MFMA_TFLOPS = 2500.0                                      # dense f16/bf16 MFMA (same table)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -111,6 +112,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
+    ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3"],
+                    help="arithmetic of the 64->64 conv layers (default: the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,8 +134,12 @@ def main():
 
     import voicesplit_amd as V
     from voicesplit_amd import _lib
+    from voicesplit_amd import ops
     from voicesplit_amd.sharding import GradientBucket
     lib = _lib.load()
+    if args.conv_math:
+        ops.set_conv_math(args.conv_math)
+    conv_math = ops.get_conv_math()
 
     B = args.batch
     train = args.mode == "train"
@@ -202,24 +209,34 @@ def main():
         _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
         # per training step: total ms of each slot / steps (a slot may be entered once per layer)
         stage_ms = {n: (ms[i] / args.steps if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
-        # dominant kernel: conv64_mfma_kernel<5,5>: cnn3..cnn7 forward (+ their data gradients in training)
+        # dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training)
         launches = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
         if train:
             launches += [stage_ms[f"dgrad_cnn{i}"] for i in range(3, 8)]
         mean_launch_ms = sum(launches) / len(launches)
-        achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # GFLOP / ms == TFLOP/s
+        achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
         value = world * B * args.steps / elapsed
+        if conv_math == "f16x3":
+            # every fp32 product is three f16 MFMA products (csrc/conv_f16x3.hip): the pipe-level
+            # ceiling for ALGORITHMIC flops is the dense f16 MFMA peak / 3
+            kname, peak = "conv64_f16x3_kernel<5,5>", PEAK_F16_MFMA_TFLOPS / 3.0
+            extra = {"mfma_pipe": "f16 (v_mfma_f32_32x32x16_f16), 3 MFMA products per fp32 product",
+                     "mfma_rate_tflops": round(3 * achieved, 1), "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS,
+                     "scale_pass_in_launch_ms": "each launch time includes the 0.55 ms absmax pass and the weight pack"}
+        else:
+            kname, peak, extra = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}
         roof = {"bound": "mfma",
-                "kernel": "conv64_mfma_kernel<5,5> (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
-                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
+                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
                 "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
+        roof.update(extra)
         if train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
-            roof["second_kernel"] = {"kernel": "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, incl. its reduce)",
-                                     "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "unit": "TFLOP/s",
+            roof["second_kernel"] = {"kernel": "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)",
+                                     "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(B * GFLOP_CONV5X5 / wg_mean / PEAK_FP32_MFMA_TFLOPS, 4),
                                      "launch_ms": [round(v, 3) for v in wg]}
         line = {
@@ -229,13 +246,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": "fp32" if conv_math == "fp32" else "fp32 (64->64 convs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
                                     "training step = forward (batch-stat BN) + backward + gradient all-reduce + Adam, "
                                     "fixed upstream gradient on the mask, random-init weights") if train else
                                    (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
                                     f"{args.model} forward-only, eval BN, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "frames": T_FRAMES, "num_freq": N_FREQ,
+                       "conv_math": conv_math,
                        "parallelism": (f"dp{world}: one flat 75.5 MB fp32 gradient all-reduce per step" if train else
                                        f"batch-sharded x{world}, no data-path collective")},
             "roofline": roof,

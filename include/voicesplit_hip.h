@@ -31,13 +31,18 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 2
+#define VS_ABI_VERSION 3
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
 #define VS_ACT_MISH 1     /* VoiceSplit conv stack  (utils/generic_utils.py:395-399)           */
 #define VS_ACT_NONE 2
 #define VS_ACT_SIGMOID 3
+
+/* arithmetic of the 64->64 conv layers (cnn2..cnn7 forward and data gradient) */
+#define VS_MATH_FP32 0    /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fmaf chain                              */
+#define VS_MATH_F16X3 1   /* fp32 operands split into two f16 halves, three v_mfma_f32_32x32x16_f16 per
+                             product term set, fp32 accumulate: fp32-class accuracy at 3/16 of the matrix time */
 
 /* BatchNorm mode */
 #define VS_BN_EVAL 0      /* running statistics (model.eval(), utils/generic_utils.py:479,533) */
@@ -51,6 +56,7 @@ typedef struct vs_dims {
   int H;    /* config.model.lstm_dim (400); must be a multiple of 8     */
   int FC1;  /* config.model.fc1_dim  (600)                              */
   int FC2;  /* config.model.fc2_dim  (601)                              */
+  int math; /* VS_MATH_FP32 or VS_MATH_F16X3 (conv layers cnn2..cnn7)   */
 } vs_dims;
 
 /* One Conv2d + BatchNorm2d pair of the nn.Sequential (state_dict conv.{i}.*, conv.{i+1}.*). */
@@ -91,6 +97,7 @@ typedef struct vs_ws_layout {
   size_t bn_stats;            /* [8][64][2] double: sum, sum of squares (train)    */
   size_t lstm_packed;         /* fragment-ordered W_hh, both directions            */
   size_t lstm_state;          /* h ping/pong + c, [3][2][H][Bpad]                  */
+  size_t conv_scales;         /* [8] x {in s, 1/s, w s, 1/s, absmax scratch x2, -, -} (VS_MATH_F16X3) */
 } vs_ws_layout;
 
 int vs_abi_version(void);
@@ -155,6 +162,16 @@ size_t vs_conv64_packed_floats(int KT, int KF);
 int vs_conv64_pack(const float* w, float* packed, int KT, int KF, void* stream);
 int vs_conv64_fwd(const float* in, const float* packed, const float* scale, const float* shift,
                   float* out, int B, int T, int F, int KT, int KF, int dil, int act, void* stream);
+/* same layer in VS_MATH_F16X3 arithmetic: vs_pow2_scale gives {s, 1/s} for the input tensor,
+ * vs_conv64_pack_f16 packs (and scales) the weights; amax_scratch = one uint32 of device scratch.
+ * transpose_flip = 1 packs the data-gradient weights. */
+size_t vs_conv64_packed_f16_floats(int KT, int KF);
+int vs_pow2_scale(const float* x, long long n, void* amax_scratch, float* scale2, void* stream);
+int vs_conv64_pack_f16(const float* w, void* packed, int KT, int KF, int transpose_flip, void* amax_scratch,
+                       float* w_scale2, void* stream);
+int vs_conv64_f16x3_fwd(const float* in, const void* packed, const float* scale, const float* shift,
+                        const float* in_scale2, const float* w_scale2, float* out,
+                        int B, int T, int F, int KT, int KF, int dil, int act, void* stream);
 /* cnn8: [B][64][T][F] -> [B][T][8][F], weight [8][64][1][1] */
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift,
                      float* out, int B, int T, int F, int act, void* stream);
@@ -222,6 +239,7 @@ typedef struct vs_tape_layout {
   size_t dvbias, conv_packed[6], pack_tmp, lstm_packed, lstm_packed_t, lstm_state, lstm_bwd_state;
   size_t consts;              /* ones[64], zeros[64] */
   size_t bn_stats, bn_coef, first_acc, colsum_tmp, partials;
+  size_t conv_scales;         /* [16] x 8 floats: power-of-two operand scales of the f16x3 conv launches */
 } vs_tape_layout;
 
 int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);

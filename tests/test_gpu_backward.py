@@ -50,7 +50,8 @@ def _conv_ref(x, w, dil):
 
 
 @pytest.mark.parametrize("KT,KF,dil,B,T,Fq", CONV_BWD_CASES)
-def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq):
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq, math):
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(KT * 1000 + dil * 10 + B)
     x = torch.randn(B, 64, T, Fq, generator=g)
@@ -60,7 +61,7 @@ def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq):
     wd = w.double().requires_grad_(True)
     (_conv_ref(xd, wd, dil) * dz.double()).sum().backward()
     d = dev()
-    dx = ops.conv64_dgrad(dz.to(d), w.to(d), dil)
+    dx = ops.conv64_dgrad(dz.to(d), w.to(d), dil, math=math)
     dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil)
     assert rel_err(dx, xd.grad) < KTOL
     assert rel_err(dw, wd.grad) < KTOL
@@ -507,14 +508,16 @@ def test_full_size_layerwise_backward_vs_fp64_oracle():
         table[f"cnn{l + 1}.dbeta"] = rel_err(dbeta, ref[f"conv.{spec.bn_idx}.bias"])
         dw = ops.conv64_wgrad(f32(dz), f32(a_in), spec.kt, spec.kf, spec.dil_t)
         table[f"cnn{l + 1}.wgrad"] = rel_err(dw, ref[f"conv.{spec.conv_idx}.weight"])
-        din = ops.conv64_dgrad(f32(dz), f32(sd[f"conv.{spec.conv_idx}.weight"]), spec.dil_t)
-        table[f"cnn{l + 1}.dgrad"] = rel_err(din, st[f"cnn{l}"])
+        for math in ("fp32", "f16x3"):
+            din = ops.conv64_dgrad(f32(dz), f32(sd[f"conv.{spec.conv_idx}.weight"]), spec.dil_t, math=math)
+            table[f"cnn{l + 1}.dgrad.{math}"] = rel_err(din, st[f"cnn{l}"])
         # and the forward kernel on every pixel of the full-size layer (the golden fixtures only
         # keep a strided subset of cnn8): y = (conv + bias)*scale + shift
         bias = sd[f"conv.{spec.conv_idx}.bias"].double()
-        out = ops.conv64(f32(a_in), f32(sd[f"conv.{spec.conv_idx}.weight"]), f32(scale), f32(shift + bias * scale),
-                         spec.dil_t, "mish")
-        table[f"cnn{l + 1}.fwd"] = rel_err(out, st[f"val/cnn{l + 1}"])
+        for math in ("fp32", "f16x3"):
+            out = ops.conv64(f32(a_in), f32(sd[f"conv.{spec.conv_idx}.weight"]), f32(scale), f32(shift + bias * scale),
+                             spec.dil_t, "mish", math=math)
+            table[f"cnn{l + 1}.fwd.{math}"] = rel_err(out, st[f"val/cnn{l + 1}"])
     _dump("layerwise_full", table)
     bad = {k: v for k, v in table.items() if v >= KTOL}
     assert not bad, bad

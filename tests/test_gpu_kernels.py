@@ -65,7 +65,8 @@ CONV64_CASES = [
 
 @pytest.mark.parametrize("KT,KF,dil,B,T,Fq", CONV64_CASES)
 @pytest.mark.parametrize("act", ["mish", "relu"])
-def test_conv64_mfma(KT, KF, dil, B, T, Fq, act):
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_conv64_mfma(KT, KF, dil, B, T, Fq, act, math):
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(KT * 100 + dil)
     x = torch.randn(B, 64, T, Fq, generator=g)
@@ -74,25 +75,50 @@ def test_conv64_mfma(KT, KF, dil, B, T, Fq, act):
     gamma, beta, mean, var = _bn(64, g)
     d = dev()
     scale, shift = ops.bn_fold(gamma.to(d), beta.to(d), mean.to(d), var.to(d), b.to(d))
-    got = ops.conv64(x.to(d), w.to(d), scale, shift, dil, act)
+    got = ops.conv64(x.to(d), w.to(d), scale, shift, dil, act, math=math)
     pt, pf = dil * (KT // 2), KF // 2
     y = F.conv2d(F.pad(x.double(), (pf, pf, pt, pt)), w.double(), b.double(), dilation=(dil, 1))
     ref = _ref_bn_act(y, gamma.double(), beta.double(), mean.double(), var.double(), act)
     assert rel_err(got, ref) < TOL
 
 
-def test_conv64_weight_layout_is_not_symmetric_blind():
-    """One-hot weight: out[co] must equal the shifted in[ci] for exactly one (co,ci,kt,kf)."""
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_conv64_weight_layout_is_not_symmetric_blind(math):
+    """One-hot weight: out[co] must equal the shifted in[ci] for exactly one (co,ci,kt,kf).
+    fp32 arithmetic reproduces the input bit for bit; the split-f16 path keeps 22 of its 24
+    significant bits (hi + lo halves of 11 bits each)."""
     from voicesplit_amd import ops
     d = dev()
     x = torch.randn(1, 64, 12, 40, generator=torch.Generator().manual_seed(3))
-    for (co, ci, kt, kf) in [(5, 11, 0, 4), (63, 0, 4, 0), (33, 62, 2, 3)]:
+    for (co, ci, kt, kf) in [(5, 11, 0, 4), (63, 0, 4, 0), (33, 62, 2, 3), (40, 17, 1, 1), (2, 9, 3, 2)]:
         w = torch.zeros(64, 64, 5, 5)
         w[co, ci, kt, kf] = 1.0
         ones, zeros = torch.ones(64, device=d), torch.zeros(64, device=d)
-        got = ops.conv64(x.to(d), w.to(d), ones, zeros, 2, "none").cpu()
+        got = ops.conv64(x.to(d), w.to(d), ones, zeros, 2, "none", math=math).cpu()
         ref = F.conv2d(F.pad(x, (2, 2, 4, 4)), w, dilation=(2, 1))
-        assert torch.equal(got, ref)
+        if math == "fp32":
+            assert torch.equal(got, ref)
+        else:
+            assert (got - ref).abs().max() <= 2.0 ** -21 * x.abs().max()
+            assert torch.equal(got == 0, ref == 0)
+
+
+def test_f16x3_dynamic_range():
+    """The per-tensor power-of-two scales make the split-f16 path indifferent to the magnitude of
+    its operands: gradients of 1e-7, activations of 1e+6, weights of 1e-5 (far outside f16)."""
+    from voicesplit_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(1, 64, 9, 40, generator=g)
+    w0 = torch.randn(64, 64, 5, 5, generator=g) * 0.025
+    ones, zeros = torch.ones(64, device=d), torch.zeros(64, device=d)
+    for xs, ws in [(1e-7, 1.0), (1e6, 1e-5), (3e-12, 7e3)]:
+        x, w = x0 * xs, w0 * ws
+        got = ops.conv64(x.to(d), w.to(d), ones, zeros, 1, "none", math="f16x3")
+        ref = F.conv2d(F.pad(x.double(), (2, 2, 2, 2)), w.double())
+        assert rel_err(got, ref) < TOL, (xs, ws)
+    z = ops.conv64(torch.zeros(1, 64, 4, 8, device=d), w0.to(d), ones, zeros, 1, "none", math="f16x3")
+    assert torch.equal(z, torch.zeros_like(z))
 
 
 @pytest.mark.parametrize("act", ["mish", "relu"])

@@ -27,10 +27,22 @@ def main():
         w = (torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5).to(dev)
         packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=dev)
         _lib.check(lib.vs_conv64_pack(ops._p(w), ops._p(packed), KT, KF, ops._stream()), "pack")
-        for act in ("mish", "none"):
+        packed16 = torch.empty(lib.vs_conv64_packed_f16_floats(KT, KF), dtype=torch.float32, device=dev)
+        scales = torch.zeros(8, dtype=torch.float32, device=dev)
+        amax = scales[4:].view(torch.int32)
+        _lib.check(lib.vs_pow2_scale(ops._p(x), x.numel(), ops._p(amax), ops._p(scales), ops._stream()), "scale")
+        _lib.check(lib.vs_conv64_pack_f16(ops._p(w), ops._p(packed16), KT, KF, 0, ops._p(amax[1:]), ops._p(scales[2:]), ops._stream()), "pack16")
+        for act in ("mish", "none", "mish_f16x3", "scale_pass"):
             def run():
-                _lib.check(lib.vs_conv64_fwd(ops._p(x), ops._p(packed), ops._p(scale), ops._p(shift), ops._p(out),
-                                             B, T, F, KT, KF, dil, ops.ACT_CODES[act], ops._stream()), "conv")
+                if act == "scale_pass":
+                    _lib.check(lib.vs_pow2_scale(ops._p(x), x.numel(), ops._p(amax), ops._p(scales), ops._stream()), "scale")
+                elif act == "mish_f16x3":
+                    _lib.check(lib.vs_conv64_f16x3_fwd(ops._p(x), ops._p(packed16), ops._p(scale), ops._p(shift), ops._p(scales),
+                                                       ops._p(scales[2:]), ops._p(out), B, T, F, KT, KF, dil,
+                                                       ops.ACT_CODES["mish"], ops._stream()), "conv16")
+                else:
+                    _lib.check(lib.vs_conv64_fwd(ops._p(x), ops._p(packed), ops._p(scale), ops._p(shift), ops._p(out),
+                                                 B, T, F, KT, KF, dil, ops.ACT_CODES[act], ops._stream()), "conv")
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

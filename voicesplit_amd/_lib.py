@@ -13,16 +13,17 @@ LIB_PATH = os.path.join(_HERE, "libvoicesplit_hip.so")
 
 ACT_RELU, ACT_MISH, ACT_NONE, ACT_SIGMOID = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN = 0, 1
+MATH_FP32, MATH_F16X3 = 0, 1
 PROF_SLOTS = 29
 PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head",
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class VsDims(Structure):
-    _fields_ = [(n, c_int) for n in ("B", "T", "F", "E", "H", "FC1", "FC2")]
+    _fields_ = [(n, c_int) for n in ("B", "T", "F", "E", "H", "FC1", "FC2", "math")]
 
 
 class VsConvLayer(Structure):
@@ -43,7 +44,7 @@ class VsWsLayout(Structure):
         ("total_bytes", c_size_t), ("act0", c_size_t), ("act1", c_size_t), ("feat", c_size_t),
         ("dvbias", c_size_t), ("xg", c_size_t), ("lstm_out", c_size_t), ("fc1_out", c_size_t),
         ("conv_packed", c_size_t * 6), ("bn_scale", c_size_t), ("bn_shift", c_size_t),
-        ("bn_stats", c_size_t), ("lstm_packed", c_size_t), ("lstm_state", c_size_t),
+        ("bn_stats", c_size_t), ("lstm_packed", c_size_t), ("lstm_state", c_size_t), ("conv_scales", c_size_t),
     ]
 
 
@@ -70,7 +71,7 @@ class VsTapeLayout(Structure):
         ("dvbias", c_size_t), ("conv_packed", c_size_t * 6), ("pack_tmp", c_size_t), ("lstm_packed", c_size_t),
         ("lstm_packed_t", c_size_t), ("lstm_state", c_size_t), ("lstm_bwd_state", c_size_t), ("consts", c_size_t),
         ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
-        ("partials", c_size_t),
+        ("partials", c_size_t), ("conv_scales", c_size_t),
     ]
 
 
@@ -93,6 +94,10 @@ SIGNATURES = {
     "vs_conv64_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "vs_conv64_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_conv_last_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vs_conv64_packed_f16_floats": (c_size_t, [c_int, c_int]),
+    "vs_pow2_scale": (c_int, [_P, c_longlong, _P, _P, _P]),
+    "vs_conv64_pack_f16": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "vs_conv64_f16x3_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_gemm_nt": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int,
                            c_int, c_int, _P]),
     "vs_lstm_packed_floats": (c_size_t, [c_int]),

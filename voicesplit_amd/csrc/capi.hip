@@ -58,6 +58,7 @@ int check_dims(const vs_dims* d) {
   VS_REQUIRE(d->B > 0 && d->T > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->FC1 > 0 && d->FC2 > 0,
              "dims must be positive: B=%d T=%d F=%d E=%d H=%d FC1=%d FC2=%d", d->B, d->T, d->F, d->E, d->H, d->FC1, d->FC2);
   VS_REQUIRE(d->H % 8 == 0, "lstm_dim H=%d must be a multiple of 8", d->H);
+  VS_REQUIRE(d->math == VS_MATH_FP32 || d->math == VS_MATH_F16X3, "dims.math=%d is not a VS_MATH_* code", d->math);
   VS_REQUIRE((long long)d->B * d->T < 2147483647LL / 8, "B*T too large");
   return 0;
 }
@@ -80,6 +81,7 @@ int layout(const vs_dims* d, vs_ws_layout* L) {
   L->bn_stats = take(8 * 64 * 2 * 8);
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
   L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
+  L->conv_scales = take(8 * 8 * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -98,6 +100,20 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
 }  // namespace
 
 int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
+
+int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8,
+                         const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
+                         int dil, int act, int transpose_flip, hipStream_t stream) {
+  if (math == VS_MATH_F16X3) {
+    unsigned* amax = reinterpret_cast<unsigned*>(scales8 + 4);
+    if (int rc = vs_pow2_scale_impl(in, (long long)B * 64 * T * F, amax, scales8, stream)) return rc;
+    if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip, amax + 1, scales8 + 2, stream)) return rc;
+    return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, scales8, scales8 + 2, out,
+                                    B, T, F, KT, KF, dil, act, stream);
+  }
+  if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(packed), KT, KF, transpose_flip, stream)) return rc;
+  return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
+}
 
 extern "C" {
 
@@ -173,6 +189,26 @@ int vs_conv64_fwd(const float* in, const float* packed, const float* scale, cons
                   int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
   VS_REQUIRE(in != out, "conv64: in-place is not supported");
   return vs_conv64_fwd_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, (hipStream_t)stream);
+}
+
+int vs_pow2_scale(const float* x, long long n, void* amax_scratch, float* scale2, void* stream) {
+  VS_REQUIRE(x && amax_scratch && scale2, "pow2_scale: NULL argument");
+  return vs_pow2_scale_impl(x, n, static_cast<unsigned*>(amax_scratch), scale2, (hipStream_t)stream);
+}
+
+int vs_conv64_pack_f16(const float* w, void* packed, int KT, int KF, int transpose_flip, void* amax_scratch,
+                       float* w_scale2, void* stream) {
+  VS_REQUIRE(w && packed && amax_scratch && w_scale2, "conv64_pack_f16: NULL argument");
+  return vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip,
+                                 static_cast<unsigned*>(amax_scratch), w_scale2, (hipStream_t)stream);
+}
+
+int vs_conv64_f16x3_fwd(const float* in, const void* packed, const float* scale, const float* shift,
+                        const float* in_scale2, const float* w_scale2, float* out,
+                        int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
+  VS_REQUIRE(in != out, "conv64_f16x3: in-place is not supported");
+  return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, in_scale2, w_scale2, out,
+                                  B, T, F, KT, KF, dil, act, (hipStream_t)stream);
 }
 
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,
@@ -252,10 +288,10 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   for (int i = 0; i < 6; ++i) {
     const int l = i + 1;
     float* packed = at<float>(ws, L.conv_packed[i]);
-    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
     ProfScope ps(VS_PROF_CNN2 + i, stream);
-    if (int rc = vs_conv64_fwd_impl(act[cur], packed, scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
-                                    kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
+    if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, at<float>(ws, L.conv_scales) + 8 * l,
+                                      scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
+                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, stream)) return rc;
     cur ^= 1;
     if (train) {
       if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,

@@ -68,6 +68,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   part = max3(part, (size_t)kSplitK * d->FC2 * d->FC1, (size_t)kSplitK * d->FC1 * 2 * H);
   part = max3(part, (size_t)kSplitK * 4 * H * H, 0);
   L->partials = take(part * 4);
+  L->conv_scales = take(16 * 8 * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -156,11 +157,11 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   for (int i = 0; i < 6; ++i) {
     const int l = i + 1;
     float* packed = at<float>(tape, L.conv_packed[i]);
-    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
     {
       VsProfScope ps(VS_PROF_CNN2 + i, stream);
-      if (int rc = vs_conv64_fwd_impl(at<float>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<float>(tape, L.z[l]), B, T, F,
-                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+      if (int rc = vs_conv64_layer_impl(d->math, at<float>(tape, L.a[l - 1]), p->conv[l].weight, packed,
+                                        at<float>(tape, L.conv_scales) + 8 * l, ones, p->conv[l].bias, at<float>(tape, L.z[l]),
+                                        B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 0, stream)) return rc;
     }
     if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false)) return rc;
   }
@@ -326,11 +327,11 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
                                         kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
     }
-    if (int rc = vs_conv64_pack_impl(p->conv[l].weight, pack_tmp, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
     {
       VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
-      if (int rc = vs_conv64_fwd_impl(gbuf[cur], pack_tmp, ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf,
-                                      kMid[i].dil, VS_ACT_NONE, stream)) return rc;
+      if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, at<float>(tape, L.conv_scales) + 8 * (8 + l),
+                                        ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 1,
+                                        stream)) return rc;
     }
     cur ^= 1;
   }

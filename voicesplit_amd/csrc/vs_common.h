@@ -51,6 +51,22 @@ __device__ __forceinline__ float vs_act(float v) {
   return v;
 }
 
+// Mish with the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each, result within ~3e-7
+// relative of vs_mish) for epilogues where the accurate expf/divide sequence (~25 VALU per element)
+// would rival the matrix work itself.
+__device__ __forceinline__ float vs_mish_fast(float x) {
+  float u = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.44269504088896340736f);
+  float n = u * (u + 2.0f);
+  float y = x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+  return x > 20.0f ? x : y;
+}
+
+template <int ACT>
+__device__ __forceinline__ float vs_act_fast(float v) {
+  if (ACT == VS_ACT_MISH) return vs_mish_fast(v);
+  return vs_act<ACT>(v);
+}
+
 __device__ __forceinline__ float vs_act_rt(float v, int act) {
   switch (act) {
     case VS_ACT_RELU: return fmaxf(v, 0.0f);

@@ -14,6 +14,18 @@ struct VsProfScope {
 int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, const float* shift, float* out,
                        int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
+// conv_f16x3.hip
+int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, float* scale2, hipStream_t);
+int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
+                            float* w_scale2, hipStream_t);
+int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
+                             const float* in_scale2, const float* w_scale2, float* out,
+                             int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
+// one 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
+// gradient) into `packed`, derives the operand scales into scales8 (8 floats of scratch) when needed
+int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8,
+                         const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
+                         int dil, int act, int transpose_flip, hipStream_t);
 // conv_edge.hip
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
 int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);

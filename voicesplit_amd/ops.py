@@ -6,6 +6,7 @@ Stage functions mirror the reference forward (models/voicesplit/model.py:66-89):
 The kernel-level functions (``conv64`` ...) exist for the unit tests.
 """
 import ctypes
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -40,8 +41,26 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_dims(B, T, F, E, H, FC1, FC2) -> VsDims:
-    return VsDims(int(B), int(T), int(F), int(E), int(H), int(FC1), int(FC2))
+MATH_CODES = {"fp32": _lib.MATH_FP32, "f16x3": _lib.MATH_F16X3}
+_DEFAULT_MATH = os.environ.get("VOICESPLIT_CONV_MATH", "fp32")
+
+
+def set_conv_math(name: str):
+    """Arithmetic of the 64->64 conv layers (forward and data gradient): "fp32" = f32 matrix cores
+    (bitwise an fmaf chain); "f16x3" = split-f16 products on the f16 matrix cores, fp32-class
+    accuracy at 3/16 of the matrix-pipe time (csrc/conv_f16x3.hip)."""
+    global _DEFAULT_MATH
+    if name not in MATH_CODES:
+        raise ValueError(f"conv math must be one of {sorted(MATH_CODES)}")
+    _DEFAULT_MATH = name
+
+
+def get_conv_math() -> str:
+    return _DEFAULT_MATH
+
+
+def make_dims(B, T, F, E, H, FC1, FC2, math: Optional[str] = None) -> VsDims:
+    return VsDims(int(B), int(T), int(F), int(E), int(H), int(FC1), int(FC2), MATH_CODES[math or _DEFAULT_MATH])
 
 
 def workspace_layout(dims: VsDims) -> VsWsLayout:
@@ -196,11 +215,29 @@ def conv_first(x, w, scale, shift, act: str):
     return out
 
 
-def conv64(x, w, scale, shift, dil: int, act: str):
+def _conv64_f16x3(x, w, scale, shift, dil: int, act_code: int, transpose_flip: int):
+    lib = _lib.load()
+    B, C, T, F = x.shape
+    KT, KF = w.shape[2], w.shape[3]
+    packed = torch.empty(lib.vs_conv64_packed_f16_floats(KT, KF), dtype=torch.float32, device=x.device)
+    scales = torch.zeros(8, dtype=torch.float32, device=x.device)
+    amax = scales[4:].view(torch.int32)
+    check(lib.vs_pow2_scale(_p(x), x.numel(), _p(amax), _p(scales), _stream()), "vs_pow2_scale")
+    check(lib.vs_conv64_pack_f16(_p(w), _p(packed), KT, KF, transpose_flip, _p(amax[1:]), _p(scales[2:]), _stream()),
+          "vs_conv64_pack_f16")
+    out = torch.empty_like(x)
+    check(lib.vs_conv64_f16x3_fwd(_p(x), _p(packed), _p(scale), _p(shift), _p(scales), _p(scales[2:]), _p(out),
+                                  B, T, F, KT, KF, dil, act_code, _stream()), "vs_conv64_f16x3_fwd")
+    return out
+
+
+def conv64(x, w, scale, shift, dil: int, act: str, math: str = "fp32"):
     """x [B,64,T,F], w [64,64,KT,KF] -> [B,64,T,F] with 'same' zero padding and time dilation."""
     lib = _lib.load()
     for n, t in (("x", x), ("w", w), ("scale", scale), ("shift", shift)):
         _dev_check(t, n)
+    if math == "f16x3":
+        return _conv64_f16x3(x, w, scale, shift, dil, ACT_CODES[act], 0)
     B, C, T, F = x.shape
     KT, KF = w.shape[2], w.shape[3]
     packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=x.device)
@@ -348,11 +385,14 @@ def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: tor
 
 # ---- backward kernels (unit tests) -------------------------------------------------------------
 
-def conv64_dgrad(dz, w, dil: int):
+def conv64_dgrad(dz, w, dil: int, math: str = "fp32"):
     """dIn [B,64,T,F] = conv^T(dz, w): the forward kernel with transposed + tap-flipped weights."""
     lib = _lib.load()
     _dev_check(dz, "dz")
     _dev_check(w, "w")
+    if math == "f16x3":
+        ones, zeros = torch.ones(64, device=dz.device), torch.zeros(64, device=dz.device)
+        return _conv64_f16x3(dz, w, ones, zeros, dil, ACT_NONE, 1)
     B, C, T, F = dz.shape
     KT, KF = w.shape[2], w.shape[3]
     packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=dz.device)
