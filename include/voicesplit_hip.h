@@ -264,6 +264,9 @@ int vs_conv64_pack_dgrad(const float* w, float* packed, int KT, int KF, void* st
 size_t vs_conv64_wgrad_partial_floats(int KT, int KF);
 int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw,
                     int B, int T, int F, int KT, int KF, int dil, void* stream);
+/* the same in VS_MATH_F16X3 arithmetic; scratch8 = 8 floats (operand scales are derived inside) */
+int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, float* dw, float* scratch8,
+                          int B, int T, int F, int KT, int KF, int dil, void* stream);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

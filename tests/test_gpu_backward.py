@@ -62,12 +62,13 @@ def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq, math):
     (_conv_ref(xd, wd, dil) * dz.double()).sum().backward()
     d = dev()
     dx = ops.conv64_dgrad(dz.to(d), w.to(d), dil, math=math)
-    dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil)
+    dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil, math=math)
     assert rel_err(dx, xd.grad) < KTOL
     assert rel_err(dw, wd.grad) < KTOL
 
 
-def test_conv64_wgrad_one_hot_indices():
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_conv64_wgrad_one_hot_indices(math):
     """dz one-hot at (b,co,t,f), input one-hot at (b,ci,t',f'): exactly one weight-gradient entry,
     at (co, ci, kt, kf) with t' = t+(kt-2)*dil, f' = f+kf-2 -- catches transposed / flipped taps."""
     from voicesplit_amd import ops
@@ -81,7 +82,7 @@ def test_conv64_wgrad_one_hot_indices():
         x = torch.zeros(B, 64, T, Fq)
         dz[b, co, t, f] = 1.0
         x[b, ci, tp, fp] = 3.0
-        dw = ops.conv64_wgrad(dz.to(d), x.to(d), 5, 5, dil).cpu()
+        dw = ops.conv64_wgrad(dz.to(d), x.to(d), 5, 5, dil, math=math).cpu()
         ref = torch.zeros(64, 64, 5, 5)
         ref[co, ci, kt, kf] = 3.0
         assert torch.equal(dw, ref), (b, co, t, f, ci, kt, kf, dw.nonzero().tolist())
@@ -506,8 +507,9 @@ def test_full_size_layerwise_backward_vs_fp64_oracle():
         table[f"cnn{l + 1}.bn_dz"] = rel_err(gdz.reshape(1, 64, T, Fq), dz)
         table[f"cnn{l + 1}.dgamma"] = rel_err(dgamma, ref[f"conv.{spec.bn_idx}.weight"])
         table[f"cnn{l + 1}.dbeta"] = rel_err(dbeta, ref[f"conv.{spec.bn_idx}.bias"])
-        dw = ops.conv64_wgrad(f32(dz), f32(a_in), spec.kt, spec.kf, spec.dil_t)
-        table[f"cnn{l + 1}.wgrad"] = rel_err(dw, ref[f"conv.{spec.conv_idx}.weight"])
+        for math in ("fp32", "f16x3"):
+            dw = ops.conv64_wgrad(f32(dz), f32(a_in), spec.kt, spec.kf, spec.dil_t, math=math)
+            table[f"cnn{l + 1}.wgrad.{math}"] = rel_err(dw, ref[f"conv.{spec.conv_idx}.weight"])
         for math in ("fp32", "f16x3"):
             din = ops.conv64_dgrad(f32(dz), f32(sd[f"conv.{spec.conv_idx}.weight"]), spec.dil_t, math=math)
             table[f"cnn{l + 1}.dgrad.{math}"] = rel_err(din, st[f"cnn{l}"])

@@ -483,3 +483,247 @@ int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc /* [64
   VS_LAUNCH_CHECK();
   return 0;
 }
+
+// =================================================================================================
+// Weight gradient in split-f16 arithmetic (VS_MATH_F16X3; see conv_f16x3.hip for the scheme):
+// same decomposition as conv64_wgrad_kernel (workgroup = one time tap kt, all KF frequency taps,
+// a contiguous range of (utterance, frame, 64-bin segment) tiles, partial sums kept in registers),
+// with K = 16 pixels per v_mfma_f32_32x32x16_f16.  Both operands sit in LDS as f16 hi / lo rows
+// [channel][pixel] (pitch 72 halves = 9 x 16 B: conflict-free b128 fragment reads with lane = row);
+// a lane's A fragment is the 8 pixels 16*kb + 8*half .. +7 of its dz row, and the KF shifted input
+// windows are cut out of ONE aligned 12-pixel read (b128 + b64) per part with v_alignbit for the
+// odd shifts -- no data movement in LDS per tap.  All kt workgroups of a group walk the SAME tile
+// sequence (tiles whose shifted input row is outside the image are skipped), so the dz segment is
+// fetched from HBM once and served to the other four time taps by the XCD's L2.
+// =================================================================================================
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+constexpr int kPH = 72;          // LDS row pitch in halves (144 B)
+constexpr int kPW = kPH / 2;     // ... in dwords (pixel pairs)
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  const h2 l = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+struct Wgrad16Args {
+  const float* dz;   // [B][64][T][F]
+  const float* in;   // [B][64][T][F]
+  const float* dz_scale;   // {s, 1/s}
+  const float* in_scale;   // {s, 1/s}
+  float* part;       // [G][KT][KF][64 co][64 ci]   (scaled by s_dz*s_in)
+  int B, T, F, dil, KT, nseg, G;
+};
+
+template <int KF>
+__global__ __launch_bounds__(256, 2)
+void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
+  constexpr int PADF = KF / 2;
+  constexpr int NPA = (kNF + KF - 1 + 1) / 2;      // input pixel pairs per row: 34 (KF=5) / 32 (KF=1)
+  constexpr int NIA = (64 * NPA + 255) / 256;      // staging iterations for the input tile
+  __shared__ __attribute__((aligned(16))) unsigned sDh[64 * kPW], sDl[64 * kPW], sAh[64 * kPW], sAl[64 * kPW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int kt = (bid >> 3) % g.KT;
+  const int grp = ((bid >> 3) / g.KT) * 8 + xcd;
+  const int off_t = (kt - g.KT / 2) * g.dil;
+
+  const int ntiles = g.B * g.T * g.nseg;          // same sequence for every kt
+  const int per = (ntiles + g.G - 1) / g.G;
+  int tile = grp * per;
+  const int tile_end = tile + per < ntiles ? tile + per : ntiles;
+
+  const size_t plane = (size_t)g.T * g.F;
+  const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
+  const float s_dz = g.dz_scale[0], s_in = g.in_scale[0];
+
+  f32x16 acc[KF];
+#pragma unroll
+  for (int k = 0; k < KF; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  // skip tiles whose input row t+off_t is outside the image
+  auto advance = [&](int tl) {
+    while (tl < tile_end) {
+      const int t = (tl / g.nseg) % g.T;
+      if (t + off_t >= 0 && t + off_t < g.T) break;
+      ++tl;
+    }
+    return tl;
+  };
+
+  float sd[8][2], sa[NIA][2];
+  int nv_next = 0;
+  auto issue = [&](int tl) {
+    const int bt = tl / g.nseg;
+    const int seg = tl - bt * g.nseg;
+    const int b = bt / g.T;
+    const int t = bt - b * g.T;
+    const int f0 = seg * kNF;
+    nv_next = g.F - f0 < kNF ? g.F - f0 : kNF;
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.dz + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.in + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int ch = idx >> 5, pp = idx & 31;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int f = f0 + 2 * pp + e;
+        const unsigned v = f < g.F ? (unsigned)(ch * plane_bytes + (t * g.F + f) * 4) : kOob;
+        sd[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, v, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int idx = tid + 256 * i;
+      const int ch = idx / NPA, pp = idx - ch * NPA;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int f = f0 - PADF + 2 * pp + e;
+        const bool ok = idx < 64 * NPA && f >= 0 && f < g.F;
+        const unsigned v = ok ? (unsigned)(ch * plane_bytes + ((t + off_t) * g.F + f) * 4) : kOob;
+        sa[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, v, 0, 0));
+      }
+    }
+  };
+
+  const int cb = wave >> 1, nb = wave & 1;
+  const int rowd = (cb * 32 + l31) * kPW + 4 * half;     // dword index of this lane's dz fragment, K-block 0
+  const int rowa = (nb * 32 + l31) * kPW + 4 * half;
+
+  tile = advance(tile);
+  if (tile < tile_end) issue(tile);
+  while (tile < tile_end) {
+    __syncthreads();          // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      unsigned hi, lo;
+      split_pair(sd[i][0] * s_dz, sd[i][1] * s_dz, hi, lo);
+      sDh[(idx >> 5) * kPW + (idx & 31)] = hi;
+      sDl[(idx >> 5) * kPW + (idx & 31)] = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 64 * NPA) {
+        const int ch = idx / NPA, pp = idx - ch * NPA;
+        unsigned hi, lo;
+        split_pair(sa[i][0] * s_in, sa[i][1] * s_in, hi, lo);
+        sAh[ch * kPW + pp] = hi;
+        sAl[ch * kPW + pp] = lo;
+      }
+    }
+    const int nkb = (nv_next + 15) >> 4;
+    __syncthreads();
+    tile = advance(tile + 1);
+    if (tile < tile_end) issue(tile);
+#pragma unroll
+    for (int kb = 0; kb < kNF / 16; ++kb) {
+      if (kb < nkb) {         // block-uniform
+        const u4 dh = *reinterpret_cast<const u4*>(&sDh[rowd + 8 * kb]);
+        const u4 dl = *reinterpret_cast<const u4*>(&sDl[rowd + 8 * kb]);
+        unsigned wh[6], wl[6];
+        {
+          const u4 a = *reinterpret_cast<const u4*>(&sAh[rowa + 8 * kb]);
+          const u4 c = *reinterpret_cast<const u4*>(&sAl[rowa + 8 * kb]);
+          wh[0] = a[0]; wh[1] = a[1]; wh[2] = a[2]; wh[3] = a[3];
+          wl[0] = c[0]; wl[1] = c[1]; wl[2] = c[2]; wl[3] = c[3];
+          if (KF > 1) {
+            const u2v a2 = *reinterpret_cast<const u2v*>(&sAh[rowa + 8 * kb + 4]);
+            const u2v c2 = *reinterpret_cast<const u2v*>(&sAl[rowa + 8 * kb + 4]);
+            wh[4] = a2[0]; wh[5] = a2[1];
+            wl[4] = c2[0]; wl[5] = c2[1];
+          }
+        }
+        // window of tap kf = halves kf .. kf+7 of the 12 read
+        u4 bh[KF], bl[KF];
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) {
+          const int m = kf >> 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (kf & 1) {
+              bh[kf][q] = __builtin_amdgcn_alignbit(wh[m + q + 1], wh[m + q], 16);
+              bl[kf][q] = __builtin_amdgcn_alignbit(wl[m + q + 1], wl[m + q], 16);
+            } else {
+              bh[kf][q] = wh[m + q];
+              bl[kf][q] = wl[m + q];
+            }
+          }
+        }
+        const h8 dhv = __builtin_bit_cast(h8, dh), dlv = __builtin_bit_cast(h8, dl);
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+          for (int kf = 0; kf < KF; ++kf) {
+            const h8 av = term == 0 ? dlv : dhv;
+            const h8 bv = __builtin_bit_cast(h8, term == 1 ? bl[kf] : bh[kf]);
+            acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[kf], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  float* out = g.part + ((size_t)grp * g.KT + kt) * KF * 4096;
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)kf * 4096 + co * 64 + nb * 32 + l31] = acc[kf][r];
+    }
+}
+
+// dW[co][ci][kt][kf] = (1/(s_dz*s_in)) * sum_g part[g][kt][kf][co][ci]
+__global__ void conv64_wgrad_reduce_scaled_kernel(const float* __restrict__ part, int G, int NT, float* __restrict__ dw,
+                                                  const float* __restrict__ dz_scale, const float* __restrict__ in_scale) {
+  const int total = NT * 4096;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int gq = 0; gq < G; ++gq) s += part[(size_t)gq * total + idx];
+  const int tap = idx >> 12, co = (idx >> 6) & 63, ci = idx & 63;
+  dw[((size_t)co * 64 + ci) * NT + tap] = s * (dz_scale[1] * in_scale[1]);
+}
+
+}  // namespace
+
+// groups for the f16 kernel: 2 workgroups per CU resident (LDS 36.9 KB, <= 256 VGPRs)
+extern "C" int vs_conv64_wgrad_f16_groups(int KT) { return KT == 7 ? 72 : 96; }
+
+int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz_scale2, const float* in_scale2,
+                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_wgrad_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad_f16x3: unsupported kernel %dx%d", KT, KF);
+  VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad_f16x3: T*F=%lld too large for 32-bit offsets", (long long)T * F);
+  VS_REQUIRE((long long)B * T * ((F + kNF - 1) / kNF) < 2147483647LL, "conv64_wgrad_f16x3: too many tiles");
+  const int G = vs_conv64_wgrad_f16_groups(KT);
+  Wgrad16Args a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, KT, (F + kNF - 1) / kNF, G};
+  dim3 grid(G * KT), block(256);
+  if (KF == 5) hipLaunchKernelGGL(conv64_wgrad_f16x3_kernel<5>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(conv64_wgrad_f16x3_kernel<1>, grid, block, 0, stream, a);
+  const int total = KT * KF * 4096;
+  hipLaunchKernelGGL(conv64_wgrad_reduce_scaled_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw,
+                     dz_scale2, in_scale2);
+  VS_LAUNCH_CHECK();
+  return 0;
+}

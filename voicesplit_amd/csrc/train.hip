@@ -322,16 +322,24 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   for (int i = 5; i >= 0; --i) {
     const int l = i + 1;   // cnn(l+1), conv index l
     if (int rc = bn_bwd(l, gbuf[cur], at<float>(tape, L.z[l]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
-    {
-      VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
-      if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
-                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
-    }
+    float* sc_bwd = at<float>(tape, L.conv_scales) + 8 * (8 + l);
     {
       VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
-      if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, at<float>(tape, L.conv_scales) + 8 * (8 + l),
+      if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, sc_bwd,
                                         ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 1,
                                         stream)) return rc;
+    }
+    {
+      // after the data gradient: in split-f16 mode it reuses the scale of dz that launch derived
+      // (sc_bwd[0..1]) and the scale of the layer input the forward derived (slot l)
+      VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
+      if (d->math == VS_MATH_F16X3 && kMid[i].kf > 1) {   // 7x1: its kt-split re-reads 7x, the fp32 kernel is faster there
+        if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + 8 * l,
+                                                part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+      } else {
+        if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
+                                          kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+      }
     }
     cur ^= 1;
   }
@@ -351,6 +359,16 @@ int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw
                     int dil, void* stream) {
   VS_REQUIRE(dz && in && partials && dw, "conv64_wgrad: NULL argument");
   return vs_conv64_wgrad_impl(dz, in, partials, dw, B, T, F, KT, KF, dil, (hipStream_t)stream);
+}
+
+int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, float* dw, float* scratch8,
+                          int B, int T, int F, int KT, int KF, int dil, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VS_REQUIRE(dz && in && partials && dw && scratch8, "conv64_wgrad_f16x3: NULL argument");
+  unsigned* amax = reinterpret_cast<unsigned*>(scratch8 + 4);
+  if (int rc = vs_pow2_scale_impl(dz, (long long)B * 64 * T * F, amax, scratch8, stream)) return rc;
+  if (int rc = vs_pow2_scale_impl(in, (long long)B * 64 * T * F, amax + 1, scratch8 + 2, stream)) return rc;
+  return vs_conv64_wgrad_f16x3_impl(dz, in, scratch8, scratch8 + 2, partials, dw, B, T, F, KT, KF, dil, stream);
 }
 
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

@@ -42,6 +42,8 @@ int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* r
                            float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
 // conv_bwd.hip
 int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
+int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz_scale2, const float* in_scale2,
+                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
 int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);

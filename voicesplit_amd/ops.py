@@ -404,13 +404,18 @@ def conv64_dgrad(dz, w, dil: int, math: str = "fp32"):
     return out
 
 
-def conv64_wgrad(dz, x, KT: int, KF: int, dil: int):
+def conv64_wgrad(dz, x, KT: int, KF: int, dil: int, math: str = "fp32"):
     lib = _lib.load()
     _dev_check(dz, "dz")
     _dev_check(x, "x")
     B, C, T, F = dz.shape
     part = torch.empty(lib.vs_conv64_wgrad_partial_floats(KT, KF), dtype=torch.float32, device=dz.device)
     dw = torch.empty(64, 64, KT, KF, dtype=torch.float32, device=dz.device)
+    if math == "f16x3":
+        scratch = torch.zeros(8, dtype=torch.float32, device=dz.device)
+        check(lib.vs_conv64_wgrad_f16x3(_p(dz), _p(x), _p(part), _p(dw), _p(scratch), B, T, F, KT, KF, dil, _stream()),
+              "vs_conv64_wgrad_f16x3")
+        return dw
     check(lib.vs_conv64_wgrad(_p(dz), _p(x), _p(part), _p(dw), B, T, F, KT, KF, dil, _stream()), "vs_conv64_wgrad")
     return dw
 
