@@ -97,7 +97,7 @@ typedef struct vs_ws_layout {
   size_t bn_stats;            /* [8][64][2] double: sum, sum of squares (train)    */
   size_t lstm_packed;         /* fragment-ordered W_hh, both directions            */
   size_t lstm_state;          /* h ping/pong + c, [3][2][H][Bpad]                  */
-  size_t conv_scales;         /* [8] x {in s, 1/s, w s, 1/s, absmax scratch x2, -, -} (VS_MATH_F16X3) */
+  size_t conv_scales;         /* [8] scale slots of the split-f16 conv launches: operand scales + running |max| arrays */
 } vs_ws_layout;
 
 int vs_abi_version(void);
@@ -239,7 +239,7 @@ typedef struct vs_tape_layout {
   size_t dvbias, conv_packed[6], pack_tmp, lstm_packed, lstm_packed_t, lstm_state, lstm_bwd_state;
   size_t consts;              /* ones[64], zeros[64] */
   size_t bn_stats, bn_coef, first_acc, colsum_tmp, partials;
-  size_t conv_scales;         /* [16] x 8 floats: power-of-two operand scales of the f16x3 conv launches */
+  size_t conv_scales;         /* [16] scale slots (8 forward, 8 backward): operand scales + running |max| arrays */
 } vs_tape_layout;
 
 int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);

@@ -81,7 +81,7 @@ int layout(const vs_dims* d, vs_ws_layout* L) {
   L->bn_stats = take(8 * 64 * 2 * 8);
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
   L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
-  L->conv_scales = take(8 * 8 * 4);
+  L->conv_scales = take(8 * VS_SCALE_SLOT_FLOATS * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -101,15 +101,19 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
 
 int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
 
-int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8,
+int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8 /* one scale slot */, int in_amax_ready,
                          const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
-                         int dil, int act, int transpose_flip, hipStream_t stream) {
+                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t stream) {
   if (math == VS_MATH_F16X3) {
-    unsigned* amax = reinterpret_cast<unsigned*>(scales8 + 4);
-    if (int rc = vs_pow2_scale_impl(in, (long long)B * 64 * T * F, amax, scales8, stream)) return rc;
-    if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip, amax + 1, scales8 + 2, stream)) return rc;
+    if (in_amax_ready) {
+      if (int rc = vs_scale_from_absmax_impl(vs_amax_slot(scales8), VS_AMAX_SLOTS, scales8, stream)) return rc;
+    } else {
+      if (int rc = vs_pow2_scale_impl(in, (long long)B * 64 * T * F, vs_amax_slot(scales8), scales8, stream)) return rc;
+    }
+    if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip,
+                                         reinterpret_cast<unsigned*>(scales8 + 4), scales8 + 2, stream)) return rc;
     return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, scales8, scales8 + 2, out,
-                                    B, T, F, KT, KF, dil, act, stream);
+                                    B, T, F, KT, KF, dil, act, amax_out, stream);
   }
   if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(packed), KT, KF, transpose_flip, stream)) return rc;
   return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
@@ -178,7 +182,7 @@ int vs_bn_fold(const float* gamma, const float* beta, const float* mean, const f
 
 int vs_conv_first_fwd(const float* x, const float* w, const float* scale, const float* shift, float* out,
                       int B, int T, int F, int act, void* stream) {
-  return vs_conv_first_fwd_impl(x, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);
+  return vs_conv_first_fwd_impl(x, w, scale, shift, out, B, T, F, act, nullptr, (hipStream_t)stream);
 }
 
 int vs_conv64_pack(const float* w, float* packed, int KT, int KF, void* stream) {
@@ -208,7 +212,7 @@ int vs_conv64_f16x3_fwd(const float* in, const void* packed, const float* scale,
                         int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
   VS_REQUIRE(in != out, "conv64_f16x3: in-place is not supported");
   return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, in_scale2, w_scale2, out,
-                                  B, T, F, KT, KF, dil, act, (hipStream_t)stream);
+                                  B, T, F, KT, KF, dil, act, nullptr, (hipStream_t)stream);
 }
 
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,
@@ -275,13 +279,22 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   }
 
   int cur = 0;
+  // split-f16 convs: every producer of a conv operand folds its |max| into the consumer's slot
+  float* cs = at<float>(ws, L.conv_scales);
+  const bool f16 = d->math == VS_MATH_F16X3;
+  if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 8 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
+  auto amax_for = [&](int consumer_layer) -> unsigned* {    // consumer_layer = conv index 1..6 (cnn2..cnn7)
+    return (f16 && consumer_layer >= 1 && consumer_layer <= 6) ? vs_amax_slot(cs + VS_SCALE_SLOT_FLOATS * consumer_layer) : nullptr;
+  };
   // cnn1
   {
   ProfScope ps(VS_PROF_CNN1, stream);
-  if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, scale, shift, act[cur], B, T, F, layer_act, stream)) return rc;
+  if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, scale, shift, act[cur], B, T, F, layer_act,
+                                      train ? nullptr : amax_for(1), stream)) return rc;
   if (train) {
     if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[0].bn_weight, p->conv[0].bn_bias, p->conv[0].bn_running_mean,
-                                  p->conv[0].bn_running_var, kBnEps, kBnMomentum, conv_act, stats, scale, shift, nullptr, nullptr, stream)) return rc;
+                                  p->conv[0].bn_running_var, kBnEps, kBnMomentum, conv_act, stats, scale, shift, nullptr, nullptr,
+                                  amax_for(1), stream)) return rc;
   }
   }
   // cnn2..cnn7
@@ -289,14 +302,14 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
     const int l = i + 1;
     float* packed = at<float>(ws, L.conv_packed[i]);
     ProfScope ps(VS_PROF_CNN2 + i, stream);
-    if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, at<float>(ws, L.conv_scales) + 8 * l,
+    if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, cs + VS_SCALE_SLOT_FLOATS * l, 1,
                                       scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
-                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, stream)) return rc;
+                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, train ? nullptr : amax_for(l + 1), stream)) return rc;
     cur ^= 1;
     if (train) {
       if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,
                                     p->conv[l].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * l,
-                                    scale + 64 * l, shift + 64 * l, nullptr, nullptr, stream)) return rc;
+                                    scale + 64 * l, shift + 64 * l, nullptr, nullptr, amax_for(l + 1), stream)) return rc;
     }
   }
   // cnn8, written straight into the LSTM feature layout

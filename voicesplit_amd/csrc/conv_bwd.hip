@@ -250,7 +250,7 @@ template <int ACT>
 __global__ __launch_bounds__(256)
 void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C, int L,
                              const float* __restrict__ scale, const float* __restrict__ shift,
-                             const float* __restrict__ coef, float* dz, int gx) {
+                             const float* __restrict__ coef, float* dz, int gx, unsigned* amax_out) {
   const long long r = blockIdx.x / gx;
   const int c = (int)(r % C);
   const float sc = scale[c], sh = shift[c], cA = coef[c], cB = coef[C + c], cC = coef[2 * C + c];
@@ -259,11 +259,15 @@ void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C
   float* po = dz + r * L;
   const int e0 = (int)(blockIdx.x % gx) * 4096;
   const int e1 = e0 + 4096 < L ? e0 + 4096 : L;
+  float m = 0.f;
   for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     const float zv = pz[e];
     const float dy = pg[e] * act_grad<ACT>(fmaf(zv, sc, sh));
-    po[e] = fmaf(cA, dy, fmaf(cB, zv, cC));
+    const float v = fmaf(cA, dy, fmaf(cB, zv, cC));
+    po[e] = v;
+    m = fmaxf(m, fabsf(v));
   }
+  vs_absmax_commit(m, amax_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,7 +423,8 @@ int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* d
 //   stats [C][2] double scratch, coef [3][C] float scratch; dz may alias da.
 int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
-                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream) {
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, unsigned* amax_out,
+                       hipStream_t stream) {
   VS_REQUIRE(C > 0 && R > 0 && L > 0 && R % C == 0, "bn_act_bwd: bad shape C=%d R=%lld L=%d", C, R, L);
   VS_REQUIRE(R <= 2147483647LL && C <= 65535, "bn_act_bwd: too many rows");
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
@@ -440,9 +445,9 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,
                      scale, mean, invstd, dgamma, dbeta, dbias, coef);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
-    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
+    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
   }
   VS_LAUNCH_CHECK();
   return 0;

@@ -31,28 +31,33 @@ void conv_first_kernel(const float* __restrict__ x,      // [B][T][F]
                        const float* __restrict__ w,      // [64][7]
                        const float* __restrict__ scale, const float* __restrict__ shift,
                        float* __restrict__ out,          // [B][64][T][F]
-                       int T, int F) {
+                       int T, int F, unsigned* amax_out) {
   const int plane = T * F;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (pix >= plane) return;
-  const int t = pix / F;
-  const int f = pix - t * F;
-  const float* row = x + (size_t)b * plane + (size_t)t * F;
-  float v[7];
+  float m = 0.f;
+  if (pix < plane) {
+    const int t = pix / F;
+    const int f = pix - t * F;
+    const float* row = x + (size_t)b * plane + (size_t)t * F;
+    float v[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    const int ff = f + k - 3;
-    v[k] = (ff >= 0 && ff < F) ? row[ff] : 0.f;
-  }
-  float* o = out + (size_t)b * 64 * plane + pix;
+    for (int k = 0; k < 7; ++k) {
+      const int ff = f + k - 3;
+      v[k] = (ff >= 0 && ff < F) ? row[ff] : 0.f;
+    }
+    float* o = out + (size_t)b * 64 * plane + pix;
 #pragma unroll 4
-  for (int c = 0; c < 64; ++c) {
-    float a = 0.f;
+    for (int c = 0; c < 64; ++c) {
+      float a = 0.f;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) a = fmaf(w[c * 7 + k], v[k], a);
-    o[(size_t)c * plane] = vs_act<ACT>(fmaf(a, scale[c], shift[c]));
+      for (int k = 0; k < 7; ++k) a = fmaf(w[c * 7 + k], v[k], a);
+      const float y = vs_act<ACT>(fmaf(a, scale[c], shift[c]));
+      o[(size_t)c * plane] = y;
+      m = fmaxf(m, fabsf(y));
+    }
   }
+  vs_absmax_commit(m, amax_out);
 }
 
 template <int ACT>
@@ -143,13 +148,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
 template <int ACT>
 __global__ __launch_bounds__(256)
 void bn_apply_kernel(const float* x, float* y, const float* __restrict__ scale, const float* __restrict__ shift,
-                     int C, int plane) {
+                     int C, int plane, unsigned* amax_out) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float* p = x + ((size_t)b * C + c) * plane;
   float* q = y + ((size_t)b * C + c) * plane;
   const float sc = scale[c], sh = shift[c];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256)
-    q[i] = vs_act<ACT>(fmaf(p[i], sc, sh));
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) {
+    const float v = vs_act<ACT>(fmaf(p[i], sc, sh));
+    q[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  vs_absmax_commit(m, amax_out);
 }
 
 // cnn8 keeps the [B][T][8][F] layout: channel stride F inside a frame, frame stride 8F
@@ -203,7 +213,7 @@ void bn_stats_feat_kernel(const float* __restrict__ x, int F, long long rows /* 
 
 }  // namespace
 
-int vs_bn_apply_impl(const float*, float*, int, int, int, int, const float*, const float*, hipStream_t);
+int vs_bn_apply_impl(const float*, float*, int, int, int, int, const float*, const float*, unsigned*, hipStream_t);
 int vs_bn_apply_feat_impl(const float*, float*, int, int, int, int, const float*, const float*, hipStream_t);
 
 int vs_bn_fold_impl(const float* gamma, const float* beta, const float* mean, const float* var,
@@ -215,14 +225,14 @@ int vs_bn_fold_impl(const float* gamma, const float* beta, const float* mean, co
 }
 
 int vs_conv_first_fwd_impl(const float* x, const float* w, const float* scale, const float* shift, float* out,
-                           int B, int T, int F, int act, hipStream_t stream) {
+                           int B, int T, int F, int act, unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "conv_first: bad shape B=%d T=%d F=%d", B, T, F);
   VS_REQUIRE((long long)T * F < 2147483647LL / 64 && B <= 65535, "conv_first: shape too large");
   dim3 grid((T * F + 255) / 256, B), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, w, scale, shift, out, T, F); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, w, scale, shift, out, T, F, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, w, scale, shift, out, T, F, amax_out); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(conv_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, w, scale, shift, out, T, F, amax_out); break;
     default: VS_REQUIRE(false, "conv_first: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
@@ -250,7 +260,7 @@ int vs_conv_last_fwd_impl(const float* in, const float* w, const float* scale, c
 int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float eps, float momentum, int act,
                      double* stats /* [C][2] */, float* scale, float* shift, float* mean_out, float* invstd_out,
-                     hipStream_t stream) {
+                     unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_train: bad shape B=%d C=%d plane=%d", B, C, plane);
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
   int gx = (plane + 256 * 16 - 1) / (256 * 16);
@@ -258,20 +268,20 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
   hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, stream, x, C, plane, C * plane, stats);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)B * plane, gamma, beta,
                      eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
-  return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, stream);
+  return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, amax_out, stream);
 }
 
 // y = act(x*scale[c] + shift[c]) over [B][C][plane]
 int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift,
-                     hipStream_t stream) {
+                     unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_apply: bad shape B=%d C=%d plane=%d", B, C, plane);
   int gx = (plane + 256 * 16 - 1) / (256 * 16);
   if (gx < 1) gx = 1;
   dim3 grid(gx, C, B), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, y, scale, shift, C, plane); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
     default: VS_REQUIRE(false, "bn_apply: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();

@@ -64,8 +64,14 @@ void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restric
 }
 
 // scale[0] = s = 2^(10 - e) with max = f * 2^e, f in [0.5,1);  scale[1] = 1/s.  0 / inf / nan -> 1.
-__global__ void scale_from_absmax_kernel(const unsigned* __restrict__ amax, float* __restrict__ scale) {
-  const float m = __uint_as_float(*amax);
+// amax: n uints (1 from absmax_kernel, VS_AMAX_SLOTS from vs_absmax_commit producers); one wave.
+__global__ void scale_from_absmax_kernel(const unsigned* __restrict__ amax, int n, float* __restrict__ scale) {
+  unsigned mb = 0;
+  for (int i = threadIdx.x; i < n; i += 64) mb = amax[i] > mb ? amax[i] : mb;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_down(mb, o, 64); mb = other > mb ? other : mb; }
+  if (threadIdx.x != 0) return;
+  const float m = __uint_as_float(mb);
   int e = 0;
   float s = 1.f, inv = 1.f;
   if (m > 0.f && m < 3.0e38f) {
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256, 2)
 void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
                          const float* __restrict__ in_scale, const float* __restrict__ w_scale,
-                         float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft) {
+                         float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft, unsigned* amax_out) {
   constexpr int R = 4 * P;
   constexpr int ROWS = R + KT - 1;
   constexpr int PX = kTileF + KF - 1 + ((kTileF + KF - 1) % 4 ? 4 - (kTileF + KF - 1) % 4 : 0);   // multiple of 4
@@ -302,6 +308,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
   if (!wave_active) return;
   const int f = f0 + l31;
   float* out_b = out + (size_t)b * kCo * plane;
+  float m = 0.f;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -313,16 +320,19 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
         const int i = i0 + wave * P + p;
         if (i < n_c && f < F) {
           const int t = cls + dil * i;
-          out_b[(size_t)co * plane + (size_t)t * F + f] = vs_act_fast<ACT>(fmaf(acc[cb][p][r], sc, sh));
+          const float y = vs_act_fast<ACT>(fmaf(acc[cb][p][r], sc, sh));
+          out_b[(size_t)co * plane + (size_t)t * F + f] = y;
+          m = fmaxf(m, fabsf(y));
         }
       }
     }
   }
+  vs_absmax_commit(m, amax_out);     // the output is the next layer's operand
 }
 
 template <int KT, int KF, int P>
 int launch_conv(const float* in, const _Float16* wp, const float* scale, const float* shift, const float* in_scale,
-                const float* w_scale, float* out, int B, int T, int F, int dil, int act, hipStream_t stream) {
+                const float* w_scale, float* out, int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream) {
   constexpr int R = 4 * P;
   const int rows_max = (T + dil - 1) / dil;
   const int n_rt = (rows_max + R - 1) / R;
@@ -331,9 +341,9 @@ int launch_conv(const float* in, const _Float16* wp, const float* scale, const f
   VS_REQUIRE(nblk > 0 && nblk < 2147483647LL, "conv64_f16x3: grid of %lld blocks out of range", nblk);
   dim3 grid((unsigned)nblk), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
     default: VS_REQUIRE(false, "conv64_f16x3: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
@@ -354,16 +364,22 @@ long long tile_rows(int T, int dil, int R) {
 // packed f16 hi/lo weights, in floats (4-byte units) so that callers size one buffer for either path
 extern "C" size_t vs_conv64_packed_f16_floats(int KT, int KF) { return (size_t)(kNChunk * KT * KF + kPadTaps) * (kTapBytes / 4); }
 
+// scale2 <- {s, 1/s} from a running |max| that the producer of the tensor already folded into *amax
+int vs_scale_from_absmax_impl(const unsigned* amax, int n, float* scale2, hipStream_t stream) {
+  hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(64), 0, stream, amax, n, scale2);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 // scale2 <- {s, 1/s} for the tensor x[0..n): s = the power of two that maps max|x| into [2^9, 2^10)
+// (one extra pass over x; the orchestration avoids it by having the producer of x track the max)
 int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, float* scale2, hipStream_t stream) {
   VS_REQUIRE(n > 0, "pow2_scale: n=%lld", n);
   VS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "pow2_scale: tensor must be 16-byte aligned");
   VS_CHECK_HIP(hipMemsetAsync(amax_scratch, 0, sizeof(unsigned), stream));
   const long long nb = ((n >> 2) + 255) / 256;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 2048 ? (nb > 0 ? nb : 1) : 2048)), dim3(256), 0, stream, x, n, amax_scratch);
-  hipLaunchKernelGGL(scale_from_absmax_kernel, dim3(1), dim3(1), 0, stream, amax_scratch, scale2);
-  VS_LAUNCH_CHECK();
-  return 0;
+  return vs_scale_from_absmax_impl(amax_scratch, 1, scale2, stream);
 }
 
 // w [64][64][KT][KF] fp32 -> fragment-ordered hi/lo f16 (scaled by w_scale2[0], which this call computes)
@@ -379,17 +395,17 @@ int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int tr
 
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
-                             int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t stream) {
+                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64_f16x3: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
   const bool p2 = tile_rows(T, dil, 8) <= tile_rows(T, dil, 4);
   if (KT == 7 && KF == 1) {
-    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, stream)
-              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, stream);
+    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
+              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
   }
   if (KT == 5 && KF == 5) {
-    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, stream)
-              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, stream);
+    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
+              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
   }
   VS_REQUIRE(false, "conv64_f16x3: unsupported kernel %dx%d", KT, KF);
   return -1;

@@ -68,7 +68,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   part = max3(part, (size_t)kSplitK * d->FC2 * d->FC1, (size_t)kSplitK * d->FC1 * 2 * H);
   part = max3(part, (size_t)kSplitK * 4 * H * H, 0);
   L->partials = take(part * 4);
-  L->conv_scales = take(16 * 8 * 4);
+  L->conv_scales = take(16 * VS_SCALE_SLOT_FLOATS * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -132,26 +132,32 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000 /* 1.0f */, 64, stream));
   VS_CHECK_HIP(hipMemsetAsync(ones + 64, 0, 64 * sizeof(float), stream));
 
+  // split-f16 convs: the BatchNorm+activation pass that produces a layer's input also folds its
+  // |max| into that layer's scale slot (slot l = conv index l: input scale of cnn(l+1))
+  float* cs = at<float>(tape, L.conv_scales);
+  const bool f16 = d->math == VS_MATH_F16X3;
+  if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 16 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
   auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout) -> int {
     VsProfScope ps(VS_PROF_FWD_BN, stream);
     const vs_conv_layer& c = p->conv[l];
+    unsigned* amax = (f16 && l + 1 <= 6) ? vs_amax_slot(cs + VS_SCALE_SLOT_FLOATS * (l + 1)) : nullptr;
     float *sc = scale + 64 * l, *sh = shift + 64 * l, *mu = mean + 64 * l, *is = invstd + 64 * l;
     if (train) {
       return feat_layout
                  ? vs_bn_train_feat_impl(z, a, B, T, F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
                                          kBnMomentum, conv_act, stats, sc, sh, mu, is, stream)
                  : vs_bn_train_impl(z, a, B, C, T * F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
-                                    kBnMomentum, conv_act, stats, sc, sh, mu, is, stream);
+                                    kBnMomentum, conv_act, stats, sc, sh, mu, is, amax, stream);
     }
     if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, C, sc, sh, mu, is, stream)) return rc;
     return feat_layout ? vs_bn_apply_feat_impl(z, a, B, T, F, conv_act, sc, sh, stream)
-                       : vs_bn_apply_impl(z, a, B, C, T * F, conv_act, sc, sh, stream);
+                       : vs_bn_apply_impl(z, a, B, C, T * F, conv_act, sc, sh, amax, stream);
   };
 
   {
     VsProfScope ps(VS_PROF_CNN1, stream);
-    if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, stream)) return rc;
+    if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, nullptr, stream)) return rc;
   }
   if (int rc = bn(0, at<float>(tape, L.z[0]), at<float>(tape, L.a[0]), 64, false)) return rc;
   for (int i = 0; i < 6; ++i) {
@@ -160,8 +166,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     {
       VsProfScope ps(VS_PROF_CNN2 + i, stream);
       if (int rc = vs_conv64_layer_impl(d->math, at<float>(tape, L.a[l - 1]), p->conv[l].weight, packed,
-                                        at<float>(tape, L.conv_scales) + 8 * l, ones, p->conv[l].bias, at<float>(tape, L.z[l]),
-                                        B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 0, stream)) return rc;
+                                        cs + VS_SCALE_SLOT_FLOATS * l, 1, ones, p->conv[l].bias, at<float>(tape, L.z[l]),
+                                        B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 0, nullptr, stream)) return rc;
     }
     if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false)) return rc;
   }
@@ -304,10 +310,16 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* invstd = at<float>(tape, L.bn_invstd);
   double* stats = at<double>(tape, L.bn_stats);
   float* coef = at<float>(tape, L.bn_coef);
+  // split-f16 convs: dz of layer l is the operand of its data- and weight-gradient launches; the
+  // BatchNorm backward pass that produces it folds its |max| into slot 8+l
+  float* cs = at<float>(tape, L.conv_scales);
+  const bool f16 = d->math == VS_MATH_F16X3;
+  if (f16) VS_CHECK_HIP(hipMemsetAsync(cs + 8 * VS_SCALE_SLOT_FLOATS, 0, 8 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   auto bn_bwd = [&](int l, const float* da, const float* z, float* dz, int C, long long R, int Lrow) -> int {
     VsProfScope ps(VS_PROF_BWD_BN, stream);
+    unsigned* amax = (f16 && l >= 1 && l <= 6) ? vs_amax_slot(cs + VS_SCALE_SLOT_FLOATS * (8 + l)) : nullptr;
     return vs_bn_act_bwd_impl(da, z, dz, C, R, Lrow, conv_act, train, scale + 64 * l, shift + 64 * l, mean + 64 * l,
-                              invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias, stats, coef, stream);
+                              invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias, stats, coef, amax, stream);
   };
   // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
   if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
@@ -322,19 +334,19 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   for (int i = 5; i >= 0; --i) {
     const int l = i + 1;   // cnn(l+1), conv index l
     if (int rc = bn_bwd(l, gbuf[cur], at<float>(tape, L.z[l]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
-    float* sc_bwd = at<float>(tape, L.conv_scales) + 8 * (8 + l);
+    float* sc_bwd = at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * (8 + l);
     {
       VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
-      if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, sc_bwd,
+      if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, sc_bwd, 1,
                                         ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 1,
-                                        stream)) return rc;
+                                        nullptr, stream)) return rc;
     }
     {
       // after the data gradient: in split-f16 mode it reuses the scale of dz that launch derived
       // (sc_bwd[0..1]) and the scale of the layer input the forward derived (slot l)
       VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
       if (d->math == VS_MATH_F16X3 && kMid[i].kf > 1) {   // 7x1: its kt-split re-reads 7x, the fp32 kernel is faster there
-        if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + 8 * l,
+        if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * l,
                                                 part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
       } else {
         if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
@@ -376,7 +388,7 @@ int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R
                   float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream) {
   VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef, "bn_act_bwd: NULL argument");
   return vs_bn_act_bwd_impl(da, z, dz, C, R, L, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
-                            stats, coef, (hipStream_t)stream);
+                            stats, coef, nullptr, (hipStream_t)stream);
 }
 
 int vs_conv_last_dgrad(const float* dz, const float* w, float* din, int B, int T, int F, void* stream) {

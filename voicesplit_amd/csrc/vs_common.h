@@ -76,6 +76,24 @@ __device__ __forceinline__ float vs_act_rt(float v, int act) {
   }
 }
 
+// Running |max| of a tensor for the split-f16 conv path: kernels that PRODUCE a conv operand fold
+// their outputs' magnitude into an array of VS_AMAX_SLOTS uints (bit pattern of a non-negative
+// float orders like the float), so the consumer needs no extra pass over the tensor.  The array
+// spreads the atomics of ~10^5 workgroups over 1024 addresses (one address serialises them in L2:
+// +40 ms per training step when tried) and a plain load first skips the atomic when it cannot
+// raise the slot (a stale value only costs a redundant atomic).  out == nullptr: no-op.
+#define VS_AMAX_SLOTS 1024
+__device__ __forceinline__ void vs_absmax_commit(float m, unsigned* out) {
+  if (out == nullptr) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    unsigned* slot = out + ((blockIdx.x * 4u + blockIdx.y * 61u + blockIdx.z * 127u + (threadIdx.x >> 6)) & (VS_AMAX_SLOTS - 1));
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side error plumbing: no exceptions cross the C ABI
 // ---------------------------------------------------------------------------

@@ -16,27 +16,35 @@ int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, con
                        int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
 // conv_f16x3.hip
 int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, float* scale2, hipStream_t);
+int vs_scale_from_absmax_impl(const unsigned* amax, int n, float* scale2, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
                             float* w_scale2, hipStream_t);
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
-                             int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
-// one 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
-// gradient) into `packed`, derives the operand scales into scales8 (8 floats of scratch) when needed
-int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8,
+                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t);
+// One 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
+// gradient) into `packed`.  Split-f16 mode keeps its operand scales in one "scale slot" of
+// VS_SCALE_SLOT_FLOATS floats: [0..1] input {s, 1/s}, [2..3] weight {s, 1/s}, [4] uint |max| of
+// the weights, [8 .. 8+VS_AMAX_SLOTS) uint running |max| array of the input.
+// in_amax_ready: the producer of `in` already folded its |max| into the slot's array
+// (vs_absmax_commit); otherwise one extra pass over `in` computes it.  amax_out: the |max| array
+// (of the consumer's slot) this launch folds its own output into, or NULL.
+#define VS_SCALE_SLOT_FLOATS (8 + VS_AMAX_SLOTS)
+int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* slot, int in_amax_ready,
                          const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
-                         int dil, int act, int transpose_flip, hipStream_t);
+                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t);
+inline unsigned* vs_amax_slot(float* slot) { return reinterpret_cast<unsigned*>(slot + 8); }
 // conv_edge.hip
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
-int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, unsigned* amax_out, hipStream_t);
 int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
-                     float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
+                     float* scale, float* shift, float* mean_out, float* invstd_out, unsigned* amax_out, hipStream_t);
 int vs_bn_train_feat_impl(const float* x, float* y, int B, int T, int F, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
                           float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
-int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift, hipStream_t);
+int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift, unsigned* amax_out, hipStream_t);
 int vs_bn_apply_feat_impl(const float* x, float* y, int B, int T, int F, int act, const float* scale, const float* shift, hipStream_t);
 int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, int C,
                            float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
@@ -46,7 +54,7 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
                                float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
 int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
-                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, unsigned* amax_out, hipStream_t);
 int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t);
 int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, hipStream_t);
 int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc, float* dw, int B, int T, int F, hipStream_t);
