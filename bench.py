@@ -222,7 +222,7 @@ def main():
             kname, peak = "conv64_f16x3_kernel<5,5>", PEAK_F16_MFMA_TFLOPS / 3.0
             extra = {"mfma_pipe": "f16 (v_mfma_f32_32x32x16_f16), 3 MFMA products per fp32 product",
                      "mfma_rate_tflops": round(3 * achieved, 1), "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS,
-                     "scale_pass_in_launch_ms": "each launch time includes the 0.55 ms absmax pass and the weight pack"}
+                     "launch_ms_includes": "operand-scale kernel + weight pack (~15 us); |max| of the operands is tracked by their producers"}
         else:
             kname, peak, extra = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}
         roof = {"bound": "mfma",

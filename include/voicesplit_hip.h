@@ -98,6 +98,7 @@ typedef struct vs_ws_layout {
   size_t lstm_packed;         /* fragment-ordered W_hh, both directions            */
   size_t lstm_state;          /* h ping/pong + c, [3][2][H][Bpad]                  */
   size_t conv_scales;         /* [8] scale slots of the split-f16 conv launches: operand scales + running |max| arrays */
+  size_t gemm_scales;         /* operand scales of the split-f16 LSTM input GEMM */
 } vs_ws_layout;
 
 int vs_abi_version(void);
@@ -240,6 +241,7 @@ typedef struct vs_tape_layout {
   size_t consts;              /* ones[64], zeros[64] */
   size_t bn_stats, bn_coef, first_acc, colsum_tmp, partials;
   size_t conv_scales;         /* [16] scale slots (8 forward, 8 backward): operand scales + running |max| arrays */
+  size_t gemm_scales;         /* operand scales of the split-f16 LSTM GEMMs (feat, W_ih, gate gradients) */
 } vs_tape_layout;
 
 int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);
@@ -285,6 +287,11 @@ int vs_conv_first_wgrad(const float* dz, const float* x, double* acc, float* dw,
 int vs_gemm(int layout_a, int layout_w, const float* A, int lda, const float* W, int ldw, float* C, int ldc,
             int M, int N, int K, const float* bias, const float* gate, int ldg, int a_relu, int w_relu, int act,
             int accumulate, int w_shift, int w_group, int splits, float* partials, void* stream);
+/* the same GEMM in VS_MATH_F16X3 arithmetic (no split-K / w_shift); scratch8 = 8 floats; A and W must
+ * be dense [rows][ld] buffers, 16-byte aligned (their power-of-two scales are derived inside) */
+int vs_gemm_f16x3(int layout_a, int layout_w, const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+                  int M, int N, int K, const float* bias, const float* gate, int ldg, int a_relu, int w_relu, int act,
+                  int accumulate, float* scratch8, void* stream);
 /* BiLSTM recurrence that also saves the activated gates (may alias xg) and cell states */
 int vs_bilstm_recurrent_train(const float* xg, const float* packed_whh, float* state, float* out,
                               float* gates_save, float* c_save, int B, int T, int H, void* stream);

@@ -169,7 +169,10 @@ GEMM_BWD_CASES = [
 
 
 @pytest.mark.parametrize("la,lw,M,N,K,pad,splits", GEMM_BWD_CASES)
-def test_gemm_layouts(la, lw, M, N, K, pad, splits):
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_gemm_layouts(la, lw, M, N, K, pad, splits, math):
+    if math == "f16x3" and splits > 1:
+        pytest.skip("split-K is only needed (and only offered) by the fp32 kernel")
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -183,7 +186,7 @@ def test_gemm_layouts(la, lw, M, N, K, pad, splits):
         buf[:, :m.shape[1]] = m
         return buf.to(d)
 
-    got = ops.gemm(store(A, la), store(W, lw), M, N, K, layout_a=la, layout_w=lw, splits=splits)
+    got = ops.gemm(store(A, la), store(W, lw), M, N, K, layout_a=la, layout_w=lw, splits=splits, math=math)
     assert rel_err(got, ref) < KTOL
 
 
@@ -198,6 +201,9 @@ def test_gemm_epilogue_gate_accumulate_relu_and_shift():
     out = c0.clone().to(d)
     ops.gemm(A.to(d), W.to(d), M, N, K, layout_a=0, layout_w=1, gate=gate.to(d), out=out, accumulate=True)
     ref = c0.double() + (A.double() @ W.double()) * (gate > 0)
+    assert rel_err(out, ref) < KTOL
+    out = c0.clone().to(d)
+    ops.gemm(A.to(d), W.to(d), M, N, K, layout_a=0, layout_w=1, gate=gate.to(d), out=out, accumulate=True, math="f16x3")
     assert rel_err(out, ref) < KTOL
     # relu on the K-major operand + bias + sigmoid
     bias = torch.randn(N, generator=g)

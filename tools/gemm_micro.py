@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the three large LSTM contractions at BASELINE size (B=64: M = 19264 rows)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from voicesplit_amd import ops  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    M, H4, K8, KE = 64 * 301, 1600, 4808, 5064
+    feat = torch.randn(M, K8, device=dev)
+    w = torch.randn(2 * H4, KE, device=dev) * 0.01
+    dxg = torch.randn(M, 2 * H4, device=dev) * 1e-3
+    res = {}
+    cases = {
+        "xg = feat @ W_ih^T (NT, N=3200)": lambda math: ops.gemm(feat, w, M, 2 * H4, K8, 0, 0, math=math),
+        "dfeat = dxg_d @ W_ih (NN, K=1600)": lambda math: ops.gemm(dxg, w, M, K8, H4, 0, 1, math=math),
+        "dW_ih = dxg_d^T @ feat (TN, K=19264)": lambda math: ops.gemm(dxg, feat, H4, K8, M, 1, 1, math=math),
+    }
+    flops = {"xg": 2.0 * M * 2 * H4 * K8, "dfeat": 2.0 * M * K8 * H4, "dW_ih": 2.0 * H4 * K8 * M}
+    for name, fn in cases.items():
+        for math in ("fp32", "f16x3"):
+            fn(math)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn(math)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            res[f"{name} [{math}]"] = {"ms": round(ms, 3), "tflops": round(flops[name.split()[0]] / ms / 1e9, 1)}
+    print(json.dumps(res, indent=1), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,7 @@ class VsWsLayout(Structure):
         ("dvbias", c_size_t), ("xg", c_size_t), ("lstm_out", c_size_t), ("fc1_out", c_size_t),
         ("conv_packed", c_size_t * 6), ("bn_scale", c_size_t), ("bn_shift", c_size_t),
         ("bn_stats", c_size_t), ("lstm_packed", c_size_t), ("lstm_state", c_size_t), ("conv_scales", c_size_t),
+        ("gemm_scales", c_size_t),
     ]
 
 
@@ -71,7 +72,7 @@ class VsTapeLayout(Structure):
         ("dvbias", c_size_t), ("conv_packed", c_size_t * 6), ("pack_tmp", c_size_t), ("lstm_packed", c_size_t),
         ("lstm_packed_t", c_size_t), ("lstm_state", c_size_t), ("lstm_bwd_state", c_size_t), ("consts", c_size_t),
         ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
-        ("partials", c_size_t), ("conv_scales", c_size_t),
+        ("partials", c_size_t), ("conv_scales", c_size_t), ("gemm_scales", c_size_t),
     ]
 
 
@@ -121,6 +122,8 @@ SIGNATURES = {
     "vs_conv_first_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vs_gemm": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vs_gemm_f16x3": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,
+                              c_int, c_int, c_int, c_int, _P, _P]),
     "vs_bilstm_recurrent_train": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vs_lstm_packed_t_floats": (c_size_t, [c_int]),
     "vs_lstm_bwd_state_floats": (c_size_t, [c_int, c_int]),

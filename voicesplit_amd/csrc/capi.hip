@@ -82,6 +82,7 @@ int layout(const vs_dims* d, vs_ws_layout* L) {
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
   L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
   L->conv_scales = take(8 * VS_SCALE_SLOT_FLOATS * 4);
+  L->gemm_scales = take(16 * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -117,6 +118,22 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
   }
   if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(packed), KT, KF, transpose_flip, stream)) return rc;
   return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
+}
+
+int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
+                            float* xg, int M, const float* rowbias, int T, float* gs, hipStream_t stream) {
+  if (math == VS_MATH_F16X3) {
+    unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
+    if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
+    VS_CHECK_HIP(hipMemsetAsync(amax + 1, 0, sizeof(unsigned), stream));
+    if (int rc = vs_absmax_accum_impl(w_ih0, (long long)4 * H * KE, amax + 1, stream)) return rc;
+    if (int rc = vs_absmax_accum_impl(w_ih1, (long long)4 * H * KE, amax + 1, stream)) return rc;
+    if (int rc = vs_scale_from_absmax_impl(amax + 1, 1, gs + 2, stream)) return rc;
+    return vs_gemm_f16x3_impl(0, 0, feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T,
+                              nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, gs + 2, stream);
+  }
+  return vs_gemm_nt2_impl(feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T, 0,
+                          VS_ACT_NONE, stream);
 }
 
 extern "C" {
@@ -347,8 +364,8 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
                                  p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
   }
   // both directions in one launch (N = 8H): twice the workgroups, half the tail quantisation
-  if (int rc = vs_gemm_nt2_impl(feat, K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
-                                nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
+  if (int rc = vs_lstm_input_gemm_impl(d->math, feat, K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
+                                       at<float>(ws, L.gemm_scales), stream)) return rc;
   }
   float* packed = at<float>(ws, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;

@@ -371,6 +371,16 @@ int vs_scale_from_absmax_impl(const unsigned* amax, int n, float* scale2, hipStr
   return 0;
 }
 
+// folds max|x| of x[0..n) into *amax (not reset: several tensors can share one scale)
+int vs_absmax_accum_impl(const float* x, long long n, unsigned* amax, hipStream_t stream) {
+  VS_REQUIRE(n > 0, "absmax: n=%lld", n);
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: tensor must be 16-byte aligned");
+  const long long nb = ((n >> 2) + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb < 2048 ? (nb > 0 ? nb : 1) : 2048)), dim3(256), 0, stream, x, n, amax);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 // scale2 <- {s, 1/s} for the tensor x[0..n): s = the power of two that maps max|x| into [2^9, 2^10)
 // (one extra pass over x; the orchestration avoids it by having the producer of x track the max)
 int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, float* scale2, hipStream_t stream) {

@@ -66,7 +66,7 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 }
 
 template <int LA, int LB, bool VEC>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 3)
 void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float sA[LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float sW[LDS_FLOATS];

@@ -69,6 +69,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   part = max3(part, (size_t)kSplitK * 4 * H * H, 0);
   L->partials = take(part * 4);
   L->conv_scales = take(16 * VS_SCALE_SLOT_FLOATS * 4);
+  L->gemm_scales = take(32 * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -187,8 +188,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
                                    p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
     }
-    if (int rc = vs_gemm_nt2_impl(at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], 4 * H, KE, xg, 8 * H, B * T, 8 * H, K,
-                                  nullptr, nullptr, dvbias, 8 * H, T, 0, VS_ACT_NONE, stream)) return rc;
+    if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
+                                         at<float>(tape, L.gemm_scales), stream)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
@@ -278,13 +279,25 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
   if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
   if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
+  // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
+  // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
+  float* gsc = at<float>(tape, L.gemm_scales);
+  const bool f16g = d->math == VS_MATH_F16X3;
+  if (f16g) {
+    if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
+  }
   for (int dir = 0; dir < 2; ++dir) {
     VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
     VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
     const float* dxg_d = dxg + (size_t)dir * 4 * H;
     // dW_ih[:, :8F] = dxg_d^T @ feat
-    if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    if (f16g) {
+      if (int rc = vs_gemm_f16x3_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, stream)) return rc;
+    } else {
+      if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
+                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    }
     // dW_ih[:, 8F:] = (sum_t dxg_d)^T @ dvec    (the repeated d-vector columns, model.py:77-81)
     if (int rc = vs_gemm_general_impl(1, 1, dsum + (size_t)dir * 4 * H, 8 * H, dvec, nullptr, 0x7fffffff, E, g->w_ih[dir] + K8, KE,
                                       4 * H, E, B, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
@@ -293,8 +306,13 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                       4 * H, H, M, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0,
                                       dir ? 1 : -1, T, kSplitK, part, stream)) return rc;
     // dfeat (+)= dxg_d @ W_ih[:, :8F]
-    if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+    if (f16g) {
+      if (int rc = vs_gemm_f16x3_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, gsc + 8, gsc + 2, stream)) return rc;
+    } else {
+      if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
+                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+    }
     if (g->dvec) {
       if (int rc = vs_gemm_general_impl(0, 1, dsum + (size_t)dir * 4 * H, 8 * H, p->w_ih[dir] + K8, nullptr, 0x7fffffff, KE, g->dvec, E,
                                         B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
@@ -409,6 +427,19 @@ int vs_gemm(int layout_a, int layout_w, const float* A, int lda, const float* W,
   VS_REQUIRE(A && W && C, "gemm: NULL argument");
   return vs_gemm_general_impl(layout_a, layout_w, A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1,
                               gate, ldg, a_relu, w_relu, act, accumulate, w_shift, w_group, splits, partials, (hipStream_t)stream);
+}
+
+int vs_gemm_f16x3(int layout_a, int layout_w, const float* A, int lda, const float* W, int ldw, float* C, int ldc,
+                  int M, int N, int K, const float* bias, const float* gate, int ldg, int a_relu, int w_relu, int act,
+                  int accumulate, float* scratch8, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VS_REQUIRE(A && W && C && scratch8, "gemm_f16x3: NULL argument");
+  unsigned* amax = reinterpret_cast<unsigned*>(scratch8 + 4);
+  // the operands are dense [rows][ld] buffers here: scale over the whole buffers
+  if (int rc = vs_pow2_scale_impl(A, (long long)(layout_a ? K : M) * lda, amax, scratch8, stream)) return rc;
+  if (int rc = vs_pow2_scale_impl(W, (long long)(layout_w ? K : N) * ldw, amax + 1, scratch8 + 2, stream)) return rc;
+  return vs_gemm_f16x3_impl(layout_a, layout_w, A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias, nullptr, nullptr, 0, 1,
+                            gate, ldg, a_relu, w_relu, act, accumulate, scratch8, scratch8 + 2, stream);
 }
 
 int vs_bilstm_recurrent_train(const float* xg, const float* packed_whh, float* state, float* out, float* gates_save,

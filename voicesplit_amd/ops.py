@@ -42,13 +42,15 @@ def _stream():
 
 
 MATH_CODES = {"fp32": _lib.MATH_FP32, "f16x3": _lib.MATH_F16X3}
-_DEFAULT_MATH = os.environ.get("VOICESPLIT_CONV_MATH", "fp32")
+_DEFAULT_MATH = os.environ.get("VOICESPLIT_CONV_MATH", "f16x3")
 
 
 def set_conv_math(name: str):
-    """Arithmetic of the 64->64 conv layers (forward and data gradient): "fp32" = f32 matrix cores
-    (bitwise an fmaf chain); "f16x3" = split-f16 products on the f16 matrix cores, fp32-class
-    accuracy at 3/16 of the matrix-pipe time (csrc/conv_f16x3.hip)."""
+    """Arithmetic of the dense contractions (64->64 convs forward / data / weight gradient, LSTM
+    input GEMMs): "f16x3" (default) = fp32 operands split into two f16 halves, three products on
+    the f16 matrix cores, fp32 accumulate -- fp32-class accuracy (same parity tolerances) at 3/16
+    of the matrix-pipe time (csrc/conv_f16x3.hip); "fp32" = the f32 matrix cores, bitwise an fmaf
+    chain.  Also selectable with VOICESPLIT_CONV_MATH."""
     global _DEFAULT_MATH
     if name not in MATH_CODES:
         raise ValueError(f"conv math must be one of {sorted(MATH_CODES)}")
@@ -470,12 +472,19 @@ def conv_first_wgrad(dz1, x):
 
 
 def gemm(A, W, M: int, N: int, K: int, layout_a: int = 0, layout_w: int = 0, bias=None, gate=None,
-         a_relu=False, w_relu=False, act="none", out=None, accumulate=False, w_shift=0, w_group=0, splits=1):
+         a_relu=False, w_relu=False, act="none", out=None, accumulate=False, w_shift=0, w_group=0, splits=1,
+         math: str = "fp32"):
     """General GEMM (see vs_gemm in the header); A/W are 2-D row-major views with their own ld."""
     lib = _lib.load()
     _dev_check(A, "A")
     _dev_check(W, "W")
     C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if math == "f16x3":
+        scratch = torch.zeros(8, dtype=torch.float32, device=A.device)
+        check(lib.vs_gemm_f16x3(layout_a, layout_w, _p(A), A.shape[1], _p(W), W.shape[1], _p(C), C.shape[1], M, N, K,
+                                _p(bias), _p(gate), gate.shape[1] if gate is not None else 0, int(a_relu), int(w_relu),
+                                ACT_CODES[act], int(accumulate), _p(scratch), _stream()), "vs_gemm_f16x3")
+        return C
     part = torch.empty(splits * M * N, dtype=torch.float32, device=A.device) if splits > 1 else None
     check(lib.vs_gemm(layout_a, layout_w, _p(A), A.shape[1], _p(W), W.shape[1], _p(C), C.shape[1], M, N, K,
                       _p(bias), _p(gate), gate.shape[1] if gate is not None else 0, int(a_relu), int(w_relu),
