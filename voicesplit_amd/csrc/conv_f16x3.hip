@@ -408,7 +408,10 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
                              int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64_f16x3: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
-  const bool p2 = tile_rows(T, dil, 8) <= tile_rows(T, dil, 4);
+  // 8-row tiles (P = 2) amortise the KT-1 halo rows and the weight staging over twice the MFMAs
+  // (measured 6.6 vs 7.45 ms per layer at equal padding); 4-row tiles only win when they avoid
+  // more than ~12 % of padded rows (short residue classes: dil = 16 at T = 301).
+  const bool p2 = tile_rows(T, dil, 8) * 100 <= tile_rows(T, dil, 4) * 112;
   if (KT == 7 && KF == 1) {
     return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
               : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
