@@ -6,9 +6,9 @@
 Workload (BASELINE.json metric "utterances/sec (3 s clips, B=64) fwd+bwd"): B=64 synthetic
 [64,301,601] spectrograms + 256-d d-vectors per GPU, fp32, random-init weights of the reference
 architecture, batch-statistics BatchNorm (model.train(), train.py:84).  A "step" is what one
-iteration of train.py:85-111 does with the model: forward (with the tape), backward from a
-fixed upstream gradient d(loss)/d(mask) (the audio-domain loss itself sits outside the hot path),
-the gradient exchange (one flat-bucket all-reduce, a no-op at N=1) and the Adam update.  Inputs
+iteration of train.py:85-111 does: forward (with the tape), the reference's SI-SNR loss through a
+GPU iSTFT (train.py:95-108, vs_sisnr_loss; --loss fixed replaces it by a fixed upstream gradient),
+backward, the gradient exchange (one flat-bucket all-reduce, a no-op at N=1) and the Adam update.  Inputs
 are resident in HBM before the timed region.  --mode forward times BASELINE configs[1]
 (forward only, eval-mode BatchNorm) instead.
 N>1 (launched by torch.distributed.run, one rank per GPU): data parallel, 64 utterances per rank
@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
     ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3"],
                     help="arithmetic of the 64->64 conv layers (default: the library default)")
+    ap.add_argument("--loss", default="sisnr", choices=["sisnr", "fixed"],
+                    help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,8 +162,14 @@ def main():
     spec = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)      # resident in HBM before timing
     dvec = torch.randn(B, EMB, generator=g)
     dvec = (dvec / dvec.norm(dim=1, keepdim=True)).to(dev)
-    # d(loss)/d(mask) of a mean-over-batch loss; stands in for train.py:95-108 (mask -> iSTFT -> SI-SNR)
+    # the rest of a training batch (train.py:85-92): target spectrogram, mixture phase, lengths
+    target = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)
+    phase = ((torch.rand(B, T_FRAMES, N_FREQ, generator=g) - 0.5) * 6.2831853).to(dev)
+    seq_len = torch.full((B,), 160 * (T_FRAMES - 1), dtype=torch.int32, device=dev)
+    audio_cfg = {"n_fft": 1200, "hop_length": 160, "win_length": 400, "min_level_db": -100.0, "ref_level_db": 20.0}
+    # --loss fixed: a fixed d(loss)/d(mask) instead of the loss head
     dmask = (torch.randn(B, T_FRAMES, N_FREQ, generator=g) / B).to(dev)
+    from voicesplit_amd import losses
 
     if train:
         bucket = GradientBucket(model.parameters()).attach()
@@ -170,7 +178,10 @@ def main():
         def step():
             bucket.zero()
             mask = model(spec, dvec)
-            mask.backward(dmask)
+            if args.loss == "sisnr":                                 # train.py:95-110
+                losses.sisnr_loss(mask, spec, target, phase, seq_len, audio_cfg).backward()
+            else:
+                mask.backward(dmask)
             bucket.all_reduce(world)                                 # the one exchange step
             opt.step()
             return mask
@@ -249,8 +260,9 @@ def main():
             "dtype": "fp32" if conv_math == "fp32" else "fp32 (64->64 convs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
-                                    "training step = forward (batch-stat BN) + backward + gradient all-reduce + Adam, "
-                                    "fixed upstream gradient on the mask, random-init weights") if train else
+                                    "training step = forward (batch-stat BN) + "
+                                    + ("SI-SNR loss through the GPU iSTFT (train.py:95-108)" if args.loss == "sisnr" else "fixed upstream gradient on the mask")
+                                    + " + backward + gradient all-reduce + Adam, random-init weights") if train else
                                    (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
                                     f"{args.model} forward-only, eval BN, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "frames": T_FRAMES, "num_freq": N_FREQ,

@@ -305,6 +305,31 @@ int vs_sigmoid_bwd(const float* dmask, const float* mask, float* dlogits, long l
 /* out[g][n] = sum over the g-th block of `rows` rows of X [groups*rows][ld] */
 int vs_colsum(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, void* stream);
 
+/* =============================================================================================
+ * The caller side of the mask during training: train.py:95-108
+ *   output = mixed*mask -> ap.torch_inv_spectrogram(output, phase)   utils/audio_processor.py:498-509
+ *   loss   = SiSNR_With_Pit()(wav, target_wav, seq_len)              utils/generic_utils.py:417-474
+ * in one call, together with d(loss)/d(mask).  The iSTFT runs as a GEMM against the windowed inverse
+ * real-DFT basis + a gather-form overlap-add; the reference's quirks are reproduced (complex
+ * spectrum = mag*exp(cos phi) + i*mag*exp(sin phi); hann(win, periodic=False) window; centre
+ * trimming; means divided by seq_len; eps 1e-16; loss = 20 - mean SI-SNR).
+ * ============================================================================================= */
+typedef struct vs_loss_dims {
+  int B, T, F;               /* spectrogram [B][T][F], F = n_fft/2 + 1                         */
+  int n_fft, hop, win;       /* config.audio.voicefilter: 1200, 160, 400                        */
+  float min_level_db;        /* -100  (denormalisation, utils/audio_processor.py:501-502)       */
+  float ref_level_db;        /*   20                                                            */
+} vs_loss_dims;
+
+size_t vs_sisnr_workspace_bytes(const vs_loss_dims* dims);
+/* mixed, mask, target, phase: [B][T][F] fp32 (target = normalised target spectrogram, phase = the
+ * mixture's phase, used for both waveforms as train.py:99-100 does); seq_len: [B] int32 sample
+ * counts or NULL (= hop*(T-1)); loss: one device float; dmask [B][T][F] = d(loss)/d(mask) or NULL;
+ * est_wav [B][hop*(T-1)] = the estimated waveform or NULL. */
+int vs_sisnr_loss(const vs_loss_dims* dims, const float* mixed, const float* mask, const float* target,
+                  const float* phase, const int* seq_len, void* workspace, size_t workspace_bytes,
+                  float* loss, float* dmask, float* est_wav, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,8 +171,29 @@ def main_grads():
         print(f"{name}: {len(list(model.parameters()))} gradients -> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def main_loss():
+    """Pins oracle/reference_loss.sisnr_with_pit to the upstream SiSNR_With_Pit
+    (utils/generic_utils.py:416-474): seeded waveforms in, loss and d(loss)/d(estimate) out."""
+    _vs, _vf, _mish, load_config, _ad = import_reference()
+    SiSNR_With_Pit = load_config.__globals__["SiSNR_With_Pit"]     # utils/generic_utils.py module namespace
+    g = torch.Generator().manual_seed(99)
+    B, T = 4, 2000
+    est = torch.randn(B, 1, T, generator=g)
+    src = 0.6 * est + 0.8 * torch.randn(B, 1, T, generator=g) + 0.05
+    lens = torch.tensor([2000, 1500, 1999, 777])
+    e = est.clone().requires_grad_(True)
+    loss = SiSNR_With_Pit()(e * 1.0, src.clone(), lens)      # the upstream forward masks its input in place
+    loss.backward()
+    path = os.path.join(GOLDEN_DIR, "sisnr_loss.npz")
+    np.savez(path, est=est.numpy(), src=src.numpy(), lens=lens.numpy(), loss=np.array(loss.item()), grad=e.grad.numpy(),
+             torch_version=np.array(torch.__version__))
+    print(f"sisnr_loss: loss {loss.item():.6f} -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if "--grads" in sys.argv:
+    if "--loss" in sys.argv:
+        main_loss()
+    elif "--grads" in sys.argv:
         main_grads()
     else:
         main()

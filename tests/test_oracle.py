@@ -171,3 +171,53 @@ def test_mish_gradient_closed_form():
     t = n / (n + 2)
     closed = torch.where(xd > 20, torch.ones_like(xd), t + xd * (2 / (n + 2)) * (1 + t) * (u / (1 + u)))
     assert (closed - x.grad).abs().max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# loss-side oracle (oracle/reference_loss.py)
+# ---------------------------------------------------------------------------------------------
+def test_sisnr_oracle_reproduces_upstream_class():
+    import os
+    from conftest import GOLDEN_DIR
+    from oracle import reference_loss as RL
+    z = np.load(os.path.join(GOLDEN_DIR, "sisnr_loss.npz"))
+    est = torch.from_numpy(z["est"]).requires_grad_(True)
+    loss = RL.sisnr_with_pit(est, torch.from_numpy(z["src"]), torch.from_numpy(z["lens"]))
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    assert np.abs(est.grad.numpy() - z["grad"]).max() <= 1e-6 * np.abs(z["grad"]).max()
+
+
+def test_istft_restatement_is_a_windowed_inverse_dft():
+    """torch_spec2wav's iSTFT == (windowed inverse real-DFT basis GEMM + overlap-add / envelope):
+    the formulation the HIP kernels use, checked here in fp64 on the CPU."""
+    import math
+    from oracle import reference_loss as RL
+    g = torch.Generator().manual_seed(4)
+    B, T, F, n_fft, hop, win = 2, 7, 21, 40, 8, 16
+    spec = torch.rand(B, T, F, generator=g, dtype=torch.float64)
+    phase = (torch.rand(B, T, F, generator=g, dtype=torch.float64) - 0.5) * 6
+    wav = RL.torch_spec2wav(spec, phase, n_fft, hop, win)
+    S = hop * (T - 1)
+    assert wav.shape == (B, S)
+    j = torch.arange(win, dtype=torch.float64)
+    w = 0.5 - 0.5 * torch.cos(2 * math.pi * j / (win - 1))
+    n = (n_fft - win) // 2 + j
+    k = torch.arange(F, dtype=torch.float64)
+    c = torch.full((F,), 2.0, dtype=torch.float64)
+    c[0] = 1.0
+    c[-1] = 1.0
+    ang = 2 * math.pi * torch.outer(n, k) / n_fft
+    basis = torch.cat([torch.cos(ang) * c, -torch.sin(ang) * c], dim=1) / n_fft * w[:, None]      # [win][2F]
+    mag = torch.pow(10.0, ((spec.clamp(0, 1) - 1) * 100 + 20) * 0.05)
+    reim = torch.cat([mag * torch.exp(torch.cos(phase)), mag * torch.exp(torch.sin(phase))], dim=2)
+    frames = reim @ basis.t()                                                                          # [B][T][win]
+    out = torch.zeros(B, S, dtype=torch.float64)
+    env = torch.zeros(S, dtype=torch.float64)
+    for t in range(T):
+        for jj in range(win):
+            sp = hop * t - win // 2 + jj
+            if 0 <= sp < S:
+                out[:, sp] += frames[:, t, jj]
+                env[sp] += w[jj] ** 2
+    assert (out / env - wav).abs().max() < 1e-12

@@ -49,6 +49,11 @@ class VsWsLayout(Structure):
     ]
 
 
+class VsLossDims(Structure):
+    _fields_ = [("B", c_int), ("T", c_int), ("F", c_int), ("n_fft", c_int), ("hop", c_int), ("win", c_int),
+                ("min_level_db", c_float), ("ref_level_db", c_float)]
+
+
 class VsConvLayerGrad(Structure):
     _fields_ = [(n, c_void_p) for n in ("weight", "bias", "bn_weight", "bn_bias")]
 
@@ -129,6 +134,8 @@ SIGNATURES = {
     "vs_lstm_bwd_state_floats": (c_size_t, [c_int, c_int]),
     "vs_lstm_pack_t": (c_int, [_P, _P, _P, c_int, _P]),
     "vs_bilstm_recurrent_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_sisnr_workspace_bytes": (c_size_t, [POINTER(VsLossDims)]),
+    "vs_sisnr_loss": (c_int, [POINTER(VsLossDims), _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P]),
     "vs_sigmoid_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),
     "vs_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
 }

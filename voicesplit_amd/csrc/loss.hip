@@ -1,0 +1,335 @@
+// The caller side of the mask during training (train.py:95-108):
+//   output = mixed * mask                                            train.py:95
+//   wav    = ap.torch_inv_spectrogram(output, spec_phase)            utils/audio_processor.py:498-509
+//   loss   = SiSNR_With_Pit()(wav, target_wav, seq_len)              utils/generic_utils.py:417-474
+// computed on the GPU together with d(loss)/d(mask), so that the training step needs no torchaudio
+// (torchaudio.functional.istft, which the reference calls, no longer exists) and no autograd graph
+// over ~1 GB of waveform-domain intermediates.
+//
+// The reference's inverse spectrogram, quirks included:
+//   S   = (clamp(spec,0,1) - 1) * (-min_level_db) + ref_level_db;   mag = 10^(S/20)
+//   re  = mag * exp(cos(phase)),  im = mag * exp(sin(phase))         (":507-509" multiplies by
+//         torch.exp of the stacked [cos, sin] -- not mag*cos, mag*sin; reproduced as is)
+//   wav = istft(re + i*im, n_fft, hop, win, hann(win, periodic=False), center=True)
+// MI355X formulation: the window is `win` <= n_fft samples wide and centred in the frame, so only
+// `win` of the n_fft time samples of every frame's inverse FFT survive the windowing.  The inverse
+// real FFT restricted to those samples, times the window, is a dense [2*(n_fft/2+1)] x [win] matrix:
+// the iSTFT is ONE GEMM on the matrix cores (19264 x 1202 x 400 at B=64) followed by a gather-form
+// overlap-add (every output sample sums its <= ceil(win/hop) frames and divides by the window
+// envelope).  The backward pass is the transposed GEMM and the same gather, and the SI-SNR (one
+// source: PIT is the identity) reduces to six per-utterance moments in fp64.
+#include <math.h>
+
+#include "../../include/voicesplit_hip.h"
+#include "vs_internal.h"
+
+namespace {
+
+constexpr float kLn10Over20 = 0.11512925464970229f;
+
+struct LossShape {
+  int B, T, F, n_fft, hop, win, S;   // S = hop*(T-1) samples per utterance
+  int K, ldk;                        // K = 2F (re | im), ldk = K rounded up to 4
+  float min_level_db, ref_level_db;
+};
+
+__device__ __forceinline__ float hann_np(int j, int win) {   // torch.hamming_window(win, periodic=False, 0.5, 0.5)
+  return win > 1 ? 0.5f - 0.5f * cospif(2.0f * (float)j / (float)(win - 1)) : 1.0f;
+}
+
+// basis[j][k]: contribution of spectrum entry k (k < F: Re_k, else Im_{k-F}) to windowed sample j
+// of a frame (time index n = (n_fft-win)/2 + j): onesided irfft weights c_k/n_fft, c = 1 for DC and
+// Nyquist, 2 otherwise.
+__global__ void istft_basis_kernel(float* __restrict__ basis, LossShape s) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= s.win * s.ldk) return;
+  const int j = idx / s.ldk, k = idx - j * s.ldk;
+  float v = 0.f;
+  if (k < s.K) {
+    const int kk = k < s.F ? k : k - s.F;
+    const int n = (s.n_fft - s.win) / 2 + j;
+    const int r = (int)(((long long)kk * n) % s.n_fft);          // exact angle reduction
+    float sn, cs;
+    sincospif(2.0f * (float)r / (float)s.n_fft, &sn, &cs);
+    const float c = (kk == 0 || 2 * kk == s.n_fft) ? 1.0f : 2.0f;
+    v = (k < s.F ? cs : -sn) * c / (float)s.n_fft * hann_np(j, s.win);
+  }
+  basis[idx] = v;
+}
+
+// window envelope after centring: env[s'] = sum over frames of win^2 at that sample
+__global__ void istft_envelope_kernel(float* __restrict__ env, LossShape s) {
+  const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sp >= s.S) return;
+  const int off = s.win / 2;                 // sample sp sits at frame-local j = sp - hop*t + off
+  float e = 0.f;
+  int t_hi = (sp + off) / s.hop;
+  if (t_hi > s.T - 1) t_hi = s.T - 1;
+  for (int t = t_hi; t >= 0; --t) {
+    const int j = sp - s.hop * t + off;
+    if (j >= s.win) break;
+    const float w = hann_np(j, s.win);
+    e = fmaf(w, w, e);
+  }
+  env[sp] = e;
+}
+
+// reim[m][k] = mag * exp(cos phi) (k < F) | mag * exp(sin phi) (k >= F);  v = a*b (mixed*mask) or a
+__global__ __launch_bounds__(256)
+void spec_to_reim_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ phase,
+                         float* __restrict__ reim, LossShape s) {
+  const long long n = (long long)s.B * s.T * s.F;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long m = i / s.F;
+    const int f = (int)(i - m * s.F);
+    float v = a[i];
+    if (b) v *= b[i];
+    const float db = (fminf(fmaxf(v, 0.f), 1.f) - 1.f) * (-s.min_level_db) + s.ref_level_db;
+    const float mag = expf(db * kLn10Over20);
+    float sn, cs;
+    sincosf(phase[i], &sn, &cs);
+    reim[m * s.ldk + f] = mag * expf(cs);
+    reim[m * s.ldk + s.F + f] = mag * expf(sn);
+  }
+}
+
+// wav[b][sp] = (sum_t frames[b*T+t][sp - hop*t + win/2]) / env[sp]
+__global__ __launch_bounds__(256)
+void overlap_add_kernel(const float* __restrict__ frames, const float* __restrict__ env, float* __restrict__ wav, LossShape s) {
+  const int sp = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (sp >= s.S) return;
+  const int off = s.win / 2;
+  int t_hi = (sp + off) / s.hop;
+  if (t_hi > s.T - 1) t_hi = s.T - 1;
+  float acc = 0.f;
+  for (int t = t_hi; t >= 0; --t) {
+    const int j = sp - s.hop * t + off;
+    if (j >= s.win) break;
+    acc += frames[((size_t)b * s.T + t) * s.win + j];
+  }
+  wav[(size_t)b * s.S + sp] = acc / env[sp];
+}
+
+// dframes[m][j] = dwav[b][sp] / env[sp],  sp = hop*t - win/2 + j  (0 outside the kept samples)
+__global__ __launch_bounds__(256)
+void overlap_add_bwd_kernel(const float* __restrict__ dwav, const float* __restrict__ env, float* __restrict__ dframes, LossShape s) {
+  const long long n = (long long)s.B * s.T * s.win;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long m = i / s.win;
+    const int j = (int)(i - m * s.win);
+    const int b = (int)(m / s.T), t = (int)(m - (long long)b * s.T);
+    const int sp = s.hop * t - s.win / 2 + j;
+    dframes[i] = (sp >= 0 && sp < s.S) ? dwav[(size_t)b * s.S + sp] / env[sp] : 0.f;
+  }
+}
+
+// six fp64 moments per utterance: sum_all s, and over the unmasked samples: n, e, s, e*s, e^2, s^2
+__global__ __launch_bounds__(256)
+void sisnr_moments_kernel(const float* __restrict__ est, const float* __restrict__ src, const int* __restrict__ len,
+                          double* __restrict__ mom /* [B][8] */, LossShape s) {
+  const int b = blockIdx.y;
+  const int L = len ? (len[b] < s.S ? (len[b] > 0 ? len[b] : 0) : s.S) : s.S;
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < s.S; i += gridDim.x * 256) {
+    const double e = est[(size_t)b * s.S + i], r = src[(size_t)b * s.S + i];
+    a[0] += r;
+    if (i < L) { a[1] += e; a[2] += r; a[3] += e * r; a[4] += e * e; a[5] += r * r; }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) atomicAdd(&mom[b * 8 + q], a[q]);
+  }
+}
+
+// per utterance: SI-SNR and the three coefficients of d(loss)/d(est[t]) = m_t*(cs*zs_t + ce*ze_t - c0);
+// utils/generic_utils.py:437-473 with C = 1 (one source: the permutation search is the identity)
+__global__ void sisnr_finalize_kernel(const double* __restrict__ mom, const int* __restrict__ len, float* __restrict__ coef /* [B][8] */,
+                                      float* __restrict__ loss, LossShape s) {
+  __shared__ double acc[64];
+  const int tid = threadIdx.x;
+  double part = 0.0;
+  const double eps = 1e-16;
+  for (int b = tid; b < s.B; b += 64) {
+    const double nlen = len ? (double)len[b] : (double)s.S;          // num_samples = source_lengths (as given)
+    const int Lm_i = len ? (len[b] < s.S ? (len[b] > 0 ? len[b] : 0) : s.S) : s.S;
+    const double Lm = Lm_i;                                          // samples the mask keeps
+    const double* m = mom + b * 8;
+    const double mu_s = m[0] / nlen, mu_e = m[1] / nlen;             // means over ALL samples / num_samples
+    const double Sze = m[1] - Lm * mu_e, Szs = m[2] - Lm * mu_s;
+    const double dot = m[3] - mu_s * m[1] - mu_e * m[2] + Lm * mu_e * mu_s;
+    const double Z = m[5] - 2 * mu_s * m[2] + Lm * mu_s * mu_s;      // sum zs^2
+    const double E = m[4] - 2 * mu_e * m[1] + Lm * mu_e * mu_e;      // sum ze^2
+    const double es = Z + eps;
+    const double P = dot * dot * Z / (es * es);
+    const double c = (es + eps) / (es * es);
+    const double N = E - c * dot * dot + eps;
+    const double snr = P / N;
+    part += 10.0 * log10(snr + eps);
+    // d l_b / d ze_t = k*( dP_t/N - P/N^2 * dN_t ),  dP_t = 2 dot Z/es^2 * zs_t,  dN_t = 2 ze_t - 2 c dot zs_t
+    const double k = 10.0 / (log(10.0) * (snr + eps)) * (-1.0 / s.B);      // loss = 20 - mean_b l_b
+    const double gs = k * (2 * dot * Z / (es * es) / N + P / (N * N) * 2 * c * dot);
+    const double ge = k * (-P / (N * N) * 2);
+    // ze_t = (e_t m_t - mu_e) m_t  ->  d/de_u = m_u ( g_u - sum_t m_t g_t / num_samples )
+    const double gsum = gs * Szs + ge * Sze;
+    float* o = coef + b * 8;
+    o[0] = (float)gs; o[1] = (float)ge; o[2] = (float)(gsum / nlen); o[3] = (float)mu_s; o[4] = (float)mu_e;
+    o[5] = (float)Lm_i;
+  }
+  acc[tid] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int i = 0; i < 64; ++i) t += acc[i];
+    *loss = (float)(20.0 - t / s.B);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void sisnr_grad_kernel(const float* __restrict__ est, const float* __restrict__ src, const float* __restrict__ coef,
+                       float* __restrict__ dwav, LossShape s) {
+  const int b = blockIdx.y;
+  const float gs = coef[b * 8], ge = coef[b * 8 + 1], g0 = coef[b * 8 + 2], mu_s = coef[b * 8 + 3], mu_e = coef[b * 8 + 4];
+  const int L = (int)coef[b * 8 + 5];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < s.S; i += gridDim.x * 256) {
+    float g = 0.f;
+    if (i < L) {
+      const float zs = src[(size_t)b * s.S + i] - mu_s, ze = est[(size_t)b * s.S + i] - mu_e;
+      g = fmaf(gs, zs, fmaf(ge, ze, -g0));
+    }
+    dwav[(size_t)b * s.S + i] = g;
+  }
+}
+
+// dmask[i] = mixed[i] * [0 <= v <= 1] * (-min_db) * ln10/20 * mag * (dre*e^{cos} + dim*e^{sin}),  v = mixed*mask
+__global__ __launch_bounds__(256)
+void reim_to_dmask_kernel(const float* __restrict__ mixed, const float* __restrict__ mask, const float* __restrict__ phase,
+                          const float* __restrict__ dreim, float* __restrict__ dmask, LossShape s) {
+  const long long n = (long long)s.B * s.T * s.F;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long m = i / s.F;
+    const int f = (int)(i - m * s.F);
+    const float x = mixed[i], v = x * mask[i];
+    float g = 0.f;
+    if (v >= 0.f && v <= 1.f) {
+      const float db = (v - 1.f) * (-s.min_level_db) + s.ref_level_db;
+      const float mag = expf(db * kLn10Over20);
+      float sn, cs;
+      sincosf(phase[i], &sn, &cs);
+      const float d = dreim[m * s.ldk + f] * expf(cs) + dreim[m * s.ldk + s.F + f] * expf(sn);
+      g = x * (-s.min_level_db) * kLn10Over20 * mag * d;
+    }
+    dmask[i] = g;
+  }
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct LossLayout { size_t basis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, total; };
+
+int make_shape(const vs_loss_dims* d, LossShape* s) {
+  VS_REQUIRE(d != nullptr, "loss dims is NULL");
+  VS_REQUIRE(d->B > 0 && d->T > 1 && d->F > 1 && d->hop > 0 && d->win > 0, "loss: bad dims B=%d T=%d F=%d hop=%d win=%d", d->B, d->T, d->F, d->hop, d->win);
+  VS_REQUIRE(d->n_fft == 2 * (d->F - 1), "loss: num_freq F=%d must be n_fft/2+1 (n_fft=%d)", d->F, d->n_fft);
+  VS_REQUIRE(d->win <= d->n_fft && d->hop <= d->win, "loss: need hop <= win <= n_fft");
+  VS_REQUIRE(d->B <= 65535, "loss: B too large");
+  s->B = d->B; s->T = d->T; s->F = d->F; s->n_fft = d->n_fft; s->hop = d->hop; s->win = d->win;
+  s->S = d->hop * (d->T - 1);
+  s->K = 2 * d->F;
+  s->ldk = (s->K + 3) & ~3;
+  s->min_level_db = d->min_level_db; s->ref_level_db = d->ref_level_db;
+  return 0;
+}
+
+void make_layout(const LossShape& s, LossLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  const size_t M = (size_t)s.B * s.T;
+  L->basis = take((size_t)s.win * s.ldk * 4);
+  L->env = take((size_t)s.S * 4);
+  L->reim_e = take(M * s.ldk * 4);       // later reused for d(reim)
+  L->reim_t = take(M * s.ldk * 4);
+  L->frames_e = take(M * s.win * 4);     // later reused for d(frames)
+  L->frames_t = take(M * s.win * 4);
+  L->wav_e = take((size_t)s.B * s.S * 4);
+  L->wav_t = take((size_t)s.B * s.S * 4);
+  L->dwav = take((size_t)s.B * s.S * 4);
+  L->mom = take((size_t)s.B * 8 * 8);
+  L->coef = take((size_t)s.B * 8 * 4);
+  L->total = off;
+}
+
+template <typename T>
+inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+}  // namespace
+
+extern "C" {
+
+size_t vs_sisnr_workspace_bytes(const vs_loss_dims* d) {
+  LossShape s;
+  if (make_shape(d, &s)) return 0;
+  LossLayout L;
+  make_layout(s, &L);
+  return L.total;
+}
+
+int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, const float* target, const float* phase,
+                  const int* seq_len, void* ws, size_t ws_bytes, float* loss, float* dmask, float* est_wav, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  LossShape s;
+  if (int rc = make_shape(d, &s)) return rc;
+  LossLayout L;
+  make_layout(s, &L);
+  VS_REQUIRE(mixed && mask && target && phase && loss, "sisnr_loss: NULL argument");
+  VS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && ws_bytes >= L.total, "sisnr_loss: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.total);
+  const int M = s.B * s.T;
+  const long long nspec = (long long)M * s.F;
+  const unsigned gspec = (unsigned)((nspec + 255) / 256 < 16384 ? (nspec + 255) / 256 : 16384);
+  float* basis = at<float>(ws, L.basis);
+  float* env = at<float>(ws, L.env);
+  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s);
+  hipLaunchKernelGGL(istft_envelope_kernel, dim3((s.S + 255) / 256), dim3(256), 0, stream, env, s);
+  // both spectrograms -> (re | im) rows -> windowed frames (one GEMM each) -> waveforms
+  float* reim[2] = {at<float>(ws, L.reim_e), at<float>(ws, L.reim_t)};
+  float* frames[2] = {at<float>(ws, L.frames_e), at<float>(ws, L.frames_t)};
+  float* wav[2] = {at<float>(ws, L.wav_e), at<float>(ws, L.wav_t)};
+  VS_CHECK_HIP(hipMemsetAsync(reim[0], 0, (size_t)M * s.ldk * 4 * 2, stream));      // the ld padding columns
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, mixed, mask, phase, reim[0], s);
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, target, (const float*)nullptr, phase, reim[1], s);
+  for (int q = 0; q < 2; ++q) {
+    if (int rc = vs_gemm_general_impl(0, 0, reim[q], s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames[q], s.win, M, s.win, s.K,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3((s.S + 255) / 256, s.B), dim3(256), 0, stream, frames[q], env, wav[q], s);
+  }
+  if (est_wav) VS_CHECK_HIP(hipMemcpyAsync(est_wav, wav[0], (size_t)s.B * s.S * 4, hipMemcpyDeviceToDevice, stream));
+  // SI-SNR
+  double* mom = at<double>(ws, L.mom);
+  float* coef = at<float>(ws, L.coef);
+  VS_CHECK_HIP(hipMemsetAsync(mom, 0, (size_t)s.B * 8 * 8, stream));
+  const int gx = (s.S + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(sisnr_moments_kernel, dim3(gx, s.B), dim3(256), 0, stream, wav[0], wav[1], seq_len, mom, s);
+  hipLaunchKernelGGL(sisnr_finalize_kernel, dim3(1), dim3(64), 0, stream, mom, seq_len, coef, loss, s);
+  if (dmask) {
+    float* dwav = at<float>(ws, L.dwav);
+    hipLaunchKernelGGL(sisnr_grad_kernel, dim3(gx, s.B), dim3(256), 0, stream, wav[0], wav[1], coef, dwav, s);
+    float* dframes = frames[0];
+    const long long nfr = (long long)M * s.win;
+    hipLaunchKernelGGL(overlap_add_bwd_kernel, dim3((unsigned)((nfr + 255) / 256 < 16384 ? (nfr + 255) / 256 : 16384)), dim3(256), 0, stream,
+                       dwav, env, dframes, s);
+    float* dreim = reim[0];
+    // d(reim)[M][K] = d(frames)[M][win] @ basis[win][K]
+    if (int rc = vs_gemm_general_impl(0, 1, dframes, s.win, basis, nullptr, 0x7fffffff, s.ldk, dreim, s.ldk, M, s.K, s.win,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+    hipLaunchKernelGGL(reim_to_dmask_kernel, dim3(gspec), dim3(256), 0, stream, mixed, mask, phase, dreim, dmask, s);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"
