@@ -137,3 +137,30 @@ def test_library_is_the_loaded_native_code():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libvoicesplit_hip.so" in maps
+
+
+def test_long_form_windows_match_per_window_calls():
+    """BASELINE configs[4]: a 30 s clip (3001 frames) cut into 10 independent 301-frame windows
+    and run as one batch gives exactly what the module gives window by window."""
+    import voicesplit_amd as V
+    from voicesplit_amd.streaming import plan_windows, separate_long
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, 0), 8.0)
+    m = V.VoiceSplit(V.default_config()).eval()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(9)
+    spec = torch.rand(3001, 601, generator=g).cuda()
+    dvec = R.synthetic_inputs(1, 301, dims_d, 9)[1][0].cuda()
+    mask = separate_long(m, spec, dvec, window=301, halo=0)
+    assert mask.shape == (3001, 601) and torch.isfinite(mask).all()
+    plan = plan_windows(3001, 301, 0)
+    assert len(plan) == 10
+    with torch.no_grad():
+        w3 = m(spec[903:1204][None].contiguous(), dvec[None])          # window 3 on its own
+    assert torch.equal(mask[903:1204], w3[0])
+    last = torch.zeros(1, 301, 601, device="cuda")
+    last[0, :292] = spec[2709:]
+    with torch.no_grad():
+        w9 = m(last, dvec[None])
+    assert torch.equal(mask[2709:], w9[0, :292])

@@ -640,9 +640,9 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
     __syncthreads();
     tile = advance(tile + 1);
     if (tile < tile_end) issue(tile);
-#pragma unroll
-    for (int kb = 0; kb < kNF / 16; ++kb) {
-      if (kb < nkb) {         // block-uniform
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+      {
         const u4 dh = *reinterpret_cast<const u4*>(&sDh[rowd + 8 * kb]);
         const u4 dl = *reinterpret_cast<const u4*>(&sDl[rowd + 8 * kb]);
         unsigned wh[6], wl[6];
@@ -658,31 +658,21 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
             wl[4] = c2[0]; wl[5] = c2[1];
           }
         }
-        // window of tap kf = halves kf .. kf+7 of the 12 read
-        u4 bh[KF], bl[KF];
-#pragma unroll
-        for (int kf = 0; kf < KF; ++kf) {
+        // window of tap kf = halves kf .. kf+7 of the 12 read (cut out right before use: few live registers)
+        auto tap = [&](const unsigned (&w)[6], int kf) {
           const int m = kf >> 1;
+          u4 r;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (kf & 1) {
-              bh[kf][q] = __builtin_amdgcn_alignbit(wh[m + q + 1], wh[m + q], 16);
-              bl[kf][q] = __builtin_amdgcn_alignbit(wl[m + q + 1], wl[m + q], 16);
-            } else {
-              bh[kf][q] = wh[m + q];
-              bl[kf][q] = wl[m + q];
-            }
-          }
-        }
+          for (int q = 0; q < 4; ++q) r[q] = (kf & 1) ? __builtin_amdgcn_alignbit(w[m + q + 1], w[m + q], 16) : w[m + q];
+          return __builtin_bit_cast(h8, r);
+        };
         const h8 dhv = __builtin_bit_cast(h8, dh), dlv = __builtin_bit_cast(h8, dl);
 #pragma unroll
         for (int term = 0; term < 3; ++term) {
 #pragma unroll
-          for (int kf = 0; kf < KF; ++kf) {
-            const h8 av = term == 0 ? dlv : dhv;
-            const h8 bv = __builtin_bit_cast(h8, term == 1 ? bl[kf] : bh[kf]);
-            acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[kf], 0, 0, 0);
-          }
+          for (int kf = 0; kf < KF; ++kf)
+            acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? dlv : dhv, term == 1 ? tap(wl, kf) : tap(wh, kf),
+                                                             acc[kf], 0, 0, 0);
         }
       }
     }
