@@ -417,7 +417,7 @@ def test_training_step_semantics():
         ref_mask = m(xc, dc)                       # inference-path kernels, batch-stat BN
     rm1 = m.conv[2].running_mean.clone()
     mask = m(xc, dc)                               # tape path
-    assert torch.allclose(mask, ref_mask, rtol=0, atol=2e-6)
+    assert torch.allclose(mask, ref_mask, rtol=0, atol=1e-5)    # two ways of summing the batch statistics
     assert int(m.conv[2].num_batches_tracked) == 2
     assert not torch.equal(m.conv[2].running_mean, rm1)
     mask.sum().backward()
