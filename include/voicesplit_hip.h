@@ -330,6 +330,18 @@ int vs_sisnr_loss(const vs_loss_dims* dims, const float* mixed, const float* mas
                   const float* phase, const int* seq_len, void* workspace, size_t workspace_bytes,
                   float* loss, float* dmask, float* est_wav, void* stream);
 
+/* ---- audio front / back end of inference: what test.py does around the model ----
+ * wav [B][hop*(T-1)] -> spec [B][T][F] (normalised dB magnitude in [0,1]) and phase [B][T][F] (may be
+ * NULL): librosa.stft(n_fft, hop, win, hann, center, reflect) + amp_to_db + normalize, transposed to
+ * [time, freq]  (utils/audio_processor.py:469-476, 511-514, 537-544). */
+size_t vs_audio_workspace_bytes(const vs_loss_dims* dims);
+int vs_wav_to_spec(const vs_loss_dims* dims, const float* wav, float* spec, float* phase,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* (spec * mask), phase -> wav [B][hop*(T-1)]: denormalize + db_to_amp + mag*exp(i*phase) + librosa.istft
+ * (utils/audio_processor.py:478-491; est_mask*mixed_spec from utils/generic_utils.py:496).  mask may be NULL. */
+int vs_spec_to_wav(const vs_loss_dims* dims, const float* spec, const float* mask, const float* phase, float* wav,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,11 +31,17 @@ struct LossShape {
   int B, T, F, n_fft, hop, win, S;   // S = hop*(T-1) samples per utterance
   int K, ldk;                        // K = 2F (re | im), ldk = K rounded up to 4
   float min_level_db, ref_level_db;
+  int periodic;      // 0: hann(win, periodic=False) (torch_spec2wav :509); 1: librosa/scipy 'hann' (fftbins=True)
+  int true_phase;    // 0: mag*e^{cos}, mag*e^{sin} (torch_spec2wav :506-509); 1: mag*cos, mag*sin (spec2wav :478-481)
 };
 
-__device__ __forceinline__ float hann_np(int j, int win) {   // torch.hamming_window(win, periodic=False, 0.5, 0.5)
-  return win > 1 ? 0.5f - 0.5f * cospif(2.0f * (float)j / (float)(win - 1)) : 1.0f;
+// Hann window of the training loss (torch.hamming_window(win, periodic=False, 0.5, 0.5)) or of
+// librosa's stft/istft (scipy get_window('hann', win, fftbins=True))
+__device__ __forceinline__ float hann_w(int j, const LossShape& s) {
+  const int den = s.periodic ? s.win : s.win - 1;
+  return den > 0 ? 0.5f - 0.5f * cospif(2.0f * (float)j / (float)den) : 1.0f;
 }
+#define hann_np(j, win) hann_w(j, s)
 
 // basis[j][k]: contribution of spectrum entry k (k < F: Re_k, else Im_{k-F}) to windowed sample j
 // of a frame (time index n = (n_fft-win)/2 + j): onesided irfft weights c_k/n_fft, c = 1 for DC and
@@ -88,8 +94,54 @@ void spec_to_reim_kernel(const float* __restrict__ a, const float* __restrict__ 
     const float mag = expf(db * kLn10Over20);
     float sn, cs;
     sincosf(phase[i], &sn, &cs);
-    reim[m * s.ldk + f] = mag * expf(cs);
-    reim[m * s.ldk + s.F + f] = mag * expf(sn);
+    reim[m * s.ldk + f] = s.true_phase ? mag * cs : mag * expf(cs);
+    reim[m * s.ldk + s.F + f] = s.true_phase ? mag * sn : mag * expf(sn);
+  }
+}
+
+// ---- analysis side: wav -> frames -> (re | im) -> normalised dB magnitude + phase ---------------
+// frames[m][j] = w[j] * wav_reflect[b][hop*t - win/2 + j]     (librosa.stft: center=True, reflect padding;
+// only the win samples under the centred window matter)
+__global__ __launch_bounds__(256)
+void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, LossShape s) {
+  const long long n = (long long)s.B * s.T * s.win;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long m = i / s.win;
+    const int j = (int)(i - m * s.win);
+    const int b = (int)(m / s.T), t = (int)(m - (long long)b * s.T);
+    int idx = s.hop * t - s.win / 2 + j;
+    if (idx < 0) idx = -idx;
+    if (idx >= s.S) idx = 2 * (s.S - 1) - idx;
+    frames[i] = hann_w(j, s) * wav[(size_t)b * s.S + idx];
+  }
+}
+
+// fwd_basis[k][j]: Re_k = sum_j x_j cos(2 pi k n_j / N), Im_k = -sum_j x_j sin(...), n_j = (N-win)/2 + j
+__global__ void stft_basis_kernel(float* __restrict__ basis, LossShape s) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= s.K * s.win) return;
+  const int k = idx / s.win, j = idx - k * s.win;
+  const int kk = k < s.F ? k : k - s.F;
+  const int n = (s.n_fft - s.win) / 2 + j;
+  const int r = (int)(((long long)kk * n) % s.n_fft);
+  float sn, cs;
+  sincospif(2.0f * (float)r / (float)s.n_fft, &sn, &cs);
+  basis[idx] = k < s.F ? cs : -sn;
+}
+
+// spec = clip((20 log10(max(1e-5, |D|)) - ref) / -min_db, -1, 0) + 1;  phase = angle(D)
+// (wav2spec, utils/audio_processor.py:469-476 with amp_to_db :537-538 and normalize :543-544)
+__global__ __launch_bounds__(256)
+void reim_to_features_kernel(const float* __restrict__ reim, float* __restrict__ spec, float* __restrict__ phase, LossShape s) {
+  const long long n = (long long)s.B * s.T * s.F;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long m = i / s.F;
+    const int f = (int)(i - m * s.F);
+    const float re = reim[m * s.ldk + f], im = reim[m * s.ldk + s.F + f];
+    const float mag = sqrtf(re * re + im * im);
+    const float db = 20.0f * log10f(fmaxf(1e-5f, mag)) - s.ref_level_db;
+    spec[i] = fminf(fmaxf(db / (-s.min_level_db), -1.0f), 0.0f) + 1.0f;
+    if (phase) phase[i] = atan2f(im, re);
   }
 }
 
@@ -230,7 +282,7 @@ void reim_to_dmask_kernel(const float* __restrict__ mixed, const float* __restri
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
-struct LossLayout { size_t basis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, total; };
+struct LossLayout { size_t basis, fbasis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, total; };
 
 int make_shape(const vs_loss_dims* d, LossShape* s) {
   VS_REQUIRE(d != nullptr, "loss dims is NULL");
@@ -243,6 +295,7 @@ int make_shape(const vs_loss_dims* d, LossShape* s) {
   s->K = 2 * d->F;
   s->ldk = (s->K + 3) & ~3;
   s->min_level_db = d->min_level_db; s->ref_level_db = d->ref_level_db;
+  s->periodic = 0; s->true_phase = 0;
   return 0;
 }
 
@@ -251,6 +304,7 @@ void make_layout(const LossShape& s, LossLayout* L) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   const size_t M = (size_t)s.B * s.T;
   L->basis = take((size_t)s.win * s.ldk * 4);
+  L->fbasis = take((size_t)s.K * s.win * 4);     // analysis basis [K][win] (vs_wav_to_spec)
   L->env = take((size_t)s.S * 4);
   L->reim_e = take(M * s.ldk * 4);       // later reused for d(reim)
   L->reim_t = take(M * s.ldk * 4);
@@ -328,6 +382,69 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
                                       nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
     hipLaunchKernelGGL(reim_to_dmask_kernel, dim3(gspec), dim3(256), 0, stream, mixed, mask, phase, dreim, dmask, s);
   }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// audio front / back end of inference: test.py's loop around the model
+//   mixed_spec, mixed_phase = ap.get_spec_from_audio(wav)        utils/audio_processor.py:469-476
+//   est_wav = ap.inv_spectrogram(est_mask*mixed_spec, mixed_phase)    :478-491, generic_utils.py:496-504
+// both as one GEMM against a windowed DFT basis plus a gather (frames in / overlap-add out).
+// ---------------------------------------------------------------------------------------------
+size_t vs_audio_workspace_bytes(const vs_loss_dims* d) { return vs_sisnr_workspace_bytes(d); }
+
+int vs_wav_to_spec(const vs_loss_dims* d, const float* wav, float* spec, float* phase, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  LossShape s;
+  if (int rc = make_shape(d, &s)) return rc;
+  s.periodic = 1;
+  LossLayout L;
+  make_layout(s, &L);
+  VS_REQUIRE(wav && spec, "wav_to_spec: NULL argument");
+  VS_REQUIRE(s.S > s.n_fft / 2, "wav_to_spec: clip shorter than the reflect padding");
+  VS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && ws_bytes >= L.total, "wav_to_spec: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.total);
+  const int M = s.B * s.T;
+  float* frames = at<float>(ws, L.frames_e);
+  float* basis = at<float>(ws, L.fbasis);
+  float* reim = at<float>(ws, L.reim_e);
+  const long long nfr = (long long)M * s.win;
+  hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)((nfr + 255) / 256 < 16384 ? (nfr + 255) / 256 : 16384)), dim3(256), 0, stream, wav, frames, s);
+  hipLaunchKernelGGL(stft_basis_kernel, dim3((s.K * s.win + 255) / 256), dim3(256), 0, stream, basis, s);
+  if (int rc = vs_gemm_general_impl(0, 0, frames, s.win, basis, nullptr, 0x7fffffff, s.win, reim, s.ldk, M, s.K, s.win,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  const long long nspec = (long long)M * s.F;
+  hipLaunchKernelGGL(reim_to_features_kernel, dim3((unsigned)((nspec + 255) / 256 < 16384 ? (nspec + 255) / 256 : 16384)), dim3(256), 0, stream,
+                     reim, spec, phase, s);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_spec_to_wav(const vs_loss_dims* d, const float* spec, const float* mask, const float* phase, float* wav,
+                   void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  LossShape s;
+  if (int rc = make_shape(d, &s)) return rc;
+  s.periodic = 1;
+  s.true_phase = 1;
+  LossLayout L;
+  make_layout(s, &L);
+  VS_REQUIRE(spec && phase && wav, "spec_to_wav: NULL argument");
+  VS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && ws_bytes >= L.total, "spec_to_wav: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.total);
+  const int M = s.B * s.T;
+  const long long nspec = (long long)M * s.F;
+  const unsigned gspec = (unsigned)((nspec + 255) / 256 < 16384 ? (nspec + 255) / 256 : 16384);
+  float* basis = at<float>(ws, L.basis);
+  float* env = at<float>(ws, L.env);
+  float* reim = at<float>(ws, L.reim_e);
+  float* frames = at<float>(ws, L.frames_e);
+  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s);
+  hipLaunchKernelGGL(istft_envelope_kernel, dim3((s.S + 255) / 256), dim3(256), 0, stream, env, s);
+  VS_CHECK_HIP(hipMemsetAsync(reim, 0, (size_t)M * s.ldk * 4, stream));
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, spec, mask, phase, reim, s);
+  if (int rc = vs_gemm_general_impl(0, 0, reim, s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames, s.win, M, s.win, s.K,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  hipLaunchKernelGGL(overlap_add_kernel, dim3((s.S + 255) / 256, s.B), dim3(256), 0, stream, frames, env, wav, s);
   VS_LAUNCH_CHECK();
   return 0;
 }
