@@ -531,8 +531,6 @@ template <int KF>
 __global__ __launch_bounds__(256, 2)
 void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
   constexpr int PADF = KF / 2;
-  constexpr int NPA = (kNF + KF - 1 + 1) / 2;      // input pixel pairs per row: 34 (KF=5) / 32 (KF=1)
-  constexpr int NIA = (64 * NPA + 255) / 256;      // staging iterations for the input tile
   __shared__ __attribute__((aligned(16))) unsigned sDh[64 * kPW], sDl[64 * kPW], sAh[64 * kPW], sAl[64 * kPW];
 
   const int tid = threadIdx.x;
@@ -571,41 +569,53 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
     return tl;
   };
 
-  float sd[8][2], sa[NIA][2];
-  int nv_next = 0;
+  // staging: one 16-byte buffer load per 4 consecutive pixels of a channel row (rows are only
+  // 4-byte aligned, which raw buffer loads accept); pixels outside the row are zeroed afterwards
+  // (a neighbouring row's data, not an out-of-range address), which only edge tiles need
+  constexpr int NQA = (kNF + KF - 1 + 3) / 4;      // float4 groups per input row: 17 (KF=5) / 16 (KF=1)
+  constexpr int NIA4 = (64 * NQA + 255) / 256;     // staging iterations for the input tile
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 sd[4], sa[NIA4];
+  int nv_next = 0, f0_next = 0;
   auto issue = [&](int tl) {
     const int bt = tl / g.nseg;
     const int seg = tl - bt * g.nseg;
     const int b = bt / g.T;
     const int t = bt - b * g.T;
     const int f0 = seg * kNF;
+    f0_next = f0;
     nv_next = g.F - f0 < kNF ? g.F - f0 : kNF;
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.dz + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.in + (size_t)b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    const unsigned base_d = (unsigned)((t * g.F + f0) * 4);
+    const int base_a = ((t + off_t) * g.F + f0 - PADF) * 4;           // may be negative at the very first pixels
+    // a 16-byte group that straddles the start or the end of the utterance's slab is split into
+    // dwords (the hardware zeroes the whole out-of-range access, valid pixels included); only the
+    // first row of channel 0 and the last row of channel 63 can get there
+    const long long slab = 64ll * plane_bytes;
+    auto load16 = [&](__amdgpu_buffer_rsrc_t r, long long off, bool live) -> f4 {
+      if (!live || (off >= 0 && off + 16 <= slab))
+        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, live ? (unsigned)off : kOob, 0, 0));
+      f4 x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      const int ch = idx >> 5, pp = idx & 31;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int f = f0 + 2 * pp + e;
-        const unsigned v = f < g.F ? (unsigned)(ch * plane_bytes + (t * g.F + f) * 4) : kOob;
-        sd[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, v, 0, 0));
+      for (int e = 0; e < 4; ++e) {
+        const long long o = off + 4 * e;
+        x[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (o >= 0 && o < slab) ? (unsigned)o : kOob, 0, 0));
       }
+      return x;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
     }
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) {
+    for (int i = 0; i < NIA4; ++i) {
       const int idx = tid + 256 * i;
-      const int ch = idx / NPA, pp = idx - ch * NPA;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int f = f0 - PADF + 2 * pp + e;
-        const bool ok = idx < 64 * NPA && f >= 0 && f < g.F;
-        const unsigned v = ok ? (unsigned)(ch * plane_bytes + ((t + off_t) * g.F + f) * 4) : kOob;
-        sa[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, v, 0, 0));
-      }
+      const int ch = idx / NQA, q = idx - ch * NQA;
+      sa[i] = load16(ra, (long long)ch * plane_bytes + base_a + q * 16, idx < 64 * NQA);
     }
   };
 
@@ -617,23 +627,47 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
   if (tile < tile_end) issue(tile);
   while (tile < tile_end) {
     __syncthreads();          // every wave is done reading the previous tile
+    {
+      const int f0 = f0_next;
+      const bool edge = f0 < PADF || f0 + kNF + KF - 1 - PADF > g.F;     // block-uniform: some pixel of the window is off the row
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      unsigned hi, lo;
-      split_pair(sd[i][0] * s_dz, sd[i][1] * s_dz, hi, lo);
-      sDh[(idx >> 5) * kPW + (idx & 31)] = hi;
-      sDl[(idx >> 5) * kPW + (idx & 31)] = lo;
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx & 15;
+        f4 x = sd[i];
+        if (edge) {
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < 64 * NPA) {
-        const int ch = idx / NPA, pp = idx - ch * NPA;
-        unsigned hi, lo;
-        split_pair(sa[i][0] * s_in, sa[i][1] * s_in, hi, lo);
-        sAh[ch * kPW + pp] = hi;
-        sAl[ch * kPW + pp] = lo;
+          for (int e = 0; e < 4; ++e) x[e] = (f0 + 4 * q + e < g.F) ? x[e] : 0.f;
+        }
+        unsigned h0, l0, h1, l1;
+        split_pair(x[0] * s_dz, x[1] * s_dz, h0, l0);
+        split_pair(x[2] * s_dz, x[3] * s_dz, h1, l1);
+        u2v hv, lv;
+        hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+        *reinterpret_cast<u2v*>(&sDh[(idx >> 4) * kPW + 2 * q]) = hv;
+        *reinterpret_cast<u2v*>(&sDl[(idx >> 4) * kPW + 2 * q]) = lv;
+      }
+#pragma unroll
+      for (int i = 0; i < NIA4; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 64 * NQA) {
+          const int ch = idx / NQA, q = idx - ch * NQA;
+          f4 x = sa[i];
+          if (edge) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int f = f0 - PADF + 4 * q + e;
+              x[e] = (f >= 0 && f < g.F) ? x[e] : 0.f;
+            }
+          }
+          unsigned h0, l0, h1, l1;
+          split_pair(x[0] * s_in, x[1] * s_in, h0, l0);
+          split_pair(x[2] * s_in, x[3] * s_in, h1, l1);
+          u2v hv, lv;
+          hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+          *reinterpret_cast<u2v*>(&sAh[ch * kPW + 2 * q]) = hv;
+          *reinterpret_cast<u2v*>(&sAl[ch * kPW + 2 * q]) = lv;
+        }
       }
     }
     const int nkb = (nv_next + 15) >> 4;

@@ -363,7 +363,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       // after the data gradient: in split-f16 mode it reuses the scale of dz that launch derived
       // (sc_bwd[0..1]) and the scale of the layer input the forward derived (slot l)
       VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
-      if (d->math == VS_MATH_F16X3 && kMid[i].kf > 1) {   // 7x1: its kt-split re-reads 7x, the fp32 kernel is faster there
+      if (d->math == VS_MATH_F16X3) {
         if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * l,
                                                 part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
       } else {
