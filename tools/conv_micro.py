@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the 64->64 conv kernel at BASELINE size (B=64, 301x601), one process per
-kernel variant (VS_CONV_VARIANT is read once by the library).  Prints one JSON line per run."""
+"""Micro-benchmark of the 64->64 conv kernels (fp32 MFMA and split-f16) at BASELINE size
+(B=64, 301x601).  Prints one JSON line."""
 import ctypes
 import json
 import os
@@ -22,7 +22,7 @@ def main():
     out = torch.empty_like(x)
     scale = (torch.rand(64, generator=g) + 0.5).to(dev)
     shift = (torch.randn(64, generator=g) * 0.1).to(dev)
-    res = {"variant": int(os.environ.get("VS_CONV_VARIANT", "0")), "B": B}
+    res = {"B": B}
     for (KT, KF, dil) in [(5, 5, 1), (5, 5, 2), (5, 5, 4), (5, 5, 8), (5, 5, 16), (7, 1, 1)]:
         w = (torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5).to(dev)
         packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=dev)

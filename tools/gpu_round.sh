@@ -1,9 +1,5 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_backward.py -m gpu -q -k "golden or module or full" 2>&1 | tail -3 | cut -c1-400
-timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/bench_q.json 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_q.json'))
-print(d['value'], d['ms_per_step']); print({k:v for k,v in d['stage_ms'].items() if v})
-PY
+timeout 600 python -m pytest tests/test_gpu_backward.py -m gpu -q -x -k "dgrad_and_wgrad or one_hot or layerwise" 2>&1 | tail -3 | cut -c1-300
+timeout 300 python tools/wgrad_micro.py 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print({k:v['ms'] for k,v in d.items() if isinstance(v,dict)})"
