@@ -91,10 +91,13 @@ def test_conv64_wgrad_one_hot_indices(math):
 @pytest.mark.parametrize("act", ["mish", "relu"])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("layout", ["nchw", "feat"])
-def test_bn_act_backward(act, training, layout):
+@pytest.mark.parametrize("shape", [(3, 11, 37, 0), (2, 33, 301, 0), (2, 33, 301, 1)])
+def test_bn_act_backward(act, training, layout, shape):
+    """shape = (B, T, F, skew): 33*301 = 9933 elements per row crosses the 8192-element chunk of the
+    row walk with every 16-byte phase; skew = 1 puts dA one float off z's phase (scalar walk)."""
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(7)
-    B, T, Fq = 3, 11, 37
+    B, T, Fq, skew = shape
     C = 64 if layout == "nchw" else 8
     z = torch.randn(B, C, T, Fq, generator=g) * 1.5 + 0.3
     da = torch.randn(B, C, T, Fq, generator=g)
@@ -120,7 +123,12 @@ def test_bn_act_backward(act, training, layout):
         zz, dd = z.permute(0, 2, 1, 3).contiguous(), da.permute(0, 2, 1, 3).contiguous()
     else:
         zz, dd = z, da
-    dz, dgamma, dbeta, dbias = ops.bn_act_bwd(dd.to(d).reshape(-1, Fq if layout == "feat" else T * Fq),
+    dd_dev = dd.to(d)
+    if skew:
+        buf = torch.empty(dd.numel() + skew, device=d)
+        buf[skew:].copy_(dd_dev.reshape(-1))
+        dd_dev = buf[skew:].view(dd.shape)
+    dz, dgamma, dbeta, dbias = ops.bn_act_bwd(dd_dev.reshape(-1, Fq if layout == "feat" else T * Fq),
                                               zz.to(d).reshape(-1, Fq if layout == "feat" else T * Fq), C, act, training,
                                               scale.float().to(d), shift.float().to(d), mean.float().to(d), invstd.float().to(d))
     dz = dz.reshape(zz.shape)

@@ -175,33 +175,49 @@ __global__ void conv64_wgrad_reduce_kernel(const float* __restrict__ part, int G
 template <int ACT>
 __device__ __forceinline__ float act_grad(float y) {
   if (ACT == VS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-  if (ACT == VS_ACT_MISH) return vs_mish_grad(y);
+  if (ACT == VS_ACT_MISH) return vs_mish_grad_fast(y);
   return 1.f;
 }
+
+// Both passes walk (row, chunk) items of one channel per block like the forward BatchNorm kernels
+// (vs_walk_chunk, conv_edge.hip): grid (blocks per channel, C), float4 middles, two packs in flight.
+template <int W> struct BnBwdPack { static constexpr int N = W; VsPack<W> g, z; };
 
 // pass 1: stats[c] += { sum dY, sum dY*xhat },  dY = dA * act'(z*scale+shift), xhat = (z-mean)*invstd
 template <int ACT>
 __global__ __launch_bounds__(256)
-void bn_act_bwd_stats_kernel(const float* __restrict__ da, const float* __restrict__ z, int C, long long R, int L,
+void bn_act_bwd_stats_kernel(const float* __restrict__ da, const float* __restrict__ z, int C, long long rows_c, int L,
                              const float* __restrict__ scale, const float* __restrict__ shift,
                              const float* __restrict__ mean, const float* __restrict__ invstd,
                              double* __restrict__ stats) {
   const int c = blockIdx.y;
   const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-  const int e0 = blockIdx.x * 4096;
-  const int e1 = e0 + 4096 < L ? e0 + 4096 : L;
-  float s1 = 0.f, s2 = 0.f;
-  for (long long r = c + (long long)C * blockIdx.z; r < R; r += (long long)C * gridDim.z) {
-    const float* pz = z + r * L;
-    const float* pg = da + r * L;
-    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-      const float zv = pz[e];
-      const float dy = pg[e] * act_grad<ACT>(fmaf(zv, sc, sh));
-      s1 += dy;
-      s2 = fmaf(dy, (zv - mu) * is, s2);
-    }
+  const int gx = vs_row_chunks(L);
+  double d1 = 0.0, d2 = 0.0;
+  for (long long it = blockIdx.x; it < rows_c * gx; it += gridDim.x) {
+    const long long off = (c + (long long)C * (it / gx)) * L;
+    const float* pz = z + off;
+    const float* pg = da + off;
+    float s1 = 0.f, s2 = 0.f;
+    vs_walk_chunk(L, vs_row_phase(pz, pg), (int)(it % gx),
+                  [&](int i, auto w) {
+                    BnBwdPack<decltype(w)::value> r;
+                    r.g = vs_ldv<decltype(w)::value>(pg + i);
+                    r.z = vs_ldv<decltype(w)::value>(pz + i);
+                    return r;
+                  },
+                  [&](int, auto v) {
+#pragma unroll
+                    for (int e = 0; e < decltype(v)::N; ++e) {
+                      const float zv = v.z.v[e];
+                      const float dy = v.g.v[e] * act_grad<ACT>(fmaf(zv, sc, sh));
+                      s1 += dy;
+                      s2 = fmaf(dy, (zv - mu) * is, s2);
+                    }
+                  });
+    d1 += s1;
+    d2 += s2;
   }
-  double d1 = s1, d2 = s2;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     d1 += __shfl_down(d1, o, 64);
@@ -248,24 +264,36 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, double 
 // pass 2: dz = cA*(dA*act'(z*scale+shift)) + cB*z + cC     (dz may alias da)
 template <int ACT>
 __global__ __launch_bounds__(256)
-void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C, int L,
+void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C, long long rows_c, int L,
                              const float* __restrict__ scale, const float* __restrict__ shift,
-                             const float* __restrict__ coef, float* dz, int gx, unsigned* amax_out) {
-  const long long r = blockIdx.x / gx;
-  const int c = (int)(r % C);
+                             const float* __restrict__ coef, float* dz, unsigned* amax_out) {
+  const int c = blockIdx.y;
   const float sc = scale[c], sh = shift[c], cA = coef[c], cB = coef[C + c], cC = coef[2 * C + c];
-  const float* pz = z + r * L;
-  const float* pg = da + r * L;
-  float* po = dz + r * L;
-  const int e0 = (int)(blockIdx.x % gx) * 4096;
-  const int e1 = e0 + 4096 < L ? e0 + 4096 : L;
+  const int gx = vs_row_chunks(L);
   float m = 0.f;
-  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-    const float zv = pz[e];
-    const float dy = pg[e] * act_grad<ACT>(fmaf(zv, sc, sh));
-    const float v = fmaf(cA, dy, fmaf(cB, zv, cC));
-    po[e] = v;
-    m = fmaxf(m, fabsf(v));
+  for (long long it = blockIdx.x; it < rows_c * gx; it += gridDim.x) {
+    const long long off = (c + (long long)C * (it / gx)) * L;
+    const float* pz = z + off;
+    const float* pg = da + off;
+    float* po = dz + off;
+    vs_walk_chunk(L, vs_row_phase(pz, pg, po), (int)(it % gx),
+                  [&](int i, auto w) {
+                    BnBwdPack<decltype(w)::value> r;
+                    r.g = vs_ldv<decltype(w)::value>(pg + i);
+                    r.z = vs_ldv<decltype(w)::value>(pz + i);
+                    return r;
+                  },
+                  [&](int i, auto v) {
+#pragma unroll
+                    for (int e = 0; e < decltype(v)::N; ++e) {
+                      const float zv = v.z.v[e];
+                      const float dy = v.g.v[e] * act_grad<ACT>(fmaf(zv, sc, sh));
+                      const float o = fmaf(cA, dy, fmaf(cB, zv, cC));
+                      v.g.v[e] = o;
+                      m = fmaxf(m, fabsf(o));
+                    }
+                    vs_stv(po + i, v.g);
+                  });
   }
   vs_absmax_commit(m, amax_out);
 }
@@ -428,26 +456,20 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   VS_REQUIRE(C > 0 && R > 0 && L > 0 && R % C == 0, "bn_act_bwd: bad shape C=%d R=%lld L=%d", C, R, L);
   VS_REQUIRE(R <= 2147483647LL && C <= 65535, "bn_act_bwd: too many rows");
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
-  const int gx = (L + 4095) / 4096;
   const long long rows_per_c = R / C;
-  int gz = (int)(rows_per_c < 512 ? rows_per_c : 512);
-  // keep the number of atomics per channel moderate when the rows are long
-  while ((long long)gx * gz > 4096 && gz > 1) gz = (gz + 1) / 2;
-  dim3 g1(gx, C, gz), block(256);
-  VS_REQUIRE(R * gx <= 2147483647LL, "bn_act_bwd: grid too large");
-  dim3 g2((unsigned)(R * gx));
+  dim3 grid(vs_bn_blocks_per_channel(C, rows_per_c, L), C), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, g1, block, 0, stream, da, z, C, R, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
     default: VS_REQUIRE(false, "bn_act_bwd: unknown activation %d", act);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,
                      scale, mean, invstd, dgamma, dbeta, dbias, coef);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
-    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, g2, block, 0, stream, da, z, C, L, scale, shift, coef, dz, gx, amax_out); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
+    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
   }
   VS_LAUNCH_CHECK();
   return 0;

@@ -90,23 +90,26 @@ void conv_last_kernel(const float* __restrict__ in,      // [B][64][T][F]
 
 
 // ---- train-mode BatchNorm (model.train(), train.py:84): batch statistics over (B,T,F) --------
-// stats[c] = {sum, sum of squares} in double; one block reduces a slab of one channel plane.
+// stats[c] = {sum, sum of squares} in double.  Rows [R][L], channel = r % C (NCHW: R = B*C,
+// L = T*F); grid (blocks per channel, C): a block walks every gridDim.x-th (row, chunk) item of its
+// channel (vs_walk_chunk), fp32 partials per item, double across items, two atomics per block.
 __global__ __launch_bounds__(256)
-void bn_stats_kernel(const float* __restrict__ x, int C, int plane, int ld_batch /* = C*plane */,
-                     double* __restrict__ stats) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float* src = x + (size_t)b * ld_batch + (size_t)c * plane;
-  float s = 0.f, q = 0.f;
-  // one contiguous 4096-element chunk per block (16 KB of one DRAM region) rather than 16 slices
-  // spread over the plane: 3.3 -> 5 TB/s
-  const int e0 = blockIdx.x * 4096;
-  const int e1 = e0 + 4096 < plane ? e0 + 4096 : plane;
-  for (int i = e0 + threadIdx.x; i < e1; i += 256) {
-    const float v = src[i];
-    s += v;
-    q = fmaf(v, v, q);
+void bn_stats_kernel(const float* __restrict__ x, int C, long long rows_c, int L, double* __restrict__ stats) {
+  const int c = blockIdx.y;
+  const int gx = vs_row_chunks(L);
+  double ds = 0.0, dq = 0.0;
+  for (long long it = blockIdx.x; it < rows_c * gx; it += gridDim.x) {
+    const float* src = x + (c + (long long)C * (it / gx)) * L;
+    float s = 0.f, q = 0.f;
+    vs_walk_chunk(L, vs_row_phase(src), (int)(it % gx),
+                  [&](int i, auto w) { return vs_ldv<decltype(w)::value>(src + i); },
+                  [&](int, auto v) {
+#pragma unroll
+                    for (int e = 0; e < decltype(v)::N; ++e) { s += v.v[e]; q = fmaf(v.v[e], v.v[e], q); }
+                  });
+    ds += s;
+    dq += q;
   }
-  double ds = s, dq = q;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     ds += __shfl_down(ds, o, 64);
@@ -148,22 +151,31 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
 }
 
-// y = act(x*scale[c] + shift[c]) over [B][C][plane]; y may alias x (in place)
+// y = act(x*scale[c] + shift[c]) over rows [R][L], channel = r % C; y may alias x (in place).
+// Same item walk as bn_stats_kernel.  Mish through v_exp/v_rcp (vs_mish_fast): with the accurate
+// expf/divide sequence the pass was VALU-bound, not HBM-bound.
 template <int ACT>
 __global__ __launch_bounds__(256)
 void bn_apply_kernel(const float* x, float* y, const float* __restrict__ scale, const float* __restrict__ shift,
-                     int C, int plane, unsigned* amax_out) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float* p = x + ((size_t)b * C + c) * plane;
-  float* q = y + ((size_t)b * C + c) * plane;
+                     int C, long long rows_c, int L, unsigned* amax_out) {
+  const int c = blockIdx.y;
+  const int gx = vs_row_chunks(L);
   const float sc = scale[c], sh = shift[c];
   float m = 0.f;
-  const int e0 = blockIdx.x * 4096;
-  const int e1 = e0 + 4096 < plane ? e0 + 4096 : plane;
-  for (int i = e0 + threadIdx.x; i < e1; i += 256) {
-    const float v = vs_act<ACT>(fmaf(p[i], sc, sh));
-    q[i] = v;
-    m = fmaxf(m, fabsf(v));
+  for (long long it = blockIdx.x; it < rows_c * gx; it += gridDim.x) {
+    const long long off = (c + (long long)C * (it / gx)) * L;
+    const float* p = x + off;
+    float* q = y + off;
+    vs_walk_chunk(L, vs_row_phase(p, q), (int)(it % gx),
+                  [&](int i, auto w) { return vs_ldv<decltype(w)::value>(p + i); },
+                  [&](int i, auto v) {
+#pragma unroll
+                    for (int e = 0; e < decltype(v)::N; ++e) {
+                      v.v[e] = vs_act_fast<ACT>(fmaf(v.v[e], sc, sh));
+                      m = fmaxf(m, fabsf(v.v[e]));
+                    }
+                    vs_stv(q + i, v);
+                  });
   }
   vs_absmax_commit(m, amax_out);
 }
@@ -269,9 +281,7 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
                      unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_train: bad shape B=%d C=%d plane=%d", B, C, plane);
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
-  int gx = (plane + 256 * 16 - 1) / (256 * 16);
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, stream, x, C, plane, C * plane, stats);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(vs_bn_blocks_per_channel(C, B, plane), C), dim3(256), 0, stream, x, C, (long long)B, plane, stats);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)B * plane, gamma, beta,
                      eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
   return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, amax_out, stream);
@@ -281,13 +291,12 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
 int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift,
                      unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_apply: bad shape B=%d C=%d plane=%d", B, C, plane);
-  int gx = (plane + 256 * 16 - 1) / (256 * 16);
-  if (gx < 1) gx = 1;
-  dim3 grid(gx, C, B), block(256);
+  dim3 grid(vs_bn_blocks_per_channel(C, B, plane), C), block(256);
+  const long long rc = B;
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, y, scale, shift, C, plane, amax_out); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, x, y, scale, shift, C, rc, plane, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, x, y, scale, shift, C, rc, plane, amax_out); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, x, y, scale, shift, C, rc, plane, amax_out); break;
     default: VS_REQUIRE(false, "bn_apply: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();

@@ -67,6 +67,20 @@ __device__ __forceinline__ float vs_act_fast(float v) {
   return vs_act<ACT>(v);
 }
 
+// vs_mish_grad with v_exp_f32 and ONE v_rcp_f32: 1/(n+2) and u/(1+u) share the reciprocal of
+// (n+2)(1+u) (<= 1.2e26 at the x = 20 clamp).  Within ~5e-7 relative of vs_mish_grad; the accurate
+// form (expf + two divides, ~60 VALU per element) made the BatchNorm backward passes VALU-bound.
+__device__ __forceinline__ float vs_mish_grad_fast(float x) {
+  float u = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.44269504088896340736f);
+  float n = u * (u + 2.0f);
+  float r = __builtin_amdgcn_rcpf((n + 2.0f) * (1.0f + u));
+  float inv = (1.0f + u) * r;
+  float sig = u * (n + 2.0f) * r;
+  float tsp = n * inv;
+  float g = tsp + x * (2.0f * inv) * (1.0f + tsp) * sig;
+  return x > 20.0f ? 1.0f : g;
+}
+
 __device__ __forceinline__ float vs_act_rt(float v, int act) {
   switch (act) {
     case VS_ACT_RELU: return fmaxf(v, 0.0f);
@@ -92,6 +106,82 @@ __device__ __forceinline__ void vs_absmax_commit(float m, unsigned* out) {
     const unsigned bits = __float_as_uint(m);
     if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Streaming row walk of the BatchNorm passes.  A tensor is seen as rows [R][L] (channel = r % C);
+// rows are cut into chunks of VS_ROW_CHUNK elements counted from the 16-byte frame of the row
+// (position a = i + ph, ph = (address of element 0 / 4) & 3), so that every chunk but a row's first
+// starts on a 16-byte boundary and its middle moves as float4 (T*F = 180901 is odd: rows have every
+// phase).  ld(ptr-index i, width tag) -> value pack, fin(i, pack) consumes it; two packs are in
+// flight per thread.  vec == 0 (operands with different phases): all-scalar walk.
+// ---------------------------------------------------------------------------
+#define VS_ROW_CHUNK 8192
+template <int W> struct VsWidth { static constexpr int value = W; };
+__host__ __device__ __forceinline__ int vs_row_chunks(int L) { return (L + 3 + VS_ROW_CHUNK - 1) / VS_ROW_CHUNK; }
+
+// grid.x of the row-walk kernels (grid.y = channel): ~2048 workgroups = 8 per CU in all
+static inline int vs_bn_blocks_per_channel(int C, long long rows_c, int L) {
+  const long long items = rows_c * vs_row_chunks(L);
+  long long nb = (2048 + C - 1) / C;
+  if (nb > items) nb = items;
+  return nb < 1 ? 1 : (int)nb;
+}
+
+template <class LD, class FIN>
+__device__ __forceinline__ void vs_walk_chunk(int L, int ph, int k, LD&& ld, FIN&& fin) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const bool vec = ph >= 0;
+  if (!vec) ph = 0;
+  const int a0 = k * VS_ROW_CHUNK > ph ? k * VS_ROW_CHUNK : ph;
+  const int a1 = (k + 1) * VS_ROW_CHUNK < L + ph ? (k + 1) * VS_ROW_CHUNK : L + ph;
+  if (a1 <= a0) return;
+  const int i0 = a0 - ph, i1 = a1 - ph;
+  if (!vec) {
+    for (int i = i0 + tid; i < i1; i += nt) fin(i, ld(i, VsWidth<1>()));
+    return;
+  }
+  int head = (4 - (a0 & 3)) & 3;
+  if (head > i1 - i0) head = i1 - i0;
+  if (tid < head) fin(i0 + tid, ld(i0 + tid, VsWidth<1>()));
+  const int v0 = i0 + head, nv = (i1 - v0) >> 2;
+  for (int j = tid; j < nv; j += 2 * nt) {
+    const int ia = v0 + 4 * j, ib = ia + 4 * nt;
+    auto pa = ld(ia, VsWidth<4>());
+    if (j + nt < nv) {
+      auto pb = ld(ib, VsWidth<4>());
+      fin(ia, pa);
+      fin(ib, pb);
+    } else {
+      fin(ia, pa);
+    }
+  }
+  const int t0 = v0 + 4 * nv;
+  if (tid < i1 - t0) fin(t0 + tid, ld(t0 + tid, VsWidth<1>()));
+}
+
+// W consecutive floats (W = 1 or 4; the 4-wide form needs 16-byte alignment)
+template <int W> struct VsPack { static constexpr int N = W; float v[W]; };
+template <int W> __device__ __forceinline__ VsPack<W> vs_ldv(const float* p) {
+  VsPack<W> r;
+  if constexpr (W == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int W> __device__ __forceinline__ void vs_stv(float* p, const VsPack<W>& r) {
+  if constexpr (W == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  else p[0] = r.v[0];
+}
+// phase shared by all operands of a row walk, or -1 when they differ (scalar walk)
+__device__ __forceinline__ int vs_row_phase(const void* a, const void* b = nullptr, const void* c = nullptr) {
+  const unsigned pa = (unsigned)((uintptr_t)a >> 2) & 3u;
+  if (b && ((unsigned)((uintptr_t)b >> 2) & 3u) != pa) return -1;
+  if (c && ((unsigned)((uintptr_t)c >> 2) & 3u) != pa) return -1;
+  return (int)pa;
 }
 
 // ---------------------------------------------------------------------------
