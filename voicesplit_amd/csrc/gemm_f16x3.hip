@@ -3,14 +3,23 @@
 // for the three large LSTM contractions of the path (models/voicesplit/model.py:82 and its
 // backward): x @ W_ih^T (NT), dxg @ W_ih (NN), dxg^T @ feat (TN).
 //
-// Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 accumulators of v_mfma_f32_32x32x16_f16.
-// Both operands are converted to f16 hi/lo halves while they are staged and sit in LDS as
-// [row][18 dwords] (16 k-pairs + 2 pad): a lane's fragment (8 consecutive k of its row) is two
-// ds_read_b64, conflict-free with lane = row (18*row mod 64 hits 32 distinct even banks).
+// Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 accumulators of v_mfma_f32_32x32x16_f16,
+// three workgroups per CU.  Both operands are converted to f16 hi/lo halves while they are staged
+// and sit in LDS as [row][18 dwords] (16 k-pairs + 2 pad): a lane's fragment (8 consecutive k of its
+// row) is two ds_read_b64, conflict-free with lane = row (18*row mod 64 hits 32 distinct even banks).
 // K-contiguous operands arrive as float4 along k and are written with ds_write_b64; K-major
-// operands arrive as dwords with lanes along the row index (coalesced per k row), each thread
-// holding the two floats of a k-pair, and are written with ds_write_b32 (2-way conflict = free):
-// the transpose costs no extra pass.
+// operands arrive as dwords with lanes along the row index (coalesced per k row) through a buffer
+// descriptor (one 32-bit lane offset, everything else scalar; flat loads with a 64-bit address and
+// a bounds branch per dword cost 50-80 more VGPRs and 1.6x the time), each thread holding the two
+// floats of a k-pair, and are written with ds_write_b32 (2-way conflict = free): the transpose
+// costs no extra pass.  Workgroups are renumbered so that each XCD (workgroup id % 8) owns a
+// contiguous range of the (m, n) tile list.
+// Measured at B=64 (rocprofv3): 19264x3200x4808 NT 3.4 ms (MFMA pipe 25 % busy, waves stalled on
+// memory 59 % of the time), 19264x4808x1600 NN 1.15 ms, 1600x4808x19264 TN 1.19 ms.  A 64-deep K
+// block, 2 vs 3 workgroups per CU and the XCD renumbering all leave the NT case within 3 %: it
+// moves 18.6 GB of operand tiles in 3.4 ms (5.5 TB/s if few of them hit in L2), which points at
+// operand re-reads rather than at the pipeline - a reading of the counters above, not yet
+// confirmed by a FETCH_SIZE pass; a larger tile is the next thing to try.
 #include "vs_common.h"
 
 namespace {
@@ -20,8 +29,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PW = 18;     // LDS row pitch in dwords
+constexpr int BM = 128, BN = 128;
+// per K-block depth BK: LDS row pitch in dwords, floats of one operand tile per thread
+constexpr int pitch_of(int BK) { return BK / 2 + 2; }
+constexpr int regs_of(int BK) { return BM * BK / 256; }
 
 struct Gemm16Args {
   const float* A; int lda;
@@ -37,6 +48,7 @@ struct Gemm16Args {
   int a_relu, w_relu, act, accumulate;
   const float* a_scale;   // {s, 1/s}
   const float* w_scale;   // {s, 1/s}
+  int tiles_m, tiles_n;
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -57,15 +69,16 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int i, int 
   return v;
 }
 
-// One operand tile [128 rows][32 k] : global -> registers (16 floats per thread)
-template <int LAYOUT, bool VEC>
-__device__ __forceinline__ void tile_load(float (&r)[16], const float* __restrict__ base, const float* __restrict__ base_hi,
+// One operand tile [128 rows][BK k] : global -> registers (RT floats per thread)
+template <int LAYOUT, bool VEC, int BK>
+__device__ __forceinline__ void tile_load(float (&r)[regs_of(BK)], const __amdgpu_buffer_rsrc_t rsrc, const float* __restrict__ base, const float* __restrict__ base_hi,
                                           int split, int ld, int row0, int nrows, int k0, int K, int tid) {
+  constexpr int RT = regs_of(BK);
   if (LAYOUT == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT / 4; ++i) {
       const int v = tid + 256 * i;
-      const int row = row0 + (v >> 3), c4 = k0 + (v & 7) * 4;
+      const int row = row0 + v / (BK / 4), c4 = k0 + (v % (BK / 4)) * 4;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < nrows) {
         const float* p = row < split ? base + (size_t)row * ld : base_hi + (size_t)(row - split) * ld;
@@ -75,24 +88,28 @@ __device__ __forceinline__ void tile_load(float (&r)[16], const float* __restric
     }
   } else {
     // item = (row m = idx & 127, k-pair kp = idx >> 7): lanes along m, two dword loads (k, k+1)
+    // through a buffer descriptor over the whole operand: one 32-bit lane offset, the K block and
+    // pair index in the scalar offset, rows k >= K out of range (-> 0).  Columns m >= nrows read
+    // the neighbouring row: they only reach output rows / columns that are never stored.
+    const unsigned voff = ((unsigned)(2 * (tid >> 7)) * (unsigned)ld + (unsigned)(tid & 127)) * 4u;
+    const unsigned so0 = ((unsigned)k0 * (unsigned)ld + (unsigned)row0) * 4u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      const int m = row0 + (idx & 127), k = k0 + 2 * (idx >> 7);
-      const bool okm = m < nrows;
-      r[2 * i + 0] = (okm && k < K) ? base[(size_t)k * ld + m] : 0.f;
-      r[2 * i + 1] = (okm && k + 1 < K) ? base[(size_t)(k + 1) * ld + m] : 0.f;
+    for (int i = 0; i < RT / 2; ++i) {
+      const unsigned so = so0 + (unsigned)(4 * i) * (unsigned)ld * 4u;
+      r[2 * i + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
+      r[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so + (unsigned)ld * 4u, 0));
     }
   }
 }
 
 // registers -> f16 hi/lo halves in LDS [row][PW dwords]
-template <int LAYOUT>
-__device__ __forceinline__ void tile_store(const float (&r)[16], unsigned* __restrict__ sh, unsigned* __restrict__ sl,
+template <int LAYOUT, int BK>
+__device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsigned* __restrict__ sh, unsigned* __restrict__ sl,
                                            float s, bool relu, int tid) {
+  constexpr int RT = regs_of(BK), PW = pitch_of(BK);
   if (LAYOUT == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT / 4; ++i) {
       const int v = tid + 256 * i;
       float x[4];
 #pragma unroll
@@ -103,12 +120,12 @@ __device__ __forceinline__ void tile_store(const float (&r)[16], unsigned* __res
       u2v hi, lo;
       hi[0] = h0; hi[1] = h1;
       lo[0] = l0; lo[1] = l1;
-      *reinterpret_cast<u2v*>(&sh[(v >> 3) * PW + (v & 7) * 2]) = hi;
-      *reinterpret_cast<u2v*>(&sl[(v >> 3) * PW + (v & 7) * 2]) = lo;
+      *reinterpret_cast<u2v*>(&sh[(v / (BK / 4)) * PW + (v % (BK / 4)) * 2]) = hi;
+      *reinterpret_cast<u2v*>(&sl[(v / (BK / 4)) * PW + (v % (BK / 4)) * 2]) = lo;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RT / 2; ++i) {
       const int idx = tid + 256 * i;
       const float x0 = (relu ? fmaxf(r[2 * i], 0.f) : r[2 * i]) * s;
       const float x1 = (relu ? fmaxf(r[2 * i + 1], 0.f) : r[2 * i + 1]) * s;
@@ -120,9 +137,10 @@ __device__ __forceinline__ void tile_store(const float (&r)[16], unsigned* __res
   }
 }
 
-template <int LA, int LB, bool VEC>
-__global__ __launch_bounds__(256, 2)
+template <int LA, int LB, bool VEC, int BK, int OCC>
+__global__ __launch_bounds__(256, OCC)
 void gemm_f16x3_kernel(Gemm16Args g) {
+  constexpr int RT = regs_of(BK), PW = pitch_of(BK);
   __shared__ __attribute__((aligned(16))) unsigned sAh[BM * PW], sAl[BM * PW], sWh[BN * PW], sWl[BN * PW];
 
   const int tid = threadIdx.x;
@@ -130,7 +148,11 @@ void gemm_f16x3_kernel(Gemm16Args g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD x takes tiles [x*per, (x+1)*per) of the row-major (m, n) tile list
+  const int per = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= g.tiles_m * g.tiles_n) return;
+  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
   const float sa = g.a_scale[0], sw = g.w_scale[0];
   const float inv = g.a_scale[1] * g.w_scale[1];
 
@@ -142,24 +164,27 @@ void gemm_f16x3_kernel(Gemm16Args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float ra[16], rw[16];
+  float ra[RT], rw[RT];
+  // K-major operands are read through buffer descriptors ((K-1)*ld + rows floats)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, LA ? (int)(((size_t)(g.K - 1) * g.lda + g.M) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, LB ? (int)(((size_t)(g.K - 1) * g.ldw + g.N) * 4) : 0, 0x00020000);
   // fragment of block x, k-step ks: 8 halves = dwords [row*PW + 8*ks + 4*half .. +3]
   const int fa = (wm * 64 + l31) * PW + 4 * half;
   const int fw = (wn * 64 + l31) * PW + 4 * half;
 
-  tile_load<LA, VEC>(ra, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, 0, g.K, tid);
-  tile_load<LB, VEC>(rw, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, 0, g.K, tid);
+  tile_load<LA, VEC, BK>(ra, rsA, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, 0, g.K, tid);
+  tile_load<LB, VEC, BK>(rw, rsW, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, 0, g.K, tid);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     __syncthreads();
-    tile_store<LA>(ra, sAh, sAl, sa, g.a_relu != 0, tid);
-    tile_store<LB>(rw, sWh, sWl, sw, g.w_relu != 0, tid);
+    tile_store<LA, BK>(ra, sAh, sAl, sa, g.a_relu != 0, tid);
+    tile_store<LB, BK>(rw, sWh, sWl, sw, g.w_relu != 0, tid);
     __syncthreads();
     if (k0 + BK < g.K) {
-      tile_load<LA, VEC>(ra, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, k0 + BK, g.K, tid);
-      tile_load<LB, VEC>(rw, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, k0 + BK, g.K, tid);
+      tile_load<LA, VEC, BK>(ra, rsA, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, k0 + BK, g.K, tid);
+      tile_load<LB, VEC, BK>(rw, rsW, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, k0 + BK, g.K, tid);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
@@ -217,8 +242,8 @@ void gemm_f16x3_kernel(Gemm16Args g) {
 
 template <int LA, int LB>
 void launch_layout(const Gemm16Args& g, bool vec, dim3 grid, hipStream_t stream) {
-  if (vec) hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, false>), grid, dim3(256), 0, stream, g);
+  if (vec) hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, true, 32, 3>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, false, 32, 3>), grid, dim3(256), 0, stream, g);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -240,15 +265,17 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
              "gemm_f16x3: leading dims lda=%d ldw=%d ldc=%d vs M=%d N=%d K=%d", lda, ldw, ldc, M, N, K);
   VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm_f16x3: rowbias needs group>0 and ldrb>=N");
   VS_REQUIRE(!gate || ldg >= N, "gemm_f16x3: gate needs ldg>=N");
-  VS_REQUIRE((M + BM - 1) / BM <= 65535, "gemm_f16x3: M=%d too large", M);
   VS_REQUIRE(act == VS_ACT_NONE || act == VS_ACT_RELU || act == VS_ACT_SIGMOID, "gemm_f16x3: unsupported activation %d", act);
   VS_REQUIRE(layout_w == 0 || (W_hi == nullptr || n_split >= N), "gemm_f16x3: stacked W needs the K-contiguous layout");
   VS_REQUIRE(n_split >= N || W_hi != nullptr, "gemm_f16x3: W_hi is NULL but n_split=%d < N=%d", n_split, N);
   VS_REQUIRE(a_scale2 && w_scale2, "gemm_f16x3: NULL scale");
+  VS_REQUIRE(!layout_a || ((size_t)(K - 1) * lda + M) * 4 < (1ull << 32), "gemm_f16x3: K-major A above 4 GiB");
+  VS_REQUIRE(!layout_w || ((size_t)(K - 1) * ldw + N) * 4 < (1ull << 32), "gemm_f16x3: K-major W above 4 GiB");
   Gemm16Args g{A, lda, W, ldw, W_hi, n_split, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1,
-               gate, ldg, a_relu, w_relu, act, accumulate, a_scale2, w_scale2};
+               gate, ldg, a_relu, w_relu, act, accumulate, a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
   const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  VS_REQUIRE((long long)g.tiles_m * g.tiles_n < (1LL << 30), "gemm_f16x3: too many tiles");
+  dim3 grid((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8));
   if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream);
   else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream);
   else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream);
