@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
     ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3"],
                     help="arithmetic of the 64->64 conv layers (default: the library default)")
-    ap.add_argument("--loss", default="sisnr", choices=["sisnr", "fixed"],
+    ap.add_argument("--loss", default="sisnr", choices=["sisnr", "powerlaw", "fixed"],
                     help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -137,7 +137,6 @@ def main():
     import voicesplit_amd as V
     from voicesplit_amd import _lib
     from voicesplit_amd import ops
-    from voicesplit_amd.sharding import GradientBucket
     lib = _lib.load()
     if args.conv_math:
         ops.set_conv_math(args.conv_math)
@@ -172,19 +171,20 @@ def main():
     from voicesplit_amd import losses
 
     if train:
-        bucket = GradientBucket(model.parameters()).attach()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)          # train.py:34
+        # the product's own training step (voicesplit_amd/trainer.py = train.py:86-117 per rank):
+        # forward, criterion, backward, one flat gradient all-reduce, Adam, loss.item()
+        from voicesplit_amd.trainer import Trainer
+        cfg = V.default_config(model_name=args.model)
+        cfg.loss["loss_name"] = {"sisnr": "si_snr", "powerlaw": "power_law_compression", "fixed": "si_snr"}[args.loss]
+        cfg.train_config["learning_rate"] = 1e-4                    # random data: keep the weights finite
+        fixed = (lambda mask, mixed, tgt, sl, ph: (mask * dmask).sum()) if args.loss == "fixed" else None
+        trainer = Trainer(model, cfg, rank, world, criterion=fixed)
+        bucket = trainer.bucket
+        batch = (dvec, target, spec, seq_len, None, phase)
 
         def step():
-            bucket.zero()
-            mask = model(spec, dvec)
-            if args.loss == "sisnr":                                 # train.py:95-110
-                losses.sisnr_loss(mask, spec, target, phase, seq_len, audio_cfg).backward()
-            else:
-                mask.backward(dmask)
-            bucket.all_reduce(world)                                 # the one exchange step
-            opt.step()
-            return mask
+            trainer.train_step(batch)
+            return bucket.flat
     else:
         def step():
             with torch.no_grad():
@@ -264,7 +264,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
                                     "training step = forward (batch-stat BN) + "
-                                    + ("SI-SNR loss through the GPU iSTFT (train.py:95-108)" if args.loss == "sisnr" else "fixed upstream gradient on the mask")
+                                    + {"sisnr": "SI-SNR loss through the GPU iSTFT (train.py:95-108)",
+                                       "powerlaw": "power-law compressed loss (train.py:74-75,108)",
+                                       "fixed": "fixed upstream gradient on the mask"}[args.loss]
                                     + " + backward + gradient all-reduce + Adam, random-init weights") if train else
                                    (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
                                     f"{args.model} forward-only, eval BN, random-init weights"),

@@ -330,6 +330,13 @@ int vs_sisnr_loss(const vs_loss_dims* dims, const float* mixed, const float* mas
                   const float* phase, const int* seq_len, void* workspace, size_t workspace_bytes,
                   float* loss, float* dmask, float* est_wav, void* stream);
 
+/* The other criterion of train.py:74-75: PowerLaw_Compressed_Loss (utils/generic_utils.py:353-373,
+ * loss_name 'power_law_compression', the voicefilter configuration; config.json: power 0.3,
+ * complex_loss_ratio 0.113).  prediction = mixed*mask (train.py:95); mixed, mask, target: n = B*T*F
+ * floats; scratch: 2 doubles on the device; loss: one device float; dmask = d(loss)/d(mask) or NULL. */
+int vs_powerlaw_loss(const float* mixed, const float* mask, const float* target, long long n, float power,
+                     float complex_loss_ratio, double* scratch, float* loss, float* dmask, void* stream);
+
 /* ---- audio front / back end of inference: what test.py does around the model ----
  * wav [B][hop*(T-1)] -> spec [B][T][F] (normalised dB magnitude in [0,1]) and phase [B][T][F] (may be
  * NULL): librosa.stft(n_fft, hop, win, hann, center, reflect) + amp_to_db + normalize, transposed to

@@ -190,8 +190,36 @@ def main_loss():
     print(f"sisnr_loss: loss {loss.item():.6f} -> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def main_powerlaw():
+    """Pins oracle/reference_loss.power_law_compressed_loss to the upstream PowerLaw_Compressed_Loss
+    (utils/generic_utils.py:353-373) as train.py:95,108 calls it: prediction = mixed * mask, target =
+    the clean spectrogram, both normalised to [0, 1] (exact zeros included: the epsilon branch)."""
+    _vs, _vf, _mish, load_config, _ad = import_reference()
+    PowerLaw = load_config.__globals__["PowerLaw_Compressed_Loss"]
+    g = torch.Generator().manual_seed(123)
+    B, T, F = 2, 9, 31
+    mixed = torch.rand(B, T, F, generator=g, dtype=torch.float64)
+    target = (mixed * torch.rand(B, T, F, generator=g, dtype=torch.float64)).clamp(0, 1)
+    mask = torch.sigmoid(torch.randn(B, T, F, generator=g, dtype=torch.float64))
+    mixed[0, 0, :5] = 0.0            # silent bins: prediction = 0 + 1e-16
+    target[0, 1, :5] = 0.0
+    out = {}
+    for power, ratio in ((0.3, 0.113), (0.5, 1.0)):
+        m = mask.clone().requires_grad_(True)
+        loss = PowerLaw(power, ratio)(mixed * m, target, None)
+        loss.backward()
+        tag = f"p{power}_r{ratio}"
+        out["loss/" + tag] = np.array(loss.item())
+        out["dmask/" + tag] = m.grad.numpy()
+    path = os.path.join(GOLDEN_DIR, "powerlaw_loss.npz")
+    np.savez(path, mixed=mixed.numpy(), target=target.numpy(), mask=mask.numpy(), torch_version=np.array(torch.__version__), **out)
+    print(f"powerlaw_loss: {[float(v) for k, v in out.items() if k.startswith('loss/')]} -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if "--loss" in sys.argv:
+    if "--powerlaw" in sys.argv:
+        main_powerlaw()
+    elif "--loss" in sys.argv:
         main_loss()
     elif "--grads" in sys.argv:
         main_grads()

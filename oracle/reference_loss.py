@@ -3,10 +3,12 @@
 Restates, in plain torch ops,
   * ``openVoiceFilterAudioProcessor.torch_spec2wav``   utils/audio_processor.py:498-509
   * ``SiSNR_With_Pit.forward`` / ``get_mask``           utils/generic_utils.py:402-474
+  * ``PowerLaw_Compressed_Loss.forward``               utils/generic_utils.py:353-373
 as composed by train.py:95-108.
 
 Pinning: ``SiSNR_With_Pit`` is pinned against the upstream class (``oracle/make_golden.py --loss``
 imports it from /root/reference and commits inputs/outputs to tests/golden/sisnr_loss.npz).
+``power_law_compressed_loss`` is pinned the same way (tests/golden/powerlaw_loss.npz).
 ``torch_spec2wav`` itself is **parity unpinned against upstream**: it calls
 ``torchaudio.functional.istft``, which no longer exists in torchaudio (and torchaudio is not in
 this image), so the reference function cannot be executed.  The restatement uses ``torch.istft``,
@@ -78,3 +80,20 @@ def training_loss(mask, mixed, target, phase, seq_len, **audio):
     out_wav = torch_spec2wav(output, phase, **audio)                      # :99
     tgt_wav = torch_spec2wav(target, phase, **audio)                      # :100
     return sisnr_with_pit(out_wav.unsqueeze(1), tgt_wav.unsqueeze(1), seq_len), out_wav
+
+
+def power_law_compressed_loss(prediction, target, power=0.3, complex_loss_ratio=0.113, epsilon=1e-16):
+    """utils/generic_utils.py:353-373 (criterion of train.py:74-75 for loss_name ==
+    'power_law_compression'; both MSELoss instances are the default 'mean' reduction)."""
+    prediction = prediction + epsilon                                      # :363
+    target = target + epsilon                                              # :364
+    prediction = torch.pow(prediction, power)                              # :366
+    target = torch.pow(target, power)                                      # :367
+    spec_loss = torch.mean((torch.abs(target) - torch.abs(prediction)) ** 2)   # :369
+    complex_loss = torch.mean((target - prediction) ** 2)                  # :370
+    return spec_loss + complex_loss * complex_loss_ratio                   # :372
+
+
+def training_loss_power_law(mask, mixed, target, power=0.3, complex_loss_ratio=0.113):
+    """train.py:95,104-108 for loss_name == 'power_law_compression' (seq_len = None, unused)."""
+    return power_law_compressed_loss(mixed * mask, target, power, complex_loss_ratio)

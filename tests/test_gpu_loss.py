@@ -62,3 +62,63 @@ def test_sisnr_loss_full_size_through_the_model():
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     opt.step()
+
+
+# ---------------------------------------------------------------------------------------------
+# PowerLaw_Compressed_Loss (loss_name 'power_law_compression', the voicefilter configuration)
+# ---------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return (a.double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-300)
+
+
+@pytest.mark.parametrize("power,ratio", [(0.3, 0.113), (0.5, 1.0)])
+def test_powerlaw_loss_matches_upstream_golden(power, ratio):
+    """Inputs, loss and d(loss)/d(mask) written by the upstream class (make_golden.py --powerlaw),
+    exact-zero bins included.  fp32 kernel vs fp64 truth: 1e-5 on the loss, 2e-5 of the largest
+    gradient entry (pow of fp32 operands; the oracle's own fp32 run sits at the same distance)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from voicesplit_amd import losses
+    z = np.load(os.path.join(GOLDEN_DIR, "powerlaw_loss.npz"))
+    tag = f"p{power}_r{ratio}"
+    mixed, target = (torch.from_numpy(z[k]).float().cuda() for k in ("mixed", "target"))
+    m = torch.from_numpy(z["mask"]).float().cuda().requires_grad_(True)
+    loss = losses.power_law_loss(m, mixed, target, power, ratio)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss/" + tag])) < 1e-5 * float(z["loss/" + tag])
+    assert _rel(m.grad, torch.from_numpy(z["dmask/" + tag])) < 2e-5
+    assert torch.isfinite(m.grad).all()
+
+
+def test_powerlaw_loss_full_size_vs_oracle_and_through_the_model():
+    """B=64 x 301 x 601 (BASELINE size): loss and gradient against the fp64 oracle on the CPU, then
+    the voicefilter training graph end to end (model -> loss -> backward) once."""
+    import voicesplit_amd as V
+    from voicesplit_amd import losses
+    g = torch.Generator().manual_seed(11)
+    B, T, F = 64, 301, 601
+    mixed = torch.rand(B, T, F, generator=g)
+    target = mixed * torch.rand(B, T, F, generator=g)
+    mask = torch.sigmoid(torch.randn(B, T, F, generator=g))
+    md = mask.double().requires_grad_(True)
+    ref = RL.training_loss_power_law(md, mixed.double(), target.double())
+    ref.backward()
+    mc = mask.cuda().requires_grad_(True)
+    loss = losses.power_law_loss(mc, mixed.cuda(), target.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * ref.item()
+    assert _rel(mc.grad, md.grad) < 2e-5
+    # scaling the upstream gradient scales dmask (autograd.Function.backward)
+    mc2 = mask.cuda().requires_grad_(True)
+    (3.0 * losses.power_law_loss(mc2, mixed.cuda(), target.cuda())).backward()
+    assert torch.allclose(mc2.grad, 3.0 * mc.grad, rtol=1e-6, atol=0)
+    del mc, mc2, md
+    torch.manual_seed(0)
+    model = V.VoiceFilter(V.default_config()).cuda().train()
+    d = torch.randn(B, 256, generator=g)
+    d = (d / d.norm(dim=1, keepdim=True)).cuda()
+    out = model(mixed.cuda(), d)
+    l2 = losses.power_law_loss(out, mixed.cuda(), target.cuda())
+    l2.backward()
+    assert torch.isfinite(l2).item()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all().item() for p in model.parameters())

@@ -1,0 +1,115 @@
+"""GPU: the training loop of voicesplit_amd/trainer.py driving the real model and both criteria of
+train.py:74-79 -- the wrapper against a hand-written zero_grad/backward/Adam loop over the same
+modules, the reference's checkpoint format through the real state_dict, the on-disk dataset with the
+GPU STFT collate, and the CLI dry run."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(model_name, T_audio_len=1):
+    import voicesplit_amd as V
+    c = V.default_config(model_name=model_name)
+    c.audio["audio_len"] = T_audio_len
+    c.train_config["learning_rate"] = 1e-3
+    return c
+
+
+def _batch(B, T, seed):
+    from voicesplit_amd.trainer import synthetic_batches
+    return next(iter(synthetic_batches(1, B, T, 601, 256, 160, torch.device("cuda"), seed)))
+
+
+@pytest.mark.parametrize("model_name", ["voicesplit", "voicefilter"])
+def test_trainer_step_equals_manual_loop_and_checkpoint_roundtrip(model_name, tmp_path):
+    import voicesplit_amd as V
+    from voicesplit_amd import losses
+    from voicesplit_amd.trainer import Trainer
+    c = _cfg(model_name)
+    cls = V.VoiceSplit if model_name == "voicesplit" else V.VoiceFilter
+    torch.manual_seed(0)
+    tr = Trainer(cls(c).cuda(), c)
+    torch.manual_seed(0)
+    ref = cls(c).cuda().train()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    acfg = c.audio["voicefilter"]
+    B, T = 3, 101
+    for s in range(2):
+        emb, target, mixed, seq_len, _tw, phase = _batch(B, T, s)
+        loss = tr.train_step((emb, target, mixed, seq_len, None, phase))
+        opt.zero_grad()
+        mask = ref(mixed, emb)
+        if model_name == "voicesplit":                      # config.json:17 -- si_snr for voicesplit
+            rl = losses.sisnr_loss(mask, mixed, target, phase, seq_len, acfg)
+        else:                                               # power_law_compression for voicefilter
+            rl = losses.power_law_loss(mask, mixed, target, 0.3, 0.113)
+        rl.backward()
+        opt.step()
+        assert abs(loss - rl.item()) <= 1e-6 * max(1.0, abs(rl.item()))
+    for (n, p), q in zip(tr.model.named_parameters(), ref.parameters()):
+        # same kernels in the same order; only the fp64 atomics of the BN reductions are unordered
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+    for a, b in zip(tr.model.buffers(), ref.buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-8)
+    # checkpoint: the reference's four keys (train.py:127-132), resumable, state_dict keys intact
+    path = tr.save_checkpoint(str(tmp_path / "checkpoint_2.pt"))
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "step", "config_str"} and ck["step"] == 2
+    assert list(ck["model"]) == list(ref.state_dict())
+    tr2 = Trainer(cls(c).cuda(), c)
+    assert tr2.load_checkpoint(path) == 2
+    b3 = _batch(B, T, 9)
+    l1, l2 = tr.train_step(b3), tr2.train_step(b3)
+    assert abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1))
+    assert all(torch.allclose(p, q, rtol=1e-5, atol=1e-7) for p, q in zip(tr.model.parameters(), tr2.model.parameters()))
+
+
+def test_dataset_collate_on_gpu_and_cli_dry_run(tmp_path):
+    from scipy.io import wavfile
+    import voicesplit_amd as V
+    from voicesplit_amd import audio, trainer
+    c = _cfg("voicesplit", 3)
+    d = tmp_path / "train"
+    d.mkdir()
+    c.dataset = {"train_dir": str(d), "test_dir": str(d),
+                 "format": {"emb": "*-emb.pt", "mixed": "*-mixed.pt", "target": "*-target.pt",
+                            "target_wav": "*-target.wav", "mixed_wav": "*-mixed.wav"}}
+    rng = np.random.default_rng(1)
+    for i in range(4):
+        stem = str(d / ("%06d" % i))
+        e = torch.randn(256)
+        torch.save(e / e.norm(), stem + "-emb.pt")
+        torch.save(torch.rand(301, 601), stem + "-target.pt")
+        wavfile.write(stem + "-mixed.wav", 16000, (rng.standard_normal(48000) * 0.05).astype(np.float32))
+        wavfile.write(stem + "-target.wav", 16000, (rng.standard_normal(48000) * 0.05).astype(np.float32))
+    ds = trainer.SpecWavDataset(c)
+    dev = torch.device("cuda")
+    emb, target, mixed, seq_len, target_wav, phase = ds.collate([ds[i] for i in (2, 0)], dev)
+    assert emb.shape == (2, 256) and target.shape == mixed.shape == phase.shape == (2, 301, 601)
+    assert seq_len.tolist() == [48000, 48000] and target_wav.shape == (2, 48000)
+    spec0, ph0 = audio.wav_to_spec(ds[2][2][None].cuda(), c.audio["voicefilter"])
+    assert torch.equal(mixed[0], spec0[0]) and torch.equal(phase[0], ph0[0])
+    assert 0.0 <= mixed.min().item() and mixed.max().item() <= 1.0
+    # two epochs of 2 steps on that directory through Trainer.fit, checkpoint cut by the interval
+    c.train_config.update({"epochs": 2, "batch_size": 2, "checkpoint_interval": 3, "summary_interval": 1,
+                           "logs_path": str(tmp_path / "logs")})
+    os.makedirs(c.train_config["logs_path"])
+    torch.manual_seed(0)
+    tr = trainer.Trainer(V.VoiceSplit(c).cuda(), c)
+    shard = trainer.EpochShard(len(ds), 2, 0, 1, 42)
+    seen = []
+    tr.fit(lambda e: (ds.collate([ds[i] for i in idx], dev) for idx in shard.epoch(e)), log_dir=c.train_config["logs_path"],
+           on_log=lambda s, l: seen.append((s, l)))
+    assert tr.step == 4 and [s for s, _ in seen] == [1, 2, 3, 4] and all(np.isfinite(l) for _, l in seen)
+    assert os.listdir(c.train_config["logs_path"]) == ["checkpoint_3.pt"]
+    # the CLI (train.py's flags) on random batches, from a JSON config with // comments
+    cfg_path = tmp_path / "config.json"
+    text = json.dumps({k: (dict(v) if isinstance(v, dict) else v) for k, v in c.items()}, indent=1)
+    cfg_path.write_text(text.replace('"model_name"', '// which model\n "model_name"', 1))
+    trainer.main(["-c", str(cfg_path), "--synthetic-steps", "2", "--epochs", "1",
+                  "--checkpoint_path", str(tmp_path / "logs" / "checkpoint_3.pt")])

@@ -188,6 +188,23 @@ def test_sisnr_oracle_reproduces_upstream_class():
     assert np.abs(est.grad.numpy() - z["grad"]).max() <= 1e-6 * np.abs(z["grad"]).max()
 
 
+def test_powerlaw_oracle_reproduces_upstream_class():
+    """tests/golden/powerlaw_loss.npz was produced by the upstream PowerLaw_Compressed_Loss
+    (oracle/make_golden.py --powerlaw), fp64, with exact-zero bins (the epsilon branch)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from oracle import reference_loss as RL
+    z = np.load(os.path.join(GOLDEN_DIR, "powerlaw_loss.npz"))
+    mixed, target = torch.from_numpy(z["mixed"]), torch.from_numpy(z["target"])
+    for power, ratio in ((0.3, 0.113), (0.5, 1.0)):
+        m = torch.from_numpy(z["mask"]).requires_grad_(True)
+        loss = RL.training_loss_power_law(m, mixed, target, power, ratio)
+        loss.backward()
+        tag = f"p{power}_r{ratio}"
+        assert abs(loss.item() - float(z["loss/" + tag])) < 1e-12
+        assert np.abs(m.grad.numpy() - z["dmask/" + tag]).max() <= 1e-12 * np.abs(z["dmask/" + tag]).max()
+
+
 def test_istft_restatement_is_a_windowed_inverse_dft():
     """torch_spec2wav's iSTFT == (windowed inverse real-DFT basis GEMM + overlap-add / envelope):
     the formulation the HIP kernels use, checked here in fp64 on the CPU."""

@@ -136,6 +136,7 @@ SIGNATURES = {
     "vs_bilstm_recurrent_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vs_sisnr_workspace_bytes": (c_size_t, [POINTER(VsLossDims)]),
     "vs_sisnr_loss": (c_int, [POINTER(VsLossDims), _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P]),
+    "vs_powerlaw_loss": (c_int, [_P, _P, _P, c_longlong, c_float, c_float, _P, _P, _P, _P]),
     "vs_audio_workspace_bytes": (c_size_t, [POINTER(VsLossDims)]),
     "vs_wav_to_spec": (c_int, [POINTER(VsLossDims), _P, _P, _P, _P, c_size_t, _P]),
     "vs_spec_to_wav": (c_int, [POINTER(VsLossDims), _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -284,6 +284,54 @@ inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct LossLayout { size_t basis, fbasis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, total; };
 
+// ---- PowerLaw_Compressed_Loss (utils/generic_utils.py:353-373), the criterion train.py:74-75 picks
+// for loss_name == 'power_law_compression' (the voicefilter configuration):
+//   o = mixed*mask + 1e-16, t = target + 1e-16, po = o^p, pt = t^p
+//   loss = mean((|pt| - |po|)^2) + ratio * mean((pt - po)^2)
+// One streaming pass: both sums in fp64 (two atomics per workgroup) and, since the gradient needs
+// nothing from the reduction but 1/n,
+//   dmask = mixed * p*o^(p-1) * ( 2(|po| - |pt|) sign(po) + 2 ratio (po - pt) ) / n
+// which is what autograd gives through mul / add / pow / abs / MSELoss.  A negative o makes po NaN,
+// as torch.pow does.
+__global__ __launch_bounds__(256)
+void powerlaw_kernel(const float* __restrict__ mixed, const float* __restrict__ mask, const float* __restrict__ target,
+                     long long n, float power, float ratio, double* __restrict__ sums, float* __restrict__ dmask) {
+  constexpr float kEps = 1e-16f;
+  const float inv_n = (float)(1.0 / (double)n);
+  double a0 = 0.0, a1 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float mx = mixed[i];
+    const float o = mx * mask[i] + kEps;
+    const float t = target[i] + kEps;
+    const float po = powf(o, power), pt = powf(t, power);
+    const float ds = fabsf(pt) - fabsf(po), dc = pt - po;
+    a0 += (double)(ds * ds);
+    a1 += (double)(dc * dc);
+    if (dmask) {
+      const float sgn = po > 0.f ? 1.f : (po < 0.f ? -1.f : 0.f);
+      const float dpo = (-2.f * ds * sgn - 2.f * ratio * dc) * inv_n;
+      dmask[i] = mx * (power * powf(o, power - 1.f)) * dpo;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+  }
+  __shared__ double sh[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[2 * w] = a0; sh[2 * w + 1] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], sh[0] + sh[2] + sh[4] + sh[6]);
+    atomicAdd(&sums[1], sh[1] + sh[3] + sh[5] + sh[7]);
+  }
+}
+
+__global__ void powerlaw_finalize_kernel(const double* __restrict__ sums, long long n, float ratio, float* __restrict__ loss) {
+  *loss = (float)(sums[0] / (double)n + (double)ratio * (sums[1] / (double)n));
+}
+
 int make_shape(const vs_loss_dims* d, LossShape* s) {
   VS_REQUIRE(d != nullptr, "loss dims is NULL");
   VS_REQUIRE(d->B > 0 && d->T > 1 && d->F > 1 && d->hop > 0 && d->win > 0, "loss: bad dims B=%d T=%d F=%d hop=%d win=%d", d->B, d->T, d->F, d->hop, d->win);
@@ -392,6 +440,20 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
 //   est_wav = ap.inv_spectrogram(est_mask*mixed_spec, mixed_phase)    :478-491, generic_utils.py:496-504
 // both as one GEMM against a windowed DFT basis plus a gather (frames in / overlap-add out).
 // ---------------------------------------------------------------------------------------------
+int vs_powerlaw_loss(const float* mixed, const float* mask, const float* target, long long n, float power,
+                     float complex_loss_ratio, double* scratch, float* loss, float* dmask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VS_REQUIRE(mixed && mask && target && scratch && loss, "powerlaw_loss: NULL argument");
+  VS_REQUIRE(n > 0, "powerlaw_loss: n=%lld", n);
+  VS_CHECK_HIP(hipMemsetAsync(scratch, 0, 2 * sizeof(double), stream));
+  const long long want = (n + 255) / 256;
+  const int grid = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(powerlaw_kernel, dim3(grid), dim3(256), 0, stream, mixed, mask, target, n, power, complex_loss_ratio, scratch, dmask);
+  hipLaunchKernelGGL(powerlaw_finalize_kernel, dim3(1), dim3(1), 0, stream, scratch, n, complex_loss_ratio, loss);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t vs_audio_workspace_bytes(const vs_loss_dims* d) { return vs_sisnr_workspace_bytes(d); }
 
 int vs_wav_to_spec(const vs_loss_dims* d, const float* wav, float* spec, float* phase, void* ws, size_t ws_bytes, void* stream_) {

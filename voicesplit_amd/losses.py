@@ -74,3 +74,34 @@ def sisnr_loss(mask, mixed, target, phase, seq_len, audio_cfg, return_wav: bool 
     B, T, F = mask.shape
     d = loss_dims(B, T, F, audio_cfg)
     return _SiSnr.apply(mask.contiguous(), mixed.contiguous(), target.contiguous(), phase.contiguous(), seq_len, d, return_wav)
+
+
+class _PowerLaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, mixed, target, power, ratio):
+        lib = _lib.load()
+        for n, t in (("mask", mask), ("mixed", mixed), ("target", target)):
+            _dev_check(t.detach(), n)
+        if mixed.shape != mask.shape or target.shape != mask.shape:
+            raise ValueError(f"power_law_loss: shapes differ: mask {tuple(mask.shape)}, mixed {tuple(mixed.shape)}, "
+                             f"target {tuple(target.shape)}")
+        scratch = torch.empty(2, dtype=torch.float64, device=mask.device)
+        loss = torch.empty((), dtype=torch.float32, device=mask.device)
+        dmask = torch.empty_like(mask) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(mask.device):
+            rc = lib.vs_powerlaw_loss(_p(mixed), _p(mask.detach()), _p(target), mask.numel(), float(power), float(ratio),
+                                      _p(scratch), _p(loss), _p(dmask), _stream())
+        _lib.check(rc, "vs_powerlaw_loss")
+        ctx.dmask = dmask
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        return ctx.dmask * grad_loss, None, None, None, None
+
+
+def power_law_loss(mask, mixed, target, power: float = 0.3, complex_loss_ratio: float = 0.113):
+    """train.py:95,108 with ``criterion = PowerLaw_Compressed_Loss(power, complex_loss_ratio)``
+    (utils/generic_utils.py:353-373; the voicefilter configuration): 0-dim loss, differentiable w.r.t.
+    ``mask``.  mask, mixed, target: same shape, fp32, on the GPU."""
+    return _PowerLaw.apply(mask.contiguous(), mixed.contiguous(), target.contiguous(), power, complex_loss_ratio)

@@ -81,12 +81,15 @@ class GradientBucket:
     (no SyncBN); ``sync_buffers`` broadcasts rank 0's running statistics when a checkpoint is cut.
     """
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, extra: int = 0):
+        """extra: spare floats at the end of the bucket (``self.extra``) that ride along in the same
+        collective -- the trainer puts the loss there so that every rank logs the averaged value."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.flat = torch.zeros(self.numel + extra, dtype=p0.dtype, device=p0.device)
+        self.extra = self.flat[self.numel:]
         self.views = []
         off = 0
         for p in self.params:

@@ -1,0 +1,356 @@
+"""Data-parallel training loop around the mask path: what train.py:25-135 does
+with the model, one process per GPU.
+
+The reference trains on one GPU (run_train.sh:1) with ``DataLoader(shuffle=True, drop_last=True)``
+(utils/dataset.py:60-68), Adam (train.py:33-35), one of two criteria (train.py:74-79) and the step
+
+    mask = model(mixed, emb); output = mixed * mask; loss = criterion(...)      train.py:94-108
+    optimizer.zero_grad(); loss.backward(); optimizer.step(); step += 1         train.py:109-112
+
+This module keeps that loop and its checkpoint format (train.py:127-132: ``model``, ``optimizer``,
+``step``, ``config_str`` -- loadable by the reference's test.py) and adds the N-GPU part:
+
+* ``EpochShard``: every rank walks the same seeded permutation of the dataset and takes its slice
+  of every global batch (world * batch_size items, incomplete global batches dropped as
+  ``drop_last=True`` does), so all ranks run the same number of steps and no collective can hang;
+* ``Trainer.train_step``: the step above with ONE collective -- the flat gradient bucket of
+  ``sharding.GradientBucket`` (RCCL sum over xGMI, divided by the world size), which also carries
+  the loss value in a spare slot so that logging and the loss-explosion guard (train.py:115-117) see
+  the same number on every rank and stop together;
+* BatchNorm statistics stay per replica as in the reference (no SyncBN); rank 0's running
+  statistics are broadcast when a checkpoint is cut and rank 0 alone writes it.
+
+Everything here is host logic over ``nn.Module`` / ``torch.distributed``: it runs under gloo with
+a CPU stand-in model in tests/test_trainer_cpu.py; with ``VoiceSplit`` / ``VoiceFilter`` and the
+criteria of ``losses.py`` every flop of the step is inside libvoicesplit_hip.so.
+"""
+import math
+import os
+from glob import glob
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence
+
+import torch
+
+from .sharding import GradientBucket, sync_buffers
+
+
+class LossExploded(RuntimeError):
+    """train.py:115-117: ``loss > 1e8 or math.isnan(loss)`` ends the epoch."""
+
+
+# ---------------------------------------------------------------------------------------------
+# which items a rank sees
+# ---------------------------------------------------------------------------------------------
+class EpochShard:
+    """Index batches of one rank.  ``for idx in EpochShard(n, b, rank, world, seed).epoch(e)`` yields
+    lists of ``b`` dataset indices; the union over ranks of the k-th lists is the k-th global batch
+    of a ``shuffle=True, drop_last=True`` loader with batch size ``world * b``."""
+
+    def __init__(self, n_items: int, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0,
+                 shuffle: bool = True):
+        if world <= 0 or not (0 <= rank < world):
+            raise ValueError(f"bad rank/world {rank}/{world}")
+        if batch_size <= 0 or n_items < 0:
+            raise ValueError("batch_size must be > 0 and n_items >= 0")
+        self.n, self.b, self.rank, self.world, self.seed, self.shuffle = n_items, batch_size, rank, world, seed, shuffle
+
+    def steps_per_epoch(self) -> int:
+        return self.n // (self.b * self.world)
+
+    def epoch(self, epoch: int) -> Iterator[List[int]]:
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed * 1000003 + epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        gb = self.b * self.world
+        for k in range(self.steps_per_epoch()):
+            lo = k * gb + self.rank * self.b
+            yield order[lo:lo + self.b]
+
+
+# ---------------------------------------------------------------------------------------------
+# criteria of train.py:74-79
+# ---------------------------------------------------------------------------------------------
+def make_criterion(c) -> Callable:
+    """``criterion(mask, mixed, target, seq_len, spec_phase) -> loss`` for ``c.loss['loss_name']``:
+    'si_snr' (train.py:97-103 + SiSNR_With_Pit) or 'power_law_compression' (PowerLaw_Compressed_Loss,
+    seq_len ignored as train.py:104-105 does).  Both are single calls into libvoicesplit_hip.so."""
+    from . import losses
+    name = c.loss["loss_name"]
+    if name == "si_snr":
+        audio_cfg = c.audio[c.audio["backend"]]
+        return lambda mask, mixed, target, seq_len, phase: losses.sisnr_loss(mask, mixed, target, phase, seq_len, audio_cfg)
+    if name == "power_law_compression":
+        power, ratio = c.loss["power"], c.loss["complex_loss_ratio"]
+        return lambda mask, mixed, target, seq_len, phase: losses.power_law_loss(mask, mixed, target, power, ratio)
+    raise Exception(" The loss '" + name + "' is not suported")          # train.py:79
+
+
+def make_optimizer(c, params):
+    """train.py:33-37."""
+    if c.train_config["optimizer"] == "adam":
+        return torch.optim.Adam(params, lr=c.train_config["learning_rate"])
+    raise Exception("The %s  not is a optimizer supported" % c.train_config["optimizer"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------
+class Trainer:
+    """One rank of the training job.  ``model``: VoiceSplit / VoiceFilter on this rank's GPU (any
+    ``nn.Module`` with the same ``forward(mixed, emb) -> mask`` works: the CPU tests use one)."""
+
+    def __init__(self, model: torch.nn.Module, c, rank: int = 0, world: int = 1, group=None,
+                 criterion: Optional[Callable] = None, optimizer: Optional[torch.optim.Optimizer] = None):
+        self.model, self.c, self.rank, self.world, self.group = model, c, rank, world, group
+        self.criterion = criterion if criterion is not None else make_criterion(c)
+        self.optimizer = optimizer if optimizer is not None else make_optimizer(c, model.parameters())
+        self.bucket = GradientBucket(model.parameters(), group, extra=1).attach()
+        self.device = self.bucket.flat.device
+        self.step = 0
+        if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
+            import torch.distributed as dist
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=group)
+
+    # -- checkpoints: train.py:38-60 (load), :125-133 (save) ---------------------------------------
+    def load_checkpoint(self, path: str, reinit_layers: Optional[Sequence[str]] = None) -> int:
+        ckpt = torch.load(path, map_location="cpu")
+        try:
+            if reinit_layers:
+                raise RuntimeError
+            self.model.load_state_dict(ckpt["model"])
+        except RuntimeError:
+            # partial initialisation, utils/generic_utils.py:647-676: same key, same numel; layers
+            # named in reinit_layers keep their fresh values
+            cur = self.model.state_dict()
+            take = {k: v for k, v in ckpt["model"].items() if k in cur and v.numel() == cur[k].numel()}
+            for name in reinit_layers or ():
+                take = {k: v for k, v in take.items() if name not in k}
+            cur.update({k: v.reshape(cur[k].shape) for k, v in take.items()})
+            self.model.load_state_dict(cur)
+        try:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        except (ValueError, KeyError):
+            pass                                  # train.py:57-58: optimizer state is optional
+        self.step = int(ckpt["step"])
+        # load_state_dict copies into the existing tensors, so .grad views into the bucket survive
+        return self.step
+
+    def save_checkpoint(self, path: str) -> Optional[str]:
+        """All ranks call this (it contains a broadcast); rank 0 writes the file."""
+        if self.world > 1:
+            sync_buffers(self.model, 0, self.group)
+        if self.rank != 0:
+            return None
+        torch.save({"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(),
+                    "step": self.step, "config_str": str(self.c)}, path)
+        return path
+
+    # -- one step: train.py:86-117 ---------------------------------------------------------------------
+    def train_step(self, batch) -> float:
+        """batch = (emb, target, mixed, seq_len, target_wav, spec_phase) as train_collate_fn returns
+        it (utils/dataset.py:84-114).  Returns the loss averaged over ranks; raises LossExploded on
+        every rank at once."""
+        emb, target, mixed, seq_len, _target_wav, phase = batch
+        dev = self.device
+        emb, target, mixed, phase = (t.to(dev, non_blocking=True) for t in (emb, target, mixed, phase))
+        if seq_len is not None:
+            seq_len = seq_len.to(dev, non_blocking=True).reshape(-1)
+        self.model.train()
+        mask = self.model(mixed, emb)                                       # train.py:94
+        loss = self.criterion(mask, mixed, target, seq_len, phase)          # :95-108
+        self.bucket.zero()                                                  # optimizer.zero_grad()
+        loss.backward()                                                     # :110
+        self.bucket.extra[0] = loss.detach()
+        self.bucket.all_reduce(self.world)                                  # the one exchange step
+        value = float(self.bucket.extra[0].item())                          # :114 (the reference syncs here too)
+        # :115-117.  Checked before the update (the reference applies the non-finite update first and
+        # then leaves the epoch; the weights it leaves behind are unusable either way)
+        if value > 1e8 or math.isnan(value):
+            raise LossExploded("Loss exploded to %.02f at step %d!" % (value, self.step + 1))
+        self.optimizer.step()                                               # :111
+        self.step += 1
+        return value
+
+    @torch.no_grad()
+    def validate(self, batches: Iterable) -> float:
+        """Mean criterion value over this rank's validation batches in eval mode, averaged over ranks
+        (the loss part of utils/generic_utils.py:476-530; its SDR column needs mir_eval and stays
+        with the reference's test.py)."""
+        self.model.eval()
+        tot, cnt = 0.0, 0
+        for emb, target, mixed, seq_len, _tw, phase in batches:
+            dev = self.device
+            emb, target, mixed, phase = (t.to(dev) for t in (emb, target, mixed, phase))
+            if seq_len is not None:
+                seq_len = seq_len.to(dev).reshape(-1)
+            tot += float(self.criterion(self.model(mixed, emb), mixed, target, seq_len, phase).item())
+            cnt += 1
+        acc = torch.tensor([tot, float(cnt)], dtype=torch.float64, device=self.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(acc, group=self.group)
+        self.model.train()
+        return float(acc[0] / acc[1]) if acc[1] > 0 else float("nan")
+
+    def fit(self, batches_for_epoch: Callable[[int], Iterable], epochs: Optional[int] = None, log_dir: Optional[str] = None,
+            on_log: Optional[Callable[[int, float], None]] = None, validation_batches: Optional[Callable[[], Iterable]] = None):
+        """train.py:81-135.  ``batches_for_epoch(e)`` yields this rank's batches of epoch e."""
+        tc = self.c.train_config
+        epochs = tc["epochs"] if epochs is None else epochs
+        for e in range(epochs):
+            if validation_batches is not None:                              # :82
+                v = self.validate(validation_batches())
+                if on_log and self.rank == 0:
+                    on_log(-self.step, v)
+            for batch in batches_for_epoch(e):
+                try:
+                    loss = self.train_step(batch)
+                except LossExploded as err:                                 # :115-117: leave this epoch
+                    if self.rank == 0:
+                        print(err)
+                    break
+                if self.step % tc["summary_interval"] == 0 and on_log and self.rank == 0:     # :120-122
+                    on_log(self.step, loss)
+                if log_dir and self.step % tc["checkpoint_interval"] == 0:                     # :125-133
+                    p = self.save_checkpoint(os.path.join(log_dir, "checkpoint_%d.pt" % self.step))
+                    if p:
+                        print("Saved checkpoint to: %s" % p)
+        return self.step
+
+
+# ---------------------------------------------------------------------------------------------
+# data: the reference's on-disk training set, STFT moved to the GPU
+# ---------------------------------------------------------------------------------------------
+def load_wav(path: str, sample_rate: int) -> torch.Tensor:
+    """float32 mono in [-1, 1] like ``librosa.load(path, sr=sample_rate)`` for files already at
+    ``sample_rate`` (utils/audio_processor.py:516-518); there is no resampler here."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path)
+    if sr != sample_rate:
+        raise ValueError(f"{path}: sample rate {sr} != {sample_rate} (resample the dataset first)")
+    t = torch.from_numpy(data.copy())
+    if t.dtype == torch.int16:
+        t = t.float() / 32768.0
+    elif t.dtype == torch.int32:
+        t = t.float() / 2147483648.0
+    elif t.dtype == torch.uint8:
+        t = (t.float() - 128.0) / 128.0
+    else:
+        t = t.float()
+    return t.mean(dim=1) if t.dim() == 2 else t
+
+
+class SpecWavDataset:
+    """The training items of utils/dataset.py:8-41 read from ``c.dataset['train_dir']`` with the
+    globs of ``c.dataset['format']``: emb ``*-emb.pt``, target spectrogram ``*-target.pt``, and the
+    two wavs.  ``__getitem__`` returns (emb, target_spec, mixed_wav, seq_len, target_wav): the mixed
+    spectrogram and phase are NOT computed here per item by librosa but once per batch on the GPU
+    (``collate``), which is the point of the front end of audio.py."""
+
+    def __init__(self, c, train: bool = True):
+        self.c = c
+        self.dir = c.dataset["train_dir"] if train else c.dataset["test_dir"]
+        if not os.path.isdir(self.dir):
+            raise FileNotFoundError("Test or Train dataset dir is incorrect! Fix it in config.json: " + str(self.dir))
+        fmt = c.dataset["format"]
+        find = lambda g: sorted(glob(os.path.join(self.dir, g)))
+        self.emb, self.target, self.target_wav, self.mixed_wav = (find(fmt[k]) for k in ("emb", "target", "target_wav", "mixed_wav"))
+        if not (len(self.emb) == len(self.target) == len(self.mixed_wav) == len(self.target_wav)):
+            raise ValueError(" The number of target and mixed Specs and Embs not Match! Check its")
+        if not self.emb:
+            raise ValueError(" Training files not found !")
+        self.sr = int(c.audio[c.audio["backend"]]["sample_rate"])
+
+    def __len__(self):
+        return len(self.emb)
+
+    def __getitem__(self, i):
+        mixed_wav = load_wav(self.mixed_wav[i], self.sr)
+        target_wav = load_wav(self.target_wav[i], self.sr)
+        seq_len = torch.tensor([mixed_wav.shape[0]])
+        return torch.load(self.emb[i]), torch.load(self.target[i]), mixed_wav, seq_len, target_wav
+
+    def collate(self, items, device) -> tuple:
+        """train_collate_fn (utils/dataset.py:84-114) + get_spec_from_audio for the whole batch on
+        ``device``: returns (emb, target, mixed, seq_len, target_wav, mixed_phase)."""
+        from . import audio
+        items = [it for it in items if it[0].tolist() != [0]]               # :93-95
+        emb = torch.stack([it[0].float().reshape(-1) for it in items]).to(device)
+        target = torch.stack([it[1].float() for it in items]).to(device)
+        wav = torch.stack([it[2] for it in items]).to(device)
+        seq_len = torch.stack([it[3] for it in items]).reshape(-1).to(device)
+        target_wav = torch.stack([it[4] for it in items])
+        mixed, phase = audio.wav_to_spec(wav, self.c.audio[self.c.audio["backend"]], want_phase=True)
+        return emb, target, mixed, seq_len, target_wav, phase
+
+
+def synthetic_batches(steps: int, B: int, T: int, F: int, E: int, hop: int, device, seed: int = 0):
+    """Batches of the reference's shape with random content (bench.py, smoke tests): one fixed batch
+    per distinct seed, yielded ``steps`` times."""
+    g = torch.Generator().manual_seed(seed)
+    mixed = torch.rand(B, T, F, generator=g).to(device)
+    target = (mixed.cpu() * torch.rand(B, T, F, generator=g)).to(device)
+    phase = ((torch.rand(B, T, F, generator=g) - 0.5) * 6.2).to(device)
+    emb = torch.randn(B, E, generator=g)
+    emb = (emb / emb.norm(dim=1, keepdim=True)).to(device)
+    seq_len = torch.full((B,), hop * (T - 1), dtype=torch.int32, device=device)
+    for _ in range(steps):
+        yield emb, target, mixed, seq_len, None, phase
+
+
+def main(argv=None):
+    """``python -m torch.distributed.run --nproc-per-node N -m voicesplit_amd.trainer -c config.json``
+    (train.py's CLI: --config_path/-c, --checkpoint_path; plus --synthetic-steps for a dry run)."""
+    import argparse
+    import torch.distributed as dist
+    from . import VoiceFilter, VoiceSplit, load_config
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config_path", required=True)
+    ap.add_argument("--checkpoint_path", default=None)
+    ap.add_argument("--synthetic-steps", type=int, default=0, help="train on random batches of the configured shape instead of c.dataset")
+    ap.add_argument("--epochs", type=int, default=None)
+    args = ap.parse_args(argv)
+    c = load_config(args.config_path)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("voicesplit_amd.trainer needs a GPU: the mask path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(c.train_config["seed"])
+    name = c.model_name
+    if name == "voicefilter":
+        model = VoiceFilter(c)
+    elif name == "voicesplit":
+        model = VoiceSplit(c)
+    else:
+        raise Exception(" The model '" + name + "' is not suported")       # train.py:31
+    tr = Trainer(model.to(dev), c, rank, world)
+    if args.checkpoint_path:
+        tr.load_checkpoint(args.checkpoint_path, c.train_config.get("reinit_layers"))
+    log_dir = c.train_config["logs_path"]
+    if rank == 0:
+        os.makedirs(log_dir, exist_ok=True)
+    acfg = c.audio[c.audio["backend"]]
+    b = c.train_config["batch_size"]
+    if args.synthetic_steps:
+        T = 1 + (int(c.audio["audio_len"]) * acfg["sample_rate"]) // acfg["hop_length"]
+        batches = lambda e: synthetic_batches(args.synthetic_steps, b, T, acfg["num_freq"], c.model["emb_dim"],
+                                              acfg["hop_length"], dev, seed=1000 * e + rank)
+    else:
+        ds = SpecWavDataset(c, train=True)
+        shard = EpochShard(len(ds), b, rank, world, c.train_config["seed"])
+        batches = lambda e: (ds.collate([ds[i] for i in idx], dev) for idx in shard.epoch(e))
+    log = lambda step, loss: print(("validation" if step <= 0 else "step %d" % step) + " loss %.5f" % loss, flush=True)
+    tr.fit(batches, args.epochs, log_dir, log)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
