@@ -274,6 +274,12 @@ int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, flo
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,
                   const float* scale, const float* shift, const float* mean, const float* invstd,
                   float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream);
+/* cnn1: the same for da, z [B][64][T][F] fused with the 1x7 weight gradient dw [64][7] against the input
+ * x [B][T][F] (dZ1 is consumed in registers, never written).  xpad: B*T*(F+6) floats of scratch;
+ * stats: 128 doubles, coef: 192 floats, acc: 448 doubles. */
+int vs_bn_act_bwd_first(const float* da, const float* z, const float* x, float* xpad, int B, int T, int F, int act, int bn_mode,
+                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream);
 /* cnn8 */
 int vs_conv_last_dgrad(const float* dz, const float* w, float* din, int B, int T, int F, void* stream);
 int vs_conv_last_wgrad_blocks(void);

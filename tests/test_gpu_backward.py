@@ -141,6 +141,47 @@ def test_bn_act_backward(act, training, layout, shape):
     assert (dbias.double().cpu() - ref_dbias).abs().max() < 1e-4 * zd.grad.abs().sum(dim=(0, 2, 3)).max()
 
 
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(3, 11, 37), (2, 33, 301), (1, 2, 5)])
+def test_bn_act_backward_fused_with_first_layer_wgrad(act, training, shape):
+    """cnn1's BatchNorm backward with dW1 folded in (dZ1 never written): rows of 37 / 301 / 5 bins put
+    frame boundaries inside the float4 packs, 33*301 crosses the 8192-element chunk."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, T, Fq = shape
+    z = torch.randn(B, 64, T, Fq, generator=g) * 1.5 + 0.3
+    da = torch.randn(B, 64, T, Fq, generator=g)
+    x = torch.rand(B, T, Fq, generator=g)
+    gamma = torch.rand(64, generator=g) + 0.5
+    beta = torch.randn(64, generator=g) * 0.1
+    rmean = torch.randn(64, generator=g) * 0.1
+    rvar = torch.rand(64, generator=g) + 0.5
+    zd = z.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    y = F.batch_norm(zd, rmean.double().clone(), rvar.double().clone(), gd, bd, training, 0.1, 1e-5)
+    (R.activation(y, act) * da.double()).sum().backward()
+    xp = F.pad(x.double(), (3, 3))
+    dw_ref = torch.stack([(zd.grad * xp[:, None, :, k:k + Fq]).sum(dim=(0, 2, 3)) for k in range(7)], dim=1)
+    if training:
+        mean = z.double().mean(dim=(0, 2, 3))
+        var = z.double().var(dim=(0, 2, 3), unbiased=False)
+    else:
+        mean, var = rmean.double(), rvar.double()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mean * scale
+    d = dev()
+    dgamma, dbeta, dbias, dw = ops.bn_act_bwd_first(da.to(d), z.to(d), x.to(d), act, training, scale.float().to(d),
+                                                    shift.float().to(d), mean.float().to(d), invstd.float().to(d))
+    assert rel_err(dw.reshape(64, 7), dw_ref) < KTOL
+    assert rel_err(dgamma, gd.grad) < KTOL
+    assert rel_err(dbeta, bd.grad) < KTOL
+    ref_dbias = zd.grad.sum(dim=(0, 2, 3))
+    assert (dbias.double().cpu() - ref_dbias).abs().max() < 1e-4 * zd.grad.abs().sum(dim=(0, 2, 3)).max()
+
+
 def test_conv_edge_layers_backward():
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(9)

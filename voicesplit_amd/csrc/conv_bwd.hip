@@ -412,6 +412,101 @@ void conv_first_wgrad_kernel(const float* __restrict__ dz, const float* __restri
   }
 }
 
+// xp[r][F+6] = {0,0,0, x[r][0..F-1], 0,0,0}: the 1x7 taps of cnn1 read it without edge tests
+__global__ void pad_rows3_kernel(const float* __restrict__ x, float* __restrict__ xp, long long rows, int F) {
+  const int P = F + 6;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * P; i += (long long)gridDim.x * 256) {
+    const long long r = i / P;
+    const int j = (int)(i - r * P);
+    xp[i] = (j >= 3 && j < F + 3) ? x[r * F + (j - 3)] : 0.f;
+  }
+}
+
+// cnn1: pass 2 of the BatchNorm backward with the 1x7 weight gradient folded in.  dZ1 has no other
+// consumer (the input needs no gradient), so it is formed in registers and contracted with the
+// seven shifted inputs on the spot, dW[c][k] += dZ1[b][c][t][f] * x[b][t][f+k-3], instead of being
+// written (2.96 GB at B=64) and read back by conv_first_wgrad_kernel.  Same (row, chunk) walk as
+// bn_act_bwd_apply_kernel; xp = zero-padded input rows (pad_rows3_kernel).
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_act_bwd_first_kernel(const float* __restrict__ da, const float* __restrict__ z, const float* __restrict__ xp,
+                             long long B, int T, int F, const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ coef, double* __restrict__ acc /* [64][7] */) {
+  constexpr int C = 64;
+  const int c = blockIdx.y;
+  const int L = T * F, P = F + 6;
+  const float sc = scale[c], sh = shift[c], cA = coef[c], cB = coef[C + c], cC = coef[2 * C + c];
+  const float invF = 1.0f / (float)F;
+  const int gx = vs_row_chunks(L);
+  double d[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) d[k] = 0.0;
+  for (long long it = blockIdx.x; it < B * gx; it += gridDim.x) {
+    const long long b = it / gx;
+    const long long off = (c + (long long)C * b) * L;
+    const float* pz = z + off;
+    const float* pg = da + off;
+    const float* xb = xp + b * T * P;
+    float s[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] = 0.f;
+    vs_walk_chunk(L, vs_row_phase(pz, pg), (int)(it % gx),
+                  [&](int i, auto w) {
+                    BnBwdPack<decltype(w)::value> r;
+                    r.g = vs_ldv<decltype(w)::value>(pg + i);
+                    r.z = vs_ldv<decltype(w)::value>(pz + i);
+                    return r;
+                  },
+                  [&](int i, auto v) {
+                    constexpr int W = decltype(v)::N;
+                    // (t, f) of element i: float quotient (i < 2^24) with a one-step correction
+                    int t = (int)((float)i * invF);
+                    int f = i - t * F;
+                    if (f < 0) { f += F; --t; } else if (f >= F) { f -= F; ++t; }
+                    float dzv[W];
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                      const float zv = v.z.v[e];
+                      const float dy = v.g.v[e] * act_grad<ACT>(fmaf(zv, sc, sh));
+                      dzv[e] = fmaf(cA, dy, fmaf(cB, zv, cC));
+                    }
+                    const float* xr = xb + (size_t)t * P + f;      // tap k of element e of this row: xr[e + k]
+                    if (f + W <= F) {
+                      float xs[W + 6];
+#pragma unroll
+                      for (int j = 0; j < W + 6; ++j) xs[j] = xr[j];
+#pragma unroll
+                      for (int e = 0; e < W; ++e)
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) s[k] = fmaf(dzv[e], xs[e + k], s[k]);
+                    } else {                                        // the pack runs into the next frame
+#pragma unroll
+                      for (int e = 0; e < W; ++e) {
+                        const float* q = (f + e < F) ? xr + e : xr + e + 6;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) s[k] = fmaf(dzv[e], q[k], s[k]);
+                      }
+                    }
+                  });
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d[k] += s[k];
+  }
+  __shared__ double red[4][7];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double x = d[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    if (lane == 0) red[w][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    atomicAdd(&acc[c * 7 + k], red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
+}
+
 __global__ void cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
@@ -506,6 +601,39 @@ int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc /* [64
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && B <= 65535, "conv_first_wgrad: bad shape B=%d T=%d F=%d", B, T, F);
   VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 448, stream));
   hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3((T * F + 4095) / 4096, 64, B), dim3(256), 0, stream, dz, x, acc, T, F);
+  hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(2), dim3(256), 0, stream, acc, dw, 448);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn1: BatchNorm+activation backward and the 1x7 weight gradient in one go (dZ1 is never stored).
+//   da, z: [B][64][T][F]; x: [B][T][F]; xpad: B*T*(F+6) floats of scratch; acc: 448 doubles.
+int vs_bn_act_bwd_first_impl(const float* da, const float* z, const float* x, float* xpad, int B, int T, int F, int act, int train,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc,
+                             hipStream_t stream) {
+  VS_REQUIRE(B > 0 && T > 0 && F >= 4 && (long long)T * F < (1 << 24), "bn_act_bwd_first: bad shape B=%d T=%d F=%d (needs F >= 4, T*F < 2^24)", B, T, F);
+  constexpr int C = 64;
+  const int L = T * F;
+  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
+  VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 448, stream));
+  dim3 grid(vs_bn_blocks_per_channel(C, B, L), C), block(256);
+  const long long rows = (long long)B * T;
+  hipLaunchKernelGGL(pad_rows3_kernel, dim3((unsigned)((rows * (F + 6) + 255) / 256 < 4096 ? (rows * (F + 6) + 255) / 256 : 4096)), block, 0, stream,
+                     x, xpad, rows, F);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, (long long)B, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, (long long)B, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, (long long)B, L, scale, shift, mean, invstd, stats); break;
+    default: VS_REQUIRE(false, "bn_act_bwd_first: unknown activation %d", act);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, (double)B * L, train, C,
+                     scale, mean, invstd, dgamma, dbeta, dbias, coef);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_first_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, xpad, (long long)B, T, F, scale, shift, coef, acc); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_first_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, xpad, (long long)B, T, F, scale, shift, coef, acc); break;
+    default: hipLaunchKernelGGL(bn_act_bwd_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, xpad, (long long)B, T, F, scale, shift, coef, acc); break;
+  }
   hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(2), dim3(256), 0, stream, acc, dw, 448);
   VS_LAUNCH_CHECK();
   return 0;

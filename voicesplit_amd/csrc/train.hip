@@ -373,9 +373,17 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     }
     cur ^= 1;
   }
-  if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
-  VsProfScope ps(VS_PROF_BWD_EDGE, stream);
-  return vs_conv_first_wgrad_impl(gbuf[cur], x, at<double>(tape, L.first_acc), g->conv[0].weight, B, T, F, stream);
+  if (F < 4 || (long long)T * F >= (1 << 24)) {   // packs spanning >2 frames / float frame index: unfused path
+    if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
+    VsProfScope ps(VS_PROF_BWD_EDGE, stream);
+    return vs_conv_first_wgrad_impl(gbuf[cur], x, at<double>(tape, L.first_acc), g->conv[0].weight, B, T, F, stream);
+  }
+  // cnn1: BatchNorm backward and dW1 together; dZ1 is never stored.  The idle gradient buffer holds
+  // the zero-padded input rows.
+  VsProfScope ps(VS_PROF_BWD_BN, stream);
+  return vs_bn_act_bwd_first_impl(gbuf[cur], at<float>(tape, L.z[0]), x, gbuf[cur ^ 1], B, T, F, conv_act, train, scale, shift, mean,
+                                  invstd, g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight, stats, coef,
+                                  at<double>(tape, L.first_acc), stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,6 +415,14 @@ int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R
   VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef, "bn_act_bwd: NULL argument");
   return vs_bn_act_bwd_impl(da, z, dz, C, R, L, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
                             stats, coef, nullptr, (hipStream_t)stream);
+}
+
+int vs_bn_act_bwd_first(const float* da, const float* z, const float* x, float* xpad, int B, int T, int F, int act, int bn_mode,
+                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream) {
+  VS_REQUIRE(da && z && x && xpad && scale && shift && mean && invstd && dw && stats && coef && acc, "bn_act_bwd_first: NULL argument");
+  return vs_bn_act_bwd_first_impl(da, z, x, xpad, B, T, F, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
+                                  dw, stats, coef, acc, (hipStream_t)stream);
 }
 
 int vs_conv_last_dgrad(const float* dz, const float* w, float* din, int B, int T, int F, void* stream) {

@@ -67,6 +67,10 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
 int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, unsigned* amax_out, hipStream_t);
+int vs_bn_act_bwd_first_impl(const float* da, const float* z, const float* x, float* xpad, int B, int T, int F, int act, int train,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc,
+                             hipStream_t stream);
 int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t);
 int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, hipStream_t);
 int vs_conv_first_wgrad_impl(const float* dz, const float* x, double* acc, float* dw, int B, int T, int F, hipStream_t);

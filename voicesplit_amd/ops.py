@@ -440,6 +440,28 @@ def bn_act_bwd(da, z, C: int, act: str, training: bool, scale, shift, mean, invs
     return dz, dgamma, dbeta, dbias
 
 
+def bn_act_bwd_first(da, z, x, act: str, training: bool, scale, shift, mean, invstd):
+    """cnn1: da, z [B,64,T,F] and the input x [B,T,F] -> dgamma, dbeta, dbias, dw [64,1,1,7]
+    (BatchNorm+activation backward fused with the 1x7 weight gradient; dZ1 is not materialised)."""
+    lib = _lib.load()
+    for n, t in (("da", da), ("z", z), ("x", x), ("scale", scale), ("shift", shift), ("mean", mean), ("invstd", invstd)):
+        _dev_check(t, n)
+    B, C, T, F = da.shape
+    if C != 64 or tuple(x.shape) != (B, T, F) or z.shape != da.shape:
+        raise ValueError(f"bn_act_bwd_first: da {tuple(da.shape)}, z {tuple(z.shape)}, x {tuple(x.shape)}")
+    dev = da.device
+    dgamma, dbeta, dbias = (torch.empty(64, device=dev) for _ in range(3))
+    dw = torch.empty(64, 1, 1, 7, device=dev)
+    xpad = torch.empty(B * T * (F + 6), device=dev)
+    stats = torch.empty(128, dtype=torch.float64, device=dev)
+    acc = torch.empty(448, dtype=torch.float64, device=dev)
+    coef = torch.empty(192, device=dev)
+    check(lib.vs_bn_act_bwd_first(_p(da), _p(z), _p(x), _p(xpad), B, T, F, ACT_CODES[act], BN_TRAIN if training else BN_EVAL,
+                                  _p(scale), _p(shift), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(dbias), _p(dw),
+                                  _p(stats), _p(coef), _p(acc), _stream()), "vs_bn_act_bwd_first")
+    return dgamma, dbeta, dbias, dw
+
+
 def conv_last_dgrad(dz8, w, B, T, F):
     lib = _lib.load()
     _dev_check(dz8, "dz8")
