@@ -23,8 +23,11 @@ def main():
         "dW_ih = dxg_d^T @ feat (TN, K=19264)": lambda math: ops.gemm(dxg, feat, H4, K8, M, 1, 1, math=math),
     }
     flops = {"xg": 2.0 * M * 2 * H4 * K8, "dfeat": 2.0 * M * K8 * H4, "dW_ih": 2.0 * H4 * K8 * M}
+    only = os.environ.get("VS_MICRO_ONLY")          # e.g. "xg:f16x3"
     for name, fn in cases.items():
         for math in ("fp32", "f16x3"):
+            if only and only != f"{name.split()[0]}:{math}":
+                continue
             fn(math)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,18 +8,22 @@
 // and sit in LDS as [row][18 dwords] (16 k-pairs + 2 pad): a lane's fragment (8 consecutive k of its
 // row) is two ds_read_b64, conflict-free with lane = row (18*row mod 64 hits 32 distinct even banks).
 // K-contiguous operands arrive as float4 along k and are written with ds_write_b64; K-major
-// operands arrive as dwords with lanes along the row index (coalesced per k row) through a buffer
-// descriptor (one 32-bit lane offset, everything else scalar; flat loads with a 64-bit address and
-// a bounds branch per dword cost 50-80 more VGPRs and 1.6x the time), each thread holding the two
-// floats of a k-pair, and are written with ds_write_b32 (2-way conflict = free): the transpose
-// costs no extra pass.  Workgroups are renumbered so that each XCD (workgroup id % 8) owns a
-// contiguous range of the (m, n) tile list.
-// Measured at B=64 (rocprofv3): 19264x3200x4808 NT 3.4 ms (MFMA pipe 25 % busy, waves stalled on
-// memory 59 % of the time), 19264x4808x1600 NN 1.15 ms, 1600x4808x19264 TN 1.19 ms.  A 64-deep K
-// block, 2 vs 3 workgroups per CU and the XCD renumbering all leave the NT case within 3 %: it
-// moves 18.6 GB of operand tiles in 3.4 ms (5.5 TB/s if few of them hit in L2), which points at
-// operand re-reads rather than at the pipeline - a reading of the counters above, not yet
-// confirmed by a FETCH_SIZE pass; a larger tile is the next thing to try.
+// operands arrive as dwords with lanes along the row index (coalesced per k row), each thread
+// holding the two floats of a k-pair, and are written with ds_write_b32 (2-way conflict = free):
+// the transpose costs no extra pass.  Every global access is a buffer load whose offset is pushed
+// out of range where the row / k index leaves the matrix (hardware returns 0): one 32-bit lane
+// offset, no bounds branches, all loads of a tile in flight together.  (Flat loads behind
+// per-access `if (row < M)` / `if (k < K)` tests compiled to one exec-masked basic block per load,
+// 50-80 more VGPRs, and 1.3-1.6x the time.)  Workgroups are renumbered so that each XCD (workgroup
+// id % 8) owns a contiguous range of the (m, n) tile list.
+// Measured at B=64 (rocprofv3, same box before -> after the branch-free loads): 19264x3200x4808 NT
+// 3.48 -> 2.60 ms, 19264x4808x1600 NN 1.43 -> 1.34 ms, 1600x4808x19264 TN 1.54 -> 1.44 ms.
+// Counters of the NT case before the change: MFMA pipe 25 % busy, waves waiting 59 % of their
+// time, L2 hit rate 83 %, 2.5 GB fetched over the fabric per launch (1.5 TB/s) - neither HBM nor L2
+// bound; a 64-deep K block, 2 vs 3 workgroups per CU and the XCD renumbering each moved it < 3 %.
+// What is left is the fp32 -> f16 hi/lo conversion in the staging path (~280 VALU per wave and K
+// block against 24 MFMAs = 768 pipe cycles): operands stored pre-split by their producers are the
+// next step.
 #include "vs_common.h"
 
 namespace {
@@ -58,46 +62,60 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int i, int n) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (VEC && i + 3 < n) return *reinterpret_cast<const float4*>(p + i);
-  if (i + 0 < n) v.x = p[i + 0];
-  if (i + 1 < n) v.y = p[i + 1];
-  if (i + 2 < n) v.z = p[i + 2];
-  if (i + 3 < n) v.w = p[i + 3];
-  return v;
-}
+// One operand's view for the loads: K-contiguous operands may be two stacked matrices (rows
+// < split from `lo`, the rest from `hi`: W_ih of the two LSTM directions); a tile lying on one side
+// uses one descriptor, a straddling tile reads both (out-of-range lanes return 0) and adds.
+struct OperandView {
+  __amdgpu_buffer_rsrc_t lo, hi;
+  int row_lo, rows_lo;    // first row of this tile inside `lo`, rows of `lo`
+  int row_hi, rows_hi;    // same for `hi` (row_hi may be negative in a straddling tile)
+  int use_lo, use_hi;
+};
 
-// One operand tile [128 rows][BK k] : global -> registers (RT floats per thread)
+constexpr unsigned kOob = 0xFFFFFFF0u;    // beyond any descriptor (operands are < 4 GiB)
+
+// One operand tile [128 rows][BK k] : global -> registers (RT floats per thread).  Every access
+// is a buffer load whose offset is pushed out of range when the row or k index is outside the
+// matrix (hardware returns 0): no branches, so all loads of a tile are in flight together.
 template <int LAYOUT, bool VEC, int BK>
-__device__ __forceinline__ void tile_load(float (&r)[regs_of(BK)], const __amdgpu_buffer_rsrc_t rsrc, const float* __restrict__ base, const float* __restrict__ base_hi,
-                                          int split, int ld, int row0, int nrows, int k0, int K, int tid) {
+__device__ __forceinline__ void tile_load(float (&r)[regs_of(BK)], const OperandView& o, int ld, int row0_kmajor, int k0, int K, int tid) {
   constexpr int RT = regs_of(BK);
+  typedef float f4 __attribute__((ext_vector_type(4)));
   if (LAYOUT == 0) {
 #pragma unroll
     for (int i = 0; i < RT / 4; ++i) {
       const int v = tid + 256 * i;
-      const int row = row0 + v / (BK / 4), c4 = k0 + (v % (BK / 4)) * 4;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < nrows) {
-        const float* p = row < split ? base + (size_t)row * ld : base_hi + (size_t)(row - split) * ld;
-        t = load4<VEC>(p, c4, K);
-      }
-      r[4 * i + 0] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+      const int lr = v / (BK / 4), c4 = k0 + (v % (BK / 4)) * 4;
+      f4 t = {0.f, 0.f, 0.f, 0.f};
+      auto fetch = [&](const __amdgpu_buffer_rsrc_t rs, int row, int nrows) {
+        const bool okr = row >= 0 && row < nrows;
+        const unsigned base = ((unsigned)row * (unsigned)ld + (unsigned)c4) * 4u;
+        if (VEC) {      // K % 4 == 0: a float4 is entirely inside or entirely outside the row
+          return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (okr && c4 < K) ? base : kOob, 0, 0));
+        } else {
+          f4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            q[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (okr && c4 + e < K) ? base + 4u * e : kOob, 0, 0));
+          return q;
+        }
+      };
+      if (o.use_lo) t = fetch(o.lo, o.row_lo + lr, o.rows_lo);
+      if (o.use_hi) t += fetch(o.hi, o.row_hi + lr, o.rows_hi);
+      r[4 * i + 0] = t[0]; r[4 * i + 1] = t[1]; r[4 * i + 2] = t[2]; r[4 * i + 3] = t[3];
     }
   } else {
     // item = (row m = idx & 127, k-pair kp = idx >> 7): lanes along m, two dword loads (k, k+1)
-    // through a buffer descriptor over the whole operand: one 32-bit lane offset, the K block and
-    // pair index in the scalar offset, rows k >= K out of range (-> 0).  Columns m >= nrows read
-    // the neighbouring row: they only reach output rows / columns that are never stored.
+    // through a descriptor over the whole operand: one 32-bit lane offset, the K block and pair
+    // index in the scalar offset, rows k >= K out of range (-> 0).  Columns m >= nrows read the
+    // neighbouring row: they only reach output rows / columns that are never stored.
     const unsigned voff = ((unsigned)(2 * (tid >> 7)) * (unsigned)ld + (unsigned)(tid & 127)) * 4u;
-    const unsigned so0 = ((unsigned)k0 * (unsigned)ld + (unsigned)row0) * 4u;
+    const unsigned so0 = ((unsigned)k0 * (unsigned)ld + (unsigned)row0_kmajor) * 4u;
 #pragma unroll
     for (int i = 0; i < RT / 2; ++i) {
       const unsigned so = so0 + (unsigned)(4 * i) * (unsigned)ld * 4u;
-      r[2 * i + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
-      r[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so + (unsigned)ld * 4u, 0));
+      r[2 * i + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.lo, voff, so, 0));
+      r[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o.lo, voff, so + (unsigned)ld * 4u, 0));
     }
   }
 }
@@ -107,13 +125,14 @@ template <int LAYOUT, int BK>
 __device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsigned* __restrict__ sh, unsigned* __restrict__ sl,
                                            float s, bool relu, int tid) {
   constexpr int RT = regs_of(BK), PW = pitch_of(BK);
+  const float floor_ = relu ? 0.f : -__builtin_inff();      // max(x, -inf) = x: one v_max either way
   if (LAYOUT == 0) {
 #pragma unroll
     for (int i = 0; i < RT / 4; ++i) {
       const int v = tid + 256 * i;
       float x[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = (relu ? fmaxf(r[4 * i + j], 0.f) : r[4 * i + j]) * s;
+      for (int j = 0; j < 4; ++j) x[j] = fmaxf(r[4 * i + j], floor_) * s;
       unsigned h0, l0, h1, l1;
       split_pair(x[0], x[1], h0, l0);
       split_pair(x[2], x[3], h1, l1);
@@ -127,8 +146,8 @@ __device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsign
 #pragma unroll
     for (int i = 0; i < RT / 2; ++i) {
       const int idx = tid + 256 * i;
-      const float x0 = (relu ? fmaxf(r[2 * i], 0.f) : r[2 * i]) * s;
-      const float x1 = (relu ? fmaxf(r[2 * i + 1], 0.f) : r[2 * i + 1]) * s;
+      const float x0 = fmaxf(r[2 * i], floor_) * s;
+      const float x1 = fmaxf(r[2 * i + 1], floor_) * s;
       unsigned hi, lo;
       split_pair(x0, x1, hi, lo);
       sh[(idx & 127) * PW + (idx >> 7)] = hi;
@@ -165,23 +184,33 @@ void gemm_f16x3_kernel(Gemm16Args g) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float ra[RT], rw[RT];
-  // K-major operands are read through buffer descriptors ((K-1)*ld + rows floats)
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, LA ? (int)(((size_t)(g.K - 1) * g.lda + g.M) * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, LB ? (int)(((size_t)(g.K - 1) * g.ldw + g.N) * 4) : 0, 0x00020000);
+  // descriptors: K-major operands span (K-1)*ld + rows floats, K-contiguous ones (rows-1)*ld + K
+  auto desc = [](const float* p, size_t floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(floats * 4), 0x00020000);
+  };
+  OperandView va, vw;
+  va.lo = va.hi = desc(g.A, LA ? (size_t)(g.K - 1) * g.lda + g.M : (size_t)(g.M - 1) * g.lda + g.K);
+  va.row_lo = m0; va.rows_lo = g.M; va.row_hi = 0; va.rows_hi = 0; va.use_lo = 1; va.use_hi = 0;
+  const int nlo = g.n_split < g.N ? g.n_split : g.N;          // rows of W held by g.W
+  vw.lo = desc(g.W, LB ? (size_t)(g.K - 1) * g.ldw + g.N : (size_t)(nlo - 1) * g.ldw + g.K);
+  vw.hi = (!LB && g.N > nlo) ? desc(g.W_hi, (size_t)(g.N - nlo - 1) * g.ldw + g.K) : vw.lo;
+  vw.row_lo = n0; vw.rows_lo = nlo; vw.row_hi = n0 - nlo; vw.rows_hi = g.N - nlo;
+  vw.use_lo = LB || n0 < nlo; vw.use_hi = !LB && n0 + BN > nlo && g.N > nlo;
+
   // fragment of block x, k-step ks: 8 halves = dwords [row*PW + 8*ks + 4*half .. +3]
   const int fa = (wm * 64 + l31) * PW + 4 * half;
   const int fw = (wn * 64 + l31) * PW + 4 * half;
 
-  tile_load<LA, VEC, BK>(ra, rsA, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, 0, g.K, tid);
-  tile_load<LB, VEC, BK>(rw, rsW, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, 0, g.K, tid);
+  tile_load<LA, VEC, BK>(ra, va, g.lda, m0, 0, g.K, tid);
+  tile_load<LB, VEC, BK>(rw, vw, g.ldw, n0, 0, g.K, tid);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     __syncthreads();
     tile_store<LA, BK>(ra, sAh, sAl, sa, g.a_relu != 0, tid);
     tile_store<LB, BK>(rw, sWh, sWl, sw, g.w_relu != 0, tid);
     __syncthreads();
     if (k0 + BK < g.K) {
-      tile_load<LA, VEC, BK>(ra, rsA, g.A, nullptr, 0x7fffffff, g.lda, m0, g.M, k0 + BK, g.K, tid);
-      tile_load<LB, VEC, BK>(rw, rsW, g.W, g.W_hi, g.n_split, g.ldw, n0, g.N, k0 + BK, g.K, tid);
+      tile_load<LA, VEC, BK>(ra, va, g.lda, m0, k0 + BK, g.K, tid);
+      tile_load<LB, VEC, BK>(rw, vw, g.ldw, n0, k0 + BK, g.K, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -273,7 +302,9 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
   VS_REQUIRE(!layout_w || ((size_t)(K - 1) * ldw + N) * 4 < (1ull << 32), "gemm_f16x3: K-major W above 4 GiB");
   Gemm16Args g{A, lda, W, ldw, W_hi, n_split, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1,
                gate, ldg, a_relu, w_relu, act, accumulate, a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
-  const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
+  const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && (K % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
+  VS_REQUIRE(layout_a || ((size_t)(M - 1) * lda + K) * 4 < (1ull << 32) - 64, "gemm_f16x3: A above 4 GiB");
+  VS_REQUIRE(layout_w || ((size_t)(N - 1) * ldw + K) * 4 < (1ull << 32) - 64, "gemm_f16x3: W above 4 GiB");
   VS_REQUIRE((long long)g.tiles_m * g.tiles_n < (1LL << 30), "gemm_f16x3: too many tiles");
   dim3 grid((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8));
   if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream);
