@@ -1,20 +1,12 @@
 set -u
-mkdir -p gpurun_out
+mkdir -p gpurun_out/final
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd /tmp
-for rep in 1 2; do
-for v in old new; do
-cp $R/tools/$v.so.bin $R/voicesplit_amd/libvoicesplit_hip.so
-for c in xg dfeat dW_ih; do
-VS_MICRO_ONLY=$c:f16x3 timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/p_$c -o t -f csv -- python $R/tools/gemm_micro.py > /dev/null 2>&1
-python - <<PY
-import csv,glob
-for f in glob.glob('/tmp/p_$c/**/*kernel_stats.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        if 'gemm_f16x3' in r['Name']: print('$v $c', r['Calls'], round(float(r['AverageNs'])/1e6,3))
-PY
-rm -rf /tmp/p_$c
-done
-done
-done
+O=gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py > $O/bench_train.json 2> $O/bench_train.err; tail -c 600 $O/bench_train.json
+timeout 300 python bench.py --mode forward > $O/bench_forward.json 2> $O/bench_forward.err; tail -c 300 $O/bench_forward.json
+timeout 300 python bench.py --conv-math fp32 --no-cpu-baseline > $O/bench_train_fp32math.json 2>/dev/null
+timeout 300 python bench.py --model voicefilter --loss powerlaw --no-cpu-baseline > $O/bench_train_voicefilter_powerlaw.json 2>/dev/null
+bash tools/profile_gpu.sh r01_train 2>&1 | tail -3
+bash tools/profile_gpu.sh r01_forward --mode forward 2>&1 | tail -3
