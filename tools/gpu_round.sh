@@ -1,12 +1,7 @@
 set -u
-mkdir -p gpurun_out/final
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-O=gpurun_out/final
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python bench.py > $O/bench_train.json 2> $O/bench_train.err; tail -c 600 $O/bench_train.json
-timeout 300 python bench.py --mode forward > $O/bench_forward.json 2> $O/bench_forward.err; tail -c 300 $O/bench_forward.json
-timeout 300 python bench.py --conv-math fp32 --no-cpu-baseline > $O/bench_train_fp32math.json 2>/dev/null
-timeout 300 python bench.py --model voicefilter --loss powerlaw --no-cpu-baseline > $O/bench_train_voicefilter_powerlaw.json 2>/dev/null
-bash tools/profile_gpu.sh r01_train 2>&1 | tail -3
-bash tools/profile_gpu.sh r01_forward --mode forward 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -q -x 2>&1 | tail -4 | cut -c1-600
+timeout 300 python bench.py --no-cpu-baseline --steps 6 --warmup 2 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step']); print({k:v for k,v in d['stage_ms'].items() if 'wgrad' in k})"

@@ -522,7 +522,9 @@ __global__ void cvt_f64_f32_kernel(const double* __restrict__ src, float* __rest
 extern "C" int vs_conv64_wgrad_groups(int KT) { return KT == 7 ? 144 : 152; }
 
 extern "C" size_t vs_conv64_wgrad_partial_floats(int KT, int KF) {
-  return (size_t)vs_conv64_wgrad_groups(KT) * KT * KF * 4096;
+  // fp32 kernel: vs_conv64_wgrad_groups slabs; split-f16 ring kernel: 128 (5x5) / 256 (7x1) slabs
+  const size_t g32 = (size_t)vs_conv64_wgrad_groups(KT), g16 = KF == 5 ? 128 : 256;
+  return (g32 > g16 ? g32 : g16) * KT * KF * 4096;
 }
 
 int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* dw,
@@ -886,6 +888,368 @@ __global__ void conv64_wgrad_reduce_scaled_kernel(const float* __restrict__ part
 
 }  // namespace
 
+// =================================================================================================
+// Weight gradient, ring form (split-f16 arithmetic, same fragments as conv64_wgrad_f16x3_kernel).
+//
+// The kt-split kernel above stages one dz row segment and ONE shifted input row segment per tile
+// and multiplies them for the KF taps of its kt: every input row is staged KT times (rocprofv3:
+// 20 GB fetched per launch against 5.9 GB of operands), and 2 staged rows feed only KF taps.
+// Here a workgroup of 8 waves owns ALL KT*KF taps and walks a column = (utterance, 64-bin segment,
+// residue class r of the frame index modulo the dilation): frames t = r, r+d, r+2d, ...  Consecutive
+// steps of a column share KT-1 of their KT input rows, which stay in an LDS ring (row m of the
+// column lives in slot m % KT): one step stages ONE new input row and one dz row and issues all
+// KT*KF taps from LDS -- every operand element is read from HBM once and converted once.
+//   5x5: the 64x64x25 accumulators (400 KB) exceed what one workgroup can hold beside its
+//        fragments, so a group = two workgroups with 32 input channels each (same XCD: the second
+//        read of the dz row is an L2 hit).  Wave = (co block, tap group): group g owns time tap
+//        kt = g (5 taps) and a share of kt = 4 ({0,1},{2},{3},{4}) -> 7/6/6/6 accumulators.
+//   7x1: one workgroup holds all 7 taps x 64x64.  Wave = (co block, ci block, tap half {0..3},{4..6}).
+// Rows outside the image are never staged; their taps are skipped (wave-uniform test).  The next
+// step's rows travel global -> registers while the current step is multiplied; a column's first
+// step brings KT/2+1 input rows at once, issued under the previous column's last step.
+// Partial sums stay in registers for the whole launch and are reduced in a fixed order afterwards.
+// =================================================================================================
+namespace {
+
+struct WgradRingArgs {
+  const float* dz;   // [B][64][T][F]
+  const float* in;   // [B][64][T][F]
+  const float* dz_scale;   // {s, 1/s}
+  const float* in_scale;   // {s, 1/s}
+  float* part;       // [G][KT*KF][64 co][64 ci]   (scaled by s_dz*s_in)
+  int B, T, F, dil, nseg, G;
+};
+
+template <int KT, int KF>
+__global__ __launch_bounds__(512)
+void conv64_wgrad_ring_kernel(WgradRingArgs g) {
+  constexpr int P = KT / 2, PADF = KF / 2;
+  constexpr int CH = KF == 5 ? 32 : 64;            // input channels per workgroup
+  constexpr int NH = 64 / CH;                      // workgroups per group
+  constexpr int NACC = KF == 5 ? 7 : 4;
+  constexpr int NQA = (kNF + KF - 1 + 3) / 4;      // 16-byte groups per input row segment: 17 / 16
+  constexpr int NIA = (CH * NQA + 511) / 512;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+  constexpr bool DB = KF == 5;                     // double-buffered LDS: ring of KT+1 slots, two dz buffers
+  constexpr int NS = DB ? KT + 1 : KT;             // ring slots
+  constexpr int NDZ = DB ? 2 : 1;
+  constexpr int D = DB ? 1 : 2;                    // steps in flight in registers
+  unsigned* const sD = smem;                       // [NDZ][hi, lo][64 rows][kPW]
+  unsigned* const sA = smem + NDZ * 2 * 64 * kPW;  // [NS slots][hi, lo][CH rows][kPW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int hh = NH == 2 ? (jj & 1) : 0;                       // which 32 input channels
+  const int grp = (NH == 2 ? (jj >> 1) : jj) * 8 + xcd;
+  int cb, nb, tg;
+  if (KF == 5) { cb = wave & 1; nb = 0; tg = wave >> 1; }
+  else { cb = (wave >> 1) & 1; nb = wave & 1; tg = wave >> 2; }
+  const int rowd = (cb * 32 + l31) * kPW + 4 * half;            // dword index of this lane's dz fragment, K-block 0
+  const int rowa = (nb * 32 + l31) * kPW + 4 * half;
+
+  const size_t plane = (size_t)g.T * g.F;
+  const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
+  const long long slab = 64ll * plane_bytes;
+  const float s_dz = g.dz_scale[0], s_in = g.in_scale[0];
+  const int NC = g.B * g.nseg * g.dil;                          // columns
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // column c -> (utterance b, residue r, segment); steps k = 0..klast, frame t = r + k*dil
+  struct Col { int b, r, f0, nv, klast; };
+  auto decode = [&](int c) {
+    Col o;
+    const int seg = c % g.nseg;
+    const int rest = c / g.nseg;
+    o.r = rest % g.dil;
+    o.b = rest / g.dil;
+    o.f0 = seg * kNF;
+    o.nv = g.F - o.f0 < kNF ? g.F - o.f0 : kNF;
+    o.klast = o.r < g.T ? (g.T - 1 - o.r) / g.dil : -1;
+    return o;
+  };
+  auto first_col = [&](int c) {                                 // skip residues beyond the last frame
+    while (c < NC && decode(c).klast < 0) c += g.G;
+    return c;
+  };
+
+  struct Regs { f4 sd[2]; f4 sa[P + 1][NIA]; };
+  struct Ev { Col c; int col, k; bool valid; };
+  // a 16-byte group that straddles the start or the end of the utterance's slab is split into
+  // dwords (the hardware zeroes the whole out-of-range access, valid pixels included)
+  auto load16 = [&](__amdgpu_buffer_rsrc_t r, long long off, bool live) -> f4 {
+    if (!live || (off >= 0 && off + 16 <= slab))
+      return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, live ? (unsigned)off : kOob, 0, 0));
+    f4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long o = off + 4 * e;
+      x[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (o >= 0 && o < slab) ? (unsigned)o : kOob, 0, 0));
+    }
+    return x;
+  };
+  // rows of one step: dz row k, and input rows 0..P (k == 0) or k+P
+  auto issue = [&](const Ev& ev, Regs& R) {
+    const Col& o = ev.c;
+    const int k = ev.k;
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.dz + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.in + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    const int t = o.r + k * g.dil;
+    const unsigned base_d = (unsigned)((t * g.F + o.f0) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i;
+      R.sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
+    }
+#pragma unroll
+    for (int j = 0; j <= P; ++j) {
+      if (j > 0 && k > 0) break;                                // later steps bring one row
+      const int m = k == 0 ? j : k + P;
+      const bool row_ok = m <= o.klast;
+      const int base_a = ((o.r + m * g.dil) * g.F + o.f0 - PADF) * 4;      // may be negative at the very first pixels
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int idx = tid + 512 * i;
+        const int ch = idx / NQA, q = idx - ch * NQA;
+        R.sa[j][i] = load16(ra, (long long)(hh * 32 + ch) * plane_bytes + base_a + q * 16, row_ok && idx < CH * NQA);
+      }
+    }
+  };
+  // registers -> f16 hi/lo rows in LDS (dz buffer `par`, input row m -> slot m % NS)
+  auto stash = [&](const Ev& ev, const Regs& R, int par) {
+    const Col& o = ev.c;
+    const int k = ev.k;
+    const bool edge = o.f0 < PADF || o.f0 + kNF + KF - 1 - PADF > g.F;      // block-uniform: some pixel of the window is off the row
+    unsigned* const zh = sD + (size_t)(par * 2) * 64 * kPW;
+    unsigned* const zl = zh + 64 * kPW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i;
+      const int q = idx & 15;
+      f4 x = R.sd[i];
+      if (edge) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (o.f0 + 4 * q + e < g.F) ? x[e] : 0.f;
+      }
+      unsigned h0, l0, h1, l1;
+      split_pair(x[0] * s_dz, x[1] * s_dz, h0, l0);
+      split_pair(x[2] * s_dz, x[3] * s_dz, h1, l1);
+      u2v hv, lv;
+      hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+      *reinterpret_cast<u2v*>(&zh[(idx >> 4) * kPW + 2 * q]) = hv;
+      *reinterpret_cast<u2v*>(&zl[(idx >> 4) * kPW + 2 * q]) = lv;
+    }
+#pragma unroll
+    for (int j = 0; j <= P; ++j) {
+      if (j > 0 && k > 0) break;
+      const int m = k == 0 ? j : k + P;
+      if (m > o.klast) continue;                                // never staged, never multiplied
+      unsigned* const dh = sA + (size_t)((m % NS) * 2) * CH * kPW;
+      unsigned* const dl = dh + CH * kPW;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int idx = tid + 512 * i;
+        if (idx < CH * NQA) {
+          const int ch = idx / NQA, q = idx - ch * NQA;
+          f4 x = R.sa[j][i];
+          if (edge) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int f = o.f0 - PADF + 4 * q + e;
+              x[e] = (f >= 0 && f < g.F) ? x[e] : 0.f;
+            }
+          }
+          unsigned h0, l0, h1, l1;
+          split_pair(x[0] * s_in, x[1] * s_in, h0, l0);
+          split_pair(x[2] * s_in, x[3] * s_in, h1, l1);
+          u2v hv, lv;
+          hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+          *reinterpret_cast<u2v*>(&dh[ch * kPW + 2 * q]) = hv;
+          *reinterpret_cast<u2v*>(&dl[ch * kPW + 2 * q]) = lv;
+        }
+      }
+    }
+  };
+  // window of tap kf = halves kf .. kf+7 of the 12 read
+  auto tap = [&](const unsigned (&w)[6], int kf) {
+    const int m = kf >> 1;
+    u4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (kf & 1) ? __builtin_amdgcn_alignbit(w[m + q + 1], w[m + q], 16) : w[m + q];
+    return __builtin_bit_cast(h8, r);
+  };
+  auto window = [&](int slot, int kb, unsigned (&wh)[6], unsigned (&wl)[6]) {
+    const unsigned* ph = sA + (size_t)(slot * 2) * CH * kPW + rowa + 8 * kb;
+    const unsigned* pl = ph + CH * kPW;
+    const u4 a = *reinterpret_cast<const u4*>(ph);
+    const u4 c = *reinterpret_cast<const u4*>(pl);
+    wh[0] = a[0]; wh[1] = a[1]; wh[2] = a[2]; wh[3] = a[3];
+    wl[0] = c[0]; wl[1] = c[1]; wl[2] = c[2]; wl[3] = c[3];
+    const u2v a2 = *reinterpret_cast<const u2v*>(ph + 4);
+    const u2v c2 = *reinterpret_cast<const u2v*>(pl + 4);
+    wh[4] = a2[0]; wh[5] = a2[1];
+    wl[4] = c2[0]; wl[5] = c2[1];
+  };
+  auto slot_of = [&](int m) { return ((m % NS) + NS) % NS; };
+  // all taps of this wave for one step; its rows are in LDS
+  auto compute = [&](const Ev& ev, int par) {
+    const Col& o = ev.c;
+    const int k = ev.k;
+    const int nkb = (o.nv + 15) >> 4;
+    const unsigned* const zh = sD + (size_t)(par * 2) * 64 * kPW + rowd;
+    const unsigned* const zl = zh + 64 * kPW;
+    if (KF == 5) {
+      const int m0 = k + tg - P, m4 = k + P;                     // input rows of time taps kt = tg and kt = 4
+      const bool ok0 = m0 >= 0 && m0 <= o.klast, ok4 = m4 <= o.klast;
+      const int s0 = slot_of(m0), s4 = slot_of(m4);
+#pragma unroll 1
+      for (int kb = 0; kb < nkb; ++kb) {
+        const h8 dhv = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(zh + 8 * kb));
+        const h8 dlv = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(zl + 8 * kb));
+        unsigned wh[6], wl[6], xh[6], xl[6];
+        if (ok0) window(s0, kb, wh, wl);
+        if (ok4) window(s4, kb, xh, xl);
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+          const h8 av = term == 0 ? dlv : dhv;
+          if (ok0) {
+#pragma unroll
+            for (int kf = 0; kf < 5; ++kf)
+              acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(wl, kf) : tap(wh, kf), acc[kf], 0, 0, 0);
+          }
+          if (ok4) {
+            // kt = 4 is shared out: tap group 0 takes kf 0,1; groups 1..3 take kf 2,3,4
+            switch (tg) {
+              case 0:
+                acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 0) : tap(xh, 0), acc[5], 0, 0, 0);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 1) : tap(xh, 1), acc[6], 0, 0, 0);
+                break;
+              case 1: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 2) : tap(xh, 2), acc[5], 0, 0, 0); break;
+              case 2: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 3) : tap(xh, 3), acc[5], 0, 0, 0); break;
+              default: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 4) : tap(xh, 4), acc[5], 0, 0, 0); break;
+            }
+          }
+        }
+      }
+    } else {
+      bool ok[4];
+      int sl[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int kt = tg * 4 + a;
+        const int m = k + kt - P;
+        ok[a] = kt < KT && m >= 0 && m <= o.klast;
+        sl[a] = slot_of(m);
+      }
+#pragma unroll 1
+      for (int kb = 0; kb < nkb; ++kb) {
+        const h8 dhv = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(zh + 8 * kb));
+        const h8 dlv = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(zl + 8 * kb));
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (ok[a]) {
+            const unsigned* ph = sA + (size_t)(sl[a] * 2) * CH * kPW + rowa + 8 * kb;
+            bh[a] = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(ph));
+            bl[a] = __builtin_bit_cast(h8, *reinterpret_cast<const u4*>(ph + CH * kPW));
+          }
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            if (ok[a]) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? dlv : dhv, term == 1 ? bl[a] : bh[a], acc[a], 0, 0, 0);
+      }
+    }
+  };
+  auto first_ev = [&](int c) {
+    Ev e;
+    e.col = first_col(c);
+    e.k = 0;
+    e.valid = e.col < NC;
+    e.c = decode(e.valid ? e.col : 0);
+    return e;
+  };
+  auto next_ev = [&](const Ev& e) {
+    if (e.k < e.c.klast) { Ev n = e; n.k = e.k + 1; return n; }
+    return first_ev(e.col + g.G);
+  };
+
+  // Software pipeline.  The rows of step e+1 are in registers R0 while step e is multiplied (7x1:
+  // step e+2 is on its way in R1 as well: a step is shorter than a trip to HBM there).  With the
+  // double-buffered LDS of the 5x5 case a wave writes them right after its own share of step e and
+  // one barrier per step publishes them; a column's first step overwrites live slots and waits
+  // for everyone, as every step of the single-buffered 7x1 ring does.
+  Regs R0, R1;
+  Ev cur = first_ev(grp);
+  if (cur.valid) {
+    issue(cur, R0);
+    stash(cur, R0, 0);
+    Ev nxt = next_ev(cur);
+    if (D == 2 && nxt.valid) issue(nxt, R0);
+    __syncthreads();
+    int par = 0;
+    while (true) {
+      Ev nn = nxt;
+      if (D == 2) {
+        if (nxt.valid) {
+          nn = next_ev(nxt);
+          if (nn.valid) issue(nn, R1);
+        }
+      } else if (nxt.valid) {
+        issue(nxt, R0);
+      }
+      compute(cur, par);
+      const int npar = DB ? par ^ 1 : 0;
+      if (nxt.valid) {
+        if (!DB || nxt.k == 0) __syncthreads();
+        stash(nxt, R0, npar);
+      }
+      __syncthreads();
+      if (!nxt.valid) break;
+      if (D == 2) { R0 = R1; cur = nxt; nxt = nn; }
+      else { cur = nxt; nxt = next_ev(cur); }
+      par = npar;
+    }
+  }
+
+  // acc[a] of this wave -> tap index, block (cb, ci block) of the group's slab
+  float* out = g.part + (size_t)grp * (KT * KF) * 4096;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    int tp;
+    if (KF == 5) {
+      if (a < 5) tp = tg * 5 + a;
+      else {
+        const int kf = tg == 0 ? a - 5 : tg + 1;
+        if (tg != 0 && a == 6) continue;
+        tp = 4 * 5 + kf;
+      }
+    } else {
+      tp = tg * 4 + a;
+      if (tp >= KT) continue;
+    }
+    const int ci = (KF == 5 ? hh * 32 : nb * 32) + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)tp * 4096 + co * 64 + ci] = acc[a][r];
+    }
+  }
+}
+
+}  // namespace
+
 // groups for the f16 kernel: 2 workgroups per CU resident (LDS 36.9 KB, <= 256 VGPRs)
 extern "C" int vs_conv64_wgrad_f16_groups(int KT) { return KT == 7 ? 72 : 96; }
 
@@ -895,6 +1259,28 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad_f16x3: unsupported kernel %dx%d", KT, KF);
   VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad_f16x3: T*F=%lld too large for 32-bit offsets", (long long)T * F);
   VS_REQUIRE((long long)B * T * ((F + kNF - 1) / kNF) < 2147483647LL, "conv64_wgrad_f16x3: too many tiles");
+  static const bool old_kernel = getenv("VS_WGRAD_KTSPLIT") != nullptr;
+  if (!old_kernel) {
+    // ring kernel: 256 workgroups (one per CU); 5x5: 128 groups of two 32-channel workgroups
+    const int nseg = (F + kNF - 1) / kNF;
+    const int G = KF == 5 ? 128 : 256;
+    VS_REQUIRE((long long)B * nseg * dil < 2147483647LL, "conv64_wgrad_f16x3: too many columns");
+    WgradRingArgs a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, nseg, G};
+    // LDS: dz rows (two buffers for 5x5) + the input-row ring (KT+1 slots of 32 channels / KT of 64)
+    const size_t lds = KF == 5 ? (size_t)(2 * 2 * 64 + (KT + 1) * 2 * 32) * kPW * 4 : (size_t)(2 * 64 + KT * 2 * 64) * kPW * 4;
+    if (KF == 5) {
+      VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_wgrad_ring_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<5, 5>), dim3(256), dim3(512), lds, stream, a);
+    } else {
+      VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_wgrad_ring_kernel<7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<7, 1>), dim3(256), dim3(512), lds, stream, a);
+    }
+    const int total = KT * KF * 4096;
+    hipLaunchKernelGGL(conv64_wgrad_reduce_scaled_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw,
+                       dz_scale2, in_scale2);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   const int G = vs_conv64_wgrad_f16_groups(KT);
   Wgrad16Args a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, KT, (F + kNF - 1) / kNF, G};
   dim3 grid(G * KT), block(256);
