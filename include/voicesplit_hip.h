@@ -269,6 +269,10 @@ int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw
 /* the same in VS_MATH_F16X3 arithmetic; scratch8 = 8 floats (operand scales are derived inside) */
 int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, float* dw, float* scratch8,
                           int B, int T, int F, int KT, int KF, int dil, void* stream);
+/* which split-f16 weight-gradient kernel vs_conv64_wgrad_f16x3 / vs_backward launch: 0 = by problem
+ * size (default: the ring kernel once every workgroup gets >= 2 columns, else the kt-split kernel),
+ * 1 = ring, 2 = kt-split.  Process-wide; returns -1 for an unknown mode. */
+int vs_set_wgrad_kernel(int mode);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

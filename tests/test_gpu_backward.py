@@ -41,7 +41,25 @@ CONV_BWD_CASES = [
     (5, 5, 1, 1, 1, 5),
     (7, 1, 1, 1, 8, 601),
     (5, 5, 2, 3, 9, 601),
+    (5, 5, 1, 1, 70, 37),      # ring kernel: the column is cut into 2 chunks of 35 steps (rows k0-2, k0-1 pre-loaded)
+    (7, 1, 1, 2, 100, 64),     # ring kernel: 3 chunks, 3 pre-loaded rows each
 ]
+WGRAD_MATH = ["fp32", "f16x3:ring", "f16x3:ktsplit"]     # both split-f16 weight-gradient kernels on every shape
+
+
+class _wgrad_kernel:
+    """Pin the split-f16 weight-gradient kernel (vs_set_wgrad_kernel) for the duration of a test."""
+
+    def __init__(self, math):
+        self.mode = {"ring": 1, "ktsplit": 2}.get(math.partition(":")[2], 0)
+
+    def __enter__(self):
+        from voicesplit_amd import _lib
+        assert _lib.load().vs_set_wgrad_kernel(self.mode) == 0
+
+    def __exit__(self, *exc):
+        from voicesplit_amd import _lib
+        _lib.load().vs_set_wgrad_kernel(0)
 
 
 def _conv_ref(x, w, dil):
@@ -50,9 +68,10 @@ def _conv_ref(x, w, dil):
 
 
 @pytest.mark.parametrize("KT,KF,dil,B,T,Fq", CONV_BWD_CASES)
-@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+@pytest.mark.parametrize("math", WGRAD_MATH)
 def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq, math):
     from voicesplit_amd import ops
+    pin, math = _wgrad_kernel(math), math.partition(":")[0]
     g = torch.Generator().manual_seed(KT * 1000 + dil * 10 + B)
     x = torch.randn(B, 64, T, Fq, generator=g)
     w = torch.randn(64, 64, KT, KF, generator=g) * (1.0 / (64 * KT * KF) ** 0.5)
@@ -62,16 +81,18 @@ def test_conv64_dgrad_and_wgrad(KT, KF, dil, B, T, Fq, math):
     (_conv_ref(xd, wd, dil) * dz.double()).sum().backward()
     d = dev()
     dx = ops.conv64_dgrad(dz.to(d), w.to(d), dil, math=math)
-    dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil, math=math)
+    with pin:
+        dw = ops.conv64_wgrad(dz.to(d), x.to(d), KT, KF, dil, math=math)
     assert rel_err(dx, xd.grad) < KTOL
     assert rel_err(dw, wd.grad) < KTOL
 
 
-@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+@pytest.mark.parametrize("math", WGRAD_MATH)
 def test_conv64_wgrad_one_hot_indices(math):
     """dz one-hot at (b,co,t,f), input one-hot at (b,ci,t',f'): exactly one weight-gradient entry,
     at (co, ci, kt, kf) with t' = t+(kt-2)*dil, f' = f+kf-2 -- catches transposed / flipped taps."""
     from voicesplit_amd import ops
+    pin, math = _wgrad_kernel(math), math.partition(":")[0]
     d = dev()
     B, T, Fq, dil = 2, 14, 75, 2
     for (b, co, t, f, ci, kt, kf) in [(0, 5, 6, 10, 11, 0, 4), (1, 63, 3, 70, 0, 4, 0), (1, 33, 7, 63, 62, 2, 3),
@@ -82,7 +103,8 @@ def test_conv64_wgrad_one_hot_indices(math):
         x = torch.zeros(B, 64, T, Fq)
         dz[b, co, t, f] = 1.0
         x[b, ci, tp, fp] = 3.0
-        dw = ops.conv64_wgrad(dz.to(d), x.to(d), 5, 5, dil, math=math).cpu()
+        with pin:
+            dw = ops.conv64_wgrad(dz.to(d), x.to(d), 5, 5, dil, math=math).cpu()
         ref = torch.zeros(64, 64, 5, 5)
         ref[co, ci, kt, kf] = 3.0
         assert torch.equal(dw, ref), (b, co, t, f, ci, kt, kf, dw.nonzero().tolist())

@@ -14,6 +14,7 @@ def main():
     B, T, F = int(os.environ.get("VS_MICRO_B", "64")), 301, 601
     reps = int(os.environ.get("VS_MICRO_REPS", "3"))
     lib = _lib.load()
+    lib.vs_set_wgrad_kernel(int(os.environ.get("VS_MICRO_WGRAD_KERNEL", "0")))     # 0 auto, 1 ring, 2 kt-split
     dev = torch.device("cuda:0")
     x = torch.randn(B, 64, T, F, device=dev)
     dz = torch.randn(B, 64, T, F, device=dev) * 1e-3

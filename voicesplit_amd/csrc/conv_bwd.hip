@@ -917,7 +917,7 @@ struct WgradRingArgs {
   const float* dz_scale;   // {s, 1/s}
   const float* in_scale;   // {s, 1/s}
   float* part;       // [G][KT*KF][64 co][64 ci]   (scaled by s_dz*s_in)
-  int B, T, F, dil, nseg, G;
+  int B, T, F, dil, nseg, G, nchunk;
 };
 
 template <int KT, int KF>
@@ -955,7 +955,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
   const long long slab = 64ll * plane_bytes;
   const float s_dz = g.dz_scale[0], s_in = g.in_scale[0];
-  const int NC = g.B * g.nseg * g.dil;                          // columns
+  const int NC = g.B * g.nseg * g.dil * g.nchunk;               // columns (x chunks of their steps)
 
   f32x16 acc[NACC];
 #pragma unroll
@@ -963,10 +963,13 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-  // column c -> (utterance b, residue r, segment); steps k = 0..klast, frame t = r + k*dil
-  struct Col { int b, r, f0, nv, klast; };
+  // column c -> (utterance b, residue r, segment, chunk); rows m = 0..klast of the residue class
+  // (frame t = r + m*dil), this chunk's steps k = k0..k1
+  struct Col { int b, r, f0, nv, klast, k0, k1; };
   auto decode = [&](int c) {
     Col o;
+    const int chunk = c % g.nchunk;
+    c /= g.nchunk;
     const int seg = c % g.nseg;
     const int rest = c / g.nseg;
     o.r = rest % g.dil;
@@ -974,15 +977,24 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     o.f0 = seg * kNF;
     o.nv = g.F - o.f0 < kNF ? g.F - o.f0 : kNF;
     o.klast = o.r < g.T ? (g.T - 1 - o.r) / g.dil : -1;
+    const int len = (o.klast + g.nchunk) / g.nchunk;           // ceil((klast+1)/nchunk)
+    o.k0 = chunk * len;
+    o.k1 = o.k0 + len - 1 < o.klast ? o.k0 + len - 1 : o.klast;
     return o;
   };
-  auto first_col = [&](int c) {                                 // skip residues beyond the last frame
-    while (c < NC && decode(c).klast < 0) c += g.G;
+  auto first_col = [&](int c) {                                 // skip empty chunks / residues beyond the last frame
+    while (c < NC) {
+      const Col o = decode(c);
+      if (o.k0 <= o.k1) break;
+      c += g.G;
+    }
     return c;
   };
 
   struct Regs { f4 sd[2]; f4 sa[P + 1][NIA]; };
-  struct Ev { Col c; int col, k; bool valid; };
+  // kind 0: step k (brings input row k+P and dz row k); 1: first step of a chunk (input rows
+  // k..k+P); 2: a chunk that starts inside its column first brings rows k0-P..k0-1, one per event (k = row)
+  struct Ev { Col c; int col, k, kind; bool valid; };
   // a 16-byte group that straddles the start or the end of the utterance's slab is split into
   // dwords (the hardware zeroes the whole out-of-range access, valid pixels included)
   auto load16 = [&](__amdgpu_buffer_rsrc_t r, long long off, bool live) -> f4 {
@@ -1006,15 +1018,17 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
         const_cast<float*>(g.in + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
     const int t = o.r + k * g.dil;
     const unsigned base_d = (unsigned)((t * g.F + o.f0) * 4);
+    if (ev.kind != 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i;
-      R.sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i;
+        R.sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
+      }
     }
 #pragma unroll
     for (int j = 0; j <= P; ++j) {
-      if (j > 0 && k > 0) break;                                // later steps bring one row
-      const int m = k == 0 ? j : k + P;
+      if (j > 0 && ev.kind != 1) break;                         // only a chunk's first step brings P+1 rows
+      const int m = ev.kind == 0 ? k + P : k + j;
       const bool row_ok = m <= o.klast;
       const int base_a = ((o.r + m * g.dil) * g.F + o.f0 - PADF) * 4;      // may be negative at the very first pixels
 #pragma unroll
@@ -1034,6 +1048,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     unsigned* const zl = zh + 64 * kPW;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (ev.kind == 2) break;
       const int idx = tid + 512 * i;
       const int q = idx & 15;
       f4 x = R.sd[i];
@@ -1051,8 +1066,8 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     }
 #pragma unroll
     for (int j = 0; j <= P; ++j) {
-      if (j > 0 && k > 0) break;
-      const int m = k == 0 ? j : k + P;
+      if (j > 0 && ev.kind != 1) break;
+      const int m = ev.kind == 0 ? k + P : k + j;
       if (m > o.klast) continue;                                // never staged, never multiplied
       unsigned* const dh = sA + (size_t)((m % NS) * 2) * CH * kPW;
       unsigned* const dl = dh + CH * kPW;
@@ -1103,6 +1118,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   auto slot_of = [&](int m) { return ((m % NS) + NS) % NS; };
   // all taps of this wave for one step; its rows are in LDS
   auto compute = [&](const Ev& ev, int par) {
+    if (ev.kind == 2) return;
     const Col& o = ev.c;
     const int k = ev.k;
     const int nkb = (o.nv + 15) >> 4;
@@ -1175,13 +1191,21 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   auto first_ev = [&](int c) {
     Ev e;
     e.col = first_col(c);
-    e.k = 0;
     e.valid = e.col < NC;
     e.c = decode(e.valid ? e.col : 0);
+    const int pre = e.c.k0 - P > 0 ? e.c.k0 - P : 0;             // first row this chunk has to bring before k0
+    e.kind = pre < e.c.k0 ? 2 : 1;
+    e.k = pre < e.c.k0 ? pre : e.c.k0;
     return e;
   };
   auto next_ev = [&](const Ev& e) {
-    if (e.k < e.c.klast) { Ev n = e; n.k = e.k + 1; return n; }
+    Ev n = e;
+    if (e.kind == 2) {
+      if (e.k + 1 < e.c.k0) { n.k = e.k + 1; return n; }
+      n.kind = 1; n.k = e.c.k0;
+      return n;
+    }
+    if (e.k < e.c.k1) { n.kind = 0; n.k = e.k + 1; return n; }
     return first_ev(e.col + g.G);
   };
 
@@ -1212,7 +1236,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
       compute(cur, par);
       const int npar = DB ? par ^ 1 : 0;
       if (nxt.valid) {
-        if (!DB || nxt.k == 0) __syncthreads();
+        if (!DB || nxt.kind != 0) __syncthreads();
         stash(nxt, R0, npar);
       }
       __syncthreads();
@@ -1250,6 +1274,15 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
 
 }  // namespace
 
+static int g_wgrad_kernel = 0;
+// 0: choose by problem size (default), 1: ring kernel, 2: kt-split kernel.  Both compute the same
+// sums in a fixed order each; the unit tests run every shape through both.
+extern "C" int vs_set_wgrad_kernel(int mode) {
+  if (mode < 0 || mode > 2) return -1;
+  g_wgrad_kernel = mode;
+  return 0;
+}
+
 // groups for the f16 kernel: 2 workgroups per CU resident (LDS 36.9 KB, <= 256 VGPRs)
 extern "C" int vs_conv64_wgrad_f16_groups(int KT) { return KT == 7 ? 72 : 96; }
 
@@ -1259,13 +1292,22 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad_f16x3: unsupported kernel %dx%d", KT, KF);
   VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad_f16x3: T*F=%lld too large for 32-bit offsets", (long long)T * F);
   VS_REQUIRE((long long)B * T * ((F + kNF - 1) / kNF) < 2147483647LL, "conv64_wgrad_f16x3: too many tiles");
-  static const bool old_kernel = getenv("VS_WGRAD_KTSPLIT") != nullptr;
-  if (!old_kernel) {
-    // ring kernel: 256 workgroups (one per CU); 5x5: 128 groups of two 32-channel workgroups
-    const int nseg = (F + kNF - 1) / kNF;
-    const int G = KF == 5 ? 128 : 256;
-    VS_REQUIRE((long long)B * nseg * dil < 2147483647LL, "conv64_wgrad_f16x3: too many columns");
-    WgradRingArgs a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, nseg, G};
+  // ring kernel: 256 workgroups (one per CU); 5x5: 128 groups of two 32-channel workgroups.
+  // Columns are cut along their steps until every group has ~4 of them (chunks of >= 32 steps);
+  // a problem too small to give every group two (a few utterances) goes to the kt-split kernel,
+  // whose (utterance, frame, segment) tiles spread over the chip at any batch size.
+  const int nseg = (F + kNF - 1) / kNF;
+  const int Gr = KF == 5 ? 128 : 256;
+  const long long ncol = (long long)B * nseg * dil;
+  const int steps = (T + dil - 1) / dil;
+  int nchunk = (int)((4LL * Gr + ncol - 1) / ncol);
+  if (nchunk > steps / 32) nchunk = steps / 32;
+  if (nchunk < 1) nchunk = 1;
+  const bool ring = g_wgrad_kernel == 1 || (g_wgrad_kernel == 0 && ncol * nchunk >= 2LL * Gr);
+  if (ring) {
+    const int G = Gr;
+    VS_REQUIRE(ncol * nchunk < 2147483647LL, "conv64_wgrad_f16x3: too many columns");
+    WgradRingArgs a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, nseg, G, nchunk};
     // LDS: dz rows (two buffers for 5x5) + the input-row ring (KT+1 slots of 32 channels / KT of 64)
     const size_t lds = KF == 5 ? (size_t)(2 * 2 * 64 + (KT + 1) * 2 * 32) * kPW * 4 : (size_t)(2 * 64 + KT * 2 * 64) * kPW * 4;
     if (KF == 5) {
