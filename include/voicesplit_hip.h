@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 3
+#define VS_ABI_VERSION 4
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */

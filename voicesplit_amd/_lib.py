@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class VsDims(Structure):

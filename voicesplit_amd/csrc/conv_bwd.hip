@@ -920,7 +920,9 @@ struct WgradRingArgs {
   int B, T, F, dil, nseg, G, nchunk;
 };
 
-template <int KT, int KF>
+// CK: columns are cut into chunks of steps (g.nchunk > 1); without it the chunk bookkeeping and the
+// row pre-load events compile away (they cost the 5x5 instance, which sits at 256 VGPRs, ~10 %).
+template <int KT, int KF, bool CK>
 __global__ __launch_bounds__(512)
 void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   constexpr int P = KT / 2, PADF = KF / 2;
@@ -955,7 +957,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
   const long long slab = 64ll * plane_bytes;
   const float s_dz = g.dz_scale[0], s_in = g.in_scale[0];
-  const int NC = g.B * g.nseg * g.dil * g.nchunk;               // columns (x chunks of their steps)
+  const int NC = g.B * g.nseg * g.dil * (CK ? g.nchunk : 1);    // columns (x chunks of their steps)
 
   f32x16 acc[NACC];
 #pragma unroll
@@ -968,8 +970,9 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   struct Col { int b, r, f0, nv, klast, k0, k1; };
   auto decode = [&](int c) {
     Col o;
-    const int chunk = c % g.nchunk;
-    c /= g.nchunk;
+    const int nchunk = CK ? g.nchunk : 1;
+    const int chunk = CK ? c % nchunk : 0;
+    if (CK) c /= nchunk;
     const int seg = c % g.nseg;
     const int rest = c / g.nseg;
     o.r = rest % g.dil;
@@ -977,7 +980,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     o.f0 = seg * kNF;
     o.nv = g.F - o.f0 < kNF ? g.F - o.f0 : kNF;
     o.klast = o.r < g.T ? (g.T - 1 - o.r) / g.dil : -1;
-    const int len = (o.klast + g.nchunk) / g.nchunk;           // ceil((klast+1)/nchunk)
+    const int len = (o.klast + nchunk) / nchunk;               // ceil((klast+1)/nchunk)
     o.k0 = chunk * len;
     o.k1 = o.k0 + len - 1 < o.klast ? o.k0 + len - 1 : o.klast;
     return o;
@@ -1018,7 +1021,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
         const_cast<float*>(g.in + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
     const int t = o.r + k * g.dil;
     const unsigned base_d = (unsigned)((t * g.F + o.f0) * 4);
-    if (ev.kind != 2) {
+    if (!CK || ev.kind != 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = tid + 512 * i;
@@ -1048,7 +1051,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     unsigned* const zl = zh + 64 * kPW;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (ev.kind == 2) break;
+      if (CK && ev.kind == 2) break;
       const int idx = tid + 512 * i;
       const int q = idx & 15;
       f4 x = R.sd[i];
@@ -1118,7 +1121,7 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   auto slot_of = [&](int m) { return ((m % NS) + NS) % NS; };
   // all taps of this wave for one step; its rows are in LDS
   auto compute = [&](const Ev& ev, int par) {
-    if (ev.kind == 2) return;
+    if (CK && ev.kind == 2) return;
     const Col& o = ev.c;
     const int k = ev.k;
     const int nkb = (o.nv + 15) >> 4;
@@ -1194,13 +1197,13 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
     e.valid = e.col < NC;
     e.c = decode(e.valid ? e.col : 0);
     const int pre = e.c.k0 - P > 0 ? e.c.k0 - P : 0;             // first row this chunk has to bring before k0
-    e.kind = pre < e.c.k0 ? 2 : 1;
-    e.k = pre < e.c.k0 ? pre : e.c.k0;
+    e.kind = (CK && pre < e.c.k0) ? 2 : 1;
+    e.k = (CK && pre < e.c.k0) ? pre : e.c.k0;
     return e;
   };
   auto next_ev = [&](const Ev& e) {
     Ev n = e;
-    if (e.kind == 2) {
+    if (CK && e.kind == 2) {
       if (e.k + 1 < e.c.k0) { n.k = e.k + 1; return n; }
       n.kind = 1; n.k = e.c.k0;
       return n;
@@ -1310,13 +1313,15 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
     WgradRingArgs a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, nseg, G, nchunk};
     // LDS: dz rows (two buffers for 5x5) + the input-row ring (KT+1 slots of 32 channels / KT of 64)
     const size_t lds = KF == 5 ? (size_t)(2 * 2 * 64 + (KT + 1) * 2 * 32) * kPW * 4 : (size_t)(2 * 64 + KT * 2 * 64) * kPW * 4;
-    if (KF == 5) {
-      VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_wgrad_ring_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<5, 5>), dim3(256), dim3(512), lds, stream, a);
-    } else {
-      VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_wgrad_ring_kernel<7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<7, 1>), dim3(256), dim3(512), lds, stream, a);
-    }
+    auto launch = [&](auto kernel) -> int {
+      VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kernel, dim3(256), dim3(512), lds, stream, a);
+      return 0;
+    };
+    int rc;
+    if (KF == 5) rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<5, 5, true>) : launch(&conv64_wgrad_ring_kernel<5, 5, false>);
+    else rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<7, 1, true>) : launch(&conv64_wgrad_ring_kernel<7, 1, false>);
+    if (rc) return rc;
     const int total = KT * KF * 4096;
     hipLaunchKernelGGL(conv64_wgrad_reduce_scaled_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw,
                        dz_scale2, in_scale2);
