@@ -246,7 +246,7 @@ def main():
         if train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
-            wname = ("conv64_wgrad_f16x3_kernel<5> (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
+            wname = ("conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
                      if conv_math == "f16x3" else
                      "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)")
             roof["second_kernel"] = {"kernel": wname,
