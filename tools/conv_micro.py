@@ -23,7 +23,10 @@ def main():
     scale = (torch.rand(64, generator=g) + 0.5).to(dev)
     shift = (torch.randn(64, generator=g) * 0.1).to(dev)
     res = {"B": B}
+    only = os.environ.get("VS_MICRO_ONLY")            # e.g. "7x1": that kernel shape, split-f16 kernel only
     for (KT, KF, dil) in [(5, 5, 1), (5, 5, 2), (5, 5, 4), (5, 5, 8), (5, 5, 16), (7, 1, 1)]:
+        if only and only != f"{KT}x{KF}":
+            continue
         w = (torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5).to(dev)
         packed = torch.empty(lib.vs_conv64_packed_floats(KT, KF), dtype=torch.float32, device=dev)
         _lib.check(lib.vs_conv64_pack(ops._p(w), ops._p(packed), KT, KF, ops._stream()), "pack")
@@ -32,7 +35,7 @@ def main():
         amax = scales[4:].view(torch.int32)
         _lib.check(lib.vs_pow2_scale(ops._p(x), x.numel(), ops._p(amax), ops._p(scales), ops._stream()), "scale")
         _lib.check(lib.vs_conv64_pack_f16(ops._p(w), ops._p(packed16), KT, KF, 0, ops._p(amax[1:]), ops._p(scales[2:]), ops._stream()), "pack16")
-        for act in ("mish", "none", "mish_f16x3", "scale_pass"):
+        for act in (("mish_f16x3",) if only else ("mish", "none", "mish_f16x3", "scale_pass")):
             def run():
                 if act == "scale_pass":
                     _lib.check(lib.vs_pow2_scale(ops._p(x), x.numel(), ops._p(amax), ops._p(scales), ops._stream()), "scale")

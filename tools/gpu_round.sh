@@ -1,12 +1,9 @@
 set -u
-mkdir -p gpurun_out/final
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-O=gpurun_out/final
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python bench.py > $O/bench_train.json 2> $O/bench_train.err; tail -c 300 $O/bench_train.json
-timeout 300 python bench.py --mode forward > $O/bench_forward.json 2> $O/bench_forward.err; tail -c 200 $O/bench_forward.json
-timeout 300 python bench.py --conv-math fp32 --no-cpu-baseline > $O/bench_train_fp32math.json 2>/dev/null
-timeout 300 python bench.py --model voicefilter --loss powerlaw --no-cpu-baseline > $O/bench_train_voicefilter_powerlaw.json 2>/dev/null
-bash tools/profile_gpu.sh r01_train 2>&1 | tail -2
-bash tools/profile_gpu.sh r01_forward --mode forward 2>&1 | tail -2
+R=$GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_backward.py -m gpu -q -x -k "conv64 or dgrad" 2>&1 | tail -2 | cut -c1-300
+for rep in 1 2; do for v in old new; do
+cp $R/tools/$v.so.bin $R/voicesplit_amd/libvoicesplit_hip.so
+VS_MICRO_ONLY=7x1 VS_MICRO_REPS=5 timeout 200 python tools/conv_micro.py 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$v', {k:v['ms'] for k,v in d.items() if isinstance(v,dict)})"
+done; done
