@@ -120,8 +120,13 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
   return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
 }
 
+// scratch: any idle device buffer (the conv activation ping-pong in inference, a gradient buffer in
+// training).  When it can hold both operands split into f16 hi/lo arrays (vs_gemm_presplit_bytes),
+// the split is a pass of its own and the GEMM streams halves; otherwise (tiny batches: the split
+// weights alone are 62 MB) the GEMM converts fp32 tiles while it stages them.
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
-                            float* xg, int M, const float* rowbias, int T, float* gs, hipStream_t stream) {
+                            float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
+                            hipStream_t stream) {
   if (math == VS_MATH_F16X3) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
     if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
@@ -129,6 +134,22 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
     if (int rc = vs_absmax_accum_impl(w_ih0, (long long)4 * H * KE, amax + 1, stream)) return rc;
     if (int rc = vs_absmax_accum_impl(w_ih1, (long long)4 * H * KE, amax + 1, stream)) return rc;
     if (int rc = vs_scale_from_absmax_impl(amax + 1, 1, gs + 2, stream)) return rc;
+    if (scratch && scratch_bytes >= vs_gemm_presplit_bytes(M, 8 * H, K) && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0) {
+      const size_t Kp = (size_t)(K + 31) / 32 * 32;
+      const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
+      char* base = static_cast<char*>(scratch);
+      _Float16* Ah = reinterpret_cast<_Float16*>(base);
+      _Float16* Al = reinterpret_cast<_Float16*>(base + na);
+      _Float16* Wh = reinterpret_cast<_Float16*>(base + 2 * na);
+      _Float16* Wl = reinterpret_cast<_Float16*>(base + 2 * na + nw);
+      if (2 * na + 2 * nw <= scratch_bytes) {
+        if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream)) return rc;
+        if (int rc = vs_split_rows_impl(w_ih0, 4 * H, K, KE, gs + 2, Wh, Wl, 0, stream)) return rc;
+        if (int rc = vs_split_rows_impl(w_ih1, 4 * H, K, KE, gs + 2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream)) return rc;
+        return vs_gemm_presplit_impl(Ah, Al, Wh, Wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
+                                     VS_ACT_NONE, 0, gs, gs + 2, stream);
+      }
+    }
     return vs_gemm_f16x3_impl(0, 0, feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T,
                               nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, gs + 2, stream);
   }
@@ -364,8 +385,11 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
                                  p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
   }
   // both directions in one launch (N = 8H): twice the workgroups, half the tail quantisation
+  // the conv stack is done: its activation ping-pong is idle (feat may be the caller's own buffer)
+  const size_t act_bytes = (size_t)B * 64 * T * d->F * sizeof(float);
   if (int rc = vs_lstm_input_gemm_impl(d->math, feat, K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
-                                       at<float>(ws, L.gemm_scales), stream)) return rc;
+                                       at<float>(ws, L.gemm_scales), at<char>(ws, L.act0),
+                                       L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes, stream)) return rc;
   }
   float* packed = at<float>(ws, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;

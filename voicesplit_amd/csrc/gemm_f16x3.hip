@@ -275,6 +275,177 @@ void launch_layout(const Gemm16Args& g, bool vec, dim3 grid, hipStream_t stream)
   else hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, false, 32, 3>), grid, dim3(256), 0, stream, g);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-split operands.  In the kernel above every operand tile is converted fp32 -> f16 hi/lo while it
+// is staged, i.e. once per tile that uses it: an A row-panel 25 times (N tiles) and the weights 151
+// times (M tiles) in the LSTM input GEMM, ~280 VALU instructions per wave and K block against 24
+// MFMAs.  Here the split is a pass of its own (split_rows_kernel: x*s -> hi, lo as two f16 arrays
+// [rows][Kp], Kp = K rounded up to the K block, zero padded) and the GEMM streams halves:
+// global b128 -> register -> ds_write_b128, no conversion, and a lane's fragment (8 consecutive k)
+// is ONE ds_read_b128 (row pitch 80 B: 5 x 16 B, conflict-free for b128 with lane = row).
+// ---------------------------------------------------------------------------------------------
+constexpr int PBK = 32;                 // K block in halves
+constexpr int PPW = 20;                 // LDS row pitch in dwords (32 halves + 8 pad)
+
+// src [rows][ld] fp32 (K valid columns) -> hi, lo [rows][Kp] f16 of src * scale[0]
+__global__ __launch_bounds__(256)
+void split_rows_kernel(const float* __restrict__ src, int rows, int K, int ld, const float* __restrict__ scale,
+                       _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Kp, int relu) {
+  const float s = scale[0];
+  const int groups = Kp >> 3;                                   // 8 halves = 16 B per thread
+  const long long total = (long long)rows * groups;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / groups;
+    const int k0 = (int)(i - r * groups) * 8;
+    const float* p = src + r * ld + k0;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (k0 + e < K) ? p[e] : 0.f;
+      if (relu) v = fmaxf(v, 0.f);
+      x[e] = v * s;
+    }
+    u4v h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hq, lq;
+      split_pair(x[2 * q], x[2 * q + 1], hq, lq);
+      h[q] = hq;
+      l[q] = lq;
+    }
+    *reinterpret_cast<u4v*>(hi + r * Kp + k0) = h;
+    *reinterpret_cast<u4v*>(lo + r * Kp + k0) = l;
+  }
+}
+
+struct GemmPreArgs {
+  const _Float16* Ah; const _Float16* Al;     // [M][Kp]
+  const _Float16* Wh; const _Float16* Wl;     // [N][Kp]
+  float* C; int ldc;
+  int M, N, Kp;
+  const float* bias1; const float* bias2;
+  const float* rowbias; int ldrb, group;
+  int act, accumulate;
+  const float* a_scale; const float* w_scale;
+  int tiles_m, tiles_n;
+};
+
+// C (+)= act((Ah+Al)(Wh+Wl)^T / (sA*sW) + bias terms): 128x128x32 tile, 4 waves (2x2) of 64x64
+__global__ __launch_bounds__(256, 3)
+void gemm_pre_kernel(GemmPreArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned sAh[BM * PPW], sAl[BM * PPW], sWh[BN * PPW], sWl[BN * PPW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int per = gridDim.x >> 3;                                // XCD x owns tiles [x*per, (x+1)*per)
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= g.tiles_m * g.tiles_n) return;
+  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  const float inv = g.a_scale[1] * g.w_scale[1];
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging: thread -> (row = tid>>2 (+64), 16-byte chunk q = tid&3) of each of the four arrays;
+  // rows beyond the matrix are pushed out of the descriptor's range (-> 0)
+  auto desc = [](const _Float16* p, size_t halves) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p), 0, (int)(halves * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rAh = desc(g.Ah, (size_t)g.M * g.Kp), rAl = desc(g.Al, (size_t)g.M * g.Kp);
+  const __amdgpu_buffer_rsrc_t rWh = desc(g.Wh, (size_t)g.N * g.Kp), rWl = desc(g.Wl, (size_t)g.N * g.Kp);
+  const int srow = tid >> 2, sq = tid & 3;                       // (row, 16-byte chunk) staged by this thread
+  unsigned offA[2], offW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = srow + 64 * i;
+    offA[i] = (m0 + row < g.M) ? (unsigned)(((size_t)(m0 + row) * g.Kp + 8 * sq) * 2) : kOob;
+    offW[i] = (n0 + row < g.N) ? (unsigned)(((size_t)(n0 + row) * g.Kp + 8 * sq) * 2) : kOob;
+  }
+  u4v ra[2][2], rw[2][2];      // [row half][hi, lo]
+  auto tile_load = [&](int k0) {
+    const unsigned so = (unsigned)k0 * 2u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rAh, offA[i], so, 0);
+      ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rAl, offA[i], so, 0);
+      rw[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rWh, offW[i], so, 0);
+      rw[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rWl, offW[i], so, 0);
+    }
+  };
+  const int st = srow * PPW + 4 * sq;                           // dword index of this thread's chunk, row half 0
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u4v*>(&sAh[st + 64 * i * PPW]) = ra[i][0];
+      *reinterpret_cast<u4v*>(&sAl[st + 64 * i * PPW]) = ra[i][1];
+      *reinterpret_cast<u4v*>(&sWh[st + 64 * i * PPW]) = rw[i][0];
+      *reinterpret_cast<u4v*>(&sWl[st + 64 * i * PPW]) = rw[i][1];
+    }
+  };
+  // fragment of 32-row block x, k-step ks: dwords [row*PPW + 8*ks + 4*half .. +3]
+  const int fa = (wm * 64 + l31) * PPW + 4 * half;
+  const int fw = (wn * 64 + l31) * PPW + 4 * half;
+
+  tile_load(0);
+  for (int k0 = 0; k0 < g.Kp; k0 += PBK) {
+    __syncthreads();
+    tile_store();
+    __syncthreads();
+    if (k0 + PBK < g.Kp) tile_load(k0 + PBK);
+#pragma unroll
+    for (int ks = 0; ks < PBK / 16; ++ks) {
+      h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int oa = fa + x * 32 * PPW + 8 * ks, ow = fw + x * 32 * PPW + 8 * ks;
+        ah[x] = __builtin_bit_cast(h8, *reinterpret_cast<const u4v*>(&sAh[oa]));
+        al[x] = __builtin_bit_cast(h8, *reinterpret_cast<const u4v*>(&sAl[oa]));
+        bh[x] = __builtin_bit_cast(h8, *reinterpret_cast<const u4v*>(&sWh[ow]));
+        bl[x] = __builtin_bit_cast(h8, *reinterpret_cast<const u4v*>(&sWl[ow]));
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mb] : ah[mb], term == 1 ? bl[nb] : bh[nb],
+                                                                 acc[mb][nb], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wn * 64 + nb * 32 + l31;
+    if (n >= g.N) continue;
+    float bcol = 0.f;
+    if (g.bias1) bcol += g.bias1[n];
+    if (g.bias2) bcol += g.bias2[n];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) {
+          float v = fmaf(acc[mb][nb][r], inv, bcol);
+          if (g.rowbias) v += g.rowbias[(size_t)(m / g.group) * g.ldrb + n];
+          v = vs_act_rt(v, g.act);
+          float* c = g.C + (size_t)m * g.ldc + n;
+          if (g.accumulate) v += *c;
+          *c = v;
+        }
+      }
+    }
+  }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -311,6 +482,41 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
   else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream);
   else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream);
   else launch_layout<1, 1>(g, vec, grid, stream);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// bytes of scratch the pre-split form of C[M][N] = A[M][K] W[N][K]^T needs (both operands, hi + lo)
+size_t vs_gemm_presplit_bytes(int M, int N, int K) {
+  const size_t Kp = (size_t)(K + PBK - 1) / PBK * PBK;
+  return ((size_t)M + (size_t)N) * Kp * 2 * sizeof(_Float16) + 1024;
+}
+
+// x [rows][ld] (K valid columns) * scale2[0] -> hi, lo [rows][Kp]
+int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* scale2, _Float16* hi, _Float16* lo, int relu,
+                       hipStream_t stream) {
+  VS_REQUIRE(rows > 0 && K > 0 && ld >= K, "split_rows: bad shape rows=%d K=%d ld=%d", rows, K, ld);
+  const int Kp = (K + PBK - 1) / PBK * PBK;
+  const long long total = (long long)rows * (Kp >> 3);
+  const long long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, x, rows, K, ld, scale2, hi, lo, Kp, relu);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// C[M][N] (+)= act(A W^T + bias terms) over operands already split by vs_split_rows_impl (Kp = K
+// rounded up to 32; scales as used for the split)
+int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, int Kp,
+                          float* C, int ldc, int M, int N, const float* bias1, const float* bias2,
+                          const float* rowbias, int ldrb, int group, int act, int accumulate,
+                          const float* a_scale2, const float* w_scale2, hipStream_t stream) {
+  VS_REQUIRE(M > 0 && N > 0 && Kp > 0 && Kp % PBK == 0 && ldc >= N, "gemm_presplit: bad shape M=%d N=%d Kp=%d ldc=%d", M, N, Kp, ldc);
+  VS_REQUIRE(((size_t)M * Kp) * 2 < (1ull << 32) - 64 && ((size_t)N * Kp) * 2 < (1ull << 32) - 64, "gemm_presplit: operand above 4 GiB");
+  VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm_presplit: rowbias needs group>0 and ldrb>=N");
+  VS_REQUIRE(aligned16(Ah) && aligned16(Al) && aligned16(Wh) && aligned16(Wl), "gemm_presplit: operands must be 16-byte aligned");
+  GemmPreArgs g{Ah, Al, Wh, Wl, C, ldc, M, N, Kp, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1, act, accumulate,
+                a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
+  hipLaunchKernelGGL(gemm_pre_kernel, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
   VS_LAUNCH_CHECK();
   return 0;
 }

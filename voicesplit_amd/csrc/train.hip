@@ -188,8 +188,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
                                    p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
     }
+    // the backward pass's gradient buffers are idle during the forward pass
     if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
-                                         at<float>(tape, L.gemm_scales), stream)) return rc;
+                                         at<float>(tape, L.gemm_scales), at<char>(tape, L.grad0),
+                                         (size_t)B * 64 * T * F * sizeof(float), stream)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;

@@ -19,6 +19,13 @@ int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, floa
 int vs_scale_from_absmax_impl(const unsigned* amax, int n, float* scale2, hipStream_t);
 int vs_absmax_accum_impl(const float* x, long long n, unsigned* amax, hipStream_t);
 // gemm_f16x3.hip
+// gemm_f16x3.hip: operands split into f16 hi/lo arrays by a pass of their own
+size_t vs_gemm_presplit_bytes(int M, int N, int K);
+int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* scale2, _Float16* hi, _Float16* lo, int relu, hipStream_t);
+int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, int Kp,
+                          float* C, int ldc, int M, int N, const float* bias1, const float* bias2,
+                          const float* rowbias, int ldrb, int group, int act, int accumulate,
+                          const float* a_scale2, const float* w_scale2, hipStream_t);
 int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
                        int n_split, int ldw, float* C, int ldc, int M, int N, int K,
                        const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
@@ -28,7 +35,8 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
 // arithmetic.  gemm_scales: 16 floats of scratch that must survive until the backward pass in
 // training: [0..1] scale of feat, [2..3] scale of the two W_ih, [4..5] uint |max| scratch.
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
-                            float* xg, int M, const float* rowbias, int T, float* gemm_scales, hipStream_t);
+                            float* xg, int M, const float* rowbias, int T, float* gemm_scales,
+                            void* scratch, size_t scratch_bytes, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
                             float* w_scale2, hipStream_t);
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
