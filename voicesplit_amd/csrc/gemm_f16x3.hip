@@ -21,9 +21,11 @@
 // Counters of the NT case before the change: MFMA pipe 25 % busy, waves waiting 59 % of their
 // time, L2 hit rate 83 %, 2.5 GB fetched over the fabric per launch (1.5 TB/s) - neither HBM nor L2
 // bound; a 64-deep K block, 2 vs 3 workgroups per CU and the XCD renumbering each moved it < 3 %.
-// What is left is the fp32 -> f16 hi/lo conversion in the staging path (~280 VALU per wave and K
-// block against 24 MFMAs = 768 pipe cycles): operands stored pre-split by their producers are the
-// next step.
+// What was left was the fp32 -> f16 hi/lo conversion in the staging path (~280 VALU per wave and K
+// block against 24 MFMAs = 768 pipe cycles).  The forward input GEMM now takes the pre-split form
+// at the bottom of this file (split pass + gemm_pre_kernel: 1.95 ms, MFMA pipe 46 % busy, 88M
+// instead of 697M VALU instructions per launch); the two backward contractions stay here: they
+// would need transposed split copies of dxg and feat (~0.45 ms) to save ~1 ms.
 #include "vs_common.h"
 
 namespace {
