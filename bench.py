@@ -42,6 +42,27 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                                      # dense f16/b
 PEAK_HBM_GBS = 8000.0
 
 
+def committed_pmc_traffic(tag, kernel_substr):
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
+    (profiles/<tag>_rocprof/pmc_per_kernel.csv, written by tools/profile_gpu.sh + summarize_prof.py in
+    separate --pmc passes): FETCH_SIZE + WRITE_SIZE as reported, in GB.  The guide's x2 correction of
+    FETCH_SIZE on gfx950 is calibrated for 16 B/lane streaming reads; this kernel stages its window with
+    dword loads, for which the raw value matches the tile geometry (12 input rows x 36 columns per
+    8 x 32 outputs = 1.69 x the 2.96 GB input; raw FETCH_SIZE 4.6 GB), so it is left uncorrected.
+    bench.py itself cannot collect counters; None when the file is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"{tag}_rocprof", "pmc_per_kernel.csv")
+    if not os.path.isfile(path):
+        return None
+    best = None
+    for r in csv.DictReader(open(path)):
+        if kernel_substr in r["kernel"] and r.get("fetch_GB_x2") and r.get("write_GB"):
+            n = int(r["dispatches"])
+            if best is None or n > best[0]:
+                best = (n, float(r["fetch_GB_x2"]) / 2 + float(r["write_GB"]))
+    return None if best is None else round(best[1], 2)
+
+
 def _pick_threads():
     """Thread count for the CPU leg: the box may expose far more logical cores than its cgroup can
     run, where one thread per core is pathological (86 s/utterance at 256 threads on the first
@@ -239,7 +260,11 @@ def main():
         roof = {"bound": "mfma",
                 "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4),
+                "traffic": (committed_pmc_traffic("r01_train" if train else "r01_forward", "conv64_f16x3_kernelILi5ELi5ELi2E")
+                            if conv_math == "f16x3" and B == 64 else None),
+                "traffic_unit": "GB per launch: FETCH_SIZE + WRITE_SIZE (uncorrected, dword-wide loads) from the committed --pmc "
+                                "passes of this command (profiles/r01_*_rocprof/pmc_per_kernel.csv); algorithmic bytes 5.9 GB",
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
                 "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
         roof.update(extra)
