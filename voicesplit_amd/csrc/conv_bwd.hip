@@ -301,25 +301,42 @@ void bn_act_bwd_apply_kernel(const float* da, const float* __restrict__ z, int C
 // ---------------------------------------------------------------------------------------------
 // cnn8 (1x1, 64->8, output in the LSTM feature layout [B][T][8][F])
 // ---------------------------------------------------------------------------------------------
-// dIn[b][ci][t][f] = sum_o W[o][ci] * dZ[b][t][o][f]
+// dIn[b][ci][t][f] = sum_o W[o][ci] * dZ[b][t][o][f].  A thread owns 4 consecutive pixels of the
+// plane and writes them as one 16-byte store per channel (1 KB per wave instruction instead of
+// 256 B; planes are only 4-byte aligned -- T*F is odd -- and the stores are issued unaligned).
 __global__ __launch_bounds__(256)
 void conv_last_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ din, int T, int F) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
   const int plane = T * F;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int b = blockIdx.y;
-  if (pix >= plane) return;
-  const int t = pix / F, f = pix - t * F;
-  const float* src = dz + ((size_t)b * T + t) * 8 * F + f;
-  float v[8];
+  if (pix0 >= plane) return;
+  const int np = plane - pix0 < 4 ? plane - pix0 : 4;
+  float v[8][4];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) v[o] = src[(size_t)o * F];
-  float* dst = din + (size_t)b * 64 * plane + pix;
-#pragma unroll 4
+  for (int e = 0; e < 4; ++e) {
+    const int pix = pix0 + (e < np ? e : 0);
+    const int t = pix / F, f = pix - t * F;
+    const float* src = dz + ((size_t)b * T + t) * 8 * F + f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) v[o][e] = src[(size_t)o * F];
+  }
+  float* dst = din + (size_t)b * 64 * plane + pix0;
+#pragma unroll 2
   for (int c = 0; c < 64; ++c) {
-    float a = 0.f;
+    f4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 8; ++o) a = fmaf(w[o * 64 + c], v[o], a);
-    dst[(size_t)c * plane] = a;
+    for (int o = 0; o < 8; ++o) {
+      const float wv = w[o * 64 + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fmaf(wv, v[o][e], a[e]);
+    }
+    float* q = dst + (size_t)c * plane;
+    if (np == 4) {
+      __builtin_memcpy(q, &a, 16);          // one global_store_dwordx4, any 4-byte alignment
+    } else {
+      for (int e = 0; e < np; ++e) q[e] = a[e];
+    }
   }
 }
 
@@ -574,7 +591,7 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
 
 int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && B <= 65535, "conv_last_dgrad: bad shape B=%d T=%d F=%d", B, T, F);
-  hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3((T * F + 255) / 256, B), dim3(256), 0, stream, dz, w, din, T, F);
+  hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3((T * F + 1023) / 1024, B), dim3(256), 0, stream, dz, w, din, T, F);
   VS_LAUNCH_CHECK();
   return 0;
 }
