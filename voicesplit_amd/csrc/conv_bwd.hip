@@ -340,43 +340,87 @@ void conv_last_dgrad_kernel(const float* __restrict__ dz, const float* __restric
   }
 }
 
-// part[blk][o][ci] = sum over this block's (b,t,64-bin segment) tiles of dZ[o][pix]*In[ci][pix]
+// part[blk][o][ci] = sum over this block's (b, t, 256-bin segment) tiles of dZ[o][pix]*In[ci][pix].
+// HBM-bound (2.96 GB of input per launch): a tile is 64 channel rows x 256 bins, each row segment one
+// 16-byte-per-lane load (1 KB per wave instruction; rows are only 4-byte aligned: issued unaligned),
+// the next tile travels to registers while this one is multiplied, and the multiply reads LDS as
+// b128 (4 bins per read, row pitch 260 floats: lane = channel hits 16 different bank quads) --
+// 3 LDS instructions per 8 FMAs.  (First version: 64-bin tiles, dword loads, 3 scalar LDS reads per
+// 2 FMAs: 1.47 ms.)
+constexpr int kLwSeg = 256;           // bins per tile
+constexpr int kLwPitch = kLwSeg + 4;  // floats
 __global__ __launch_bounds__(256)
 void conv_last_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ in, float* __restrict__ part,
                             int B, int T, int F, int nseg) {
-  __shared__ float sA[64 * 65];
-  __shared__ float sD[8 * 64];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float lw_smem[];
+  float* const sA = lw_smem;                       // [64][kLwPitch]
+  float* const sD = lw_smem + 64 * kLwPitch;       // [8][kLwPitch]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ci = lane, og = w;
-  float acc0 = 0.f, acc1 = 0.f;
+  f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const long long ntiles = (long long)B * T * nseg;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const size_t plane = (size_t)T * F;
+
+  f4 ra[16], rd[2];
+  // 4 bins of one row starting at p (row has `left` bins from p on): full groups as one 16-byte load
+  auto load4 = [&](const float* p, int left) -> f4 {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (left >= 4) {
+      __builtin_memcpy(&v, p, 16);
+    } else {
+      for (int e = 0; e < left; ++e) v[e] = p[e];
+    }
+    return v;
+  };
+  auto issue = [&](long long tile) {
     const int seg = (int)(tile % nseg);
     const long long bt = tile / nseg;
-    const int f = seg * 64 + lane;
-    const bool ok = f < F;
-    __syncthreads();
+    const long long b = bt / T, t = bt % T;
+    const int f = seg * kLwSeg + 4 * lane;
+    const int left = F - f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ch = w + 4 * i;
-      const long long b = bt / T, t = bt % T;
-      sA[ch * 65 + lane] = ok ? in[((b * 64 + ch) * T + t) * F + f] : 0.f;
+      ra[i] = load4(in + ((size_t)(b * 64 + ch)) * plane + (size_t)t * F + f, left);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int o = w + 4 * i;
-      sD[o * 64 + lane] = ok ? dz[(bt * 8 + o) * F + f] : 0.f;
+      rd[i] = load4(dz + ((size_t)bt * 8 + o) * F + f, left);
     }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int seg = (int)(tile % nseg);
+    const int nv = F - seg * kLwSeg < kLwSeg ? F - seg * kLwSeg : kLwSeg;
     __syncthreads();
-#pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-      const float a = sA[ci * 65 + p];
-      acc0 = fmaf(a, sD[(2 * og) * 64 + p], acc0);
-      acc1 = fmaf(a, sD[(2 * og + 1) * 64 + p], acc1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<f4*>(&sA[(w + 4 * i) * kLwPitch + 4 * lane]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f4*>(&sD[(w + 4 * i) * kLwPitch + 4 * lane]) = rd[i];
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
+    const int n4 = (nv + 3) >> 2;                  // bins beyond nv were staged as zeros
+    const float* pa = sA + ci * kLwPitch;
+    const float* p0 = sD + (2 * og) * kLwPitch;
+    const float* p1 = p0 + kLwPitch;
+#pragma unroll 4
+    for (int q = 0; q < n4; ++q) {
+      const f4 a = *reinterpret_cast<const f4*>(pa + 4 * q);
+      const f4 d0 = *reinterpret_cast<const f4*>(p0 + 4 * q);
+      const f4 d1 = *reinterpret_cast<const f4*>(p1 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0[e] = fmaf(a[e], d0[e], acc0[e]);
+        acc1[e] = fmaf(a[e], d1[e], acc1[e]);
+      }
     }
   }
-  part[(size_t)blockIdx.x * 512 + (2 * og) * 64 + ci] = acc0;
-  part[(size_t)blockIdx.x * 512 + (2 * og + 1) * 64 + ci] = acc1;
+  part[(size_t)blockIdx.x * 512 + (2 * og) * 64 + ci] = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
+  part[(size_t)blockIdx.x * 512 + (2 * og + 1) * 64 + ci] = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
 }
 
 // out[i] = sum_g part[g][i]
@@ -596,13 +640,15 @@ int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, 
   return 0;
 }
 
-extern "C" int vs_conv_last_wgrad_blocks(void) { return 1024; }
+extern "C" int vs_conv_last_wgrad_blocks(void) { return 512; }   // two resident workgroups per CU: one round
 
-int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part /* [1024][512] */, float* dw,
+int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part /* [blocks][512] */, float* dw,
                             int B, int T, int F, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "conv_last_wgrad: bad shape B=%d T=%d F=%d", B, T, F);
   const int nblk = vs_conv_last_wgrad_blocks();
-  hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nblk), dim3(256), 0, stream, dz, in, part, B, T, F, (F + 63) / 64);
+  const size_t lds = (size_t)72 * kLwPitch * sizeof(float);        // 74.9 KB: two workgroups per CU
+  VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_last_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nblk), dim3(256), lds, stream, dz, in, part, B, T, F, (F + kLwSeg - 1) / kLwSeg);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, stream, part, nblk, 512, dw);
   VS_LAUNCH_CHECK();
   return 0;
