@@ -4,7 +4,8 @@ Restates, in numpy, ``openVoiceFilterAudioProcessor`` of utils/audio_processor.p
   * ``wav2spec``          :469-476  (stft :511-514, amp_to_db :537-538, normalize :543-544)
   * ``spec2wav`` w/ phase :483-491  (denormalize :546-547, db_to_amp :540-541, istft_phase :478-481)
 
-**Parity unpinned against upstream**: both call librosa (0.6-era ``librosa.stft`` / ``librosa.istft``),
+**Parity unpinned against upstream** (pinned instead to an independent implementation of the same
+algorithm, torch.stft / torch.istft, in tests/test_oracle.py): both call librosa (0.6-era ``librosa.stft`` / ``librosa.istft``),
 which is a third-party dependency that is not installed in this image, so the reference functions
 cannot be executed here.  Their published algorithm is restated instead:
 ``stft``: reflect-pad n_fft//2, frames of n_fft at stride hop, times the periodic Hann window of
