@@ -216,8 +216,51 @@ def main_powerlaw():
     print(f"powerlaw_loss: {[float(v) for k, v in out.items() if k.startswith('loss/')]} -> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def main_real():
+    """BASELINE configs[0] / SURVEY.md 8(c) "realistic input": a 3 s crop of one of the reference's own
+    two-speaker demo mixtures (datasets/LibriSpeech/audios_demo/2_speakers/noisy, 16 kHz float32 mono)
+    -> the voicefilter front end (oracle/reference_audio.wav2spec = utils/audio_processor.py:469-476)
+    -> the UPSTREAM VoiceSplit in eval mode.  The fixture keeps the waveform crop (192 kB) and the mask;
+    the spectrogram is recomputed from the waveform by whoever reads it."""
+    from scipy.io import wavfile
+    from oracle import reference_audio as RA
+    from oracle._refimport import REFERENCE_ROOT
+    VoiceSplit, _vf, _mish, _lc, AttrDict = import_reference()
+    path = os.path.join(REFERENCE_ROOT, "datasets", "LibriSpeech", "audios_demo", "2_speakers", "noisy",
+                        "1701-141760-0023.251-136532-0023.wav")
+    sr, wav = wavfile.read(path)
+    assert sr == 16000 and wav.dtype == np.float32 and wav.ndim == 1
+    wav = np.ascontiguousarray(wav[16000:16000 + 48000])          # seconds 1..4
+    spec, _phase = RA.wav2spec(wav.astype(np.float64))
+    x = torch.from_numpy(spec.astype(np.float32))[None]             # [1, 301, 601]
+    dims, seed, gain = R.default_dims(), 2, 8.0
+    sd = R.spread_logits(R.build_state_dict(dims, seed), gain)
+    g = torch.Generator().manual_seed(seed)
+    dvec = torch.randn(1, dims["emb_dim"], generator=g)
+    dvec = dvec / dvec.norm(dim=1, keepdim=True)                    # an L2-normalised d-vector (no GE2E encoder here)
+    model = VoiceSplit(make_config(AttrDict, dims))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    grabbed = {}
+    h = model.fc2.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach()))
+    with torch.no_grad():
+        mask = model(x, dvec)
+    h.remove()
+    out = {"model": np.array("voicesplit"), "B": 1, "T": 301, "seed": seed, "training": False, "gain": gain,
+           "dims": np.array([dims[k] for k in ("num_freq", "emb_dim", "lstm_dim", "fc1_dim", "fc2_dim")]),
+           "sd_sha256": np.array(state_dict_digest(sd)), "torch_version": np.array(torch.__version__),
+           "wav": wav, "dvec": dvec.numpy(), "mask": mask.numpy(), "logits": grabbed["logits"].numpy()[:, ::4],
+           "source": np.array("datasets/LibriSpeech/audios_demo/2_speakers/noisy/1701-141760-0023.251-136532-0023.wav[16000:64000]")}
+    p = os.path.join(GOLDEN_DIR, "vs_real_clip.npz")
+    np.savez(p, **out)
+    print(f"vs_real_clip: spec[{spec.min():.3f},{spec.max():.3f}] mean {spec.mean():.3f} mask[{mask.min():.3f},{mask.max():.3f}] "
+          f"-> {os.path.getsize(p) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if "--powerlaw" in sys.argv:
+    if "--real" in sys.argv:
+        main_real()
+    elif "--powerlaw" in sys.argv:
         main_powerlaw()
     elif "--loss" in sys.argv:
         main_loss()

@@ -64,3 +64,39 @@ def test_separate_runs_end_to_end():
     dvec = R.synthetic_inputs(2, 301, R.default_dims(), 4)[1].cuda()
     est = audio.separate(m, wav, dvec, AUDIO)
     assert est.shape == wav.shape and torch.isfinite(est).all()
+
+
+def test_real_clip_waveform_to_mask_matches_upstream():
+    """BASELINE configs[0] on the device: the stored 3 s crop of a reference demo mixture -> GPU STFT
+    front end -> VoiceSplit -> mask, against the mask the UPSTREAM module produced from the oracle's
+    spectrogram (tests/golden/vs_real_clip.npz).  (a) the model alone on the oracle's spectrogram at
+    the contract tolerance; (b) the GPU front end against the oracle's; (c) end to end: the fp32 STFT
+    moves -100 dB bins by ~1e-4 of the normalised scale, which the network amplifies a little."""
+    from conftest import load_golden
+    import voicesplit_amd as V
+    from voicesplit_amd import audio
+    from oracle import reference_forward as R
+    g = load_golden("vs_real_clip")
+    d = g["dims"]
+    m = V.VoiceSplit(V.default_config(d["num_freq"], d["emb_dim"], d["lstm_dim"], d["fc1_dim"], d["fc2_dim"]))
+    m.load_state_dict(R.spread_logits(R.build_state_dict(d, g["seed"]), g["gain"]), strict=True)
+    m = m.cuda().eval()
+    dvec = torch.from_numpy(g["dvec"]).cuda()
+    spec_ref, phase_ref = RA.wav2spec(g["wav"].astype(np.float64))
+    ref = g["mask"].astype(np.float64)
+    with torch.no_grad():
+        mask_a = m(torch.from_numpy(spec_ref.astype(np.float32))[None].cuda(), dvec).cpu().numpy()
+    assert np.abs(mask_a - ref).max() / np.abs(ref).max() < 1e-4
+    assert ((mask_a - ref) ** 2).mean() < 1e-4
+    acfg = V.default_config().audio["voicefilter"]
+    spec_gpu, phase_gpu = audio.wav_to_spec(torch.from_numpy(g["wav"])[None].cuda(), acfg)
+    # linear-domain comparison as in test_wav_to_spec_matches_librosa_restatement (an fp32 DFT resolves
+    # a bin to ~1e-6 of the frame's largest bin; real speech has bins at both dB clips)
+    lin = lambda s_: np.power(10.0, ((s_ - 1.0) * 100.0 + 20.0) / 20.0)
+    got, want = lin(spec_gpu[0].cpu().double().numpy()), lin(spec_ref)
+    assert (np.abs(got - want) <= 2e-5 * want + 3e-6 * want.max(axis=1, keepdims=True)).all()
+    assert np.median(np.abs(spec_gpu[0].cpu().double().numpy() - spec_ref)) < 1e-6
+    with torch.no_grad():
+        mask_c = m(spec_gpu, dvec).cpu().numpy()
+    assert ((mask_c - ref) ** 2).mean() < 1e-4                                  # BASELINE: mask MSE <= 1e-4
+    assert np.quantile(np.abs(mask_c - ref), 0.999) < 1e-2

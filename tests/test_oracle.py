@@ -265,3 +265,21 @@ def test_audio_oracle_matches_an_independent_stft_istft():
     S, ph = RA.wav2spec(y * 0.05)
     assert S.shape == ph.shape == (31, 601) and S.min() >= 0.0 and S.max() <= 1.0
     assert np.allclose(ph, np.angle(RA.stft(y * 0.05, n_fft, hop, win)).T)
+
+
+def test_oracle_reproduces_upstream_mask_on_a_real_clip():
+    """tests/golden/vs_real_clip.npz: a 3 s crop of one of the reference's demo mixtures through the
+    voicefilter front end and the UPSTREAM VoiceSplit (make_golden.py --real; BASELINE configs[0]).
+    The oracle recomputes the spectrogram from the stored waveform and must return the same mask."""
+    from oracle import reference_audio as RA
+    g = load_golden("vs_real_clip")
+    sd = R.spread_logits(R.build_state_dict(g["dims"], g["seed"]), g["gain"])
+    assert _digest(sd) == g["sd_sha256"], "seeded weights differ from the run that made the fixture (torch RNG drift)"
+    spec, _ = RA.wav2spec(g["wav"].astype(np.float64))
+    assert spec.shape == (301, 601) and 0.0 <= spec.min() and spec.max() <= 1.0 and 0.3 < spec.mean() < 0.8
+    x = torch.from_numpy(spec.astype(np.float32))[None]
+    with torch.no_grad():
+        out = R.forward(sd, x, torch.from_numpy(g["dvec"]), act="mish", training=False)
+    assert np.array_equal(out["mask"].numpy(), g["mask"])
+    assert np.array_equal(out["logits"].numpy()[:, ::4], g["logits"])
+    assert g["mask"].min() < 0.05 and g["mask"].max() > 0.95        # a mask that actually separates
