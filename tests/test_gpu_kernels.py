@@ -60,6 +60,7 @@ CONV64_CASES = [
     (5, 5, 1, 1, 1, 5),        # single frame, single partial tile
     (5, 5, 2, 1, 301, 64),     # full T, exact F tile
     (7, 1, 1, 1, 8, 601),      # full F
+    (5, 5, 16, 1, 301, 33),    # residue classes of 19 and 18 rows: two 8-row tiles + a 4-row tail launch
 ]
 
 

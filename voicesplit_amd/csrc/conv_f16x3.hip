@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256, 2)
 void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
                          const float* __restrict__ in_scale, const float* __restrict__ w_scale,
-                         float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft, unsigned* amax_out) {
+                         float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft, unsigned* amax_out,
+                         int i_base, int i_end) {     // this launch covers rows [i_base, i_end) of every residue class
   constexpr int R = 4 * P;
   constexpr int ROWS = R + KT - 1;
   constexpr int PX = kTileF + KF - 1 + ((kTileF + KF - 1) % 4 ? 4 - (kTileF + KF - 1) % 4 : 0);   // multiple of 4
@@ -148,8 +149,9 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
   const int rt = bid % n_rt; bid /= n_rt;
   const int cls = bid % dil;
   const int b = bid / dil;
-  const int n_c = (T - cls + dil - 1) / dil;
-  const int i0 = rt * R;
+  const int n_all = (T - cls + dil - 1) / dil;
+  const int n_c = n_all < i_end ? n_all : i_end;          // rows of the class this launch may write
+  const int i0 = i_base + rt * R;
   if (i0 >= n_c) return;
   const int f0 = ft * kTileF;
   const size_t plane = (size_t)T * F;
@@ -167,7 +169,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
     const int x = pix - rr * PX;
     const int iin = i0 - KT / 2 + rr;
     const int f = f0 - KF / 2 + x;
-    const bool ok = (pix < NPIX) && (iin >= 0) && (iin < n_c) && (f >= 0) && (f < F);
+    const bool ok = (pix < NPIX) && (iin >= 0) && (iin < n_all) && (f >= 0) && (f < F);
     voff[i] = ok ? (unsigned)(((cls + dil * iin) * F + f) * 4) : kOob;
   }
   float stage[NPP][kChunk];
@@ -332,18 +334,20 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
 
 template <int KT, int KF, int P>
 int launch_conv(const float* in, const _Float16* wp, const float* scale, const float* shift, const float* in_scale,
-                const float* w_scale, float* out, int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream) {
+                const float* w_scale, float* out, int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream,
+                int i_base = 0, int i_end = 0x7fffffff) {
   constexpr int R = 4 * P;
-  const int rows_max = (T + dil - 1) / dil;
+  const int rows_all = (T + dil - 1) / dil;
+  const int rows_max = (rows_all < i_end ? rows_all : i_end) - i_base;
   const int n_rt = (rows_max + R - 1) / R;
   const int n_ft = (F + kTileF - 1) / kTileF;
   const long long nblk = (long long)B * dil * n_rt * n_ft;
   VS_REQUIRE(nblk > 0 && nblk < 2147483647LL, "conv64_f16x3: grid of %lld blocks out of range", nblk);
   dim3 grid((unsigned)nblk), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
     default: VS_REQUIRE(false, "conv64_f16x3: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
@@ -412,6 +416,14 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
   // (measured 6.6 vs 7.45 ms per layer at equal padding); 4-row tiles only win when they avoid
   // more than ~12 % of padded rows (short residue classes: dil = 16 at T = 301).
   const bool p2 = tile_rows(T, dil, 8) * 100 <= tile_rows(T, dil, 4) * 112;
+  // Mixed tiling: when the residue classes end 1..4 rows past a multiple of 8 (dil = 16 at T = 301:
+  // 19 rows), the 8-row kernel takes the full tiles and the 4-row kernel the tail, instead of
+  // running everything on the less efficient 4-row tiles or padding a third 8-row tile.
+  const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
+  if (KT == 5 && KF == 5 && full8 > 0 && rem > 0 && rem <= 4) {
+    if (int rc = launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, full8)) return rc;
+    return launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff);
+  }
   if (KT == 7 && KF == 1) {
     return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
               : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
