@@ -265,3 +265,16 @@ def test_world2_gloo_training_job_equals_one_process_on_the_global_batch(tmp_pat
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_cli_refuses_to_run_without_a_gpu(tmp_path):
+    """The training CLI has no CPU path: on a box without an MI355X it must say so, not fall back."""
+    import json
+    from voicesplit_amd import default_config, trainer
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    c = default_config()
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps({k: (dict(v) if isinstance(v, dict) else v) for k, v in c.items()}))
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        trainer.main(["-c", str(p), "--synthetic-steps", "1"])
