@@ -22,12 +22,21 @@ def import_reference():
     if not reference_available():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
     sys.dont_write_bytecode = True          # never write __pycache__ into the read-only tree
-    for name in ("librosa", "librosa.util", "mir_eval", "mir_eval.separation"):
-        if name not in sys.modules:
+    import importlib.util as _ilu
+    stub_names = ("librosa", "librosa.util", "mir_eval", "mir_eval.separation")
+    # stub only what is genuinely absent, and take the stubs out again afterwards (a later
+    # `import librosa` in the same process must not silently get an empty module)
+    stubbed = []
+    for name in stub_names:
+        top = name.split(".")[0]
+        if name not in sys.modules and (top in stubbed or _ilu.find_spec(top) is None):
             sys.modules[name] = types.ModuleType(name)
-    sys.modules["librosa"].util = sys.modules["librosa.util"]
-    sys.modules["mir_eval"].separation = sys.modules["mir_eval.separation"]
-    sys.modules["mir_eval.separation"].bss_eval_sources = lambda *a, **k: None
+            stubbed.append(name)
+    if "librosa.util" in stubbed:
+        sys.modules["librosa"].util = sys.modules["librosa.util"]
+    if "mir_eval.separation" in stubbed:
+        sys.modules["mir_eval"].separation = sys.modules["mir_eval.separation"]
+        sys.modules["mir_eval.separation"].bss_eval_sources = lambda *a, **k: None
     # the repo's own drop-in `models/` package would shadow upstream's: load upstream
     # under private names straight from the files.
     import importlib.util
@@ -53,4 +62,6 @@ def import_reference():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+        for name in stubbed:
+            sys.modules.pop(name, None)
     return vs.VoiceSplit, vf.VoiceFilter, gu.Mish, gu.load_config, gu.AttrDict

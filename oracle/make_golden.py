@@ -122,6 +122,9 @@ GRAD_CASES = [
     ("vf_small_train_grads", "voicefilter", SMALL, 3, 35, 16, True,  6.0),
     ("vs_small_evalbn_grads", "voicesplit", SMALL, 2, 50, 17, False, 6.0),   # frozen BatchNorm (model.eval())
     ("vs_full_b1_grads",     "voicesplit",  R.default_dims(), 1, 301, 1, True, 8.0),
+    # the configuration BASELINE.json's metric is quoted on (full size, several utterances, batch-stat
+    # BatchNorm, train.py:84,94-110): forward intermediates, BN buffers after the step and every gradient
+    ("vs_full_b8_train_grads", "voicesplit", R.default_dims(), 8, 301, 3, True, 8.0),
 ]
 
 
@@ -133,7 +136,10 @@ def main_grads():
     VoiceSplit, VoiceFilter, _Mish, _load_config, AttrDict = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for name, model_name, dims, B, T, seed, training, gain in GRAD_CASES:
+        if only and name not in only:
+            continue
         sd = R.spread_logits(R.build_state_dict(dims, seed), gain)
         x, dvec = R.synthetic_inputs(B, T, dims, seed)
         w = RB.loss_weights(B, T, dims["fc2_dim"], seed)
@@ -141,7 +147,18 @@ def main_grads():
         model = cls(make_config(AttrDict, dims))
         model.load_state_dict(sd, strict=True)
         model.train(training)
+        full_batch = dims["num_freq"] > 100 and B > 1
+        grabbed = {}
+        hooks = []
+        if full_batch:
+            hooks = [
+                model.conv.register_forward_hook(lambda m, i, o: grabbed.__setitem__("cnn8", o.detach())),
+                model.lstm.register_forward_hook(lambda m, i, o: grabbed.__setitem__("lstm_out", o[0].detach())),
+                model.fc2.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach())),
+            ]
         mask = model(x, dvec)
+        for h in hooks:
+            h.remove()
         (mask * w).sum().backward()
         out = {
             "model": np.array(model_name), "B": B, "T": T, "seed": seed,
@@ -151,6 +168,15 @@ def main_grads():
             "torch_version": np.array(torch.__version__),
             "mask_sum": np.array(float(mask.detach().double().sum())),
         }
+        if full_batch:     # thinned forward tensors + the BatchNorm buffers after this one training-mode forward
+            out["fwd/cnn8"] = grabbed["cnn8"].numpy()[:, :, ::16, ::4]
+            out["fwd/lstm_out"] = grabbed["lstm_out"].numpy()[:, ::8]
+            out["fwd/logits"] = grabbed["logits"].numpy()[:, ::8]
+            out["fwd/mask"] = mask.detach().numpy()[:, ::8]
+            after = model.state_dict()
+            for k in after:
+                if "running_" in k or "num_batches" in k:
+                    out["after/" + k] = after[k].numpy()
         for k, p in model.named_parameters():
             out["grad/" + k] = RB.thin_grad(p.grad.detach()).numpy()
             out["gabs/" + k] = np.array(float(p.grad.detach().abs().max()))

@@ -43,7 +43,8 @@ def load_golden(name):
 GOLDEN_CASES = ["vs_small_eval", "vf_small_eval", "vs_small_train", "vs_short_T", "vs_T1",
                 "vs_full_b1", "vf_full_b1"]
 
-GOLDEN_GRAD_CASES = ["vs_small_train_grads", "vf_small_train_grads", "vs_small_evalbn_grads", "vs_full_b1_grads"]
+GOLDEN_GRAD_CASES = ["vs_small_train_grads", "vf_small_train_grads", "vs_small_evalbn_grads", "vs_full_b1_grads",
+                     "vs_full_b8_train_grads"]
 
 
 def load_golden_grads(name):

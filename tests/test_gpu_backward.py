@@ -430,8 +430,73 @@ def test_module_backward_matches_fp64_oracle(cls_name, act, training, B, T):
     assert rel_err(emb.grad, ref["speaker_embedding"]) < MTOL
 
 
-@pytest.mark.parametrize("name", GOLDEN_GRAD_CASES)
-def test_module_backward_matches_upstream_golden_gradients(name):
+def _align_fragile_relus(tape, dims, act, g):
+    """Put the HIP tape on the upstream's side of every near-kink ReLU input the fixture lists.
+
+    d(relu)/dx jumps at 0: an implementation whose forward differs from the upstream's by rounding
+    can sit on the other side of a kink for the few elements with |x| ~ 1e-7 and then differentiates
+    a different, equally valid branch.  The fixture (oracle/make_golden.py --grads) records every
+    upstream ReLU input within 5e-5 (relative) of zero; before the backward pass those elements of the
+    tape are overwritten with the upstream's values (a perturbation <= 5e-5 of the tensor's range on
+    a handful of elements), so the comparison is deterministic and never skipped.  Returns the
+    number of elements whose branch actually differed."""
+    from voicesplit_amd import ops
+    lay = ops.tape_layout(dims)
+    B, T, Fq, H = dims.B, dims.T, dims.F, dims.H
+    dev_ = tape.device
+    n_flip = 0
+
+    def fragile(nm):
+        idx = torch.from_numpy(np.asarray(g["fragile_idx/" + nm])).long().to(dev_)
+        val = torch.from_numpy(np.asarray(g["fragile_val/" + nm])).float().to(dev_)
+        return idx, val
+
+    idx, val = fragile("lstm_out")          # stored raw; relu is applied by the consumers
+    if idx.numel():
+        v = ops.ws_view(tape, lay.lstm_out, (B * T * 2 * H,))
+        n_flip += int(((v[idx] > 0) != (val > 0)).sum())
+        v[idx] = val
+    idx, val = fragile("fc1_pre")           # stored after the ReLU: gate = (h1 > 0)
+    if idx.numel():
+        v = ops.ws_view(tape, lay.fc1_out, (B * T * dims.FC1,))
+        n_flip += int(((v[idx] > 0) != (val > 0)).sum())
+        v[idx] = val.clamp_min(0)
+    if act == "relu":                        # VoiceFilter: y_l = z_l*scale_l + shift_l feeds a ReLU after every BatchNorm
+        for l in range(8):
+            idx, val = fragile(f"y{l + 1}")
+            if not idx.numel():
+                continue
+            C = 64 if l < 7 else 8
+            sc = ops.ws_view(tape, lay.bn_scale + 64 * 4 * l, (C,))
+            sh = ops.ws_view(tape, lay.bn_shift + 64 * 4 * l, (C,))
+            c = (idx // (T * Fq)) % C                     # the oracle's y is [B][C][T][F]
+            if l < 7:
+                z = ops.ws_view(tape, lay.z[l], (B * 64 * T * Fq,))
+                a = ops.ws_view(tape, lay.a[l], (B * 64 * T * Fq,))
+                k = idx
+            else:                                         # cnn8 lives in the LSTM feature layout [B][T][8][F]
+                z = ops.ws_view(tape, lay.z8, (B * T * 8 * Fq,))
+                a = ops.ws_view(tape, lay.feat, (B * T * 8 * Fq,))
+                b_, t_, f_ = idx // (8 * T * Fq), (idx // Fq) % T, idx % Fq
+                k = ((b_ * T + t_) * 8 + c) * Fq + f_
+            y_now = z[k] * sc[c] + sh[c]
+            n_flip += int(((y_now > 0) != (val > 0)).sum())
+            # far enough from zero that the fp32 fma of the backward kernel cannot round across it
+            tgt = torch.where(val > 0, 1.0, -1.0) * torch.maximum(val.abs(), 1e-5 * sh[c].abs().clamp_min(1.0))
+            z[k] = ((tgt.double() - sh[c].double()) / sc[c].double()).float()
+            assert bool((((z[k] * sc[c] + sh[c]) > 0) == (val > 0)).all())
+            a[k] = tgt.clamp_min(0)
+    return n_flip
+
+
+def _golden_grad_params():
+    # the metric configuration (full size, several utterances, batch-stat BatchNorm) in both arithmetics
+    return [(n, "f16x3") for n in GOLDEN_GRAD_CASES] + [("vs_full_b8_train_grads", "fp32")]
+
+
+@pytest.mark.parametrize("name,math", _golden_grad_params())
+def test_module_backward_matches_upstream_golden_gradients(name, math):
+    from voicesplit_amd import ops
     g = load_golden_grads(name)
     d = g["dims"]
     sd = R.spread_logits(R.build_state_dict(d, g["seed"]), g["gain"])
@@ -439,27 +504,36 @@ def test_module_backward_matches_upstream_golden_gradients(name):
     w = RB.loss_weights(g["B"], g["T"], d["fc2_dim"], g["seed"])
     m = _module("VoiceSplit" if g["model"] == "voicesplit" else "VoiceFilter", d, sd)
     m.train(g["training"])
-    mask = m(x.cuda(), dvec.cuda())
-    assert abs(float(mask.detach().double().sum()) - float(g["mask_sum"])) < 1e-4 * abs(float(g["mask_sum"]))
-    tape = mask.grad_fn.tape
-    (mask * w.cuda()).sum().backward()
-    # ReLU kinks: the fixture lists the upstream ReLU inputs within 5e-5 of zero.  If the HIP forward
-    # sits on the other side of one of them it differentiates a different (equally valid) branch
-    # and elementwise parity with THIS fixture is undefined; the branch-consistent fp64 oracle
-    # tests above/below are the check in that case.
-    from voicesplit_amd import ops
-    dims = ops.make_dims(g["B"], g["T"], d["num_freq"], d["emb_dim"], d["lstm_dim"], d["fc1_dim"], d["fc2_dim"])
-    act = "mish" if g["model"] == "voicesplit" else "relu"
-    signs = _our_relu_signs(tape, dims, act, g["B"], g["T"])
-    flipped = []
-    for nm in RB.relu_inputs(act):
-        idx = torch.from_numpy(g["fragile_idx/" + nm]).long()
-        if idx.numel():
-            ours = signs[nm].reshape(-1)[idx]
-            theirs = torch.from_numpy(g["fragile_val/" + nm]) > 0
-            flipped += [(nm, int(i), float(v)) for i, v, o, t in zip(idx, g["fragile_val/" + nm], ours, theirs) if bool(o) != bool(t)]
-    if flipped:
-        pytest.skip(f"HIP forward is on the other side of {len(flipped)} ReLU kink(s) of this fixture: {flipped[:4]}")
+    prev = ops.get_conv_math()
+    ops.set_conv_math(math)
+    try:
+        mask = m(x.cuda(), dvec.cuda())
+        assert abs(float(mask.detach().double().sum()) - float(g["mask_sum"])) < 1e-4 * abs(float(g["mask_sum"]))
+        tape = mask.grad_fn.tape
+        dims = ops.make_dims(g["B"], g["T"], d["num_freq"], d["emb_dim"], d["lstm_dim"], d["fc1_dim"], d["fc2_dim"])
+        B, T, Fq, H = g["B"], g["T"], d["num_freq"], d["lstm_dim"]
+        if "fwd/mask" in g:      # forward intermediates + BatchNorm buffers of the same training-mode call
+            lay = ops.tape_layout(dims)
+            feat = ops.ws_view(tape, lay.feat, (B, T, 8, Fq)).cpu().permute(0, 2, 1, 3)
+            assert rel_err(feat[:, :, ::16, ::4], torch.from_numpy(g["fwd/cnn8"])) < MTOL
+            assert rel_err(ops.ws_view(tape, lay.lstm_out, (B, T, 2 * H))[:, ::8], torch.from_numpy(g["fwd/lstm_out"])) < MTOL
+            assert rel_err(mask[:, ::8], torch.from_numpy(g["fwd/mask"])) < MTOL
+            sdc = {k: v.detach() for k, v in m.state_dict().items()}
+            _, lg = ops.head(sdc, ops.ws_view(tape, lay.lstm_out, (B, T, 2 * H)).clone(), dims, want_logits=True)
+            assert rel_err(lg[:, ::8], torch.from_numpy(g["fwd/logits"])) < MTOL
+            after = m.state_dict()
+            for k in after:
+                if "running_" in k:
+                    assert rel_err(after[k], torch.from_numpy(g["after/" + k])) < MTOL, k
+                if "num_batches" in k:
+                    assert int(after[k]) == int(g["after/" + k])
+        act = "mish" if g["model"] == "voicesplit" else "relu"
+        n_frag = sum(len(g["fragile_idx/" + nm]) for nm in RB.relu_inputs(act))
+        n_flip = _align_fragile_relus(tape, dims, act, g)
+        assert n_flip <= 5 + 0.05 * n_frag, f"{n_flip} of {n_frag} near-kink ReLU inputs on the other side"
+        (mask * w.cuda()).sum().backward()
+    finally:
+        ops.set_conv_math(prev)
     zero = _zero_bias_keys(g["training"])
     bad, table = {}, {}
     for k, p in m.named_parameters():
@@ -470,7 +544,7 @@ def test_module_backward_matches_upstream_golden_gradients(name):
         table[k] = float(err)
         if err >= MTOL:
             bad[k] = err
-    _dump(name, table)
+    _dump(f"{name}_{math}", table)
     assert not bad, bad
 
 

@@ -130,8 +130,14 @@ def test_backward_oracle_reproduces_upstream_gradients(name):
     assert _digest(sd) == g["sd_sha256"]
     act = "mish" if g["model"] == "voicesplit" else "relu"
     w = RB.loss_weights(g["B"], g["T"], g["dims"]["fc2_dim"], g["seed"])
-    grads = RB.gradients(sd, x, dvec, w, act=act, training=g["training"])
+    stages = {} if "fwd/mask" in g else None
+    grads = RB.gradients(sd, x, dvec, w, act=act, training=g["training"], stages=stages)
     assert sorted(grads) == sorted(g["grads"])
+    if stages is not None:     # the metric configuration: forward tensors of the same training-mode call
+        for nm, got in (("cnn8", stages["val/cnn8"][:, :, ::16, ::4]), ("lstm_out", stages["val/lstm_out"][:, ::8]),
+                        ("logits", stages["val/logits"][:, ::8]), ("mask", stages["mask"][:, ::8])):
+            ref = g["fwd/" + nm]
+            assert np.abs(got.numpy() - ref).max() <= 2e-6 * np.abs(ref).max(), f"{name}:fwd/{nm}"
     for k, ref in g["grads"].items():
         got = RB.thin_grad(grads[k]).numpy()
         assert got.shape == ref.shape, k

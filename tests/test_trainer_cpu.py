@@ -114,7 +114,7 @@ def test_train_step_is_zero_grad_backward_adam_step():
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.bucket.params, tr.bucket.views))
 
 
-def test_loss_explosion_stops_before_the_update_and_fit_leaves_the_epoch():
+def test_loss_explosion_follows_train_py_order_and_fit_leaves_the_epoch():
     c = _cfg(epochs=2)
     calls = {"n": 0}
 
@@ -124,16 +124,17 @@ def test_loss_explosion_stops_before_the_update_and_fit_leaves_the_epoch():
 
     tr = Trainer(_Standin(), c, criterion=crit)
     tr.train_step(_batch(2, 0))
-    before = [p.detach().clone() for p in tr.model.parameters()]
-    with pytest.raises(LossExploded, match="Loss exploded"):
+    # train.py:109-117: optimizer.step(); step += 1; THEN loss.item() and the guard -- the step is counted
+    with pytest.raises(LossExploded, match="Loss exploded to nan at step 2!"):
         tr.train_step(_batch(2, 1))
-    assert tr.step == 1 and all(torch.equal(a, b) for a, b in zip(before, tr.model.parameters()))
+    assert tr.step == 2
     # fit(): the exploding step ends its epoch (train.py:115-117 `break`), the next epoch still runs
     calls["n"] = 0
     tr2 = Trainer(_Standin(), c, criterion=crit)
     logged = []
     tr2.fit(lambda e: (_batch(2, 10 * e + i) for i in range(3)), on_log=lambda s, l: logged.append(s))
-    assert tr2.step == 1 + 3 and logged == [1, 2, 3, 4]
+    # as in the reference the NaN update has gone into the weights, so the next epoch explodes at once too
+    assert tr2.step == 3 and logged == [1]
 
 
 def test_checkpoint_format_resume_and_partial_init(tmp_path):
@@ -230,14 +231,24 @@ def _dp_worker(rank, world, port, tmp, q):
     out = tr.save_checkpoint(path)
     dist.barrier()
     ok = ok and ((rank == 0) == (out is not None)) and os.path.isfile(path)
-    # a NaN on ONE rank stops both, before either applies the update
+    # one rank's slice filtered out entirely (utils/dataset.py:93-95): both ranks skip the step together
+    from voicesplit_amd.trainer import EmptyBatch
     before = [p.detach().clone() for p in tr.model.parameters()]
+    try:
+        tr.train_step((None,) * 6 if rank == 1 else pick([0, 1]))
+        ok = False
+    except EmptyBatch:
+        ok = ok and all(torch.equal(a, b) for a, b in zip(before, tr.model.parameters())) and tr.step == 3
+    # a NaN on ONE rank stops both at the same step (counted, as train.py:111-117 does)
     tr.criterion = lambda m, x, t, s, p: _mse(m, x, t, s, p) * (float("nan") if rank == 1 else 1.0)
     try:
         tr.train_step(pick([0, 1]))
         ok = False
     except LossExploded:
-        ok = ok and all(torch.equal(a, b) for a, b in zip(before, tr.model.parameters())) and tr.step == 3
+        ok = ok and tr.step == 4
+    with torch.no_grad():      # the NaN update went into the weights (as in the reference): restore for the rest
+        for p_, b_ in zip(tr.model.parameters(), before):
+            p_.copy_(b_)
     # validation mean over ranks
     tr.criterion = _mse
     v = tr.validate([pick([2 * rank, 2 * rank + 1])])

@@ -347,6 +347,47 @@ int make_shape(const vs_loss_dims* d, LossShape* s) {
   return 0;
 }
 
+// The overlap-add divides by the window envelope.  With little or no overlap (hop close to win) a Hann
+// window leaves samples whose envelope is 0 (w[0] = 0, and w[win-1] = 0 for the non-periodic form):
+// torchaudio.functional.istft asserts `window_envelop.abs().min() > 1e-11` there and librosa only
+// divides where the envelope exceeds tiny -- refuse such configurations instead of emitting inf/nan.
+// Same formula as istft_envelope_kernel, evaluated on the host (first / last window and one steady
+// period are enough: the envelope is hop-periodic in between); cached for the last shape seen.
+int check_envelope(const LossShape& s) {
+  static thread_local int c_key[5] = {0, 0, 0, 0, 0};
+  static thread_local double c_min = 0.0;
+  const int key[5] = {s.hop, s.win, s.T, s.periodic, 1};
+  bool hit = true;
+  for (int i = 0; i < 5; ++i) hit = hit && key[i] == c_key[i];
+  if (!hit) {
+    const int off = s.win / 2, den = s.periodic ? s.win : s.win - 1;
+    auto env_at = [&](int sp) {
+      double e = 0.0;
+      int t_hi = (sp + off) / s.hop;
+      if (t_hi > s.T - 1) t_hi = s.T - 1;
+      for (int t = t_hi; t >= 0; --t) {
+        const int j = sp - s.hop * t + off;
+        if (j >= s.win) break;
+        const double w = den > 0 ? 0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * (double)j / (double)den) : 1.0;
+        e += w * w;
+      }
+      return e;
+    };
+    double mn = 1e300;
+    const int span = s.win + s.hop;
+    for (int sp = 0; sp < s.S; ++sp) {
+      if (sp >= span && sp < s.S - span) { sp = s.S - span - 1; continue; }
+      const double e = env_at(sp);
+      if (e < mn) mn = e;
+    }
+    c_min = mn;
+    for (int i = 0; i < 5; ++i) c_key[i] = key[i];
+  }
+  VS_REQUIRE(c_min > 1e-11, "istft: window envelope reaches %.3g (hop=%d win=%d %s Hann): the overlap-add would divide by zero; "
+             "use hop <= win/2", c_min, s.hop, s.win, s.periodic ? "periodic" : "symmetric");
+  return 0;
+}
+
 void make_layout(const LossShape& s, LossLayout* L) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
@@ -389,6 +430,7 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
   LossLayout L;
   make_layout(s, &L);
   VS_REQUIRE(mixed && mask && target && phase && loss, "sisnr_loss: NULL argument");
+  if (int rc = check_envelope(s)) return rc;
   VS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && ws_bytes >= L.total, "sisnr_loss: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.total);
   const int M = s.B * s.T;
   const long long nspec = (long long)M * s.F;
@@ -492,6 +534,7 @@ int vs_spec_to_wav(const vs_loss_dims* d, const float* spec, const float* mask, 
   LossLayout L;
   make_layout(s, &L);
   VS_REQUIRE(spec && phase && wav, "spec_to_wav: NULL argument");
+  if (int rc = check_envelope(s)) return rc;
   VS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && ws_bytes >= L.total, "spec_to_wav: workspace too small or misaligned (%zu < %zu)", ws_bytes, L.total);
   const int M = s.B * s.T;
   const long long nspec = (long long)M * s.F;

@@ -121,6 +121,10 @@ class _MaskNet(nn.Module):
 
     def forward(self, x, speaker_embedding):
         # x: [B, T, num_freq]; speaker_embedding: [B, emb_dim]  ->  mask [B, T, fc2_dim]
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError(
+                "voicesplit_amd: the gradient wrt the input spectrogram is not produced (the reference "
+                "never asks for it: x is data, train.py:85-94); detach x")
         if torch.is_grad_enabled() and (speaker_embedding.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _MaskForward.apply(self, x, speaker_embedding, *self.parameters())
         return self._run(x, speaker_embedding)

@@ -304,31 +304,40 @@ def tape_layout(dims: VsDims) -> "_lib.VsTapeLayout":
     return lay
 
 
-_TAPE_POOL: Dict[tuple, list] = {}
+_TAPE_POOL: Dict[int, list] = {}       # device index -> free tapes
+_TAPE_POOL_MAX = int(os.environ.get("VOICESPLIT_TAPE_POOL", "1"))
 
 
 def new_tape(dims: VsDims, device) -> torch.Tensor:
     """Caller-owned training tape (saved activations + backward scratch, 49 GB at B=64).  Tapes
-    are recycled through a small pool: a forward takes one, its backward hands it back
-    (``recycle_tape``), so steady-state training touches no allocator at all; a second forward
-    before the first backward simply gets a second tape."""
+    are recycled through a small per-device pool: a forward takes one, its backward hands it back
+    (``recycle_tape``), so steady-state training touches no allocator at all.  Any free tape with
+    enough capacity is reused (variable B / T: the largest shape seen so far serves the smaller
+    ones); at most ``VOICESPLIT_TAPE_POOL`` (default 1) free tapes are retained per device, and
+    free tapes that are too small are released before a larger one is allocated."""
     nbytes = _lib.load().vs_tape_bytes(ctypes.byref(dims))
     if nbytes == 0:
         check(-1, "vs_tape_bytes")
-    key = (torch.device(device).index, nbytes)
-    free = _TAPE_POOL.get(key)
-    if free:
-        return free.pop()
-    for k in [k for k in _TAPE_POOL if k[0] == key[0]]:     # other sizes on this device: let go
-        _TAPE_POOL.pop(k)
+    free = _TAPE_POOL.setdefault(torch.device(device).index, [])
+    fit = [t for t in free if t.numel() >= nbytes]
+    if fit:
+        t = min(fit, key=lambda u: u.numel())
+        free.remove(t)
+        return t
+    free.clear()                                              # too small: let go before the big allocation
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 def recycle_tape(tape: torch.Tensor):
-    key = (tape.device.index, tape.numel())
-    pool = _TAPE_POOL.setdefault(key, [])
-    if len(pool) < 2:
+    pool = _TAPE_POOL.setdefault(tape.device.index, [])
+    if len(pool) < _TAPE_POOL_MAX:
         pool.append(tape)
+
+
+def tape_pool_bytes(device=None) -> int:
+    """Bytes held by free tapes (outside torch's caching allocator statistics of live tensors)."""
+    idx = None if device is None else torch.device(device).index
+    return sum(t.numel() for k, v in _TAPE_POOL.items() if idx is None or k == idx for t in v)
 
 
 def forward_train(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor) -> torch.Tensor:

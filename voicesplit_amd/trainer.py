@@ -38,6 +38,11 @@ class LossExploded(RuntimeError):
     """train.py:115-117: ``loss > 1e8 or math.isnan(loss)`` ends the epoch."""
 
 
+class EmptyBatch(RuntimeError):
+    """Some rank's slice of this global batch was filtered out entirely (utils/dataset.py:93-95);
+    raised on every rank at once, ``fit`` moves on to the next batch."""
+
+
 # ---------------------------------------------------------------------------------------------
 # which items a rank sees
 # ---------------------------------------------------------------------------------------------
@@ -153,6 +158,18 @@ class Trainer:
         """batch = (emb, target, mixed, seq_len, target_wav, spec_phase) as train_collate_fn returns
         it (utils/dataset.py:84-114).  Returns the loss averaged over ranks; raises LossExploded on
         every rank at once."""
+        # utils/dataset.py:93-95 drops items whose embedding is [0]; a rank whose whole slice was dropped
+        # has nothing to run.  With several ranks that must be a collective decision (a rank that
+        # raised or skipped alone would leave the others blocked in the gradient all-reduce): every
+        # rank contributes "I have a batch", and the step is skipped everywhere unless all do.
+        have = batch is not None and batch[0] is not None and len(batch[0]) > 0
+        if self.world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if have else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            have = bool(flag.item() > 0)
+        if not have:
+            raise EmptyBatch("a rank has no items in this step (all filtered by the collate): step skipped on every rank")
         emb, target, mixed, seq_len, _target_wav, phase = batch
         dev = self.device
         emb, target, mixed, phase = (t.to(dev, non_blocking=True) for t in (emb, target, mixed, phase))
@@ -165,13 +182,13 @@ class Trainer:
         loss.backward()                                                     # :110
         self.bucket.extra[0] = loss.detach()
         self.bucket.all_reduce(self.world)                                  # the one exchange step
-        value = float(self.bucket.extra[0].item())                          # :114 (the reference syncs here too)
-        # :115-117.  Checked before the update (the reference applies the non-finite update first and
-        # then leaves the epoch; the weights it leaves behind are unusable either way)
-        if value > 1e8 or math.isnan(value):
-            raise LossExploded("Loss exploded to %.02f at step %d!" % (value, self.step + 1))
         self.optimizer.step()                                               # :111
-        self.step += 1
+        self.step += 1                                                      # :112
+        value = float(self.bucket.extra[0].item())                          # :114 (the reference syncs here too)
+        # :115-117, in the reference's order: the update has been applied and counted when the guard
+        # fires, so step numbering and checkpoint cadence after an explosion match train.py
+        if value > 1e8 or math.isnan(value):
+            raise LossExploded("Loss exploded to %.02f at step %d!" % (value, self.step))
         return value
 
     @torch.no_grad()
@@ -208,16 +225,22 @@ class Trainer:
             for batch in batches_for_epoch(e):
                 try:
                     loss = self.train_step(batch)
+                except EmptyBatch:
+                    continue
                 except LossExploded as err:                                 # :115-117: leave this epoch
                     if self.rank == 0:
                         print(err)
                     break
                 if self.step % tc["summary_interval"] == 0 and on_log and self.rank == 0:     # :120-122
                     on_log(self.step, loss)
-                if log_dir and self.step % tc["checkpoint_interval"] == 0:                     # :125-133
+                if log_dir and self.step % tc["checkpoint_interval"] == 0:                     # :125-134
                     p = self.save_checkpoint(os.path.join(log_dir, "checkpoint_%d.pt" % self.step))
                     if p:
                         print("Saved checkpoint to: %s" % p)
+                    if validation_batches is not None:                      # :134 validation after every checkpoint
+                        v = self.validate(validation_batches())
+                        if on_log and self.rank == 0:
+                            on_log(-self.step, v)
         return self.step
 
 
@@ -278,6 +301,8 @@ class SpecWavDataset:
         ``device``: returns (emb, target, mixed, seq_len, target_wav, mixed_phase)."""
         from . import audio
         items = [it for it in items if it[0].tolist() != [0]]               # :93-95
+        if not items:
+            return (None,) * 6              # Trainer.train_step turns this into a collective skip
         emb = torch.stack([it[0].float().reshape(-1) for it in items]).to(device)
         target = torch.stack([it[1].float() for it in items]).to(device)
         wav = torch.stack([it[2] for it in items]).to(device)
@@ -333,7 +358,7 @@ def main(argv=None):
     tr = Trainer(model.to(dev), c, rank, world)
     if args.checkpoint_path:
         tr.load_checkpoint(args.checkpoint_path, c.train_config.get("reinit_layers"))
-    log_dir = c.train_config["logs_path"]
+    log_dir = os.path.join(c.train_config["logs_path"], c.model_name)      # train.py:154
     if rank == 0:
         os.makedirs(log_dir, exist_ok=True)
     acfg = c.audio[c.audio["backend"]]
