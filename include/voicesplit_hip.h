@@ -273,6 +273,11 @@ int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, flo
  * size (default: the ring kernel once every workgroup gets >= 2 columns, else the kt-split kernel),
  * 1 = ring, 2 = kt-split.  Process-wide; returns -1 for an unknown mode. */
 int vs_set_wgrad_kernel(int mode);
+/* which 5x5 split-f16 forward / data-gradient kernel vs_conv64_f16x3_fwd and the whole-path calls
+ * launch: 0 = default (the persistent pipelined kernel, csrc/conv_f16x3_pk.hip), 1 = one tile per
+ * workgroup (csrc/conv_f16x3.hip), 2 = persistent.  Both give bit-identical results (same K order);
+ * the switch exists for A/B timing and the bitwise cross-check.  Process-wide. */
+int vs_set_conv_kernel(int mode);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

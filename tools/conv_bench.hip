@@ -1,0 +1,154 @@
+// Standalone A/B harness for the 64->64 split-f16 conv kernels (no Python: a fresh GPU box pays
+// ~2 minutes for its first `import torch`).  Links libvoicesplit_hip.so and drives it through the
+// C ABI only.  For every case: the one-tile-per-workgroup kernel (vs_set_conv_kernel(1)) and the
+// persistent pipelined kernel (2) run on the same operands; outputs must be BIT-identical (same K
+// order, fp32 accumulation), repeated launches of the persistent kernel must be bit-stable (race
+// screen), and both are timed with HIP events.
+//   tools/conv_bench [B=64] [reps=10]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../include/voicesplit_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define VS(x) do { int rc_ = (x); if (rc_) { printf("vs error %d (%s) at %s:%d\n", rc_, vs_last_error(), __FILE__, __LINE__); exit(3); } } while (0)
+
+static unsigned g_seed = 12345u;
+static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xffffff) / 8388608.0f - 1.0f; }
+
+__global__ void diff_kernel(const unsigned* a, const unsigned* b, long long n, unsigned long long* cnt, unsigned* firstbad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = 0;
+  for (; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (a[i] != b[i]) { ++c; atomicMin(firstbad, (unsigned)(i < 0xffffffffLL ? i : 0xfffffffe)); }
+  if (c) atomicAdd(cnt, c);
+}
+
+struct Case { int B, T, F, dil, act; };
+
+int main(int argc, char** argv) {
+  const int Bbig = argc > 1 ? atoi(argv[1]) : 64;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const bool prof = argc > 3 && !strcmp(argv[3], "prof");
+  std::vector<Case> cases = {
+      {2, 19, 37, 1, 1}, {1, 23, 70, 2, 1}, {2, 21, 133, 4, 0}, {1, 50, 64, 8, 1}, {2, 40, 31, 16, 1}, {1, 20, 37, 16, 2},
+      {1, 1, 5, 1, 1}, {3, 9, 601, 2, 1}, {1, 70, 37, 1, 1}, {5, 301, 601, 1, 1}, {3, 301, 601, 16, 1},
+      {Bbig, 301, 601, 1, 1}, {Bbig, 301, 601, 2, 1}, {Bbig, 301, 601, 4, 1}, {Bbig, 301, 601, 8, 1}, {Bbig, 301, 601, 16, 1},
+      {Bbig, 301, 601, 4, 2},
+  };
+  if (prof) cases = {{Bbig, 301, 601, 1, 1}, {Bbig, 301, 601, 4, 1}};
+  size_t maxn = 0;
+  for (auto& c : cases) { size_t n = (size_t)c.B * 64 * c.T * c.F; if (n > maxn) maxn = n; }
+  float *in, *out0, *out1, *out2, *w, *scale, *shift, *sc_in, *sc_w;
+  void *packed, *amax;
+  unsigned long long* cnt; unsigned* firstbad;
+  CK(hipMalloc(&in, maxn * 4)); CK(hipMalloc(&out0, maxn * 4)); CK(hipMalloc(&out1, maxn * 4)); CK(hipMalloc(&out2, maxn * 4));
+  CK(hipMalloc(&w, 64 * 64 * 25 * 4)); CK(hipMalloc(&scale, 256)); CK(hipMalloc(&shift, 256));
+  CK(hipMalloc(&sc_in, 64)); CK(hipMalloc(&sc_w, 64)); CK(hipMalloc(&amax, 64));
+  CK(hipMalloc(&packed, vs_conv64_packed_f16_floats(5, 5) * 4));
+  CK(hipMalloc(&cnt, 8)); CK(hipMalloc(&firstbad, 4));
+  {
+    std::vector<float> h(maxn);
+    for (size_t i = 0; i < maxn; ++i) h[i] = frand() * 3.0f;
+    CK(hipMemcpy(in, h.data(), maxn * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw(64 * 64 * 25), hs(64), hb(64);
+    for (auto& v : hw) v = frand() * 0.05f;
+    for (auto& v : hs) v = 0.5f + 0.5f * (frand() + 1.0f);
+    for (auto& v : hb) v = 0.3f * frand();
+    CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(scale, hs.data(), 256, hipMemcpyHostToDevice));
+    CK(hipMemcpy(shift, hb.data(), 256, hipMemcpyHostToDevice));
+  }
+  VS(vs_conv64_pack_f16(w, packed, 5, 5, 0, amax, sc_w, nullptr));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  int bad_total = 0;
+  for (auto& c : cases) {
+    const long long n = (long long)c.B * 64 * c.T * c.F;
+    VS(vs_pow2_scale(in, n, amax, sc_in, nullptr));
+    auto run = [&](int mode, float* out) {
+      VS(vs_set_conv_kernel(mode));
+      VS(vs_conv64_f16x3_fwd(in, packed, scale, shift, sc_in, sc_w, out, c.B, c.T, c.F, 5, 5, c.dil, c.act, nullptr));
+    };
+    auto ndiff = [&](const float* a, const float* b) {
+      CK(hipMemset(cnt, 0, 8)); CK(hipMemset(firstbad, 0xff, 4));
+      hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, nullptr, (const unsigned*)a, (const unsigned*)b, n, cnt, firstbad);
+      unsigned long long h; unsigned fb;
+      CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&fb, firstbad, 4, hipMemcpyDeviceToHost));
+      if (h) printf("    first mismatch at flat index %u (b %lld co %lld t %lld f %lld)\n", fb, fb / (64LL * c.T * c.F), (fb / ((long long)c.T * c.F)) % 64,
+                    (fb / c.F) % c.T, (long long)fb % c.F);
+      return h;
+    };
+    CK(hipMemset(out0, 0xcd, n * 4)); CK(hipMemset(out1, 0xab, n * 4)); CK(hipMemset(out2, 0xef, n * 4));
+    run(1, out0);
+    run(2, out1);
+    run(2, out2);
+    CK(hipDeviceSynchronize());
+    const unsigned long long d01 = ndiff(out0, out1), d12 = ndiff(out1, out2);
+    float ms[3] = {0, 0, 0};
+    const bool big = n > 50000000LL;
+    if (big) {
+      for (int mode = 1; mode <= 2; ++mode) {
+        run(mode, out2);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) run(mode, out2);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[mode], e0, e1));
+        ms[mode] /= reps;
+      }
+      // stability of the persistent kernel under back-to-back launches
+      const unsigned long long d_again = ndiff(out1, out2);
+      if (d_again) { printf("    UNSTABLE: %llu elements differ between launches\n", d_again); ++bad_total; }
+    }
+    const double gflop = 2.0 * 64 * 64 * 25 * (double)c.B * c.T * c.F / 1e9;
+    printf("B=%d T=%d F=%d dil=%d act=%d: legacy-vs-pk mismatches %llu, pk-vs-pk %llu", c.B, c.T, c.F, c.dil, c.act, d01, d12);
+    if (big) printf("  | legacy %.3f ms (%.0f TF)  pk %.3f ms (%.0f TF)  x%.3f", ms[1], gflop / ms[1], ms[2], gflop / ms[2], ms[1] / ms[2]);
+    printf("\n");
+    if (d01 || d12) ++bad_total;
+  }
+  // ---- timing ablations of the persistent kernel and the data-dependence of the clock -------------
+  if (!prof) {
+    Case c{Bbig, 301, 601, 1, 1};
+    const long long n = (long long)c.B * 64 * c.T * c.F;
+    const double gflop = 2.0 * 64 * 64 * 25 * (double)c.B * c.T * c.F / 1e9;
+    VS(vs_pow2_scale(in, n, amax, sc_in, nullptr));
+    auto timeit = [&](int mode, const char* what) {
+      VS(vs_set_conv_kernel(mode));
+      VS(vs_conv64_f16x3_fwd(in, packed, scale, shift, sc_in, sc_w, out2, c.B, c.T, c.F, 5, 5, c.dil, c.act, nullptr));
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r)
+        VS(vs_conv64_f16x3_fwd(in, packed, scale, shift, sc_in, sc_w, out2, c.B, c.T, c.F, 5, 5, c.dil, c.act, nullptr));
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      printf("  %-58s %.3f ms  (%.0f TF algorithmic, %.0f TF on the f16 pipe)\n", what, ms, gflop / ms, 3 * gflop / ms);
+    };
+    printf("ablations, B=%d dil=1 (random data):\n", c.B);
+    timeit(1, "legacy (one tile per workgroup)");
+    timeit(2, "persistent pipeline");
+    timeit(123, "  pinned issue pattern, 1 MFMA : 3 others");
+    timeit(124, "  pinned issue pattern, 1 MFMA : 4 others");
+    timeit(125, "  pinned issue pattern, 1 MFMA : 5 others");
+    timeit(126, "  pinned issue pattern, 1 MFMA : 6 others");
+    timeit(128, "  pinned issue pattern, 1 MFMA : 8 others");
+    timeit(101, "  - no fragment ds_reads");
+    timeit(102, "  - no staging (window/weight loads, cvt, ds_write)");
+    timeit(104, "  - no in-loop epilogue");
+    timeit(108, "  - no barriers");
+    timeit(106, "  - no staging, no epilogue");
+    timeit(107, "  - no staging, no epilogue, no fragment reads");
+    timeit(115, "  - MFMA stream only (all of the above + no barriers)");
+    CK(hipMemset(in, 0, n * 4));
+    printf("same, all-zero input (the guide: +15..21 %% from DVFS on zero operands):\n");
+    timeit(1, "legacy, zero input");
+    timeit(2, "persistent, zero input");
+    timeit(115, "  - MFMA stream only, zero input");
+    VS(vs_set_conv_kernel(0));
+  }
+  printf(bad_total ? "FAILED: %d case(s) differ\n" : "ALL BITWISE EQUAL\n", bad_total);
+  return bad_total ? 1 : 0;
+}

@@ -29,7 +29,7 @@
 //    from L2, as in the fp32 kernel, would need 42 B/clk/CU at this MFMA rate: first version,
 //    7.0 ms per layer against a 2.9 ms matrix-pipe floor.)
 //  * Epilogue: y = act(acc * (1/(s_in*s_w)) * scale[co] + shift[co]).
-#include "vs_common.h"
+#include "vs_internal.h"
 
 namespace {
 
@@ -407,11 +407,29 @@ int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int tr
   return 0;
 }
 
+// which 5x5 kernel vs_conv64_f16x3_fwd_impl launches: 0 = default (persistent pipeline), 1 = one tile per
+// workgroup (this file), 2 = persistent pipeline (conv_f16x3_pk.hip).  Test / A-B switch, process-global.
+static int g_conv_kernel = 0;
+extern "C" int vs_set_conv_kernel(int mode) {
+  VS_REQUIRE((mode >= 0 && mode <= 2) || (mode >= 100 && mode <= 130), "vs_set_conv_kernel: mode %d", mode);   // 100+abl: timing ablations
+  g_conv_kernel = mode;
+  return 0;
+}
+
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
                              int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64_f16x3: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
+  if (KT == 5 && KF == 5 && g_conv_kernel != 1 && (long long)kCo * T * F * 4 < (long long)kOob) {
+    // persistent pipelined kernel on 8-row tiles; when the residue classes end 1..4 rows past a multiple
+    // of 8 (dil = 16 at T = 301: 19 rows) the 4-row one-tile kernel takes that tail, as in the legacy path
+    const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
+    const bool tail = full8 > 0 && rem > 0 && rem <= 4;
+    if (int rc = vs_conv64_f16x3_pk_impl(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream,
+                                         g_conv_kernel >= 100 ? g_conv_kernel - 100 : 0, tail ? full8 : 0x7fffffff)) return rc;
+    return tail ? launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff) : 0;
+  }
   // 8-row tiles (P = 2) amortise the KT-1 halo rows and the weight staging over twice the MFMAs
   // (measured 6.6 vs 7.45 ms per layer at equal padding); 4-row tiles only win when they avoid
   // more than ~12 % of padded rows (short residue classes: dil = 16 at T = 301).

@@ -42,6 +42,11 @@ int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int tr
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
                              int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t);
+// conv_f16x3_pk.hip: persistent, software-pipelined form of the 5x5 kernel (same contract, bit-identical results)
+int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
+                            const float* in_scale2, const float* w_scale2, float* out,
+                            int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t, int ablation = 0,
+                            int i_end = 0x7fffffff);
 // One 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
 // gradient) into `packed`.  Split-f16 mode keeps its operand scales in one "scale slot" of
 // VS_SCALE_SLOT_FLOATS floats: [0..1] input {s, 1/s}, [2..3] weight {s, 1/s}, [4] uint |max| of
