@@ -278,6 +278,13 @@ int vs_set_wgrad_kernel(int mode);
  * workgroup (csrc/conv_f16x3.hip), 2 = persistent.  Both give bit-identical results (same K order);
  * the switch exists for A/B timing and the bitwise cross-check.  Process-wide. */
 int vs_set_conv_kernel(int mode);
+/* which BiLSTM recurrence / BPTT runs: 0 = default (the persistent kernels whenever all their workgroups
+ * fit on the device at once, else one launch per time step), 1 = one launch per step, 2 = persistent
+ * (error when the grid cannot be resident).  Both forms give bit-identical results.  Process-wide.
+ * The persistent kernels keep an error word in the caller's state buffer (the first of its last 64
+ * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
+ * (a workgroup of the launch was not resident): results are then invalid. */
+int vs_set_lstm_kernel(int mode);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

@@ -334,6 +334,37 @@ def test_bilstm_train_forward_and_bptt(B, T, H):
     assert rel_err(dxg, xgd.grad) < KTOL, (worst.indices.tolist(), worst.values.tolist())
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 11, 24), (33, 5, 16), (2, 40, 400), (64, 37, 400), (100, 4, 400), (130, 6, 16), (5, 9, 424)])
+def test_persistent_lstm_matches_the_step_kernels(B, T, H):
+    """The persistent recurrence / BPTT (one launch, flag hand-off between workgroups) against one launch per
+    time step: same decomposition, same reduction order, so every output (h, saved gates, cell states, gate
+    gradients) agrees to rounding -- the two kernels are separate compilations, and fma contraction of the gate
+    arithmetic may differ by an ulp, which the recurrence carries along: 2e-6 of each tensor's range, an order
+    below the 3e-5 both hold against the fp64 reference.  B = 64 at H = 400 is the bench shape (2 batch tiles x 50 workgroups x 2
+    directions resident at once), B = 100 needs two launches of the persistent kernel, H = 424 exceeds the
+    register-resident part of W_hh."""
+    from voicesplit_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 31 + T + H)
+    xg = torch.randn(B, T, 8 * H, generator=g)
+    whh = [torch.randn(4 * H, H, generator=g) * (1.5 / H ** 0.5) for _ in range(2)]
+    dout = torch.randn(B, T, 2 * H, generator=g)
+    d = dev()
+    res = {}
+    try:
+        for mode in (1, 2):
+            assert lib.vs_set_lstm_kernel(mode) == 0
+            o_inf = ops.bilstm_recurrent(xg.to(d), whh[0].to(d), whh[1].to(d))
+            out, gates, c = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d))
+            dxg = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d))
+            res[mode] = (o_inf.cpu(), out.cpu(), gates.cpu(), c.cpu(), dxg.cpu())
+    finally:
+        lib.vs_set_lstm_kernel(0)
+    worst = {name: rel_err(y, x) for name, x, y in zip(("out", "out_train", "gates", "c", "dxg"), res[1], res[2])}
+    assert max(worst.values()) < 2e-6, worst
+    assert torch.isfinite(res[2][4]).all()
+
+
 def test_sigmoid_bwd_and_colsum():
     from voicesplit_amd import ops
     g = torch.Generator().manual_seed(1)

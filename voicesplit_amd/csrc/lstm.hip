@@ -19,6 +19,8 @@
 
 namespace {
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 // packed recurrent weights: [dir][jg = H/8][q = H/8][lane 64][4]; element j of the float4:
 //   W_hh[dir][(i>>3)*H + jg*8 + (i&7)][8q + 2j + (lane>>5)],  i = lane & 31
 __global__ void lstm_pack_whh_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_b,
@@ -160,6 +162,192 @@ void lstm_step_kernel(LstmStepArgs a) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
         *reinterpret_cast<float4*>(grow + gq * a.H) = make_float4(gact[gq][0], gact[gq][1], gact[gq][2], gact[gq][3]);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the recurrence: ONE launch for all T steps (north_star: "persistent-RNN style
+// kernel"; SURVEY.md 0.5: W_hh is 2.56 MB per direction, so it is partitioned over the CUs and the
+// hidden state is exchanged once per step).
+//
+// Same decomposition and arithmetic as lstm_step_kernel (bit-identical results): workgroup (dir, bt,
+// jg) owns 8 hidden units x 32 batch rows for the whole sequence.  What the launch boundary used to
+// provide is now explicit:
+//  * this workgroup's slice of W_hh (32 gate rows x H) is loaded ONCE and stays in registers
+//    (13 float4 per lane and wave at H = 400), c stays in the registers of wave 0;
+//  * h travels through L2 in MFMA fragment order: the owner stores its 1 KB quad write-through
+//    (sc1), drains its store queue, then raises its own flag word to step+1; a consumer sweeps the
+//    H/8 flag words of its (dir, batch tile) group with one relaxed agent-scope load per lane until
+//    all carry the epoch, and then reads the quads with sc1 loads (L1-bypassing: the hand-off form
+//    of cdna_hip_programming.md Guideline 16 R1 that needs no acquire fence) -- no atomics, no
+//    counter serialisation, 50 producers <-> 50 consumers per group, groups never wait for each other;
+//  * ping-pong buffers: a workgroup can only overwrite h_{s-1} after every member of its group has
+//    published step s, i.e. has finished reading it.
+// All workgroups of a launch must be co-resident (grid <= number of CUs, checked by the launcher,
+// which otherwise walks the batch tiles in several launches); every spin is bounded and reports
+// through *err instead of hanging.
+// ---------------------------------------------------------------------------------------------
+struct LstmPersistArgs {
+  const float* xg;
+  const float* wp;
+  float* hbuf0;         // fragment order [2 dir][NBT][H/8][64 lane][4]
+  float* hbuf1;
+  unsigned* flags;      // [2 dir][NBT][H/8] epoch words, zeroed by the launcher before every launch
+  unsigned* err;        // set to 1 when a spin gave up
+  float* out;
+  float* gates_save;
+  float* c_save;
+  int B, T, H, Bpad, bt0;
+};
+
+constexpr unsigned kSpinLimit = 1u << 22;
+
+__global__ __launch_bounds__(256)
+void lstm_persistent_kernel(LstmPersistArgs a) {
+  __shared__ float sRed[3 * 16 * 64];
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HQ = a.H / 8;
+  const int NBT = a.Bpad / 32;
+  const int jg = blockIdx.x % HQ;
+  const int bt = a.bt0 + blockIdx.x / HQ;
+  const int dir = blockIdx.y;
+  const int b = bt * 32 + l31;
+  if (tid == 0) sDead = 0;
+
+  // W_hh slice: resident for the whole sequence
+  const float4* wq = reinterpret_cast<const float4*>(a.wp) + ((size_t)(dir * HQ + jg) * HQ) * 64 + lane;
+  float4 w4[kMaxQ];
+#pragma unroll
+  for (int i = 0; i < kMaxQ; ++i) {
+    const int q = wave + 4 * i;
+    w4[i] = q < HQ ? wq[(size_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const size_t group = ((size_t)dir * NBT + bt) * HQ;                     // first quad / flag of this (dir, bt) group
+  const unsigned hbytes = (unsigned)((size_t)2 * NBT * HQ * 64 * 16);
+  __amdgpu_buffer_rsrc_t hrs[2] = {__builtin_amdgcn_make_buffer_rsrc(a.hbuf0, 0, hbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.hbuf1, 0, hbytes, 0x00020000)};
+  unsigned* const gflags = a.flags + group;
+  float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? (a.T - 1 - s) : s;
+    // wave 0 owns the epilogue: its xg reads do not depend on h and go out before the wait
+    float xgv[16];
+    if (wave == 0) {
+      const bool ok = b < a.B;
+      const float* xrow = a.xg + ((size_t)(ok ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xgv[r] = ok ? xrow[(r >> 2) * a.H + (r & 3)] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      if (wave == 0 && !sDead) {
+        // every producer of this group has published h_{s-1} (epoch s)
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int j = lane; j < HQ; j += 64)
+            ok = ok && (__hip_atomic_load(gflags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) {
+            if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      const unsigned hoff = (unsigned)((group * 64 + lane) * 16);
+      float4 h4[kMaxQ];
+#pragma unroll
+      for (int i = 0; i < kMaxQ; ++i) {
+        const int q = wave + 4 * i;
+        const u32x4_t v = q < HQ ? __builtin_amdgcn_raw_buffer_load_b128(hrs[s & 1], hoff + (unsigned)q * 1024u, 0, 16 /* sc1 */)
+                                 : u32x4_t{0u, 0u, 0u, 0u};
+        h4[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxQ; ++i) {
+        if (wave + 4 * i < HQ) {          // wave-uniform
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].x, h4[i].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].y, h4[i].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].z, h4[i].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].w, h4[i].w, acc, 0, 0, 0);
+        }
+      }
+      // hidden sizes beyond 4*kMaxQ*8 = 416: remaining quads, weights re-read from L2 each step
+      for (int q = wave + 4 * kMaxQ; q < HQ; q += 4) {
+        const float4 w = wq[(size_t)q * 64];
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs[s & 1], hoff + (unsigned)q * 1024u, 0, 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, __uint_as_float(v[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, __uint_as_float(v[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, __uint_as_float(v[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, __uint_as_float(v[3]), acc, 0, 0, 0);
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sRed[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sRed[(w * 16 + r) * 64 + lane];
+      float hv[4], cnew[4], gact[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float gi = vs_sigmoid(acc[0 + u] + xgv[0 + u]);
+        const float gf = vs_sigmoid(acc[4 + u] + xgv[4 + u]);
+        const float gg = vs_tanh(acc[8 + u] + xgv[8 + u]);
+        const float go = vs_sigmoid(acc[12 + u] + xgv[12 + u]);
+        const float cn = gf * cprev[u] + gi * gg;
+        hv[u] = go * vs_tanh(cn);
+        cnew[u] = cn;
+        cprev[u] = cn;
+        gact[0][u] = gi; gact[1][u] = gf; gact[2][u] = gg; gact[3][u] = go;
+      }
+      // h quad jg in fragment order: lane (hl, b) holds units {hl, 2+hl, 4+hl, 6+hl} of this workgroup's
+      // 8; this lane computed units 4*half .. 4*half+3 -> two values come from the other half-wave
+      {
+        const float s0 = half ? hv[0] : hv[1], s1 = half ? hv[2] : hv[3];
+        const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+        u32x4_t v;
+        v[0] = __float_as_uint(half ? r0 : hv[0]);
+        v[1] = __float_as_uint(half ? r1 : hv[2]);
+        v[2] = __float_as_uint(half ? hv[1] : r0);
+        v[3] = __float_as_uint(half ? hv[3] : r1);
+        __builtin_amdgcn_raw_buffer_store_b128(v, hrs[(s + 1) & 1], (unsigned)(((group + jg) * 64 + lane) * 16), 0, 16 /* sc1: write-through */);
+      }
+      // publish: the quad has left this wave's store queue, then the flag (one lane).  The
+      // outputs below are off the step-to-step critical path and go out after the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(gflags + jg, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b < a.B) {
+        float4* o = reinterpret_cast<float4*>(a.out + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+        *o = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (a.c_save) {
+          float4* cs = reinterpret_cast<float4*>(a.c_save + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+          *cs = make_float4(cnew[0], cnew[1], cnew[2], cnew[3]);
+        }
+        if (a.gates_save) {
+          float* grow = a.gates_save + ((size_t)b * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(grow + gq * a.H) = make_float4(gact[gq][0], gact[gq][1], gact[gq][2], gact[gq][3]);
+        }
+      }
     }
   }
 }
@@ -322,10 +510,201 @@ void lstm_bwd_step_kernel(LstmBwdArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Persistent BPTT: lstm_bwd_step_kernel's decomposition and arithmetic (bit-identical results) in ONE
+// launch.  Workgroup (dir, bt, ut) keeps its slice of W_hh^T (32 units x 4H rows: 25 float4 per lane
+// and wave at H = 400) in registers and the dc carry in the registers of the thread that owns the
+// (4 units, batch row) item; the gate gradients travel in MFMA fragment order with the same
+// write-through store -> drain -> flag / flag sweep -> sc1 load hand-off as the forward recurrence
+// (one flag per STORING WAVE, so no workgroup barrier sits between the stores and the flags).
+// ---------------------------------------------------------------------------------------------
+struct LstmBwdPersistArgs {
+  const float* wpt;
+  float* gbuf0;          // fragment-order gate gradients [2 dir][NBT][H/2][64][4]
+  float* gbuf1;
+  unsigned* flags;       // [2 dir][NBT][NUT*4]
+  unsigned* err;
+  float* gates;
+  const float* c_all;
+  const float* dout;
+  int B, T, H, Bpad, bt0;
+};
+
+constexpr int kBwdResident = 25;   // K-quads of W_hh^T per wave held in registers (H <= 400); the rest streams from L2
+
+__global__ __launch_bounds__(512)
+void lstm_bwd_persistent_kernel(LstmBwdPersistArgs a) {
+  __shared__ float sRed[8 * 16 * 64];
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int NQ = a.H / 2;
+  const int NUT = (a.H + 31) / 32;
+  const int NBT = a.Bpad / 32;
+  const int HQ = a.H / 8;
+  const int ut = blockIdx.x % NUT;
+  const int bt = a.bt0 + blockIdx.x / NUT;
+  const int dir = blockIdx.y;
+  if (tid == 0) sDead = 0;
+
+  const int b31 = tid & 31, ug = (tid >> 5) & 7;
+  const int b = bt * 32 + b31;
+  const int u0 = ut * 32 + 4 * ug;
+  const bool units_ok = tid < 256 && u0 < a.H;          // wave-uniform (H % 8 == 0)
+  const bool item = units_ok && b < a.B;
+
+  const float4* wq = reinterpret_cast<const float4*>(a.wpt) + ((size_t)(dir * NUT + ut) * NQ) * 64 + lane;
+  float4 w4[kBwdResident];
+#pragma unroll
+  for (int i = 0; i < kBwdResident; ++i) {
+    const int q = wave + 8 * i;
+    w4[i] = q < NQ ? wq[(size_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const size_t group = (size_t)dir * NBT + bt;
+  const unsigned gbytes = (unsigned)((size_t)2 * NBT * NQ * 64 * 16);
+  __amdgpu_buffer_rsrc_t grs[2] = {__builtin_amdgcn_make_buffer_rsrc(a.gbuf0, 0, gbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.gbuf1, 0, gbytes, 0x00020000)};
+  const int nflag = NUT * 4;
+  unsigned* const gflags = a.flags + group * nflag;
+  float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? s : (a.T - 1 - s);
+    const int tp = dir ? t + 1 : t - 1;                 // forward-order predecessor (c_{t-1})
+    // gate-math operands of this thread's item: independent of the exchange, issued before the wait
+    float4 gi4, gf4, gg4, go4, c4, cp4, dh4;
+    gi4 = gf4 = gg4 = go4 = c4 = cp4 = dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* grow = a.gates + ((size_t)(item ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + (item ? u0 : 0);
+    if (item) {
+      gi4 = *reinterpret_cast<const float4*>(grow);
+      gf4 = *reinterpret_cast<const float4*>(grow + a.H);
+      gg4 = *reinterpret_cast<const float4*>(grow + 2 * a.H);
+      go4 = *reinterpret_cast<const float4*>(grow + 3 * a.H);
+      const size_t so = ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + u0;
+      c4 = *reinterpret_cast<const float4*>(a.c_all + so);
+      dh4 = *reinterpret_cast<const float4*>(a.dout + so);
+      if (tp >= 0 && tp < a.T)
+        cp4 = *reinterpret_cast<const float4*>(a.c_all + ((size_t)b * a.T + tp) * (2 * a.H) + (size_t)dir * a.H + u0);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      if (wave == 0 && !sDead) {
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int j = lane; j < nflag; j += 64)
+            ok = ok && (__hip_atomic_load(gflags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) {
+            if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      const unsigned goff = (unsigned)((group * NQ * 64 + lane) * 16);
+      // resident quads in register batches
+      constexpr int kBatch = 9;        // loads in flight per wave (25 = 9 + 9 + 7); same MFMA order as the step kernel
+#pragma unroll
+      for (int base = 0; base < kBwdResident; base += kBatch) {
+        u32x4_t g4[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          const int q = wave + 8 * (base + i);
+          g4[i] = (base + i < kBwdResident && q < NQ) ? __builtin_amdgcn_raw_buffer_load_b128(grs[s & 1], goff + (unsigned)q * 1024u, 0, 16 /* sc1 */)
+                                                      : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          if (base + i < kBwdResident && wave + 8 * (base + i) < NQ) {      // wave-uniform
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[base + i].x, __uint_as_float(g4[i][0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[base + i].y, __uint_as_float(g4[i][1]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[base + i].z, __uint_as_float(g4[i][2]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[base + i].w, __uint_as_float(g4[i][3]), acc, 0, 0, 0);
+          }
+        }
+      }
+      for (int q = wave + 8 * kBwdResident; q < NQ; q += 8) {        // H > 400: weights re-read from L2 each step
+        const float4 w = wq[(size_t)q * 64];
+        const u32x4_t g = __builtin_amdgcn_raw_buffer_load_b128(grs[s & 1], goff + (unsigned)q * 1024u, 0, 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, __uint_as_float(g[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, __uint_as_float(g[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, __uint_as_float(g[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, __uint_as_float(g[3]), acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+      float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += sRed[(w * 16 + 4 * wave + u) * 64 + lane];
+      const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+      const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+      float dg4[4][4];        // [gate i,f,g,o][unit]
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float tc = vs_tanh(cc[u]);
+        dg4[3][u] = dh[u] * tc * go[u] * (1.f - go[u]);
+        const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
+        dg4[0][u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
+        dg4[1][u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
+        dg4[2][u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
+        dcc[u] = dc * gf[u];
+      }
+      if (!item) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dg4[gate][u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dcc[u] = 0.f;
+      }
+      // fragment-order copy for the next step: quad (gate, ut, wave) = rows gate*H + ut*32 + 8*wave .. +7,
+      // lane (hl, b) holds rows {hl, 2+hl, 4+hl, 6+hl}; this lane computed 4*half .. 4*half+3
+      if (units_ok) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+          const float s0 = half ? dg4[gate][0] : dg4[gate][1], s1 = half ? dg4[gate][2] : dg4[gate][3];
+          const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+          u32x4_t v;
+          v[0] = __float_as_uint(half ? r0 : dg4[gate][0]);
+          v[1] = __float_as_uint(half ? r1 : dg4[gate][2]);
+          v[2] = __float_as_uint(half ? dg4[gate][1] : r0);
+          v[3] = __float_as_uint(half ? dg4[gate][3] : r1);
+          const size_t quad = group * NQ + (size_t)gate * HQ + ut * 4 + wave;
+          __builtin_amdgcn_raw_buffer_store_b128(v, grs[(s + 1) & 1], (unsigned)((quad * 64 + lane) * 16), 0, 16 /* sc1 */);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(gflags + ut * 4 + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (item) {           // the batched GEMMs' operand, in place of the saved gates
+        *reinterpret_cast<float4*>(grow) = make_float4(dg4[0][0], dg4[0][1], dg4[0][2], dg4[0][3]);
+        *reinterpret_cast<float4*>(grow + a.H) = make_float4(dg4[1][0], dg4[1][1], dg4[1][2], dg4[1][3]);
+        *reinterpret_cast<float4*>(grow + 2 * a.H) = make_float4(dg4[2][0], dg4[2][1], dg4[2][2], dg4[2][3]);
+        *reinterpret_cast<float4*>(grow + 3 * a.H) = make_float4(dg4[3][0], dg4[3][1], dg4[3][2], dg4[3][3]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t vs_lstm_packed_floats(int H) { return (size_t)2 * (H / 8) * (H / 8) * 256; }
-extern "C" size_t vs_lstm_state_floats(int B, int H) { return (size_t)3 * 2 * H * (((size_t)B + 31) / 32 * 32); }
+// + 64: the persistent kernel's error word lives in the last 64 floats (never touched by the step kernels)
+extern "C" size_t vs_lstm_state_floats(int B, int H) { return (size_t)3 * 2 * H * (((size_t)B + 31) / 32 * 32) + 64; }
 
 int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream) {
   VS_REQUIRE(H > 0 && H % 8 == 0, "lstm: hidden size %d must be a multiple of 8", H);
@@ -335,16 +714,45 @@ int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, 
   return 0;
 }
 
-// state: 3 * [2][H][Bpad] floats (h ping, h pong, c), zeroed here (zero initial state).
+// which recurrence runs: 0 = persistent when its grid is resident (default), 1 = one launch per step,
+// 2 = persistent (error if it cannot be).  Test / A-B switch, process-global.
+static int g_lstm_kernel = 0;
+extern "C" int vs_set_lstm_kernel(int mode) {
+  VS_REQUIRE(mode >= 0 && mode <= 2, "vs_set_lstm_kernel: mode %d", mode);
+  g_lstm_kernel = mode;
+  return 0;
+}
+
+// state: 3 * [2][H][Bpad] floats.  Step kernels: h ping, h pong, c, zeroed here (zero initial state).
+// Persistent kernel: h ping, h pong (fragment order), then the flag words + the error word.
 int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,
                              int B, int T, int H, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, "lstm: bad shape B=%d T=%d H=%d (H must be a multiple of 8)", B, T, H);
   const int Bpad = (B + 31) / 32 * 32;
   const size_t per = (size_t)2 * H * Bpad;
-  VS_CHECK_HIP(hipMemsetAsync(state, 0, 3 * per * sizeof(float), stream));
+  VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_state_floats(B, H) * sizeof(float), stream));
   float* hbuf[2] = {state, state + per};
+  const int HQ = H / 8, NBT = Bpad / 32;
+  int dev = 0, cus = 0;
+  VS_CHECK_HIP(hipGetDevice(&dev));
+  VS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // one workgroup per CU at most: every workgroup of a launch must be resident for the flag protocol
+  const int bt_per_launch = cus / (2 * HQ);
+  const bool persistent = g_lstm_kernel != 1 && bt_per_launch >= 1;
+  VS_REQUIRE(g_lstm_kernel != 2 || persistent, "lstm: persistent recurrence needs 2*H/8 = %d workgroups <= %d CUs", 2 * HQ, cus);
+  if (persistent) {
+    unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * per);      // zeroed above
+    unsigned* err = reinterpret_cast<unsigned*>(state + 3 * per);         // first of the 64 trailing words
+    for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
+      const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
+      LstmPersistArgs a{xg, wp, hbuf[0], hbuf[1], flags, err, out, gates_save, c_save, B, T, H, Bpad, bt0};
+      hipLaunchKernelGGL(lstm_persistent_kernel, dim3(HQ * nbt, 2), dim3(256), 0, stream, a);
+    }
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   float* c = state + 2 * per;
-  dim3 grid((H / 8) * (Bpad / 32), 2), block(256);
+  dim3 grid(HQ * NBT, 2), block(256);
   for (int s = 0; s < T; ++s) {
     LstmStepArgs a{xg, wp, hbuf[s & 1], hbuf[(s + 1) & 1], c, out, gates_save, c_save, B, T, H, Bpad, s};
     hipLaunchKernelGGL(lstm_step_kernel, grid, block, 0, stream, a);
@@ -357,7 +765,7 @@ extern "C" size_t vs_lstm_packed_t_floats(int H) { return (size_t)2 * ((H + 31) 
 // backward state: dgates fragments ping/pong [2][2][NBT][H/2][256] + dc carry [2][Bpad][H]
 extern "C" size_t vs_lstm_bwd_state_floats(int B, int H) {
   const size_t Bpad = ((size_t)B + 31) / 32 * 32;
-  return 2 * (2 * (Bpad / 32) * (size_t)(H / 2) * 256) + 2 * Bpad * H;
+  return 2 * (2 * (Bpad / 32) * (size_t)(H / 2) * 256) + 2 * Bpad * H + 64;   // + 64: error word of the persistent kernel
 }
 
 int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream) {
@@ -369,6 +777,8 @@ int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H
 }
 
 // gates: activated gates from the training forward, overwritten with d(loss)/d(gate pre-activations).
+// state: step kernels = dgates fragments ping/pong + dc carry; persistent kernel = the two fragment
+// buffers, then (in the dc region) the flag words and the error word.
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
                                  int B, int T, int H, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, "lstm_bwd: bad shape B=%d T=%d H=%d (H must be a multiple of 8)", B, T, H);
@@ -376,8 +786,26 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
   const size_t frag = (size_t)2 * (Bpad / 32) * (H / 2) * 256;
   VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_bwd_state_floats(B, H) * sizeof(float), stream));
   float* gbuf[2] = {state, state + frag};
+  const int NUT = (H + 31) / 32, NBT = Bpad / 32;
+  int dev = 0, cus = 0;
+  VS_CHECK_HIP(hipGetDevice(&dev));
+  VS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int bt_per_launch = cus / (2 * NUT);
+  const bool persistent = g_lstm_kernel != 1 && bt_per_launch >= 1;
+  VS_REQUIRE(g_lstm_kernel != 2 || persistent, "lstm_bwd: persistent recurrence needs %d workgroups <= %d CUs", 2 * NUT, cus);
+  if (persistent) {
+    unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * frag);      // 2*Bpad*H words available, 2*NBT*NUT*4 used
+    unsigned* err = reinterpret_cast<unsigned*>(state + 2 * frag + (size_t)2 * Bpad * H);
+    for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
+      const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
+      LstmBwdPersistArgs a{wpt, gbuf[0], gbuf[1], flags, err, gates, c_all, dout, B, T, H, Bpad, bt0};
+      hipLaunchKernelGGL(lstm_bwd_persistent_kernel, dim3(NUT * nbt, 2), dim3(512), 0, stream, a);
+    }
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   float* dc = state + 2 * frag;
-  dim3 grid(((H + 31) / 32) * (Bpad / 32), 2), block(512);
+  dim3 grid(NUT * NBT, 2), block(512);
   for (int s = 0; s < T; ++s) {
     LstmBwdArgs a{wpt, gbuf[s & 1], gbuf[(s + 1) & 1], gates, c_all, dout, dc, B, T, H, Bpad, s};
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);

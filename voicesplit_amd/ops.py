@@ -289,7 +289,16 @@ def bilstm_recurrent(xg, w_hh_f, w_hh_b):
     state = torch.empty(lib.vs_lstm_state_floats(B, H), dtype=torch.float32, device=xg.device)
     out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
     check(lib.vs_bilstm_recurrent(_p(xg), _p(packed), _p(state), _p(out), B, T, H, _stream()), "vs_bilstm_recurrent")
+    _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent")
     return out
+
+
+def _lstm_check_err(state: torch.Tensor, word: int, what: str):
+    """The persistent recurrences report a spin that gave up (a workgroup of the launch was not
+    resident) through a word in the state buffer; the step kernels leave it 0.  Unit-test helper:
+    synchronises."""
+    if int(state.view(torch.int32)[word].item()) != 0:
+        raise _lib.VoiceSplitHipError(f"{what}: the persistent LSTM kernel gave up waiting for a peer workgroup")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -538,6 +547,7 @@ def bilstm_recurrent_train(xg, w_hh_f, w_hh_b):
     c = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
     check(lib.vs_bilstm_recurrent_train(_p(gates), _p(packed), _p(state), _p(out), _p(gates), _p(c), B, T, H, _stream()),
           "vs_bilstm_recurrent_train")
+    _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent_train")
     return out, gates, c
 
 
@@ -554,6 +564,7 @@ def bilstm_recurrent_bwd(gates, c, dout, w_hh_f, w_hh_b):
     dxg = gates.clone()
     check(lib.vs_bilstm_recurrent_bwd(_p(packed_t), _p(state), _p(dxg), _p(c), _p(dout), B, T, H, _stream()),
           "vs_bilstm_recurrent_bwd")
+    _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent_bwd")
     return dxg
 
 
