@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
-    ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3"],
+    ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3", "bf16"],
                     help="arithmetic of the 64->64 conv layers (default: the library default)")
     ap.add_argument("--loss", default="sisnr", choices=["sisnr", "powerlaw", "fixed"],
                     help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
@@ -165,6 +165,8 @@ def main():
 
     B = args.batch
     train = args.mode == "train"
+    MATH_LABEL = {"fp32": "fp32 MFMA", "f16x3": "fp32 I/O, split-f16 MFMA (3 f16 products per fp32 product)",
+                  "bf16": "bf16 MFMA operands (single pass), fp32 accumulate / tape / statistics"}[conv_math]
     torch.manual_seed(0)
     cls = V.VoiceSplit if args.model == "voicesplit" else V.VoiceFilter
     model = cls(V.default_config())
@@ -248,30 +250,38 @@ def main():
         mean_launch_ms = sum(launches) / len(launches)
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
         value = world * B * args.steps / elapsed
-        if conv_math == "f16x3":
+        if conv_math == "bf16":
+            kname, peak = "conv64_f16x3_pk_kernel<NT=1> (bf16 single pass)", PEAK_F16_MFMA_TFLOPS
+            extra = {"mfma_pipe": "bf16 (v_mfma_f32_32x32x16_bf16), one MFMA product per product", "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS}
+        elif conv_math == "f16x3":
             # every fp32 product is three f16 MFMA products (csrc/conv_f16x3.hip): the pipe-level
             # ceiling for ALGORITHMIC flops is the dense f16 MFMA peak / 3
-            kname, peak = "conv64_f16x3_kernel<5,5>", PEAK_F16_MFMA_TFLOPS / 3.0
+            kname, peak = "conv64_f16x3_pk_kernel<5,5> (persistent pipeline)", PEAK_F16_MFMA_TFLOPS / 3.0
             extra = {"mfma_pipe": "f16 (v_mfma_f32_32x32x16_f16), 3 MFMA products per fp32 product",
                      "mfma_rate_tflops": round(3 * achieved, 1), "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS,
-                     "launch_ms_includes": "operand-scale kernel + weight pack (~15 us); |max| of the operands is tracked by their producers"}
+                     "launch_ms_includes": "operand-scale kernel + weight pack (~15 us); |max| of the operands is tracked by their producers",
+                     "empirical_ceiling": "a stream of nothing but this layer's MFMAs reaches 1659 TF on the f16 pipe with its real operand values "
+                                          "(2345 TF on zero operands): the chip clocks down with operand toggling; 553 TF algorithmic = 0.66 of `peak` "
+                                          "is the most any schedule of this arithmetic reaches on random data (profiles/r02_conv_ablation.md)"}
         else:
             kname, peak, extra = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}
         roof = {"bound": "mfma",
                 "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": (committed_pmc_traffic("r01_train" if train else "r01_forward", "conv64_f16x3_kernelILi5ELi5ELi2E")
+                "traffic": (committed_pmc_traffic("r02_train" if train else "r02_forward", "conv64_f16x3_pk_kernel")
                             if conv_math == "f16x3" and B == 64 else None),
-                "traffic_unit": "GB per launch: FETCH_SIZE + WRITE_SIZE (uncorrected, dword-wide loads) from the committed --pmc "
-                                "passes of this command (profiles/r01_*_rocprof/pmc_per_kernel.csv); algorithmic bytes 5.9 GB",
+                "traffic_unit": "GB per launch: FETCH_SIZE + WRITE_SIZE from the committed --pmc passes of this command "
+                                "(profiles/r02_*_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
+                                "algorithmic bytes 5.9 GB",
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
                 "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
         roof.update(extra)
         if train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
-            wname = ("conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
+            wname = ("conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, bf16 single pass, incl. its reduce)" if conv_math == "bf16" else
+                     "conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
                      if conv_math == "f16x3" else
                      "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)")
             roof["second_kernel"] = {"kernel": wname,
@@ -279,13 +289,13 @@ def main():
                                      "frac": round(B * GFLOP_CONV5X5 / wg_mean / peak, 4),
                                      "launch_ms": [round(v, 3) for v in wg]}
         line = {
-            "metric": "utterances/sec (3 s clips, B=64/GPU) fwd+bwd, fp32" if train
-                      else "utterances/sec (3 s clips, B=64/GPU) forward, fp32",
+            "metric": f"utterances/sec (3 s clips, B={B}/GPU) " + ("fwd+bwd, " if train else "forward, ") + MATH_LABEL,
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if conv_math == "fp32" else "fp32 (64->64 convs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)",
+            "dtype": {"fp32": "fp32", "bf16": "bf16 (dense contractions: operands rounded to bf16, one bf16 MFMA product, fp32 accumulate; tape, BatchNorm, recurrence, head in fp32)",
+                      "f16x3": "fp32 (64->64 convs + LSTM GEMMs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)"}[conv_math],
             "data": "synthetic",
             "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
                                     "training step = forward (batch-stat BN) + "

@@ -43,6 +43,10 @@ extern "C" {
 #define VS_MATH_FP32 0    /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fmaf chain                              */
 #define VS_MATH_F16X3 1   /* fp32 operands split into two f16 halves, three v_mfma_f32_32x32x16_f16 per
                              product term set, fp32 accumulate: fp32-class accuracy at 3/16 of the matrix time */
+#define VS_MATH_BF16 2    /* BASELINE configs[2]: operands rounded to bf16 (round to nearest even), ONE
+                             v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, fp32 everywhere else (tape,
+                             BatchNorm statistics, master weights).  NOT fp32-class: ~3e-3 relative per layer;
+                             opt-in only, never a default (tests state its tolerance)                           */
 
 /* BatchNorm mode */
 #define VS_BN_EVAL 0      /* running statistics (model.eval(), utils/generic_utils.py:479,533) */
@@ -56,7 +60,7 @@ typedef struct vs_dims {
   int H;    /* config.model.lstm_dim (400); must be a multiple of 8     */
   int FC1;  /* config.model.fc1_dim  (600)                              */
   int FC2;  /* config.model.fc2_dim  (601)                              */
-  int math; /* VS_MATH_FP32 or VS_MATH_F16X3 (conv layers cnn2..cnn7)   */
+  int math; /* VS_MATH_FP32, VS_MATH_F16X3 or VS_MATH_BF16 (dense contractions) */
 } vs_dims;
 
 /* One Conv2d + BatchNorm2d pair of the nn.Sequential (state_dict conv.{i}.*, conv.{i+1}.*). */

@@ -1,0 +1,148 @@
+"""GPU: VS_MATH_BF16 (BASELINE configs[2]: bf16 forward + backward) -- the opt-in arithmetic in which the
+dense contractions of the path (64->64 convs forward / data / weight gradient, the LSTM input GEMM and its
+two backward contractions) round their operands to bf16 and issue ONE v_mfma_f32_32x32x16_bf16 product with
+fp32 accumulation; the tape, BatchNorm statistics, the recurrence, the head and the master weights stay fp32.
+
+bf16 keeps 8 significant bits (2^-9 = 2e-3 relative rounding per operand), so this mode does NOT meet the
+path's fp32 contract (1e-4) and never runs unless asked for.  It is held to the bounds below against the
+same oracles as the default arithmetic, on the same stress fixtures (randomised BatchNorm statistics,
+recurrent / head weights scaled up so that logits spread -- chosen to make errors visible).
+Measured on MI355X (round 2; every value is dumped to gpurun_out/errors_bf16_*.json):
+
+                                   frozen BatchNorm      batch-statistics BatchNorm     bound asserted
+  conv stack output (rel. range)   4e-4 .. 6e-4          8e-3 .. 1.1e-2                 3e-2
+  LSTM output                      3e-3 .. 5e-3          3.6e-2 .. 4.5e-2               8e-2
+  mask, max abs                    2e-3 .. 4e-3          1.9e-2 .. 3.7e-2               6e-2
+  mask MSE (BASELINE: <= 1e-4)     1e-7 .. 3e-7          1.3e-5 .. 2.8e-5               1e-4
+  gradients, max / tensor max      6.5e-2                0.23 .. 0.41 (W_ih)            0.6
+  gradients, cosine vs fp64        >= 0.9986             >= 0.948                       0.93
+
+(batch statistics subtract each channel's mean, so a rounding error that is 2e-3 of |z| becomes a larger
+fraction of the normalised value whenever the mean dominates the spread; the recurrence with scaled-up
+W_hh amplifies what reaches it.)  The BASELINE bound on the mask (MSE <= 1e-4) holds in every case."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden_grads
+from oracle import reference_backward as RB
+from oracle import reference_forward as R
+
+pytestmark = pytest.mark.gpu
+FEAT_TOL = 3e-2
+LSTM_TOL = 8e-2
+MASK_ABS_TOL = 6e-2
+GRAD_TOL = 0.6
+COS_MIN = 0.93
+
+
+def _rel(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def _cos(got, ref):
+    got = got.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    return float((got @ ref) / (got.norm() * ref.norm()).clamp_min(1e-300))
+
+
+def _dump(name, table):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"errors_bf16_{name}.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+
+
+class _math:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from voicesplit_amd import ops
+        self.prev = ops.get_conv_math()
+        ops.set_conv_math(self.name)
+
+    def __exit__(self, *exc):
+        from voicesplit_amd import ops
+        ops.set_conv_math(self.prev)
+
+
+@pytest.mark.parametrize("cls_name,act", [("VoiceSplit", "mish"), ("VoiceFilter", "relu")])
+@pytest.mark.parametrize("training", [True, False])
+def test_bf16_module_forward_and_backward_vs_fp64_oracle(cls_name, act, training):
+    import voicesplit_amd as V
+    from voicesplit_amd import ops
+    dims_d = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53)
+    B, T = 3, 45
+    sd = R.spread_logits(R.build_state_dict(dims_d, 21), 6.0)
+    x, dvec = R.synthetic_inputs(B, T, dims_d, 21)
+    w = RB.loss_weights(B, T, 53, 21)
+    m = getattr(V, cls_name)(V.default_config(53, 24, 32, 44, 53))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train(training)
+    with _math("bf16"):
+        mask = m(x.cuda(), dvec.cuda())
+        tape = mask.grad_fn.tape
+        dims = ops.make_dims(B, T, 53, 24, 32, 44, 53)
+        lay = ops.tape_layout(dims)
+        feat = ops.ws_view(tape, lay.feat, (B, T, 8 * 53)).clone()
+        lstm_out = ops.ws_view(tape, lay.lstm_out, (B, T, 64)).clone()
+        (mask * w.cuda()).sum().backward()
+    stages = {}
+    ref = RB.gradients(sd, x, dvec, w, act=act, training=training, dtype=torch.float64, lstm_impl="loop", stages=stages)
+    table = {"fwd/feat": _rel(feat, stages["val/feat"]), "fwd/lstm_out": _rel(lstm_out, stages["val/lstm_out"]),
+             "fwd/mask_abs": float((mask.detach().double().cpu() - stages["mask"]).abs().max()),
+             "fwd/mask_mse": float(((mask.detach().double().cpu() - stages["mask"]) ** 2).mean())}
+    zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)} if training else set()
+    for k, p in m.named_parameters():
+        if k in zero:
+            assert p.grad.abs().max().item() == 0.0
+            continue
+        table["grad/" + k] = _rel(p.grad, ref[k])
+        table["cos/" + k] = _cos(p.grad, ref[k])
+    _dump(f"{cls_name}_{training}", table)
+    assert table["fwd/feat"] < FEAT_TOL and table["fwd/lstm_out"] < LSTM_TOL, table
+    assert table["fwd/mask_abs"] < MASK_ABS_TOL and table["fwd/mask_mse"] < 1e-4, table
+    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and v >= GRAD_TOL) or (k.startswith("cos/") and v < COS_MIN)}
+    assert not bad, bad
+
+
+def test_bf16_metric_configuration_vs_upstream_golden():
+    """Full size, 8 utterances, batch-statistics BatchNorm (the pinned metric configuration) in bf16 arithmetic
+    against the UPSTREAM module's forward tensors and gradients."""
+    import voicesplit_amd as V
+    from voicesplit_amd import ops
+    g = load_golden_grads("vs_full_b8_train_grads")
+    d = g["dims"]
+    sd = R.spread_logits(R.build_state_dict(d, g["seed"]), g["gain"])
+    x, dvec = R.synthetic_inputs(g["B"], g["T"], d, g["seed"])
+    w = RB.loss_weights(g["B"], g["T"], d["fc2_dim"], g["seed"])
+    m = V.VoiceSplit(V.default_config())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train(True)
+    with _math("bf16"):
+        mask = m(x.cuda(), dvec.cuda())
+        (mask * w.cuda()).sum().backward()
+    table = {"fwd/mask_abs": float(np.abs(mask.detach().cpu().numpy()[:, ::8] - g["fwd/mask"]).max()),
+             "fwd/mask_mse": float(((mask.detach().cpu().numpy()[:, ::8] - g["fwd/mask"]) ** 2).mean())}
+    zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}
+    for k, p in m.named_parameters():
+        if k in zero:
+            continue
+        got = RB.thin_grad(p.grad.detach().cpu()).double().numpy()
+        ref = g["grads"][k].astype(np.float64)
+        table["grad/" + k] = float(np.abs(got - ref).max() / max(g["gabs"][k], 1e-30))
+        table["cos/" + k] = float((got @ ref) / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-300))
+    _dump("vs_full_b8_train", table)
+    assert table["fwd/mask_abs"] < MASK_ABS_TOL and table["fwd/mask_mse"] < 1e-4, table
+    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and v >= GRAD_TOL) or (k.startswith("cos/") and v < COS_MIN)}
+    assert not bad, bad
+
+
+def test_bf16_is_never_the_default():
+    from voicesplit_amd import ops
+    assert ops.get_conv_math() in ("f16x3", "fp32")

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvoicesplit_hip.so")
 
 ACT_RELU, ACT_MISH, ACT_NONE, ACT_SIGMOID = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN = 0, 1
-MATH_FP32, MATH_F16X3 = 0, 1
+MATH_FP32, MATH_F16X3, MATH_BF16 = 0, 1, 2
 PROF_SLOTS = 29
 PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "lstm_gemm", "lstm_rec", "head",
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",

@@ -58,7 +58,7 @@ int check_dims(const vs_dims* d) {
   VS_REQUIRE(d->B > 0 && d->T > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->FC1 > 0 && d->FC2 > 0,
              "dims must be positive: B=%d T=%d F=%d E=%d H=%d FC1=%d FC2=%d", d->B, d->T, d->F, d->E, d->H, d->FC1, d->FC2);
   VS_REQUIRE(d->H % 8 == 0, "lstm_dim H=%d must be a multiple of 8", d->H);
-  VS_REQUIRE(d->math == VS_MATH_FP32 || d->math == VS_MATH_F16X3, "dims.math=%d is not a VS_MATH_* code", d->math);
+  VS_REQUIRE(d->math == VS_MATH_FP32 || d->math == VS_MATH_F16X3 || d->math == VS_MATH_BF16, "dims.math=%d is not a VS_MATH_* code", d->math);
   VS_REQUIRE((long long)d->B * d->T < 2147483647LL / 8, "B*T too large");
   return 0;
 }
@@ -105,16 +105,16 @@ int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
 int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8 /* one scale slot */, int in_amax_ready,
                          const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
                          int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t stream) {
-  if (math == VS_MATH_F16X3) {
+  if (math != VS_MATH_FP32) {      // split-f16 or single-pass bf16: same operand plumbing (power-of-two scales, packed images)
     if (in_amax_ready) {
       if (int rc = vs_scale_from_absmax_impl(vs_amax_slot(scales8), VS_AMAX_SLOTS, scales8, stream)) return rc;
     } else {
       if (int rc = vs_pow2_scale_impl(in, (long long)B * 64 * T * F, vs_amax_slot(scales8), scales8, stream)) return rc;
     }
     if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip,
-                                         reinterpret_cast<unsigned*>(scales8 + 4), scales8 + 2, stream)) return rc;
+                                         reinterpret_cast<unsigned*>(scales8 + 4), scales8 + 2, stream, math)) return rc;
     return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, scales8, scales8 + 2, out,
-                                    B, T, F, KT, KF, dil, act, amax_out, stream);
+                                    B, T, F, KT, KF, dil, act, amax_out, stream, math);
   }
   if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(packed), KT, KF, transpose_flip, stream)) return rc;
   return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
@@ -127,7 +127,7 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
                             hipStream_t stream) {
-  if (math == VS_MATH_F16X3) {
+  if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
     if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
     VS_CHECK_HIP(hipMemsetAsync(amax + 1, 0, sizeof(unsigned), stream));
@@ -143,15 +143,15 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
       _Float16* Wh = reinterpret_cast<_Float16*>(base + 2 * na);
       _Float16* Wl = reinterpret_cast<_Float16*>(base + 2 * na + nw);
       if (2 * na + 2 * nw <= scratch_bytes) {
-        if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream)) return rc;
-        if (int rc = vs_split_rows_impl(w_ih0, 4 * H, K, KE, gs + 2, Wh, Wl, 0, stream)) return rc;
-        if (int rc = vs_split_rows_impl(w_ih1, 4 * H, K, KE, gs + 2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream)) return rc;
+        if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc;
+        if (int rc = vs_split_rows_impl(w_ih0, 4 * H, K, KE, gs + 2, Wh, Wl, 0, stream, math)) return rc;
+        if (int rc = vs_split_rows_impl(w_ih1, 4 * H, K, KE, gs + 2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream, math)) return rc;
         return vs_gemm_presplit_impl(Ah, Al, Wh, Wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
-                                     VS_ACT_NONE, 0, gs, gs + 2, stream);
+                                     VS_ACT_NONE, 0, gs, gs + 2, stream, math);
       }
     }
     return vs_gemm_f16x3_impl(0, 0, feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T,
-                              nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, gs + 2, stream);
+                              nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, gs + 2, stream, math);
   }
   return vs_gemm_nt2_impl(feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T, 0,
                           VS_ACT_NONE, stream);
@@ -319,7 +319,7 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   int cur = 0;
   // split-f16 convs: every producer of a conv operand folds its |max| into the consumer's slot
   float* cs = at<float>(ws, L.conv_scales);
-  const bool f16 = d->math == VS_MATH_F16X3;
+  const bool f16 = d->math != VS_MATH_FP32;
   if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 8 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   auto amax_for = [&](int consumer_layer) -> unsigned* {    // consumer_layer = conv index 1..6 (cnn2..cnn7)
     return (f16 && consumer_layer >= 1 && consumer_layer <= 6) ? vs_amax_slot(cs + VS_SCALE_SLOT_FLOATS * consumer_layer) : nullptr;

@@ -726,11 +726,21 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 constexpr int kPH = 72;          // LDS row pitch in halves (144 B)
 constexpr int kPW = kPH / 2;     // ... in dwords (pixel pairs)
 
+// BF (VS_MATH_BF16): one bf16 rounding per element in the hi image, nothing in the lo image; the
+// kernels then issue only the hi x hi product on v_mfma_f32_32x32x16_bf16
+template <bool BF>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  if (BF) { hi = vs_pack_bf16(x0, x1); lo = 0u; return; }
   const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
   const h2 l = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x16 wg_mma(h8 a, h8 b, f32x16 c, int, int, int) {
+  if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vs_bf16x8, a), __builtin_bit_cast(vs_bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 struct Wgrad16Args {
@@ -742,7 +752,7 @@ struct Wgrad16Args {
   int B, T, F, dil, KT, nseg, G;
 };
 
-template <int KF>
+template <int KF, bool BF = false>
 __global__ __launch_bounds__(256, 2)
 void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
   constexpr int PADF = KF / 2;
@@ -855,8 +865,8 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
           for (int e = 0; e < 4; ++e) x[e] = (f0 + 4 * q + e < g.F) ? x[e] : 0.f;
         }
         unsigned h0, l0, h1, l1;
-        split_pair(x[0] * s_dz, x[1] * s_dz, h0, l0);
-        split_pair(x[2] * s_dz, x[3] * s_dz, h1, l1);
+        split_pair<BF>(x[0] * s_dz, x[1] * s_dz, h0, l0);
+        split_pair<BF>(x[2] * s_dz, x[3] * s_dz, h1, l1);
         u2v hv, lv;
         hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
         *reinterpret_cast<u2v*>(&sDh[(idx >> 4) * kPW + 2 * q]) = hv;
@@ -876,8 +886,8 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
             }
           }
           unsigned h0, l0, h1, l1;
-          split_pair(x[0] * s_in, x[1] * s_in, h0, l0);
-          split_pair(x[2] * s_in, x[3] * s_in, h1, l1);
+          split_pair<BF>(x[0] * s_in, x[1] * s_in, h0, l0);
+          split_pair<BF>(x[2] * s_in, x[3] * s_in, h1, l1);
           u2v hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
           *reinterpret_cast<u2v*>(&sAh[ch * kPW + 2 * q]) = hv;
@@ -917,10 +927,10 @@ void conv64_wgrad_f16x3_kernel(Wgrad16Args g) {
         };
         const h8 dhv = __builtin_bit_cast(h8, dh), dlv = __builtin_bit_cast(h8, dl);
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
+        for (int term = BF ? 2 : 0; term < 3; ++term) {
 #pragma unroll
           for (int kf = 0; kf < KF; ++kf)
-            acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? dlv : dhv, term == 1 ? tap(wl, kf) : tap(wh, kf),
+            acc[kf] = wg_mma<BF>(term == 0 ? dlv : dhv, term == 1 ? tap(wl, kf) : tap(wh, kf),
                                                              acc[kf], 0, 0, 0);
         }
       }
@@ -985,7 +995,7 @@ struct WgradRingArgs {
 
 // CK: columns are cut into chunks of steps (g.nchunk > 1); without it the chunk bookkeeping and the
 // row pre-load events compile away (they cost the 5x5 instance, which sits at 256 VGPRs, ~10 %).
-template <int KT, int KF, bool CK>
+template <int KT, int KF, bool CK, bool BF = false>
 __global__ __launch_bounds__(512)
 void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   constexpr int P = KT / 2, PADF = KF / 2;
@@ -1123,8 +1133,8 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
         for (int e = 0; e < 4; ++e) x[e] = (o.f0 + 4 * q + e < g.F) ? x[e] : 0.f;
       }
       unsigned h0, l0, h1, l1;
-      split_pair(x[0] * s_dz, x[1] * s_dz, h0, l0);
-      split_pair(x[2] * s_dz, x[3] * s_dz, h1, l1);
+      split_pair<BF>(x[0] * s_dz, x[1] * s_dz, h0, l0);
+      split_pair<BF>(x[2] * s_dz, x[3] * s_dz, h1, l1);
       u2v hv, lv;
       hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
       *reinterpret_cast<u2v*>(&zh[(idx >> 4) * kPW + 2 * q]) = hv;
@@ -1151,8 +1161,8 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
             }
           }
           unsigned h0, l0, h1, l1;
-          split_pair(x[0] * s_in, x[1] * s_in, h0, l0);
-          split_pair(x[2] * s_in, x[3] * s_in, h1, l1);
+          split_pair<BF>(x[0] * s_in, x[1] * s_in, h0, l0);
+          split_pair<BF>(x[2] * s_in, x[3] * s_in, h1, l1);
           u2v hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
           *reinterpret_cast<u2v*>(&dh[ch * kPW + 2 * q]) = hv;
@@ -1202,23 +1212,23 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
         if (ok0) window(s0, kb, wh, wl);
         if (ok4) window(s4, kb, xh, xl);
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
+        for (int term = BF ? 2 : 0; term < 3; ++term) {
           const h8 av = term == 0 ? dlv : dhv;
           if (ok0) {
 #pragma unroll
             for (int kf = 0; kf < 5; ++kf)
-              acc[kf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(wl, kf) : tap(wh, kf), acc[kf], 0, 0, 0);
+              acc[kf] = wg_mma<BF>(av, term == 1 ? tap(wl, kf) : tap(wh, kf), acc[kf], 0, 0, 0);
           }
           if (ok4) {
             // kt = 4 is shared out: tap group 0 takes kf 0,1; groups 1..3 take kf 2,3,4
             switch (tg) {
               case 0:
-                acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 0) : tap(xh, 0), acc[5], 0, 0, 0);
-                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 1) : tap(xh, 1), acc[6], 0, 0, 0);
+                acc[5] = wg_mma<BF>(av, term == 1 ? tap(xl, 0) : tap(xh, 0), acc[5], 0, 0, 0);
+                acc[6] = wg_mma<BF>(av, term == 1 ? tap(xl, 1) : tap(xh, 1), acc[6], 0, 0, 0);
                 break;
-              case 1: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 2) : tap(xh, 2), acc[5], 0, 0, 0); break;
-              case 2: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 3) : tap(xh, 3), acc[5], 0, 0, 0); break;
-              default: acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, term == 1 ? tap(xl, 4) : tap(xh, 4), acc[5], 0, 0, 0); break;
+              case 1: acc[5] = wg_mma<BF>(av, term == 1 ? tap(xl, 2) : tap(xh, 2), acc[5], 0, 0, 0); break;
+              case 2: acc[5] = wg_mma<BF>(av, term == 1 ? tap(xl, 3) : tap(xh, 3), acc[5], 0, 0, 0); break;
+              default: acc[5] = wg_mma<BF>(av, term == 1 ? tap(xl, 4) : tap(xh, 4), acc[5], 0, 0, 0); break;
             }
           }
         }
@@ -1247,10 +1257,10 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
           }
         }
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = BF ? 2 : 0; term < 3; ++term)
 #pragma unroll
           for (int a = 0; a < 4; ++a)
-            if (ok[a]) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? dlv : dhv, term == 1 ? bl[a] : bh[a], acc[a], 0, 0, 0);
+            if (ok[a]) acc[a] = wg_mma<BF>(term == 0 ? dlv : dhv, term == 1 ? bl[a] : bh[a], acc[a], 0, 0, 0);
       }
     }
   };
@@ -1353,7 +1363,8 @@ extern "C" int vs_set_wgrad_kernel(int mode) {
 extern "C" int vs_conv64_wgrad_f16_groups(int KT) { return KT == 7 ? 72 : 96; }
 
 int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz_scale2, const float* in_scale2,
-                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t stream) {
+                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t stream, int math) {
+  const bool bf = math == VS_MATH_CODE_BF16;
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_wgrad_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_wgrad_f16x3: unsupported kernel %dx%d", KT, KF);
   VS_REQUIRE((long long)64 * T * F * 4 < (long long)kOob, "conv64_wgrad_f16x3: T*F=%lld too large for 32-bit offsets", (long long)T * F);
@@ -1382,8 +1393,13 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
       return 0;
     };
     int rc;
-    if (KF == 5) rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<5, 5, true>) : launch(&conv64_wgrad_ring_kernel<5, 5, false>);
-    else rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<7, 1, true>) : launch(&conv64_wgrad_ring_kernel<7, 1, false>);
+    if (bf) {
+      if (KF == 5) rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<5, 5, true, true>) : launch(&conv64_wgrad_ring_kernel<5, 5, false, true>);
+      else rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<7, 1, true, true>) : launch(&conv64_wgrad_ring_kernel<7, 1, false, true>);
+    } else {
+      if (KF == 5) rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<5, 5, true>) : launch(&conv64_wgrad_ring_kernel<5, 5, false>);
+      else rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<7, 1, true>) : launch(&conv64_wgrad_ring_kernel<7, 1, false>);
+    }
     if (rc) return rc;
     const int total = KT * KF * 4096;
     hipLaunchKernelGGL(conv64_wgrad_reduce_scaled_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw,
@@ -1394,7 +1410,10 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
   const int G = vs_conv64_wgrad_f16_groups(KT);
   Wgrad16Args a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, KT, (F + kNF - 1) / kNF, G};
   dim3 grid(G * KT), block(256);
-  if (KF == 5) hipLaunchKernelGGL(conv64_wgrad_f16x3_kernel<5>, grid, block, 0, stream, a);
+  if (bf) {
+    if (KF == 5) hipLaunchKernelGGL((conv64_wgrad_f16x3_kernel<5, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv64_wgrad_f16x3_kernel<1, true>), grid, block, 0, stream, a);
+  } else if (KF == 5) hipLaunchKernelGGL(conv64_wgrad_f16x3_kernel<5>, grid, block, 0, stream, a);
   else hipLaunchKernelGGL(conv64_wgrad_f16x3_kernel<1>, grid, block, 0, stream, a);
   const int total = KT * KF * 4096;
   hipLaunchKernelGGL(conv64_wgrad_reduce_scaled_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, G, KT * KF, dw,

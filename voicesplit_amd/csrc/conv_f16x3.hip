@@ -94,7 +94,7 @@ __device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
 //   part(W[co = cb*32 + (lane&31)][ci = chunk*16 + 8*(lane>>5) + j][kt][kf] * s_w)
 // transpose_flip = 1: the data-gradient weights W'[co'][ci'][kt][kf] = W[ci'][co'][KT-1-kt][KF-1-kf]
 __global__ void conv_pack_weights_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int KT, int KF,
-                                             int transpose_flip, const float* __restrict__ wscale) {
+                                             int transpose_flip, const float* __restrict__ wscale, int bf16) {
   const int NT = KT * KF;
   const int total = kNChunk * NT * 2 * 2 * 64 * 8;
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,12 +111,17 @@ __global__ void conv_pack_weights_f16_kernel(const float* __restrict__ w, _Float
   const int ci = chunk * kChunk + 8 * (lane >> 5) + j;
   const float v = (transpose_flip ? w[((ci * kCi + co) * KT + (KT - 1 - kt)) * KF + (KF - 1 - kf)]
                                   : w[((co * kCi + ci) * KT + kt) * KF + kf]) * wscale[0];
+  if (bf16) {      // VS_MATH_BF16: the hi slot carries the bf16 rounding of the weight, the lo slot is unused
+    const unsigned short b = (unsigned short)(vs_pack_bf16(v, 0.f) & 0xffffu);
+    wp[idx] = part ? (_Float16)0.f : __builtin_bit_cast(_Float16, b);
+    return;
+  }
   f16x2 hi, lo;
   split2(v, 0.f, hi, lo);
   wp[idx] = part ? lo[0] : hi[0];
 }
 
-template <int KT, int KF, int P, int ACT>
+template <int KT, int KF, int P, int ACT, int NTERM = 3>
 __global__ __launch_bounds__(256, 2)
 void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
@@ -190,6 +195,13 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
         const int sw = ((pix % PX) >> 2) & 3;     // swizzle by window column (a row is 9*64 banks: no effect)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {        // ci 8h..8h+7
+          if (NTERM == 1) {                  // VS_MATH_BF16: one bf16 rounding per element, no lo half
+            u32x4 vb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vb[q] = vs_pack_bf16(stage[i][8 * h + 2 * q] * s_in, stage[i][8 * h + 2 * q + 1] * s_in);
+            sIn[pix * 4 + ((0 + h) ^ sw)] = vb;
+            continue;
+          }
           f16x2 hi[4], lo[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) split2(stage[i][8 * h + 2 * q] * s_in, stage[i][8 * h + 2 * q + 1] * s_in, hi[q], lo[q]);
@@ -235,7 +247,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int part = 0; part < 2; ++part) a[cb][part] = sW[buf][g * kTapVec + (cb * 2 + part) * 64 + lane];
+      for (int part = 0; part < (NTERM == 1 ? 1 : 2); ++part) a[cb][part] = sW[buf][g * kTapVec + (cb * 2 + part) * 64 + lane];
   };
   // B fragments of one tap: [row p][part]; pixel = (wave*P + p + kt)*PX + l31 + kf.  The lane-
   // dependent part of the (swizzled) address is precomputed per (kf, part); the row part is a
@@ -252,7 +264,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bf[p][0] = bbase[kf][0][(p + kt) * PX * 4];
-      bf[p][1] = bbase[kf][1][(p + kt) * PX * 4];
+      if (NTERM != 1) bf[p][1] = bbase[kf][1][(p + kt) * PX * 4];
     }
   };
 
@@ -283,6 +295,14 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
           __builtin_amdgcn_sched_barrier(0);
           // product term outermost: consecutive MFMAs go to 2*P different accumulators, so no
           // MFMA waits on the result of the one issued just before it
+          if (NTERM == 1) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb)
+                acc[cb][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vs_bf16x8, a_cur[cb][0]),
+                                                                    __builtin_bit_cast(vs_bf16x8, b_cur[p][0]), acc[cb][p], 0, 0, 0);
+          } else {
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
 #pragma unroll
@@ -294,6 +314,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
                 acc[cb][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, bq, acc[cb][p], 0, 0, 0);
               }
             }
+          }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -335,7 +356,7 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
 template <int KT, int KF, int P>
 int launch_conv(const float* in, const _Float16* wp, const float* scale, const float* shift, const float* in_scale,
                 const float* w_scale, float* out, int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream,
-                int i_base = 0, int i_end = 0x7fffffff) {
+                int i_base = 0, int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3) {
   constexpr int R = 4 * P;
   const int rows_all = (T + dil - 1) / dil;
   const int rows_max = (rows_all < i_end ? rows_all : i_end) - i_base;
@@ -344,6 +365,16 @@ int launch_conv(const float* in, const _Float16* wp, const float* scale, const f
   const long long nblk = (long long)B * dil * n_rt * n_ft;
   VS_REQUIRE(nblk > 0 && nblk < 2147483647LL, "conv64_f16x3: grid of %lld blocks out of range", nblk);
   dim3 grid((unsigned)nblk), block(256);
+  if (math == VS_MATH_CODE_BF16) {
+    switch (act) {
+      case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+      case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+      case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+      default: VS_REQUIRE(false, "conv64_f16x3: unknown activation %d", act);
+    }
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   switch (act) {
     case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
     case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
@@ -398,11 +429,12 @@ int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, floa
 
 // w [64][64][KT][KF] fp32 -> fragment-ordered hi/lo f16 (scaled by w_scale2[0], which this call computes)
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
-                            float* w_scale2, hipStream_t stream) {
+                            float* w_scale2, hipStream_t stream, int math) {
   VS_REQUIRE((KT == 7 && KF == 1) || (KT == 5 && KF == 5), "conv64_f16x3: unsupported kernel %dx%d", KT, KF);
   if (int rc = vs_pow2_scale_impl(w, (long long)kCo * kCi * KT * KF, amax_scratch, w_scale2, stream)) return rc;
   const int total = (int)(vs_conv64_packed_f16_floats(KT, KF) * 2);
-  hipLaunchKernelGGL(conv_pack_weights_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wp, KT, KF, transpose_flip, w_scale2);
+  hipLaunchKernelGGL(conv_pack_weights_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wp, KT, KF, transpose_flip, w_scale2,
+                     math == VS_MATH_CODE_BF16 ? 1 : 0);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -418,7 +450,7 @@ extern "C" int vs_set_conv_kernel(int mode) {
 
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
-                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream) {
+                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream, int math) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64_f16x3: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
   if (KT == 5 && KF == 5 && g_conv_kernel != 1 && (long long)kCo * T * F * 4 < (long long)kOob) {
@@ -427,8 +459,8 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
     const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
     const bool tail = full8 > 0 && rem > 0 && rem <= 4;
     if (int rc = vs_conv64_f16x3_pk_impl(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream,
-                                         g_conv_kernel >= 100 ? g_conv_kernel - 100 : 0, tail ? full8 : 0x7fffffff)) return rc;
-    return tail ? launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff) : 0;
+                                         g_conv_kernel >= 100 ? g_conv_kernel - 100 : 0, tail ? full8 : 0x7fffffff, math)) return rc;
+    return tail ? launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math) : 0;
   }
   // 8-row tiles (P = 2) amortise the KT-1 halo rows and the weight staging over twice the MFMAs
   // (measured 6.6 vs 7.45 ms per layer at equal padding); 4-row tiles only win when they avoid
@@ -439,16 +471,16 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
   // running everything on the less efficient 4-row tiles or padding a third 8-row tile.
   const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
   if (KT == 5 && KF == 5 && full8 > 0 && rem > 0 && rem <= 4) {
-    if (int rc = launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, full8)) return rc;
-    return launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff);
+    if (int rc = launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, full8, math)) return rc;
+    return launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math);
   }
   if (KT == 7 && KF == 1) {
-    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
-              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
+    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math)
+              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math);
   }
   if (KT == 5 && KF == 5) {
-    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream)
-              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream);
+    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math)
+              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math);
   }
   VS_REQUIRE(false, "conv64_f16x3: unsupported kernel %dx%d", KT, KF);
   return -1;

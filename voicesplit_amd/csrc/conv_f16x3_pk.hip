@@ -135,7 +135,9 @@ __device__ __forceinline__ Tile seek_tile(TileWalk& w, const PkArgs& a) {
 // ABL: timing ablations (results are garbage unless 0): 1 = no fragment reads, 2 = no staging (window and
 // weight loads / conversions / LDS writes), 4 = no in-loop epilogue, 8 = no barriers.
 // FILL > 0: pin the issue pattern of a tap to (1 MFMA, up to FILL other instructions) x 12.
-template <int P, int ACT, int ABL = 0, int FILL = 0>
+// NT: product terms per fp32 product: 3 = split f16 (hi*hi + hi*lo + lo*hi), 1 = single-pass bf16 (VS_MATH_BF16:
+// operands rounded to bf16, the lo slots of the LDS images stay unused).
+template <int P, int ACT, int ABL = 0, int FILL = 0, int NT = 3>
 __global__ __launch_bounds__(256, 1)
 void conv64_f16x3_pk_kernel(PkArgs a) {
   constexpr int R = 4 * P;
@@ -208,11 +210,17 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
   auto store_unit = [&](u32x4* win, int i, int h) {
     const int sw = (unsigned)pdst[i] >> 28;
     u32x4* dst = win + (pdst[i] & 0x0fffffff);
-    f16x2 hi[4], lo[4];
     asm volatile("" : "+v"(stage[i][8 * h]));     // pins the unit's conversion to the tap it was placed in
+    u32x4 vh, vl;
+    if (NT == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vh[q] = vs_pack_bf16(stage[i][8 * h + 2 * q] * s_in, stage[i][8 * h + 2 * q + 1] * s_in);
+      dst[(0 + h) ^ sw] = vh;
+      return;
+    }
+    f16x2 hi[4], lo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) split2(stage[i][8 * h + 2 * q] * s_in, stage[i][8 * h + 2 * q + 1] * s_in, hi[q], lo[q]);
-    u32x4 vh, vl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       vh[q] = __builtin_bit_cast(unsigned, hi[q]);
@@ -290,13 +298,13 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int part = 0; part < 2; ++part) af[cb][part] = wb[g * kTapVec + (cb * 2 + part) * 64 + lane];
+      for (int part = 0; part < (NT == 1 ? 1 : 2); ++part) af[cb][part] = wb[g * kTapVec + (cb * 2 + part) * 64 + lane];
   };
   auto load_b = [&](const u32x4* wn, int kt, int kf, u32x4 (&bf)[P][2]) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bf[p][0] = wn[boff[kf][0] + (p + kt) * PX * 4];
-      bf[p][1] = wn[boff[kf][1] + (p + kt) * PX * 4];
+      if (NT != 1) bf[p][1] = wn[boff[kf][1] + (p + kt) * PX * 4];
     }
   };
 
@@ -392,6 +400,14 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
           // (3) the weights fetched at the head of this group go to the ring
           if (g == 3 && !(ABL & 2)) store_w(wbuf2);
           // --- the tap: term outermost so consecutive MFMAs hit different accumulators ---------------
+          if (NT == 1) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb)
+                acc[cb * P + p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vs_bf16x8, a_cur[cb][0]),
+                                                                         __builtin_bit_cast(vs_bf16x8, b_cur[p][0]), acc[cb * P + p], 0, 0, 0);
+          } else {
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
 #pragma unroll
@@ -404,11 +420,12 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
               }
             }
           }
+          }
           // issue pattern of the tap: one MFMA, then up to FILL instructions of any other kind -- the
           // matrix pipe is busy 32 cycles per MFMA, which covers ~7 issue slots of this (only) wave
           if (FILL > 0) {
 #pragma unroll
-            for (int m = 0; m < 3 * 2 * P; ++m) {
+            for (int m = 0; m < NT * 2 * P; ++m) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
               __builtin_amdgcn_sched_group_barrier(0x6f6, FILL, 0);   // VALU | SALU | VMEM | DS | TRANS
             }
@@ -458,7 +475,7 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
 }
 
 template <int P>
-int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stream, int abl = 0) {
+int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stream, int abl = 0, int math = VS_MATH_CODE_F16X3) {
   constexpr int R = 4 * P;
   PkArgs a = a0;
   a.i_base = i_base;
@@ -498,6 +515,16 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
     VS_LAUNCH_CHECK();
     return 0;
   }
+  if (math == VS_MATH_CODE_BF16) {
+    switch (act) {
+      case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_RELU, 0, 0, 1>), grid, block, 0, stream, a); break;
+      case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_MISH, 0, 0, 1>), grid, block, 0, stream, a); break;
+      case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_NONE, 0, 0, 1>), grid, block, 0, stream, a); break;
+      default: VS_REQUIRE(false, "conv64_f16x3_pk: unknown activation %d", act);
+    }
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   switch (act) {
     case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_RELU>), grid, block, 0, stream, a); break;
     case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_MISH>), grid, block, 0, stream, a); break;
@@ -514,9 +541,9 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
 int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                             const float* in_scale2, const float* w_scale2, float* out,
                             int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream, int abl,
-                            int i_end) {
+                            int i_end, int math) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3_pk: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kCo * T * F * 4 < (long long)kOob, "conv64_f16x3_pk: T*F=%lld too large for 32-bit offsets", (long long)T * F);
   PkArgs a{in, wp, scale, shift, in_scale2, w_scale2, out, amax_out, B, T, F, dil, 0, 0, 0, 0, 0, 0, 0};
-  return launch_pk<2>(a, act, 0, i_end, stream, abl);
+  return launch_pk<2>(a, act, 0, i_end, stream, abl, math);
 }

@@ -57,11 +57,21 @@ struct Gemm16Args {
   int tiles_m, tiles_n;
 };
 
+// BF (VS_MATH_BF16): one bf16 rounding per element in the hi image, nothing in the lo image; the kernels
+// then issue only the hi x hi product on v_mfma_f32_32x32x16_bf16
+template <bool BF = false>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  if (BF) { hi = vs_pack_bf16(x0, x1); lo = 0u; return; }
   const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
   const h2 l = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <bool BF, class HV>
+__device__ __forceinline__ f32x16 g_mma(HV a, HV b, f32x16 c, int, int, int) {
+  if (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vs_bf16x8, a), __builtin_bit_cast(vs_bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 // One operand's view for the loads: K-contiguous operands may be two stacked matrices (rows
@@ -123,7 +133,7 @@ __device__ __forceinline__ void tile_load(float (&r)[regs_of(BK)], const Operand
 }
 
 // registers -> f16 hi/lo halves in LDS [row][PW dwords]
-template <int LAYOUT, int BK>
+template <int LAYOUT, int BK, bool BF = false>
 __device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsigned* __restrict__ sh, unsigned* __restrict__ sl,
                                            float s, bool relu, int tid) {
   constexpr int RT = regs_of(BK), PW = pitch_of(BK);
@@ -136,8 +146,8 @@ __device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsign
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = fmaxf(r[4 * i + j], floor_) * s;
       unsigned h0, l0, h1, l1;
-      split_pair(x[0], x[1], h0, l0);
-      split_pair(x[2], x[3], h1, l1);
+      split_pair<BF>(x[0], x[1], h0, l0);
+      split_pair<BF>(x[2], x[3], h1, l1);
       u2v hi, lo;
       hi[0] = h0; hi[1] = h1;
       lo[0] = l0; lo[1] = l1;
@@ -151,14 +161,14 @@ __device__ __forceinline__ void tile_store(const float (&r)[regs_of(BK)], unsign
       const float x0 = fmaxf(r[2 * i], floor_) * s;
       const float x1 = fmaxf(r[2 * i + 1], floor_) * s;
       unsigned hi, lo;
-      split_pair(x0, x1, hi, lo);
+      split_pair<BF>(x0, x1, hi, lo);
       sh[(idx & 127) * PW + (idx >> 7)] = hi;
       sl[(idx & 127) * PW + (idx >> 7)] = lo;
     }
   }
 }
 
-template <int LA, int LB, bool VEC, int BK, int OCC>
+template <int LA, int LB, bool VEC, int BK, int OCC, bool BF = false>
 __global__ __launch_bounds__(256, OCC)
 void gemm_f16x3_kernel(Gemm16Args g) {
   constexpr int RT = regs_of(BK), PW = pitch_of(BK);
@@ -207,8 +217,8 @@ void gemm_f16x3_kernel(Gemm16Args g) {
   tile_load<LB, VEC, BK>(rw, vw, g.ldw, n0, 0, g.K, tid);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     __syncthreads();
-    tile_store<LA, BK>(ra, sAh, sAl, sa, g.a_relu != 0, tid);
-    tile_store<LB, BK>(rw, sWh, sWl, sw, g.w_relu != 0, tid);
+    tile_store<LA, BK, BF>(ra, sAh, sAl, sa, g.a_relu != 0, tid);
+    tile_store<LB, BK, BF>(rw, sWh, sWl, sw, g.w_relu != 0, tid);
     __syncthreads();
     if (k0 + BK < g.K) {
       tile_load<LA, VEC, BK>(ra, va, g.lda, m0, k0 + BK, g.K, tid);
@@ -235,12 +245,12 @@ void gemm_f16x3_kernel(Gemm16Args g) {
         bl[x] = __builtin_bit_cast(h8, t);
       }
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+      for (int term = BF ? 2 : 0; term < 3; ++term)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mb] : ah[mb], term == 1 ? bl[nb] : bh[nb],
+            acc[mb][nb] = g_mma<BF>(term == 0 ? al[mb] : ah[mb], term == 1 ? bl[nb] : bh[nb],
                                                                  acc[mb][nb], 0, 0, 0);
     }
   }
@@ -272,7 +282,12 @@ void gemm_f16x3_kernel(Gemm16Args g) {
 }
 
 template <int LA, int LB>
-void launch_layout(const Gemm16Args& g, bool vec, dim3 grid, hipStream_t stream) {
+void launch_layout(const Gemm16Args& g, bool vec, dim3 grid, hipStream_t stream, bool bf) {
+  if (bf) {
+    if (vec) hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, true, 32, 3, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, false, 32, 3, true>), grid, dim3(256), 0, stream, g);
+    return;
+  }
   if (vec) hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, true, 32, 3>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_f16x3_kernel<LA, LB, false, 32, 3>), grid, dim3(256), 0, stream, g);
 }
@@ -292,7 +307,7 @@ constexpr int PPW = 20;                 // LDS row pitch in dwords (32 halves + 
 // src [rows][ld] fp32 (K valid columns) -> hi, lo [rows][Kp] f16 of src * scale[0]
 __global__ __launch_bounds__(256)
 void split_rows_kernel(const float* __restrict__ src, int rows, int K, int ld, const float* __restrict__ scale,
-                       _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Kp, int relu) {
+                       _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Kp, int relu, int bf) {
   const float s = scale[0];
   const int groups = Kp >> 3;                                   // 8 halves = 16 B per thread
   const long long total = (long long)rows * groups;
@@ -311,7 +326,8 @@ void split_rows_kernel(const float* __restrict__ src, int rows, int K, int ld, c
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       unsigned hq, lq;
-      split_pair(x[2 * q], x[2 * q + 1], hq, lq);
+      if (bf) split_pair<true>(x[2 * q], x[2 * q + 1], hq, lq);
+      else split_pair<false>(x[2 * q], x[2 * q + 1], hq, lq);
       h[q] = hq;
       l[q] = lq;
     }
@@ -333,6 +349,7 @@ struct GemmPreArgs {
 };
 
 // C (+)= act((Ah+Al)(Wh+Wl)^T / (sA*sW) + bias terms): 128x128x32 tile, 4 waves (2x2) of 64x64
+template <bool BF>
 __global__ __launch_bounds__(256, 3)
 void gemm_pre_kernel(GemmPreArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned sAh[BM * PPW], sAl[BM * PPW], sWh[BN * PPW], sWl[BN * PPW];
@@ -413,12 +430,12 @@ void gemm_pre_kernel(GemmPreArgs g) {
         bl[x] = __builtin_bit_cast(h8, *reinterpret_cast<const u4v*>(&sWl[ow]));
       }
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+      for (int term = BF ? 2 : 0; term < 3; ++term)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? al[mb] : ah[mb], term == 1 ? bl[nb] : bh[nb],
+            acc[mb][nb] = g_mma<BF>(term == 0 ? al[mb] : ah[mb], term == 1 ? bl[nb] : bh[nb],
                                                                  acc[mb][nb], 0, 0, 0);
     }
   }
@@ -460,7 +477,8 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
                        int n_split, int ldw, float* C, int ldc, int M, int N, int K,
                        const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
                        const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
-                       const float* a_scale2, const float* w_scale2, hipStream_t stream) {
+                       const float* a_scale2, const float* w_scale2, hipStream_t stream, int math) {
+  const bool bf = math == VS_MATH_CODE_BF16;
   VS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f16x3: bad shape M=%d N=%d K=%d", M, N, K);
   VS_REQUIRE((layout_a == 0 || layout_a == 1) && (layout_w == 0 || layout_w == 1), "gemm_f16x3: bad layout");
   VS_REQUIRE(lda >= (layout_a ? M : K) && ldw >= (layout_w ? N : K) && ldc >= N,
@@ -480,10 +498,10 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
   VS_REQUIRE(layout_w || ((size_t)(N - 1) * ldw + K) * 4 < (1ull << 32) - 64, "gemm_f16x3: W above 4 GiB");
   VS_REQUIRE((long long)g.tiles_m * g.tiles_n < (1LL << 30), "gemm_f16x3: too many tiles");
   dim3 grid((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8));
-  if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream);
-  else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream);
-  else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream);
-  else launch_layout<1, 1>(g, vec, grid, stream);
+  if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream, bf);
+  else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream, bf);
+  else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream, bf);
+  else launch_layout<1, 1>(g, vec, grid, stream, bf);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -496,12 +514,13 @@ size_t vs_gemm_presplit_bytes(int M, int N, int K) {
 
 // x [rows][ld] (K valid columns) * scale2[0] -> hi, lo [rows][Kp]
 int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* scale2, _Float16* hi, _Float16* lo, int relu,
-                       hipStream_t stream) {
+                       hipStream_t stream, int math) {
   VS_REQUIRE(rows > 0 && K > 0 && ld >= K, "split_rows: bad shape rows=%d K=%d ld=%d", rows, K, ld);
   const int Kp = (K + PBK - 1) / PBK * PBK;
   const long long total = (long long)rows * (Kp >> 3);
   const long long nb = (total + 255) / 256;
-  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, x, rows, K, ld, scale2, hi, lo, Kp, relu);
+  hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, x, rows, K, ld, scale2, hi, lo, Kp, relu,
+                     math == VS_MATH_CODE_BF16 ? 1 : 0);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -511,14 +530,15 @@ int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* sca
 int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, int Kp,
                           float* C, int ldc, int M, int N, const float* bias1, const float* bias2,
                           const float* rowbias, int ldrb, int group, int act, int accumulate,
-                          const float* a_scale2, const float* w_scale2, hipStream_t stream) {
+                          const float* a_scale2, const float* w_scale2, hipStream_t stream, int math) {
   VS_REQUIRE(M > 0 && N > 0 && Kp > 0 && Kp % PBK == 0 && ldc >= N, "gemm_presplit: bad shape M=%d N=%d Kp=%d ldc=%d", M, N, Kp, ldc);
   VS_REQUIRE(((size_t)M * Kp) * 2 < (1ull << 32) - 64 && ((size_t)N * Kp) * 2 < (1ull << 32) - 64, "gemm_presplit: operand above 4 GiB");
   VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm_presplit: rowbias needs group>0 and ldrb>=N");
   VS_REQUIRE(aligned16(Ah) && aligned16(Al) && aligned16(Wh) && aligned16(Wl), "gemm_presplit: operands must be 16-byte aligned");
   GemmPreArgs g{Ah, Al, Wh, Wl, C, ldc, M, N, Kp, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1, act, accumulate,
                 a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
-  hipLaunchKernelGGL(gemm_pre_kernel, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
+  if (math == VS_MATH_CODE_BF16) hipLaunchKernelGGL(gemm_pre_kernel<true>, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_pre_kernel<false>, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
   VS_LAUNCH_CHECK();
   return 0;
 }

@@ -136,7 +136,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   // split-f16 convs: the BatchNorm+activation pass that produces a layer's input also folds its
   // |max| into that layer's scale slot (slot l = conv index l: input scale of cnn(l+1))
   float* cs = at<float>(tape, L.conv_scales);
-  const bool f16 = d->math == VS_MATH_F16X3;
+  const bool f16 = d->math != VS_MATH_FP32;
   if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 16 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
   auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout) -> int {
@@ -284,7 +284,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
   // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
   float* gsc = at<float>(tape, L.gemm_scales);
-  const bool f16g = d->math == VS_MATH_F16X3;
+  const bool f16g = d->math != VS_MATH_FP32;
   if (f16g) {
     if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
   }
@@ -295,7 +295,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     // dW_ih[:, :8F] = dxg_d^T @ feat
     if (f16g) {
       if (int rc = vs_gemm_f16x3_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, stream)) return rc;
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, stream, d->math)) return rc;
     } else {
       if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
                                         nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
@@ -310,7 +310,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     // dfeat (+)= dxg_d @ W_ih[:, :8F]
     if (f16g) {
       if (int rc = vs_gemm_f16x3_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, gsc + 8, gsc + 2, stream)) return rc;
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, gsc + 8, gsc + 2, stream, d->math)) return rc;
     } else {
       if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
                                         nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
@@ -333,7 +333,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // split-f16 convs: dz of layer l is the operand of its data- and weight-gradient launches; the
   // BatchNorm backward pass that produces it folds its |max| into slot 8+l
   float* cs = at<float>(tape, L.conv_scales);
-  const bool f16 = d->math == VS_MATH_F16X3;
+  const bool f16 = d->math != VS_MATH_FP32;
   if (f16) VS_CHECK_HIP(hipMemsetAsync(cs + 8 * VS_SCALE_SLOT_FLOATS, 0, 8 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   auto bn_bwd = [&](int l, const float* da, const float* z, float* dz, int C, long long R, int Lrow) -> int {
     VsProfScope ps(VS_PROF_BWD_BN, stream);
@@ -365,9 +365,9 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       // after the data gradient: in split-f16 mode it reuses the scale of dz that launch derived
       // (sc_bwd[0..1]) and the scale of the layer input the forward derived (slot l)
       VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
-      if (d->math == VS_MATH_F16X3) {
+      if (d->math != VS_MATH_FP32) {
         if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * l,
-                                                part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+                                                part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream, d->math)) return rc;
       } else {
         if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
                                           kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;

@@ -9,6 +9,20 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 operands of the single-pass matrix-core mode (VS_MATH_BF16): round-to-nearest-even pairs
+typedef __bf16 vs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vs_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vs_pack_bf16(float a, float b) {
+  vs_bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);       // one v_cvt_pk_bf16_f32
+}
+// arithmetic codes of the dense contractions (dims.math in include/voicesplit_hip.h)
+#define VS_MATH_CODE_FP32 0
+#define VS_MATH_CODE_F16X3 1
+#define VS_MATH_CODE_BF16 2
+
 // activation codes shared with include/voicesplit_hip.h
 #define VS_ACT_RELU 0
 #define VS_ACT_MISH 1

@@ -21,16 +21,17 @@ int vs_absmax_accum_impl(const float* x, long long n, unsigned* amax, hipStream_
 // gemm_f16x3.hip
 // gemm_f16x3.hip: operands split into f16 hi/lo arrays by a pass of their own
 size_t vs_gemm_presplit_bytes(int M, int N, int K);
-int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* scale2, _Float16* hi, _Float16* lo, int relu, hipStream_t);
+int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* scale2, _Float16* hi, _Float16* lo, int relu, hipStream_t,
+                       int math = VS_MATH_CODE_F16X3);
 int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, int Kp,
                           float* C, int ldc, int M, int N, const float* bias1, const float* bias2,
                           const float* rowbias, int ldrb, int group, int act, int accumulate,
-                          const float* a_scale2, const float* w_scale2, hipStream_t);
+                          const float* a_scale2, const float* w_scale2, hipStream_t, int math = VS_MATH_CODE_F16X3);
 int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
                        int n_split, int ldw, float* C, int ldc, int M, int N, int K,
                        const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
                        const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
-                       const float* a_scale2, const float* w_scale2, hipStream_t);
+                       const float* a_scale2, const float* w_scale2, hipStream_t, int math = VS_MATH_CODE_F16X3);
 // The LSTM input projection x @ [W_ih; W_ih_reverse]^T (+ per-utterance row bias) in either
 // arithmetic.  gemm_scales: 16 floats of scratch that must survive until the backward pass in
 // training: [0..1] scale of feat, [2..3] scale of the two W_ih, [4..5] uint |max| scratch.
@@ -38,15 +39,16 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
                             float* xg, int M, const float* rowbias, int T, float* gemm_scales,
                             void* scratch, size_t scratch_bytes, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
-                            float* w_scale2, hipStream_t);
+                            float* w_scale2, hipStream_t, int math = VS_MATH_CODE_F16X3);
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
-                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t);
+                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t,
+                             int math = VS_MATH_CODE_F16X3);
 // conv_f16x3_pk.hip: persistent, software-pipelined form of the 5x5 kernel (same contract, bit-identical results)
 int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                             const float* in_scale2, const float* w_scale2, float* out,
                             int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t, int ablation = 0,
-                            int i_end = 0x7fffffff);
+                            int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3);
 // One 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
 // gradient) into `packed`.  Split-f16 mode keeps its operand scales in one "scale slot" of
 // VS_SCALE_SLOT_FLOATS floats: [0..1] input {s, 1/s}, [2..3] weight {s, 1/s}, [4] uint |max| of
@@ -76,7 +78,8 @@ int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* r
 // conv_bwd.hip
 int vs_conv64_wgrad_impl(const float* dz, const float* in, float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
 int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz_scale2, const float* in_scale2,
-                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
+                               float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t,
+                               int math = VS_MATH_CODE_F16X3);
 int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int train,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, unsigned* amax_out, hipStream_t);

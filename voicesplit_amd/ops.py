@@ -41,7 +41,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-MATH_CODES = {"fp32": _lib.MATH_FP32, "f16x3": _lib.MATH_F16X3}
+MATH_CODES = {"fp32": _lib.MATH_FP32, "f16x3": _lib.MATH_F16X3, "bf16": _lib.MATH_BF16}
 _DEFAULT_MATH = os.environ.get("VOICESPLIT_CONV_MATH", "f16x3")
 
 
@@ -50,7 +50,10 @@ def set_conv_math(name: str):
     input GEMMs): "f16x3" (default) = fp32 operands split into two f16 halves, three products on
     the f16 matrix cores, fp32 accumulate -- fp32-class accuracy (same parity tolerances) at 3/16
     of the matrix-pipe time (csrc/conv_f16x3.hip); "fp32" = the f32 matrix cores, bitwise an fmaf
-    chain.  Also selectable with VOICESPLIT_CONV_MATH."""
+    chain; "bf16" (BASELINE configs[2], opt-in only) = operands rounded to bf16, ONE product on the
+    bf16 matrix cores, fp32 accumulate and fp32 everywhere else -- a third of the matrix work of f16x3 at
+    bf16 accuracy (not the 1e-4 contract: tests/test_gpu_bf16.py states what it holds).  Also
+    selectable with VOICESPLIT_CONV_MATH."""
     global _DEFAULT_MATH
     if name not in MATH_CODES:
         raise ValueError(f"conv math must be one of {sorted(MATH_CODES)}")
