@@ -236,11 +236,80 @@ def main():
     assert torch.isfinite(out).all()
     if train:
         assert torch.isfinite(bucket.flat).all()
-
-    if rank == 0:
+    if rank == 0:                  # close the per-stage timers before anything else calls into the library
         ms = (ctypes.c_float * _lib.PROF_SLOTS)()
         calls = (ctypes.c_int * _lib.PROF_SLOTS)()
         _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
+
+    # ---- RCCL leg (outside the timed region) ---------------------------------------------------------
+    # N > 1: every rank must hold the same bucket after the step's all-reduce (a checksum per rank, gathered).
+    # N = 1: the step's exchange is a no-op, so the device collective is exercised once on its own: a
+    # one-rank process group, the 75.5 MB bucket through ncclAllReduce, timed with HIP events.
+    rccl = None
+    if train:
+        try:
+            import torch.distributed as tdist
+            if world > 1:
+                chk = torch.stack([bucket.flat.double().sum(), bucket.flat.double().abs().sum()])
+                allc = [torch.empty_like(chk) for _ in range(world)]
+                tdist.all_gather(allc, chk)
+                same = all(torch.equal(allc[0], c) for c in allc)
+                assert same, "gradient buckets differ between ranks after the all-reduce"
+                rccl = {"rccl_ranks": world, "bucket_identical_on_all_ranks": True, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1)}
+            else:
+                import socket
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    port = s_.getsockname()[1]
+                tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                keep = bucket.flat.clone()
+                bucket.all_reduce(1, force=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    bucket.all_reduce(1, force=True)
+                e1.record()
+                torch.cuda.synchronize()
+                assert torch.equal(bucket.flat, keep)
+                rccl = {"rccl_ranks": 1, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1),
+                        "one_rank_allreduce_ms": round(e0.elapsed_time(e1) / 5, 3),
+                        "note": "one-rank ncclAllReduce of the gradient bucket on the device, outside the timed region; "
+                                "no multi-GPU node was available to the builder"}
+                tdist.destroy_process_group()
+        except AssertionError:
+            raise
+        except Exception as exc:                      # RCCL unavailable on this box: report, do not fail the bench
+            rccl = {"rccl_ranks": 0, "error": str(exc)[:200]}
+
+    # ---- BASELINE configs[1] next to the training line: forward only, eval-mode BatchNorm ---------------
+    fwd = None
+    if train:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                fo = model(spec, dvec)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            FK = 10
+            tf0 = time.perf_counter()
+            for _ in range(FK):
+                fo = model(spec, dvec)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            fel = time.perf_counter() - tf0
+        if dist:
+            t = torch.tensor([fel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fel = float(t.item())
+        assert torch.isfinite(fo).all()
+        fwd = {"metric": f"utterances/sec (3 s clips, B={B}/GPU) forward only, eval BatchNorm (BASELINE configs[1]), " + MATH_LABEL,
+               "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
+               "ms_per_step": round(1e3 * fel / FK, 3)}
+        model.train()
+
+    if rank == 0:
         # per training step: total ms of each slot / steps (a slot may be entered once per layer)
         stage_ms = {n: (ms[i] / args.steps if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
         # dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training)
@@ -313,11 +382,24 @@ def main():
             "stage_ms": {k: (round(v, 3) if v is not None else None) for k, v in stage_ms.items()},
             "model_tflops": round(value / world * GFLOP_FWD_TOTAL * (3 if train else 1) / 1e3, 2),
         }
+        if fwd is not None:
+            line["forward"] = fwd
+        if rccl is not None:
+            line["rccl"] = rccl
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.mode)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist:
         dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a file:
+    # push it out first so that the JSON line is the LAST line on stdout
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -164,3 +164,36 @@ def test_long_form_windows_match_per_window_calls():
     with torch.no_grad():
         w9 = m(last, dvec[None])
     assert torch.equal(mask[2709:], w9[0, :292])
+
+
+def test_exact_long_form_equals_a_whole_clip_pass():
+    """a 1000-frame clip as 6 windows of 301 frames with 65-frame halos through the conv stack,
+    then ONE full-length BiLSTM + head pass (LSTM state carried across every window boundary), against (a) the
+    module run on the whole clip and (b) the CPU oracle on the whole clip.  Residual error stated below."""
+    import voicesplit_amd as V
+    from voicesplit_amd.streaming import separate_long, separate_long_exact
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, 3), 8.0)
+    m = V.VoiceSplit(V.default_config()).eval()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(11)
+    T_long = 1000
+    spec = torch.rand(T_long, 601, generator=g)
+    dvec = R.synthetic_inputs(1, 301, dims_d, 11)[1][0]
+    conv_stage, sequence_stage = m.long_form_stages()
+    got = separate_long_exact(conv_stage, sequence_stage, spec.cuda(), dvec.cuda(), window=301, halo=65).cpu()
+    with torch.no_grad():
+        whole = m(spec[None].cuda(), dvec[None].cuda())[0].cpu()
+        ref = R.forward(sd, spec[None], dvec[None], act="mish")["mask"][0]
+    # (a) same kernels, same arithmetic; only the per-tensor power-of-two operand scales of the split-f16 convs
+    #     can differ between a window batch and the whole clip: rounding level
+    assert _rel(got.numpy(), whole.numpy()) < 2e-5
+    # (b) the path's contract against the oracle, at 3.3x the training length
+    assert _rel(got.numpy(), ref.numpy()) < REL_TOL
+    assert ((got.numpy() - ref.numpy()) ** 2).mean() < MSE_TOL
+    # restarting the BiLSTM in every window (BASELINE configs[4] as literally stated) is a different function
+    restart = separate_long(m, spec.cuda(), dvec.cuda(), window=301, halo=65).cpu()
+    assert _rel(restart.numpy(), ref.numpy()) > 10 * REL_TOL
+    with pytest.raises(RuntimeError):
+        m.train().long_form_stages()

@@ -113,3 +113,34 @@ def test_dataset_collate_on_gpu_and_cli_dry_run(tmp_path):
     cfg_path.write_text(text.replace('"model_name"', '// which model\n "model_name"', 1))
     trainer.main(["-c", str(cfg_path), "--synthetic-steps", "2", "--epochs", "1",
                   "--checkpoint_path", str(tmp_path / "logs" / "checkpoint_3.pt")])
+
+
+def test_rccl_world1_bucket_all_reduce_on_device():
+    """The RCCL leg of the training step on the hardware that IS available (one GPU): init_process_group("nccl")
+    at world 1, the flat gradient bucket all-reduced on the device through RCCL, group destroyed.  (The N > 1
+    exchange is covered by the world-2 gloo tests on CPU; no multi-GPU box is available to these tests.)"""
+    import socket
+    import torch.distributed as dist
+    from voicesplit_amd.sharding import GradientBucket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        lin = torch.nn.Linear(37, 19).to(dev)
+        bucket = GradientBucket(lin.parameters(), None, extra=1).attach()
+        lin(torch.randn(5, 37, device=dev)).square().sum().backward()
+        bucket.extra[0] = 3.25
+        before = bucket.flat.clone()
+        assert before.abs().sum() > 0 and bucket.flat.is_cuda
+        bucket.all_reduce(1, force=True)           # through RCCL even at world 1
+        torch.cuda.synchronize()
+        assert torch.equal(bucket.flat, before) and float(bucket.extra[0]) == 3.25
+        # a raw device all-reduce of the same buffer (sum over one rank = identity)
+        dist.all_reduce(bucket.flat)
+        torch.cuda.synchronize()
+        assert torch.equal(bucket.flat, before)
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()

@@ -119,6 +119,23 @@ class _MaskNet(nn.Module):
                     if isinstance(m, nn.BatchNorm2d):
                         m.num_batches_tracked += 1           # running_mean/var were updated in place by the library
 
+    def long_form_stages(self):
+        """(conv_stage, sequence_stage) for ``streaming.separate_long_exact``: the conv stack on a batch
+        of windows and BiLSTM + head on one full-length feature sequence, both in eval mode
+        (running BatchNorm statistics), both straight into the C ABI stage entry points."""
+        if self.training:
+            raise RuntimeError("long-form inference runs in eval mode: call model.eval() first")
+        sd = {k: v.detach() for k, v in self._tensors().items()}
+
+        def conv_stage(xw):
+            return ops.conv_stack(sd, xw.contiguous(), self._dims(xw.shape[0], xw.shape[1]), self.conv_act)
+
+        def sequence_stage(feat, dvec):
+            dims = self._dims(feat.shape[0], feat.shape[1])
+            return ops.head(sd, ops.bilstm(sd, feat.contiguous(), dvec.contiguous(), dims), dims)
+
+        return conv_stage, sequence_stage
+
     def forward(self, x, speaker_embedding):
         # x: [B, T, num_freq]; speaker_embedding: [B, emb_dim]  ->  mask [B, T, fc2_dim]
         if torch.is_grad_enabled() and x.requires_grad:

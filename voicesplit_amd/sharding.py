@@ -104,9 +104,10 @@ class GradientBucket:
             p.grad = v
         return self
 
-    def all_reduce(self, world: int):
+    def all_reduce(self, world: int, force: bool = False):
         """Sum over ranks, then divide by `world` (call after backward has finished: the
-        collective must not be co-scheduled with the persistent LSTM kernels)."""
+        collective must not be co-scheduled with the persistent LSTM kernels).  force: issue the
+        collective even at world 1 (a one-rank RCCL all-reduce: used to exercise the device path)."""
         import torch.distributed as dist
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -114,9 +115,10 @@ class GradientBucket:
             elif p.grad.data_ptr() != v.data_ptr():        # someone re-created .grad: copy in
                 v.copy_(p.grad)
                 p.grad = v
-        if world > 1:
+        if world > 1 or force:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(world)
+            if world > 1:
+                self.flat.div_(world)
         return self.flat
 
     def zero(self):
