@@ -27,11 +27,49 @@ __global__ void diff_kernel(const unsigned* a, const unsigned* b, long long n, u
   if (c) atomicAdd(cnt, c);
 }
 
+// ---- FETCH_SIZE / WRITE_SIZE calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own
+// access pattern"): stream n floats once with (a) one dword per lane per instruction through a buffer
+// descriptor -- the conv kernels' window loads -- and (b) one dwordx4 per lane; write n floats once with dword
+// stores.  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `conv_bench 0 0 calib` then shows what the counters
+// report for exactly 1 GiB read / written.
+__global__ void calib_read_dword(const float* x, long long n, float* sink) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0xffffffffu, 0x00020000);
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)(i * 4), 0, 0));
+  if (acc == 12345.678f) sink[0] = acc;
+}
+__global__ void calib_read_dwordx4(const float4* x, long long n4, float* sink) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = x[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+__global__ void calib_write_dword(float* y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = (float)i;
+}
+
 struct Case { int B, T, F, dil, act; };
 
 int main(int argc, char** argv) {
   const int Bbig = argc > 1 ? atoi(argv[1]) : 64;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  if (argc > 3 && !strcmp(argv[3], "calib")) {
+    const long long n = 1LL << 28;      // 2^28 floats = exactly 1 GiB
+    float *x, *y, *sink;
+    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&y, n * 4)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(x, 1, n * 4));
+    for (int rep = 0; rep < 3; ++rep) {
+      hipLaunchKernelGGL(calib_read_dword, dim3(4096), dim3(256), 0, nullptr, x, n, sink);
+      hipLaunchKernelGGL(calib_read_dwordx4, dim3(4096), dim3(256), 0, nullptr, (const float4*)x, n / 4, sink);
+      hipLaunchKernelGGL(calib_write_dword, dim3(4096), dim3(256), 0, nullptr, y, n);
+    }
+    CK(hipDeviceSynchronize());
+    printf("calib: 3 x (1 GiB dword read, 1 GiB dwordx4 read, 1 GiB dword write)\n");
+    return 0;
+  }
   const bool prof = argc > 3 && !strcmp(argv[3], "prof");
   std::vector<Case> cases = {
       {2, 19, 37, 1, 1}, {1, 23, 70, 2, 1}, {2, 21, 133, 4, 0}, {1, 50, 64, 8, 1}, {2, 40, 31, 16, 1}, {1, 20, 37, 16, 2},

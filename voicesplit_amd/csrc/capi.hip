@@ -78,7 +78,7 @@ int layout(const vs_dims* d, vs_ws_layout* L) {
   for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
   L->bn_scale = take(8 * 64 * 4);
   L->bn_shift = take(8 * 64 * 4);
-  L->bn_stats = take(8 * 64 * 2 * 8);
+  L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);    // partial slots of one layer at a time (stream-ordered reuse)
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
   L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
   L->conv_scales = take(8 * VS_SCALE_SLOT_FLOATS * 4);
@@ -104,7 +104,7 @@ int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
 
 int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* scales8 /* one scale slot */, int in_amax_ready,
                          const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
-                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t stream) {
+                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t stream, double* bn_stats) {
   if (math != VS_MATH_FP32) {      // split-f16 or single-pass bf16: same operand plumbing (power-of-two scales, packed images)
     if (in_amax_ready) {
       if (int rc = vs_scale_from_absmax_impl(vs_amax_slot(scales8), VS_AMAX_SLOTS, scales8, stream)) return rc;
@@ -114,8 +114,9 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
     if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(packed), KT, KF, transpose_flip,
                                          reinterpret_cast<unsigned*>(scales8 + 4), scales8 + 2, stream, math)) return rc;
     return vs_conv64_f16x3_fwd_impl(in, static_cast<const _Float16*>(packed), scale, shift, scales8, scales8 + 2, out,
-                                    B, T, F, KT, KF, dil, act, amax_out, stream, math);
+                                    B, T, F, KT, KF, dil, act, amax_out, stream, math, bn_stats);
   }
+  VS_REQUIRE(bn_stats == nullptr, "conv64 layer: fused BatchNorm statistics are not offered by the fp32 kernels");
   if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(packed), KT, KF, transpose_flip, stream)) return rc;
   return vs_conv64_fwd_impl(in, static_cast<const float*>(packed), scale, shift, out, B, T, F, KT, KF, dil, act, stream);
 }
@@ -340,14 +341,18 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
     const int l = i + 1;
     float* packed = at<float>(ws, L.conv_packed[i]);
     ProfScope ps(VS_PROF_CNN2 + i, stream);
+    const bool fuse = train && f16;        // statistics of this layer accumulated by the conv epilogue
+    if (fuse) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
     if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, cs + VS_SCALE_SLOT_FLOATS * l, 1,
                                       scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
-                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, train ? nullptr : amax_for(l + 1), stream)) return rc;
+                                      kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, train ? nullptr : amax_for(l + 1), stream,
+                                      fuse ? stats : nullptr)) return rc;
     cur ^= 1;
     if (train) {
       if (int rc = vs_bn_train_impl(act[cur], act[cur], B, 64, T * F, p->conv[l].bn_weight, p->conv[l].bn_bias, p->conv[l].bn_running_mean,
-                                    p->conv[l].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * l,
-                                    scale + 64 * l, shift + 64 * l, nullptr, nullptr, amax_for(l + 1), stream)) return rc;
+                                    p->conv[l].bn_running_var, kBnEps, kBnMomentum, conv_act, stats,
+                                    scale + 64 * l, shift + 64 * l, nullptr, nullptr, amax_for(l + 1), stream,
+                                    fuse ? VS_BN_STAT_SLOTS : 0)) return rc;
     }
   }
   // cnn8, written straight into the LSTM feature layout
@@ -355,7 +360,7 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   if (int rc = vs_conv_last_fwd_impl(act[cur], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat, B, T, F, layer_act, stream)) return rc;
   if (train) {
     if (int rc = vs_bn_train_feat_impl(feat, feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
-                                       p->conv[7].bn_running_var, kBnEps, kBnMomentum, conv_act, stats + 128 * 7,
+                                       p->conv[7].bn_running_var, kBnEps, kBnMomentum, conv_act, stats,
                                        scale + 64 * 7, shift + 64 * 7, nullptr, nullptr, stream)) return rc;
   }
   return 0;

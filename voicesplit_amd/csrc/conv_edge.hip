@@ -297,13 +297,28 @@ int vs_conv_last_fwd_impl(const float* in, const float* w, const float* scale, c
 // Train-mode BatchNorm over a raw conv output x held as [B][C][T*F]:
 // statistics -> scale/shift (+ running buffers, + mean/invstd when requested) -> y = act(BN(x)).
 // y may alias x (in place, inference-only callers) or be a separate buffer (training keeps x).
+// stats_slots > 0: the conv that produced x already accumulated {sum, sum of squares} of every channel into
+// `stats_slots` partial slots of [C][2] doubles (its epilogue: conv_f16x3*.hip STATS); they are folded into slot 0
+// here and the statistics pass over x is skipped.
+__global__ void bn_stats_fold_kernel(double* __restrict__ stats, int n, int slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < slots; ++k) v += stats[(size_t)k * n + i];
+  stats[i] = v;
+}
+
 int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float eps, float momentum, int act,
                      double* stats /* [C][2] */, float* scale, float* shift, float* mean_out, float* invstd_out,
-                     unsigned* amax_out, hipStream_t stream) {
+                     unsigned* amax_out, hipStream_t stream, int stats_slots) {
   VS_REQUIRE(B > 0 && C > 0 && plane > 0 && B <= 65535 && C <= 65535, "bn_train: bad shape B=%d C=%d plane=%d", B, C, plane);
-  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(vs_bn_blocks_per_channel(C, B, plane), C), dim3(256), 0, stream, x, C, (long long)B, plane, stats);
+  if (stats_slots > 0) {
+    hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, stats_slots);
+  } else {
+    VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(vs_bn_blocks_per_channel(C, B, plane), C), dim3(256), 0, stream, x, C, (long long)B, plane, stats);
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)B * plane, gamma, beta,
                      eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
   return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, amax_out, stream);

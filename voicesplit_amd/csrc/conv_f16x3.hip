@@ -121,13 +121,14 @@ __global__ void conv_pack_weights_f16_kernel(const float* __restrict__ w, _Float
   wp[idx] = part ? lo[0] : hi[0];
 }
 
-template <int KT, int KF, int P, int ACT, int NTERM = 3>
+template <int KT, int KF, int P, int ACT, int NTERM = 3, bool STATS = false>
 __global__ __launch_bounds__(256, 2)
 void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
                          const float* __restrict__ in_scale, const float* __restrict__ w_scale,
                          float* __restrict__ out, int T, int F, int dil, int n_rt, int n_ft, unsigned* amax_out,
-                         int i_base, int i_end) {     // this launch covers rows [i_base, i_end) of every residue class
+                         int i_base, int i_end,       // this launch covers rows [i_base, i_end) of every residue class
+                         double* bn_stats = nullptr) {   // STATS: [VS_BN_STAT_SLOTS][64][2] partial {sum, sum of squares} of the output
   constexpr int R = 4 * P;
   constexpr int ROWS = R + KT - 1;
   constexpr int PX = kTileF + KF - 1 + ((kTileF + KF - 1) % 4 ? 4 - (kTileF + KF - 1) % 4 : 0);   // multiple of 4
@@ -328,35 +329,69 @@ void conv64_f16x3_kernel(const float* __restrict__ in, const _Float16* __restric
     }
   }
 
-  if (!wave_active) return;
+  if (!STATS && !wave_active) return;
   const int f = f0 + l31;
   float* out_b = out + (size_t)b * kCo * plane;
   float m = 0.f;
+  float stS[2][16], stQ[2][16];      // STATS: this lane's sums over its rows, per (co block, register)
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const float sc = scale[co] * inv, sh = shift[co];
+      stS[cb][r] = 0.f; stQ[cb][r] = 0.f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = i0 + wave * P + p;
-        if (i < n_c && f < F) {
+        if (wave_active && i < n_c && f < F) {
           const int t = cls + dil * i;
           const float y = vs_act_fast<ACT>(fmaf(acc[cb][p][r], sc, sh));
           out_b[(size_t)co * plane + (size_t)t * F + f] = y;
           m = fmaxf(m, fabsf(y));
+          if (STATS) { stS[cb][r] += y; stQ[cb][r] = fmaf(y, y, stQ[cb][r]); }
         }
       }
     }
   }
   vs_absmax_commit(m, amax_out);     // the output is the next layer's operand
+  if (STATS) {
+    // train-mode BatchNorm statistics of this layer (same scheme as conv_f16x3_pk.hip): half-wave
+    // reduction (32 lanes share their channels), the four waves through LDS, one fp64 atomic per channel
+    // and statistic into one of VS_BN_STAT_SLOTS partial slots (spreads ~10^4 workgroups over 64 addresses each)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = stS[cb][r], qv = stQ[cb][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+        stS[cb][r] = sv; stQ[cb][r] = qv;
+      }
+    __syncthreads();                              // everyone is done with the LDS window
+    float* red = reinterpret_cast<float*>(sIn);    // [4 waves][64 co][2]
+    if (l31 == 0) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          red[(wave * 64 + co) * 2 + 0] = stS[cb][r];
+          red[(wave * 64 + co) * 2 + 1] = stQ[cb][r];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const double v = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
+      atomicAdd(bn_stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + tid, v);
+    }
+  }
 }
 
 template <int KT, int KF, int P>
 int launch_conv(const float* in, const _Float16* wp, const float* scale, const float* shift, const float* in_scale,
                 const float* w_scale, float* out, int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream,
-                int i_base = 0, int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3) {
+                int i_base = 0, int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3, double* bn_stats = nullptr) {
   constexpr int R = 4 * P;
   const int rows_all = (T + dil - 1) / dil;
   const int rows_max = (rows_all < i_end ? rows_all : i_end) - i_base;
@@ -365,20 +400,27 @@ int launch_conv(const float* in, const _Float16* wp, const float* scale, const f
   const long long nblk = (long long)B * dil * n_rt * n_ft;
   VS_REQUIRE(nblk > 0 && nblk < 2147483647LL, "conv64_f16x3: grid of %lld blocks out of range", nblk);
   dim3 grid((unsigned)nblk), block(256);
+  if (bn_stats) {        // train-mode forward: conv + bias, statistics fused into the epilogue
+    VS_REQUIRE(act == VS_ACT_NONE, "conv64_f16x3: fused BatchNorm statistics need act = NONE");
+    if (math == VS_MATH_CODE_BF16) hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE, 1, true>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, bn_stats);
+    else hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE, 3, true>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, bn_stats);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   if (math == VS_MATH_CODE_BF16) {
     switch (act) {
-      case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
-      case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
-      case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+      case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
+      case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
+      case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE, 1>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
       default: VS_REQUIRE(false, "conv64_f16x3: unknown activation %d", act);
     }
     VS_LAUNCH_CHECK();
     return 0;
   }
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_RELU>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_MISH>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL((conv64_f16x3_kernel<KT, KF, P, VS_ACT_NONE>), grid, block, 0, stream, in, wp, scale, shift, in_scale, w_scale, out, T, F, dil, n_rt, n_ft, amax_out, i_base, i_end, (double*)nullptr); break;
     default: VS_REQUIRE(false, "conv64_f16x3: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
@@ -450,7 +492,8 @@ extern "C" int vs_set_conv_kernel(int mode) {
 
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
-                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream, int math) {
+                             int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t stream, int math,
+                             double* bn_stats) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kChunk * T * F * 4 < (long long)kOob, "conv64_f16x3: T*F=%lld too large for 32-bit slab offsets", (long long)T * F);
   if (KT == 5 && KF == 5 && g_conv_kernel != 1 && (long long)kCo * T * F * 4 < (long long)kOob) {
@@ -459,8 +502,8 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
     const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
     const bool tail = full8 > 0 && rem > 0 && rem <= 4;
     if (int rc = vs_conv64_f16x3_pk_impl(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream,
-                                         g_conv_kernel >= 100 ? g_conv_kernel - 100 : 0, tail ? full8 : 0x7fffffff, math)) return rc;
-    return tail ? launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math) : 0;
+                                         g_conv_kernel >= 100 ? g_conv_kernel - 100 : 0, tail ? full8 : 0x7fffffff, math, bn_stats)) return rc;
+    return tail ? launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math, bn_stats) : 0;
   }
   // 8-row tiles (P = 2) amortise the KT-1 halo rows and the weight staging over twice the MFMAs
   // (measured 6.6 vs 7.45 ms per layer at equal padding); 4-row tiles only win when they avoid
@@ -471,16 +514,16 @@ int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* s
   // running everything on the less efficient 4-row tiles or padding a third 8-row tile.
   const int rows_all = (T + dil - 1) / dil, full8 = rows_all / 8 * 8, rem = rows_all - full8;
   if (KT == 5 && KF == 5 && full8 > 0 && rem > 0 && rem <= 4) {
-    if (int rc = launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, full8, math)) return rc;
-    return launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math);
+    if (int rc = launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, full8, math, bn_stats)) return rc;
+    return launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, full8, 0x7fffffff, math, bn_stats);
   }
   if (KT == 7 && KF == 1) {
-    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math)
-              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math);
+    return p2 ? launch_conv<7, 1, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math, bn_stats)
+              : launch_conv<7, 1, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math, bn_stats);
   }
   if (KT == 5 && KF == 5) {
-    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math)
-              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math);
+    return p2 ? launch_conv<5, 5, 2>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math, bn_stats)
+              : launch_conv<5, 5, 1>(in, wp, scale, shift, in_scale2, w_scale2, out, B, T, F, dil, act, amax_out, stream, 0, 0x7fffffff, math, bn_stats);
   }
   VS_REQUIRE(false, "conv64_f16x3: unsupported kernel %dx%d", KT, KF);
   return -1;

@@ -53,6 +53,7 @@ struct PkArgs {
   const float* w_scale;
   float* out;
   unsigned* amax_out;
+  double* bn_stats;       // [VS_BN_STAT_SLOTS][64][2] partial {sum z, sum z^2} accumulated by the STATS instances (train-mode BatchNorm), else NULL
   int B, T, F, dil, n_rt, n_ft, i_base, i_end;
   int rows_q, rows_r;     // T / dil, T % dil: residue class c has rows_q + (c < rows_r) rows
   long long n_tiles;
@@ -135,9 +136,12 @@ __device__ __forceinline__ Tile seek_tile(TileWalk& w, const PkArgs& a) {
 // ABL: timing ablations (results are garbage unless 0): 1 = no fragment reads, 2 = no staging (window and
 // weight loads / conversions / LDS writes), 4 = no in-loop epilogue, 8 = no barriers.
 // FILL > 0: pin the issue pattern of a tap to (1 MFMA, up to FILL other instructions) x 12.
+// STATS: the epilogue also accumulates the per-channel sum and sum of squares of what it stores (train-mode
+// BatchNorm statistics of the layer, SURVEY.md 7 hard-part 3): per-lane fp32 partial sums over all tiles of the
+// workgroup, combined across lanes / waves once at the end, one fp64 atomicAdd per channel and workgroup.
 // NT: product terms per fp32 product: 3 = split f16 (hi*hi + hi*lo + lo*hi), 1 = single-pass bf16 (VS_MATH_BF16:
 // operands rounded to bf16, the lo slots of the LDS images stay unused).
-template <int P, int ACT, int ABL = 0, int FILL = 0, int NT = 3>
+template <int P, int ACT, int ABL = 0, int FILL = 0, int NT = 3, bool STATS = false>
 __global__ __launch_bounds__(256, 1)
 void conv64_f16x3_pk_kernel(PkArgs a) {
   constexpr int R = 4 * P;
@@ -278,13 +282,25 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
     e_tab[s] = sSc + cb * 32 + 4 * half;
   };
   // element r of the slice: out[b][co][t][f] = act(accE * scale[co]*inv + shift[co]), co = cb*32 + cr + 4*half
-  auto epilogue_elem = [&](int s, const f32x16& v, int r, float sc, float sh) {
+  // STATS: stS/stQ[0] belong to the co block whose slices are being retired, [1] to the other one; the two
+  // swap when the retiring slices move to the other co block (static register indices throughout)
+  float stS[2][16], stQ[2][16];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { stS[k][r] = 0.f; stQ[k][r] = 0.f; }
+  auto epilogue_elem = [&](int s, const f32x16& v, int r, float sc, float sh, int slot = 0) {
     const int cr = (r & 3) + 8 * (r >> 2);
     float vr = v[r];
     asm volatile("" : "+v"(vr));        // opaque here: the element's arithmetic cannot be hoisted out of its tap
     const float y = vs_act_fast<ACT>(fmaf(vr, sc, sh));
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), orsrc, e_voff[s], cr * plane_bytes, 0);
     e_max = e_ok[s] ? fmaxf(e_max, fabsf(y)) : e_max;
+    if (STATS) {
+      const float yz = e_ok[s] ? y : 0.f;
+      stS[slot][r] += yz;
+      stQ[slot][r] = fmaf(yz, yz, stQ[slot][r]);
+    }
   };
 
   TileWalk walk;
@@ -444,6 +460,18 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
       // retire the slices handled in this chunk: accE[s] <- accE[s + SPC]
 #pragma unroll
       for (int s = 0; s + SPC < NSL; ++s) accE[s] = accE[s + SPC];
+      if (STATS) {
+        // slices are retired in the order q = cb*P + p: the co block changes after chunk (P/SPC - 1) and after the last
+        constexpr int CPB = P / SPC;                 // chunks per co block (2 for P = 2)
+        if (chunk % CPB == CPB - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a0 = stS[0][r], q0 = stQ[0][r];
+            stS[0][r] = stS[1][r]; stQ[0][r] = stQ[1][r];
+            stS[1][r] = a0; stQ[1][r] = q0;
+          }
+        }
+      }
     }
 
     // ---- tile done: its accumulators become the pending epilogue --------------------------------------
@@ -468,10 +496,39 @@ void conv64_f16x3_pk_kernel(PkArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cr = (r & 3) + 8 * (r >> 2);
-      epilogue_elem(0, accE[q], r, e_tab[0][cr], e_tab[0][64 + cr]);
+      epilogue_elem(0, accE[q], r, e_tab[0][cr], e_tab[0][64 + cr], q / P);     // after whole tiles slot k = co block k
     }
   }
   vs_absmax_commit(e_max, a.amax_out);
+  if (STATS) {
+    // lanes of one half-wave hold the same 32 channels: co = cb*32 + cr(r) + 4*half
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = stS[k][r], qv = stQ[k][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+        stS[k][r] = sv; stQ[k][r] = qv;
+      }
+    __syncthreads();                             // every wave is out of the pipeline: the LDS is free
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][64 co][2]
+    if (l31 == 0) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          red[(wave * 64 + co) * 2 + 0] = stS[k][r];
+          red[(wave * 64 + co) * 2 + 1] = stQ[k][r];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const double v = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
+      atomicAdd(a.bn_stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + tid, v);     // tid = co*2 + {0: sum, 1: sum of squares}
+    }
+  }
 }
 
 template <int P>
@@ -515,6 +572,13 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
     VS_LAUNCH_CHECK();
     return 0;
   }
+  if (a.bn_stats) {      // train-mode forward: conv + bias, no activation, statistics fused
+    VS_REQUIRE(act == VS_ACT_NONE, "conv64_f16x3_pk: fused BatchNorm statistics need act = NONE");
+    if (math == VS_MATH_CODE_BF16) hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_NONE, 0, 0, 1, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_NONE, 0, 0, 3, true>), grid, block, 0, stream, a);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   if (math == VS_MATH_CODE_BF16) {
     switch (act) {
       case VS_ACT_RELU: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_RELU, 0, 0, 1>), grid, block, 0, stream, a); break;
@@ -541,9 +605,9 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
 int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                             const float* in_scale2, const float* w_scale2, float* out,
                             int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t stream, int abl,
-                            int i_end, int math) {
+                            int i_end, int math, double* bn_stats) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "conv64_f16x3_pk: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((long long)kCo * T * F * 4 < (long long)kOob, "conv64_f16x3_pk: T*F=%lld too large for 32-bit offsets", (long long)T * F);
-  PkArgs a{in, wp, scale, shift, in_scale2, w_scale2, out, amax_out, B, T, F, dil, 0, 0, 0, 0, 0, 0, 0};
+  PkArgs a{in, wp, scale, shift, in_scale2, w_scale2, out, amax_out, bn_stats, B, T, F, dil, 0, 0, 0, 0, 0, 0, 0};
   return launch_pk<2>(a, act, 0, i_end, stream, abl, math);
 }

@@ -57,7 +57,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   L->lstm_state = take(vs_lstm_state_floats(d->B, d->H) * 4);
   L->lstm_bwd_state = take(vs_lstm_bwd_state_floats(d->B, d->H) * 4);
   L->consts = take(128 * 4);
-  L->bn_stats = take(64 * 2 * 8);
+  L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);
   L->bn_coef = take(3 * 64 * 4);
   L->first_acc = take(448 * 8);
   L->colsum_tmp = take(B * max3(8 * H, d->FC1, d->FC2) * 4);
@@ -139,7 +139,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   const bool f16 = d->math != VS_MATH_FP32;
   if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 16 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
   // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
-  auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout) -> int {
+  auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout, int stats_slots = 0) -> int {
     VsProfScope ps(VS_PROF_FWD_BN, stream);
     const vs_conv_layer& c = p->conv[l];
     unsigned* amax = (f16 && l + 1 <= 6) ? vs_amax_slot(cs + VS_SCALE_SLOT_FLOATS * (l + 1)) : nullptr;
@@ -149,7 +149,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
                  ? vs_bn_train_feat_impl(z, a, B, T, F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
                                          kBnMomentum, conv_act, stats, sc, sh, mu, is, stream)
                  : vs_bn_train_impl(z, a, B, C, T * F, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
-                                    kBnMomentum, conv_act, stats, sc, sh, mu, is, amax, stream);
+                                    kBnMomentum, conv_act, stats, sc, sh, mu, is, amax, stream, stats_slots);
     }
     if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, C, sc, sh, mu, is, stream)) return rc;
     return feat_layout ? vs_bn_apply_feat_impl(z, a, B, T, F, conv_act, sc, sh, stream)
@@ -164,13 +164,17 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   for (int i = 0; i < 6; ++i) {
     const int l = i + 1;
     float* packed = at<float>(tape, L.conv_packed[i]);
+    // batch statistics of z accumulated by the conv epilogue itself (split-f16 / bf16 kernels): one pass less over z
+    const bool fuse = train && f16;
     {
       VsProfScope ps(VS_PROF_CNN2 + i, stream);
+      if (fuse) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
       if (int rc = vs_conv64_layer_impl(d->math, at<float>(tape, L.a[l - 1]), p->conv[l].weight, packed,
                                         cs + VS_SCALE_SLOT_FLOATS * l, 1, ones, p->conv[l].bias, at<float>(tape, L.z[l]),
-                                        B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 0, nullptr, stream)) return rc;
+                                        B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 0, nullptr, stream,
+                                        fuse ? stats : nullptr)) return rc;
     }
-    if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false)) return rc;
+    if (int rc = bn(l, at<float>(tape, L.z[l]), at<float>(tape, L.a[l]), 64, false, fuse ? VS_BN_STAT_SLOTS : 0)) return rc;
   }
   {
     VsProfScope ps(VS_PROF_CNN8, stream);

@@ -110,6 +110,8 @@ __device__ __forceinline__ float vs_act_rt(float v, int act) {
 // spreads the atomics of ~10^5 workgroups over 1024 addresses (one address serialises them in L2:
 // +40 ms per training step when tried) and a plain load first skips the atomic when it cannot
 // raise the slot (a stale value only costs a redundant atomic).  out == nullptr: no-op.
+// partial-sum slots of the BatchNorm statistics the conv epilogues accumulate ([slot][64 channels][2] doubles)
+#define VS_BN_STAT_SLOTS 64
 #define VS_AMAX_SLOTS 1024
 __device__ __forceinline__ void vs_absmax_commit(float m, unsigned* out) {
   if (out == nullptr) return;

@@ -43,12 +43,12 @@ int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int tr
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                              const float* in_scale2, const float* w_scale2, float* out,
                              int B, int T, int F, int KT, int KF, int dil, int act, unsigned* amax_out, hipStream_t,
-                             int math = VS_MATH_CODE_F16X3);
+                             int math = VS_MATH_CODE_F16X3, double* bn_stats = nullptr);
 // conv_f16x3_pk.hip: persistent, software-pipelined form of the 5x5 kernel (same contract, bit-identical results)
 int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,
                             const float* in_scale2, const float* w_scale2, float* out,
                             int B, int T, int F, int dil, int act, unsigned* amax_out, hipStream_t, int ablation = 0,
-                            int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3);
+                            int i_end = 0x7fffffff, int math = VS_MATH_CODE_F16X3, double* bn_stats = nullptr);
 // One 64->64 conv launch in either arithmetic: packs the weights (transpose_flip for the data
 // gradient) into `packed`.  Split-f16 mode keeps its operand scales in one "scale slot" of
 // VS_SCALE_SLOT_FLOATS floats: [0..1] input {s, 1/s}, [2..3] weight {s, 1/s}, [4] uint |max| of
@@ -59,7 +59,8 @@ int vs_conv64_f16x3_pk_impl(const float* in, const _Float16* wp, const float* sc
 #define VS_SCALE_SLOT_FLOATS (8 + VS_AMAX_SLOTS)
 int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed, float* slot, int in_amax_ready,
                          const float* scale, const float* shift, float* out, int B, int T, int F, int KT, int KF,
-                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t);
+                         int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t,
+                         double* bn_stats = nullptr);   // split-f16 / bf16 only: fused train-mode BatchNorm statistics of `out`
 inline unsigned* vs_amax_slot(float* slot) { return reinterpret_cast<unsigned*>(slot + 8); }
 // conv_edge.hip
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
@@ -67,7 +68,8 @@ int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float
 int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
-                     float* scale, float* shift, float* mean_out, float* invstd_out, unsigned* amax_out, hipStream_t);
+                     float* scale, float* shift, float* mean_out, float* invstd_out, unsigned* amax_out, hipStream_t,
+                     int stats_slots = 0);
 int vs_bn_train_feat_impl(const float* x, float* y, int B, int T, int F, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float eps, float momentum, int act, double* stats,
                           float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
