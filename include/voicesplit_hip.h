@@ -274,8 +274,9 @@ int vs_conv64_wgrad(const float* dz, const float* in, float* partials, float* dw
 int vs_conv64_wgrad_f16x3(const float* dz, const float* in, float* partials, float* dw, float* scratch8,
                           int B, int T, int F, int KT, int KF, int dil, void* stream);
 /* which split-f16 weight-gradient kernel vs_conv64_wgrad_f16x3 / vs_backward launch: 0 = by problem
- * size (default: the ring kernel once every workgroup gets >= 2 columns, else the kt-split kernel),
- * 1 = ring, 2 = kt-split.  Process-wide; returns -1 for an unknown mode. */
+ * size (default: a ring kernel once every workgroup gets >= 2 columns -- the four-wave form for 5x5 --
+ * else the kt-split kernel), 1 = eight-wave ring, 2 = kt-split, 3 = four-wave ring (5x5; 7x1 falls back
+ * to the eight-wave ring).  Process-wide; returns -1 for an unknown mode. */
 int vs_set_wgrad_kernel(int mode);
 /* which 5x5 split-f16 forward / data-gradient kernel vs_conv64_f16x3_fwd and the whole-path calls
  * launch: 0 = default (the persistent pipelined kernel, csrc/conv_f16x3_pk.hip), 1 = one tile per

@@ -44,14 +44,14 @@ CONV_BWD_CASES = [
     (5, 5, 1, 1, 70, 37),      # ring kernel: the column is cut into 2 chunks of 35 steps (rows k0-2, k0-1 pre-loaded)
     (7, 1, 1, 2, 100, 64),     # ring kernel: 3 chunks, 3 pre-loaded rows each
 ]
-WGRAD_MATH = ["fp32", "f16x3:ring", "f16x3:ktsplit"]     # both split-f16 weight-gradient kernels on every shape
+WGRAD_MATH = ["fp32", "f16x3:ring", "f16x3:ktsplit", "f16x3:ring4"]     # every split-f16 weight-gradient kernel on every shape
 
 
 class _wgrad_kernel:
     """Pin the split-f16 weight-gradient kernel (vs_set_wgrad_kernel) for the duration of a test."""
 
     def __init__(self, math):
-        self.mode = {"ring": 1, "ktsplit": 2}.get(math.partition(":")[2], 0)
+        self.mode = {"ring": 1, "ktsplit": 2, "ring4": 3}.get(math.partition(":")[2], 0)
 
     def __enter__(self):
         from voicesplit_amd import _lib

@@ -70,6 +70,62 @@ int main(int argc, char** argv) {
     printf("calib: 3 x (1 GiB dword read, 1 GiB dwordx4 read, 1 GiB dword write)\n");
     return 0;
   }
+  if (argc > 3 && !strcmp(argv[3], "wgrad")) {
+    // weight-gradient ring kernel (5x5): default vs timing ablations, random and zero operands
+    const int B = Bbig, T = 301, F = 601;
+    const long long n = (long long)B * 64 * T * F;
+    float *dz, *in, *part, *dw, *dw2, *scr;
+    CK(hipMalloc(&dz, n * 4)); CK(hipMalloc(&in, n * 4));
+    CK(hipMalloc(&part, vs_conv64_wgrad_partial_floats(5, 5) * 4)); CK(hipMalloc(&dw, 64 * 64 * 25 * 4)); CK(hipMalloc(&dw2, 64 * 64 * 25 * 4));
+    CK(hipMalloc(&scr, 64));
+    {
+      std::vector<float> h(n);
+      for (long long i = 0; i < n; ++i) h[i] = frand() * 2.0f;
+      CK(hipMemcpy(dz, h.data(), n * 4, hipMemcpyHostToDevice));
+      for (long long i = 0; i < n; ++i) h[i] = frand() * 3.0f;
+      CK(hipMemcpy(in, h.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double gflop = 2.0 * 64 * 64 * 25 * (double)B * T * F / 1e9;
+    auto timeit = [&](int mode, int dil, const char* what) {
+      VS(vs_set_wgrad_kernel(mode));
+      CK(hipMemset(scr, 0, 64));
+      VS(vs_conv64_wgrad_f16x3(dz, in, part, dw, scr, B, T, F, 5, 5, dil, nullptr));
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) VS(vs_conv64_wgrad_f16x3(dz, in, part, dw, scr, B, T, F, 5, 5, dil, nullptr));
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      printf("  dil=%-2d %-52s %.3f ms  (%.0f TF algorithmic; includes 2 operand |max| passes ~0.25 ms)\n", dil, what, ms, gflop / ms);
+    };
+    if (argc > 4) {          // one variant only (for counter passes): tools/conv_bench 64 3 wgrad <mode>
+      timeit(atoi(argv[4]), 1, "selected variant");
+      return 0;
+    }
+    printf("wgrad ring kernel 5x5, B=%d (random operands):\n", B);
+    for (int dil : {1, 4, 16}) timeit(1, dil, "eight-wave ring kernel (round 1)");
+    for (int dil : {1, 4, 16}) timeit(3, dil, "four-wave ring kernel");
+    timeit(164, 1, "  - every load out of range (no memory access)");
+    timeit(168, 1, "  - loads only + out of range");
+    timeit(228, 1, "  - every load from the slab's first 64 KB (L2-hot)");
+    timeit(232, 1, "  - loads only + L2-hot");
+    timeit(356, 1, "  - all staging pieces behind K block 3");
+    timeit(101, 1, "  - fragments read once per step");
+    timeit(102, 1, "  - no staging (loads, conversion, LDS writes)");
+    timeit(108, 1, "  - no barriers");
+    timeit(104, 1, "  - loads issued + waited for, no conversion / LDS writes");
+    timeit(116, 1, "  - conversion + LDS writes, no loads");
+    timeit(103, 1, "  - no staging, fragments once");
+    timeit(111, 1, "  - MFMA stream only");
+    CK(hipMemset(in, 0, n * 4));
+    printf("same, all-zero input operand:\n");
+    timeit(1, 1, "eight-wave ring kernel, zero input");
+    timeit(3, 1, "four-wave ring kernel, zero input");
+    timeit(111, 1, "  - MFMA stream only, zero input");
+    VS(vs_set_wgrad_kernel(0));
+    return 0;
+  }
   const bool prof = argc > 3 && !strcmp(argv[3], "prof");
   std::vector<Case> cases = {
       {2, 19, 37, 1, 1}, {1, 23, 70, 2, 1}, {2, 21, 133, 4, 0}, {1, 50, 64, 8, 1}, {2, 40, 31, 16, 1}, {1, 20, 37, 16, 2},

@@ -22,6 +22,8 @@
 // row lies outside the image contribute nothing and are skipped (10 % of the rows at dil = 16).
 // The partial sums of the G workgroups of each kt go to a workspace and are summed in a fixed
 // order by conv64_wgrad_reduce_kernel (deterministic, no atomics).
+#include <type_traits>
+
 #include "vs_common.h"
 
 namespace {
@@ -1348,13 +1350,497 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
   }
 }
 
+// =================================================================================================
+// 5x5 ring kernel, four waves per workgroup (one per SIMD, up to 512 registers each).
+//
+// Why a second form (round 2, profiles/r02_conv_ablation.md): in the eight-wave kernel above the K-block
+// loop tests `ok0` / `ok4` and switches on the tap group INSIDE every product term, which cuts a term into
+// 2-3 basic blocks of 1-5 MFMAs; with staging, fragment reads and barriers ablated away that stream still
+// left the matrix pipe idle ~40 % of the cycles.  Making the loop straight-line needs registers the
+// eight-wave form does not have (256 per wave, all used: the in-flight rows of the next step were spilled
+// and every step waited for HBM).  Here a wave is (co block, tap half): half 0 owns time taps kt = 0,1 and
+// kf = 0,1,2 of kt = 4, half 1 owns kt = 2,3 and kf = 3,4 of kt = 4 -- 13 / 12 accumulators (a 4 % imbalance
+// instead of 7 / 6), 208 accumulator registers, no spill.  Interior steps (all three input rows of the wave
+// inside the image) run a straight-line K-block loop specialised on the tap half; the first / last two
+// steps of a column keep a generic loop.  Products are issued hi*hi, lo*hi, hi*lo so that the two that share
+// the hi windows come first and the lo windows reuse their registers.  Same staging, ring, barriers,
+// chunking and partial-sum layout as the eight-wave kernel; results agree to summation order.
+// ABL: timing ablations (results are garbage unless 0): 1 = fragments read once per step, 2 = no staging
+// (global loads, conversion, LDS writes), 8 = no barriers.
+// =================================================================================================
+template <bool CK, bool BF = false, int ABL = 0>
+__global__ __launch_bounds__(256, 1)
+void conv64_wgrad_ring4_kernel(WgradRingArgs g) {
+  constexpr int KT = 5, KF = 5;
+  constexpr int NTHR = 256;
+  constexpr int P = KT / 2, PADF = KF / 2;
+  constexpr int CH = KF == 5 ? 32 : 64;            // input channels per workgroup
+  constexpr int NH = 64 / CH;                      // workgroups per group
+  constexpr int NACC = 13;
+  constexpr int NQA = (kNF + KF - 1 + 3) / 4;      // 16-byte groups per input row segment: 17 / 16
+  constexpr int RPP = NTHR / NQA;                  // input channel rows one pass of the workgroup covers: 15
+  constexpr int NIA = (CH + RPP - 1) / RPP;        // passes: thread -> (channel tid / NQA + RPP * pass, group tid % NQA),
+                                                   // the SAME group (= pixel mask) in every pass
+  constexpr int NID = 64 * 16 / NTHR;              // 16-byte groups of the dz row per thread
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+  constexpr bool DB = KF == 5;                     // double-buffered LDS: ring of KT+1 slots, two dz buffers
+  constexpr int NS = DB ? KT + 1 : KT;             // ring slots
+  constexpr int NDZ = DB ? 2 : 1;
+  constexpr int D = DB ? 1 : 2;                    // steps in flight in registers
+  unsigned* const sD = smem;                       // [NDZ][hi, lo][64 rows][kPW]
+  unsigned* const sA = smem + NDZ * 2 * 64 * kPW;  // [NS slots][hi, lo][CH rows][kPW]
+
+  const int tid = threadIdx.x;
+  // every ring slot holds finite values from the start (border steps multiply stale slots by zero, see compute)
+  for (int i = tid; i < (NDZ * 2 * 64 + NS * 2 * CH) * kPW; i += NTHR) smem[i] = 0u;
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int hh = NH == 2 ? (jj & 1) : 0;                       // which 32 input channels
+  const int grp = (NH == 2 ? (jj >> 1) : jj) * 8 + xcd;
+  const int cb = wave & 1, nb = 0, th = wave >> 1;             // co block, (ci block), tap half
+  const int rowd = (cb * 32 + l31) * kPW + 4 * half;            // dword index of this lane's dz fragment, K-block 0
+  const int rowa = (nb * 32 + l31) * kPW + 4 * half;
+  const int chl = tid / NQA, qa = tid - chl * NQA, qd = tid & 15;   // staging role: input (channel row, group), dz group
+  unsigned* const dump = smem + (NDZ * 2 * 64 + NS * 2 * CH) * kPW;  // where idle staging lanes write (16 dwords)
+
+  const size_t plane = (size_t)g.T * g.F;
+  const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
+  const long long slab = 64ll * plane_bytes;
+  const float s_dz = g.dz_scale[0], s_in = g.in_scale[0];
+  const int NC = g.B * g.nseg * g.dil * (CK ? g.nchunk : 1);    // columns (x chunks of their steps)
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // column c -> (utterance b, residue r, segment, chunk); rows m = 0..klast of the residue class
+  // (frame t = r + m*dil), this chunk's steps k = k0..k1
+  struct Col { int b, r, f0, nv, klast, k0, k1; };
+  auto decode = [&](int c) {
+    Col o;
+    const int nchunk = CK ? g.nchunk : 1;
+    const int chunk = CK ? c % nchunk : 0;
+    if (CK) c /= nchunk;
+    const int seg = c % g.nseg;
+    const int rest = c / g.nseg;
+    o.r = rest % g.dil;
+    o.b = rest / g.dil;
+    o.f0 = seg * kNF;
+    o.nv = g.F - o.f0 < kNF ? g.F - o.f0 : kNF;
+    o.klast = o.r < g.T ? (g.T - 1 - o.r) / g.dil : -1;
+    const int len = (o.klast + nchunk) / nchunk;               // ceil((klast+1)/nchunk)
+    o.k0 = chunk * len;
+    o.k1 = o.k0 + len - 1 < o.klast ? o.k0 + len - 1 : o.klast;
+    return o;
+  };
+  auto first_col = [&](int c) {                                 // skip empty chunks / residues beyond the last frame
+    while (c < NC) {
+      const Col o = decode(c);
+      if (o.k0 <= o.k1) break;
+      c += g.G;
+    }
+    return c;
+  };
+
+  struct Regs { f4 sd[NID]; f4 sa[P + 1][NIA]; };
+  // kind 0: step k (brings input row k+P and dz row k); 1: first step of a chunk (input rows
+  // k..k+P); 2: a chunk that starts inside its column first brings rows k0-P..k0-1, one per event (k = row)
+  struct Ev { Col c; int col, k, kind; bool valid; };
+  // a 16-byte group that straddles the start or the end of the utterance's slab is split into
+  // dwords (the hardware zeroes the whole out-of-range access, valid pixels included)
+  auto load16 = [&](__amdgpu_buffer_rsrc_t r, long long off, bool live) -> f4 {
+    if (!live || (off >= 0 && off + 16 <= slab))
+      return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, live ? (unsigned)off : kOob, 0, 0));
+    f4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long o = off + 4 * e;
+      x[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (o >= 0 && o < slab) ? (unsigned)o : kOob, 0, 0));
+    }
+    return x;
+  };
+  // rows of one step: dz row k, and input rows 0..P (k == 0) or k+P.
+  // A 16-byte group can only straddle the utterance's slab in the first row (first segment) or the last row (last
+  // segment) of the image -- a block-uniform test; everywhere else the loads are plain 32-bit-offset b128 loads
+  // with no per-lane bounds logic.  (load16's per-lane test expanded to 40-90 instructions around EVERY load:
+  // ~800 instructions per step and thread, as much issue time as the step's 156 MFMAs.)
+  auto fast16 = [&](__amdgpu_buffer_rsrc_t r, int off, bool live) -> f4 {
+    if (ABL & 64) live = false;                                  // ablation: every load out of range (no memory access)
+    if (ABL & 128) off = (unsigned)off % (64u * 1024u) & ~15u;   // ablation: every load from the slab's first 64 KB
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, live ? (unsigned)off : kOob, 0, 0));
+  };
+  auto issue = [&](const Ev& ev, Regs& R) {
+    if ((ABL & 2) || (ABL & 16)) return;
+    const Col& o = ev.c;
+    const int k = ev.k;
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.dz + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.in + (size_t)o.b * 64 * plane), 0, 64u * plane_bytes, 0x00020000);
+    const int t = o.r + k * g.dil;
+    const bool last_seg = o.f0 + kNF + KF - 1 - PADF > g.F;
+    const unsigned base_d = (unsigned)((t * g.F + o.f0) * 4);
+    if (!CK || ev.kind != 2) {
+      const bool risky = !(ABL & 192) && t == g.T - 1 && last_seg;
+#pragma unroll
+      for (int i = 0; i < NID; ++i) {
+        const int idx = tid + NTHR * i;
+        if (!risky) R.sd[i] = fast16(rd, (int)((idx >> 4) * plane_bytes + base_d + (idx & 15) * 16), true);
+        else R.sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j <= P; ++j) {
+      if (j > 0 && ev.kind != 1) break;                         // only a chunk's first step brings P+1 rows
+      const int m = ev.kind == 0 ? k + P : k + j;
+      const bool row_ok = m <= o.klast;
+      const int tm = o.r + m * g.dil;
+      const int base_a = (tm * g.F + o.f0 - PADF) * 4;          // may be negative at the very first pixels
+      const bool risky = !(ABL & 192) && ((tm == 0 && o.f0 < PADF) || (tm >= g.T - 1 && last_seg));
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int ch = chl + RPP * i;
+        const bool live = row_ok && chl < RPP && ch < CH;
+        if (!risky) R.sa[j][i] = fast16(ra, (int)((hh * 32 + ch) * plane_bytes) + base_a + qa * 16, live);
+        else R.sa[j][i] = load16(ra, (long long)(hh * 32 + ch) * plane_bytes + base_a + qa * 16, live);
+      }
+    }
+  };
+  // Pixel masks of a column's segment as scale factors: the operand scale where the pixel is on the row, 0 where it
+  // is not (what was loaded there is a finite value of the neighbouring row).  The staging multiplies by the scale
+  // anyway, so masking costs nothing and needs no branch.  One group per thread and operand: 4 + 4 factors.
+  struct Mask { float dz[4], in[4]; };
+  auto masks_of = [&](const Col& o) {
+    Mask mk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mk.dz[e] = (o.f0 + 4 * qd + e < g.F) ? s_dz : 0.f;
+      mk.in[e] = ((unsigned)(o.f0 - PADF + 4 * qa + e) < (unsigned)g.F) ? s_in : 0.f;
+    }
+    return mk;
+  };
+  // registers -> f16 hi/lo rows in LDS (dz buffer `par`, input row m -> slot m % NS)
+  auto stash = [&](const Ev& ev, const Regs& R, int par) {
+    if (ABL & 2) return;
+    const Col& o = ev.c;
+    const int k = ev.k;
+    const Mask mk = masks_of(o);
+    unsigned* const zh = sD + (size_t)(par * 2) * 64 * kPW;
+    unsigned* const zl = zh + 64 * kPW;
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      if (CK && ev.kind == 2) break;
+      const int idx = tid + NTHR * i;
+      const f4 x = R.sd[i];
+      unsigned h0, l0, h1, l1;
+      split_pair<BF>(x[0] * mk.dz[0], x[1] * mk.dz[1], h0, l0);
+      split_pair<BF>(x[2] * mk.dz[2], x[3] * mk.dz[3], h1, l1);
+      u2v hv, lv;
+      hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+      *reinterpret_cast<u2v*>(&zh[(idx >> 4) * kPW + 2 * qd]) = hv;
+      *reinterpret_cast<u2v*>(&zl[(idx >> 4) * kPW + 2 * qd]) = lv;
+    }
+#pragma unroll
+    for (int j = 0; j <= P; ++j) {
+      if (j > 0 && ev.kind != 1) break;
+      const int m = ev.kind == 0 ? k + P : k + j;
+      if (m > o.klast) continue;                                // never staged, never multiplied
+      unsigned* const dh = sA + (size_t)((m % NS) * 2) * CH * kPW;
+      unsigned* const dl = dh + CH * kPW;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int ch = chl + RPP * i;
+        if (chl < RPP && ch < CH) {
+          const f4 x = R.sa[j][i];
+          unsigned h0, l0, h1, l1;
+          split_pair<BF>(x[0] * mk.in[0], x[1] * mk.in[1], h0, l0);
+          split_pair<BF>(x[2] * mk.in[2], x[3] * mk.in[3], h1, l1);
+          u2v hv, lv;
+          hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+          *reinterpret_cast<u2v*>(&dh[ch * kPW + 2 * qa]) = hv;
+          *reinterpret_cast<u2v*>(&dl[ch * kPW + 2 * qa]) = lv;
+        }
+      }
+    }
+  };
+  // One piece of a regular step's (kind 0) staging: u < NID = a 16-byte group of its dz row, else a group of its
+  // new input row.  compute() places these BETWEEN the MFMAs of the previous step's last two K blocks: with one wave
+  // per SIMD nothing else covers them (the eight-wave kernel has the SIMD's second wave for that).  Straight-line on
+  // purpose -- a piece with a branch in it ends the basic block, and the compiler then runs the whole staging AFTER
+  // the K block's MFMAs instead of under them (that was 2.3 ms of an 8.2 ms launch).  So: pixels off the row are
+  // multiplied by a zero scale (Mask), lanes without a group write to a dump word, and a row beyond the image is
+  // staged as the zeros its out-of-range loads returned.  Both targets are free by construction: the other dz
+  // buffer and the one ring slot the current step does not read.
+  auto stash_unit = [&](const Ev& ev, const Regs& R, int par, int u, const Mask& mk) __attribute__((always_inline)) {
+    if (ABL & 2) return;
+    if (ABL & 4) {      // keep the loads alive (and waited for) without converting them
+      if (u < NID) asm volatile("" :: "v"(R.sd[u])); else asm volatile("" :: "v"(R.sa[0][u - NID]));
+      return;
+    }
+    if (u < NID) {
+      unsigned* const zh = sD + (size_t)(par * 2) * 64 * kPW;
+      unsigned* const zl = zh + 64 * kPW;
+      const int idx = tid + NTHR * u;
+      const f4 x = R.sd[u];
+      unsigned h0, l0, h1, l1;
+      split_pair<BF>(x[0] * mk.dz[0], x[1] * mk.dz[1], h0, l0);
+      split_pair<BF>(x[2] * mk.dz[2], x[3] * mk.dz[3], h1, l1);
+      u2v hv, lv;
+      hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+      *reinterpret_cast<u2v*>(&zh[(idx >> 4) * kPW + 2 * qd]) = hv;
+      *reinterpret_cast<u2v*>(&zl[(idx >> 4) * kPW + 2 * qd]) = lv;
+    } else {
+      const int i2 = u - NID;
+      const int m = ev.k + P;
+      unsigned* const dh = sA + (size_t)((m % NS) * 2) * CH * kPW;
+      const int ch = chl + RPP * i2;
+      const bool ok = chl < RPP && ch < CH;
+      unsigned* const ph = ok ? dh + ch * kPW + 2 * qa : dump;
+      unsigned* const pl = ok ? dh + CH * kPW + ch * kPW + 2 * qa : dump + 2;
+      const f4 x = R.sa[0][i2];
+      unsigned h0, l0, h1, l1;
+      split_pair<BF>(x[0] * mk.in[0], x[1] * mk.in[1], h0, l0);
+      split_pair<BF>(x[2] * mk.in[2], x[3] * mk.in[3], h1, l1);
+      u2v hv, lv;
+      hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
+      *reinterpret_cast<u2v*>(ph) = hv;
+      *reinterpret_cast<u2v*>(pl) = lv;
+    }
+  };
+  // window of tap kf = halves kf .. kf+7 of the 12 read
+  auto tap = [&](const unsigned (&w)[6], int kf) {
+    const int m = kf >> 1;
+    u4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (kf & 1) ? __builtin_amdgcn_alignbit(w[m + q + 1], w[m + q], 16) : w[m + q];
+    return __builtin_bit_cast(h8, r);
+  };
+  auto window = [&](int slot, int kb, unsigned (&wh)[6], unsigned (&wl)[6]) {
+    const unsigned* ph = sA + (size_t)(slot * 2) * CH * kPW + rowa + 8 * kb;
+    const unsigned* pl = ph + CH * kPW;
+    const u4 a = *reinterpret_cast<const u4*>(ph);
+    const u4 c = *reinterpret_cast<const u4*>(pl);
+    wh[0] = a[0]; wh[1] = a[1]; wh[2] = a[2]; wh[3] = a[3];
+    wl[0] = c[0]; wl[1] = c[1]; wl[2] = c[2]; wl[3] = c[3];
+    const u2v a2 = *reinterpret_cast<const u2v*>(ph + 4);
+    const u2v c2 = *reinterpret_cast<const u2v*>(pl + 4);
+    wh[4] = a2[0]; wh[5] = a2[1];
+    wl[4] = c2[0]; wl[5] = c2[1];
+  };
+  auto slot_of = [&](int m) { return ((m % NS) + NS) % NS; };
+  // half-window reader: the hi (part 0) or lo (part 1) image of a ring slot, 12 halves of the lane's row
+  auto window1 = [&](int slot, int kb, int part, unsigned (&w)[6]) {
+    const unsigned* ph = sA + (size_t)(slot * 2 + part) * CH * kPW + rowa + 8 * kb;
+    const u4 a = *reinterpret_cast<const u4*>(ph);
+    const u2v a2 = *reinterpret_cast<const u2v*>(ph + 4);
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = a2[0]; w[5] = a2[1];
+  };
+  // all taps of this wave for one step; its rows are in LDS.  TH = the wave's tap half, compile-time.
+  // nxe / Rn / npar: the rows of a regular next step, in registers; they are converted and written to LDS (dz buffer
+  // npar, the free ring slot) one piece every third MFMA of K blocks 2 and 3.  When the next step is not a regular
+  // one the caller passes a stand-in with the same free targets and the pieces write harmless values there.
+  auto compute = [&](const Ev& ev, int par, auto THc, const Ev& nxe, const Regs& Rn, int npar) __attribute__((always_inline)) {
+    constexpr int TH = decltype(THc)::value;
+    constexpr int KFX0 = TH == 0 ? 0 : 3, NX = TH == 0 ? 3 : 2;      // this half's share of time tap kt = 4: kf KFX0 .. KFX0+NX-1
+    if (CK && ev.kind == 2) return;
+    const Col& o = ev.c;
+    const int k = ev.k;
+    const int nkb = (o.nv + 15) >> 4;
+    const unsigned* const zh = sD + (size_t)(par * 2) * 64 * kPW + rowd;
+    const unsigned* const zl = zh + 64 * kPW;
+    // input rows of time taps kt = 2*TH, 2*TH + 1 and 4
+    const int ma = k + 2 * TH - P, mb = ma + 1, m4 = k + P;
+    const bool oka = ma >= 0 && ma <= o.klast, okb = mb >= 0 && mb <= o.klast, ok4 = m4 <= o.klast;
+    const int sa_ = slot_of(ma), sb_ = slot_of(mb), s4 = slot_of(m4);
+    // A row outside the image (the first / last two steps of a column) was never staged: its ring slot holds
+    // some other row of the column -- finite f16 values, the whole ring is zeroed when the kernel starts -- and
+    // its taps are multiplied by a ZERO dz fragment instead of being branched around: ONE straight-line K-block
+    // loop for every step.  (Two loops -- a fast one and a branchy one for the borders -- made the compiler
+    // keep a second copy of the 208 accumulator registers: 512 registers and spills.)
+    const unsigned ka = oka ? 0xffffffffu : 0u, kb_ = okb ? 0xffffffffu : 0u, k4 = ok4 ? 0xffffffffu : 0u;
+    const Mask mk = masks_of(nxe.c);
+    constexpr int NU = NID + NIA;                 // staging pieces of a regular step
+    constexpr int U2 = (ABL & 256) ? 0 : (NU + 1) / 2;   // pieces 0..U2-1 behind K block 2, the rest behind K block 3
+    constexpr int PER = BF ? 1 : 3;               // one piece every PER MFMAs
+    constexpr int NMF = 10 + NX;                  // MFMAs of a product term
+    // the piece that goes behind MFMA number i of K block kb (if any)
+    auto hook = [&](int kb, int i) __attribute__((always_inline)) {
+      if (kb < 2 || i % PER != 0) return;
+      const int u = (kb == 2 ? 0 : U2) + i / PER;
+      if (u < (kb == 2 ? U2 : NU)) stash_unit(nxe, Rn, npar, u, mk);
+    };
+    // one product term: dz fragment a4 against the windows wa, wb (5 taps each) and x (this half's share of kt = 4)
+    auto term = [&](u4 a4, const unsigned (&wa)[6], const unsigned (&wb)[6], const unsigned (&x)[6], int kb, int i0) __attribute__((always_inline)) {
+      u4 ma_, mb_, mx_;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ma_[q] = a4[q] & ka; mb_[q] = a4[q] & kb_; mx_[q] = a4[q] & k4; }
+      const h8 ava = __builtin_bit_cast(h8, ma_), avb = __builtin_bit_cast(h8, mb_), avx = __builtin_bit_cast(h8, mx_);
+#pragma unroll
+      for (int kf = 0; kf < 5; ++kf) { acc[kf] = wg_mma<BF>(ava, tap(wa, kf), acc[kf], 0, 0, 0); hook(kb, i0 + kf); }
+#pragma unroll
+      for (int kf = 0; kf < 5; ++kf) { acc[5 + kf] = wg_mma<BF>(avb, tap(wb, kf), acc[5 + kf], 0, 0, 0); hook(kb, i0 + 5 + kf); }
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { acc[10 + j] = wg_mma<BF>(avx, tap(x, KFX0 + j), acc[10 + j], 0, 0, 0); hook(kb, i0 + 10 + j); }
+    };
+    // pieces of K block kb that found no MFMA to hide behind (the tap half with 12 MFMAs a term), or all of them
+    auto rest = [&](int kb, int i_from) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < PER * NU; ++i)
+        if (i >= i_from) hook(kb, i);
+    };
+    // Fragments are read one product term ahead: the lo windows of a K block while its two hi-window terms run, the
+    // hi windows and dz fragments of the NEXT K block while the lo-window term runs (the hi windows' registers are
+    // free by then).  Reading them where they are used left the matrix pipe idle for a trip to LDS twice per K block:
+    // 8 x ~450 of a step's ~6500 cycles.
+    unsigned ha[6], hb[6], hx[6];
+    window1(sa_, 0, 0, ha); window1(sb_, 0, 0, hb); window1(s4, 0, 0, hx);
+    u4 dh4 = *reinterpret_cast<const u4*>(zh), dl4 = dh4;
+    if (!BF) dl4 = *reinterpret_cast<const u4*>(zl);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {                // a segment is at most 64 pixels = 4 K blocks
+      if (kb < nkb) {
+        const int kbr = (ABL & 1) ? 0 : kb, kbn = (ABL & 1) ? 0 : kb + 1;
+        if (!BF) {
+          unsigned la[6], lb[6], lx[6];
+          window1(sa_, kbr, 1, la); window1(sb_, kbr, 1, lb); window1(s4, kbr, 1, lx);
+          __builtin_amdgcn_sched_barrier(0);        // reads first: left alone, the scheduler sinks them to their first use
+          term(dh4, ha, hb, hx, kb, 0);
+          term(dl4, ha, hb, hx, kb, NMF);
+          __builtin_amdgcn_sched_barrier(0);        // the next K block's hi windows take over the registers of this one's
+          u4 dhn = dh4, dln = dl4;
+          if (kb < 3) {
+            window1(sa_, kbn, 0, ha); window1(sb_, kbn, 0, hb); window1(s4, kbn, 0, hx);
+            dhn = *reinterpret_cast<const u4*>(zh + 8 * kbn);
+            dln = *reinterpret_cast<const u4*>(zl + 8 * kbn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          term(dh4, la, lb, lx, kb, 2 * NMF);
+          rest(kb, 3 * NMF);
+          dh4 = dhn; dl4 = dln;
+        } else {
+          unsigned na[6], nb_[6], nx[6];
+          u4 dhn = dh4;
+          if (kb < 3) {
+            window1(sa_, kbn, 0, na); window1(sb_, kbn, 0, nb_); window1(s4, kbn, 0, nx);
+            dhn = *reinterpret_cast<const u4*>(zh + 8 * kbn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          term(dh4, ha, hb, hx, kb, 0);
+          rest(kb, NMF);
+          if (kb < 3) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { ha[q] = na[q]; hb[q] = nb_[q]; hx[q] = nx[q]; }
+          }
+          dh4 = dhn;
+        }
+      } else {
+        rest(kb, 0);                                // a short segment: nothing to hide behind
+      }
+    }
+  };
+  auto first_ev = [&](int c) {
+    Ev e;
+    e.col = first_col(c);
+    e.valid = e.col < NC;
+    e.c = decode(e.valid ? e.col : 0);
+    const int pre = e.c.k0 - P > 0 ? e.c.k0 - P : 0;             // first row this chunk has to bring before k0
+    e.kind = (CK && pre < e.c.k0) ? 2 : 1;
+    e.k = (CK && pre < e.c.k0) ? pre : e.c.k0;
+    return e;
+  };
+  auto next_ev = [&](const Ev& e) {
+    Ev n = e;
+    if (CK && e.kind == 2) {
+      if (e.k + 1 < e.c.k0) { n.k = e.k + 1; return n; }
+      n.kind = 1; n.k = e.c.k0;
+      return n;
+    }
+    if (e.k < e.c.k1) { n.kind = 0; n.k = e.k + 1; return n; }
+    return first_ev(e.col + g.G);
+  };
+
+  // Software pipeline.  The rows of step e+1 are in registers R0 while step e is multiplied (7x1:
+  // step e+2 is on its way in R1 as well: a step is shorter than a trip to HBM there).  With the
+  // double-buffered LDS of the 5x5 case a wave writes them right after its own share of step e and
+  // one barrier per step publishes them; a column's first step overwrites live slots and waits
+  // for everyone, as every step of the single-buffered 7x1 ring does.
+  // Software pipeline: the rows of step e+1 are loaded into registers when step e starts and are converted and
+  // written to LDS inside compute(e) (behind its last two K blocks); one barrier per step publishes them.  A
+  // column's first step (and a chunk's pre-load events) overwrite live ring slots: they wait for everyone and are
+  // staged in one piece, as in the eight-wave kernel.  Instantiated per tap half; a wave picks its copy once, so
+  // TH is a compile-time constant inside.
+  auto pipeline = [&](auto THw) __attribute__((always_inline)) {
+    Regs R0;
+    Ev cur = first_ev(grp);
+    if (!cur.valid) return;
+    issue(cur, R0);
+    stash(cur, R0, 0);
+    Ev nxt = next_ev(cur);
+    __syncthreads();
+    int par = 0;
+    while (true) {
+      Ev nn = nxt;
+      if (nxt.valid) {
+        issue(nxt, R0);
+        nn = next_ev(nxt);
+      }
+      const int npar = par ^ 1;
+      // a regular next step is staged inside compute(); anything else (a column's first step, a chunk's pre-load
+      // event) after it, in one piece.  compute()'s staging pieces then get a stand-in with the same free targets
+      // -- the other dz buffer and the ring slot of row cur.k + 1 + P -- and write values nobody reads there.
+      const bool inl = nxt.valid && nxt.kind == 0;
+      Ev standin = cur;
+      standin.k = cur.k + 1;
+      compute(cur, par, THw, inl ? nxt : standin, R0, npar);
+      if (nxt.valid && !inl) {
+        if (!(ABL & 8)) __syncthreads();
+        stash(nxt, R0, npar);
+      }
+      if (!(ABL & 8)) __syncthreads();
+      if (!nxt.valid) break;
+      cur = nxt;
+      nxt = nn;
+      par = npar;
+    }
+  };
+  if (th == 0) pipeline(std::integral_constant<int, 0>());
+  else pipeline(std::integral_constant<int, 1>());
+
+  // acc[a] of this wave -> tap index, block (cb, ci block) of the group's slab
+  float* out = g.part + (size_t)grp * (KT * KF) * 4096;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    int tp;
+    if (a < 10) tp = (2 * th + a / 5) * 5 + a % 5;              // time taps 2*th and 2*th + 1
+    else {
+      const int j = a - 10;
+      if (th == 1 && j >= 2) continue;                           // half 1 owns two taps of kt = 4
+      tp = 4 * 5 + (th == 0 ? j : 3 + j);
+    }
+    const int ci = hh * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)tp * 4096 + co * 64 + ci] = acc[a][r];
+    }
+  }
+}
+
 }  // namespace
 
 static int g_wgrad_kernel = 0;
 // 0: choose by problem size (default), 1: ring kernel, 2: kt-split kernel.  Both compute the same
 // sums in a fixed order each; the unit tests run every shape through both.
 extern "C" int vs_set_wgrad_kernel(int mode) {
-  if (mode < 0 || mode > 2) return -1;
+  // 3 = the four-wave 5x5 ring kernel (default where it applies), 1 = the eight-wave ring kernel, 2 = kt-split;
+  // 100 + ABL: timing ablations of the four-wave kernel
+  if ((mode < 0 || mode > 3) && (mode < 100 || mode > 100 + 511)) return -1;
   g_wgrad_kernel = mode;
   return 0;
 }
@@ -1380,19 +1866,40 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
   int nchunk = (int)((4LL * Gr + ncol - 1) / ncol);
   if (nchunk > steps / 32) nchunk = steps / 32;
   if (nchunk < 1) nchunk = 1;
-  const bool ring = g_wgrad_kernel == 1 || (g_wgrad_kernel == 0 && ncol * nchunk >= 2LL * Gr);
+  const bool ring = g_wgrad_kernel == 1 || g_wgrad_kernel == 3 || g_wgrad_kernel >= 100 ||
+                    (g_wgrad_kernel == 0 && ncol * nchunk >= 2LL * Gr);
   if (ring) {
     const int G = Gr;
     VS_REQUIRE(ncol * nchunk < 2147483647LL, "conv64_wgrad_f16x3: too many columns");
     WgradRingArgs a{dz, in, dz_scale2, in_scale2, part, B, T, F, dil, nseg, G, nchunk};
     // LDS: dz rows (two buffers for 5x5) + the input-row ring (KT+1 slots of 32 channels / KT of 64)
-    const size_t lds = KF == 5 ? (size_t)(2 * 2 * 64 + (KT + 1) * 2 * 32) * kPW * 4 : (size_t)(2 * 64 + KT * 2 * 64) * kPW * 4;
-    auto launch = [&](auto kernel) -> int {
+    const size_t lds = KF == 5 ? (size_t)(2 * 2 * 64 + (KT + 1) * 2 * 32) * kPW * 4 + 256 : (size_t)(2 * 64 + KT * 2 * 64) * kPW * 4;
+    auto launch = [&](auto kernel, int threads = 512) -> int {
       VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kernel, dim3(256), dim3(512), lds, stream, a);
+      hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), lds, stream, a);
       return 0;
     };
     int rc;
+    if (KF == 5 && g_wgrad_kernel != 1) {         // four waves, straight-line K-block loop
+      if (g_wgrad_kernel >= 100 && nchunk == 1 && !bf) {
+        switch (g_wgrad_kernel - 100) {
+          case 1: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 1>, 256); break;
+          case 2: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 2>, 256); break;
+          case 3: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 3>, 256); break;
+          case 8: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 8>, 256); break;
+          case 11: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 11>, 256); break;
+          case 4: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 4>, 256); break;
+          case 16: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 16>, 256); break;
+          case 64: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 64>, 256); break;
+          case 128: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 128>, 256); break;
+          case 256: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 256>, 256); break;
+          case 68: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 68>, 256); break;
+          case 132: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 132>, 256); break;
+          default: rc = launch(&conv64_wgrad_ring4_kernel<false>, 256); break;
+        }
+      } else if (bf) rc = nchunk > 1 ? launch(&conv64_wgrad_ring4_kernel<true, true>, 256) : launch(&conv64_wgrad_ring4_kernel<false, true>, 256);
+      else rc = nchunk > 1 ? launch(&conv64_wgrad_ring4_kernel<true>, 256) : launch(&conv64_wgrad_ring4_kernel<false>, 256);
+    } else
     if (bf) {
       if (KF == 5) rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<5, 5, true, true>) : launch(&conv64_wgrad_ring_kernel<5, 5, false, true>);
       else rc = nchunk > 1 ? launch(&conv64_wgrad_ring_kernel<7, 1, true, true>) : launch(&conv64_wgrad_ring_kernel<7, 1, false, true>);
