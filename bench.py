@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--loss", default="sisnr", choices=["sisnr", "powerlaw", "fixed"],
                     help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-backward", action="store_true",
+                    help="weight gradients in order on the one stream (default: on the library's side stream, "
+                         "beside the BatchNorm backward passes; same results)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +165,8 @@ def main():
     if args.conv_math:
         ops.set_conv_math(args.conv_math)
     conv_math = ops.get_conv_math()
+    if args.serial_backward:
+        assert lib.vs_set_backward_overlap(0) == 0
 
     B = args.batch
     train = args.mode == "train"

@@ -290,6 +290,12 @@ int vs_set_conv_kernel(int mode);
  * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
  * (a workgroup of the launch was not resident): results are then invalid. */
 int vs_set_lstm_kernel(int mode);
+
+/* vs_backward schedule: 1 (default) = the 64->64 weight gradients run on a second HIP stream of the library beside
+ * the BatchNorm backward passes of the next layer (matrix-pipe kernel beside an HBM stream); 0 = everything in
+ * order on the caller's stream.  Same kernels and summation order: results are bit-identical.  The caller's stream
+ * is joined before vs_backward returns.  Returns 0, or -1 for any other value. */
+int vs_set_backward_overlap(int on);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */
 int vs_bn_act_bwd(const float* da, const float* z, float* dz, int C, long long R, int L, int act, int bn_mode,

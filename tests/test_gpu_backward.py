@@ -611,6 +611,40 @@ def test_training_step_semantics():
     assert not torch.equal(before, m.fc1.weight.detach())
 
 
+def test_side_stream_weight_gradients_are_bit_identical():
+    """vs_set_backward_overlap: the 64->64 weight gradients on the library's second stream (beside the BatchNorm
+    backward passes of the next layer) vs everything in order on the caller's stream -- same kernels, same
+    summation order, so every parameter gradient must be bit-identical; twice, to catch a missing join."""
+    from voicesplit_amd import _lib
+    dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=32, fc1_dim=48, fc2_dim=601)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 5), 6.0)
+    x, dvec = R.synthetic_inputs(3, 70, dims_d, 5)
+    xc, dc = x.cuda(), dvec.cuda()
+    w = torch.randn(3, 70, 601, generator=torch.Generator().manual_seed(9)).cuda()
+    lib = _lib.load()
+
+    def grads(overlap):
+        assert lib.vs_set_backward_overlap(overlap) == 0
+        m = _module("VoiceSplit", dims_d, sd).train()
+        out = []
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            (m(xc, dc) * w).sum().backward()
+            torch.cuda.synchronize()
+            out.append({k: v.grad.clone() for k, v in m.named_parameters()})
+        return out
+
+    try:
+        serial = grads(0)
+        overlapped = grads(1)
+    finally:
+        lib.vs_set_backward_overlap(1)
+    assert lib.vs_set_backward_overlap(2) == -1
+    for a, b in zip(serial, overlapped):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_full_batch_backward_properties():
     """BASELINE size (B=64, 301x601): finite gradients; with frozen BatchNorm utterances are
     independent, so a loss that only touches utterance 5 must give the gradients of that utterance

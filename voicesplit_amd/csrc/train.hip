@@ -218,6 +218,42 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Weight gradients on a side stream.  Layer l's weight gradient needs dz_l and the tape's a_{l-1}; nothing on the
+// data-gradient chain (BatchNorm backward of layer l-1 -> data gradient of layer l-1 -> ...) needs ITS result.  It
+// is a matrix-pipe kernel with one workgroup per CU and an idle memory system; the two BatchNorm backward passes
+// of the next layer are pure HBM streams with idle matrix pipes (2.65 ms per layer, 16 ms per step).  So the weight
+// gradient of layer l is launched on a second stream right after the data gradient of layer l and runs beside the
+// BatchNorm backward of layer l-1; the data gradient of layer l-1 -- which overwrites dz_l -- waits for it.
+// Same kernels, same order of every sum: results are bit-identical to the one-stream schedule.
+// One side stream + event pair per device, created on first use; the caller's stream is joined before vs_backward
+// returns, so the fork is invisible outside (and legal under stream capture).
+// ---------------------------------------------------------------------------------------------
+namespace {
+int g_bwd_overlap = 1;
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream g_side[16];
+int side_stream(SideStream** out) {
+  int dev = 0;
+  VS_CHECK_HIP(hipGetDevice(&dev));
+  VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
+  SideStream& ss = g_side[dev];
+  if (!ss.s) {
+    VS_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return 0;
+}
+}  // namespace
+
+extern "C" int vs_set_backward_overlap(int on) {
+  if (on != 0 && on != 1) return -1;
+  g_bwd_overlap = on;
+  return 0;
+}
+
 int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
                 void* tape, size_t tape_bytes, const float* mask, const float* dmask, const vs_grads* g, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -281,50 +317,69 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* dsum = at<float>(tape, L.dsum);
   float* feat = at<float>(tape, L.feat);
   float* dfeat = at<float>(tape, L.dfeat);
-  {
-  VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
-  if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
-  if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
-  // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
-  // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
+  // Only dfeat continues down the conv stack; the LSTM's own parameter gradients (dW_ih, dW_hh, biases, d-vector)
+  // are leaves.  They go to the side stream (see vs_set_backward_overlap above) and run beside the HBM-bound
+  // cnn8 / BatchNorm backward kernels that follow the dfeat GEMMs on the caller's stream.
+  SideStream* side = nullptr;
+  if (g_bwd_overlap) { if (int rc = side_stream(&side)) return rc; }
   float* gsc = at<float>(tape, L.gemm_scales);
   const bool f16g = d->math != VS_MATH_FP32;
-  if (f16g) {
-    if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
-  }
-  for (int dir = 0; dir < 2; ++dir) {
-    VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
-    VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, stream));
-    const float* dxg_d = dxg + (size_t)dir * 4 * H;
-    // dW_ih[:, :8F] = dxg_d^T @ feat
+  {
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+    if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
+    if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
+    // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
+    // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
     if (f16g) {
-      if (int rc = vs_gemm_f16x3_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, stream, d->math)) return rc;
-    } else {
-      if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
-                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
-    }
-    // dW_ih[:, 8F:] = (sum_t dxg_d)^T @ dvec    (the repeated d-vector columns, model.py:77-81)
-    if (int rc = vs_gemm_general_impl(1, 1, dsum + (size_t)dir * 4 * H, 8 * H, dvec, nullptr, 0x7fffffff, E, g->w_ih[dir] + K8, KE,
-                                      4 * H, E, B, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
-    // dW_hh = sum_t dgates_t^T h_{t-1}: the lstm_out rows shifted by one frame inside each utterance
-    if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, lstm_out + (size_t)dir * H, nullptr, 0x7fffffff, 2 * H, g->w_hh[dir], H,
-                                      4 * H, H, M, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0,
-                                      dir ? 1 : -1, T, kSplitK, part, stream)) return rc;
-    // dfeat (+)= dxg_d @ W_ih[:, :8F]
-    if (f16g) {
-      if (int rc = vs_gemm_f16x3_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
-                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, gsc + 8, gsc + 2, stream, d->math)) return rc;
-    } else {
-      if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
-                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
-    }
-    if (g->dvec) {
-      if (int rc = vs_gemm_general_impl(0, 1, dsum + (size_t)dir * 4 * H, 8 * H, p->w_ih[dir] + K8, nullptr, 0x7fffffff, KE, g->dvec, E,
-                                        B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+      if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
     }
   }
-
+  hipStream_t ls = stream;
+  if (side) {
+    VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+    VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    ls = side->s;
+  }
+  {
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+    for (int dir = 0; dir < 2; ++dir) {
+      const float* dxg_d = dxg + (size_t)dir * 4 * H;
+      // dfeat (+)= dxg_d @ W_ih[:, :8F]
+      if (f16g) {
+        if (int rc = vs_gemm_f16x3_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
+                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, gsc + 8, gsc + 2, stream, d->math)) return rc;
+      } else {
+        if (int rc = vs_gemm_general_impl(0, 1, dxg_d, 8 * H, p->w_ih[dir], nullptr, 0x7fffffff, KE, dfeat, K8, M, K8, 4 * H,
+                                          nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, stream)) return rc;
+      }
+    }
+  }
+  {
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, ls);
+    for (int dir = 0; dir < 2; ++dir) {
+      VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
+      VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
+      const float* dxg_d = dxg + (size_t)dir * 4 * H;
+      // dW_ih[:, :8F] = dxg_d^T @ feat
+      if (f16g) {
+        if (int rc = vs_gemm_f16x3_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
+                                        nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, ls, d->math)) return rc;
+      } else {
+        if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
+                                          nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, ls)) return rc;
+      }
+      // dW_ih[:, 8F:] = (sum_t dxg_d)^T @ dvec    (the repeated d-vector columns, model.py:77-81)
+      if (int rc = vs_gemm_general_impl(1, 1, dsum + (size_t)dir * 4 * H, 8 * H, dvec, nullptr, 0x7fffffff, E, g->w_ih[dir] + K8, KE,
+                                        4 * H, E, B, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, ls)) return rc;
+      // dW_hh = sum_t dgates_t^T h_{t-1}: the lstm_out rows shifted by one frame inside each utterance
+      if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, lstm_out + (size_t)dir * H, nullptr, 0x7fffffff, 2 * H, g->w_hh[dir], H,
+                                        4 * H, H, M, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0,
+                                        dir ? 1 : -1, T, kSplitK, part, ls)) return rc;
+      if (g->dvec) {
+        if (int rc = vs_gemm_general_impl(0, 1, dsum + (size_t)dir * 4 * H, 8 * H, p->w_ih[dir] + K8, nullptr, 0x7fffffff, KE, g->dvec, E,
+                                          B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, ls)) return rc;
+      }
+    }
   }
 
   // ---- conv stack, cnn8 .. cnn1 (models/voicesplit/model.py:15-52 backwards) ------------------
@@ -350,34 +405,64 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;
   {
+    // cnn8's weight gradient: a leaf as well, and the partial-sum scratch it shares with the side stream's other
+    // users is then only ever touched there, in stream order
+    if (side) {
+      VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+      VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    }
+    {
+      VsProfScope ps(VS_PROF_BWD_EDGE, ls);
+      if (int rc = vs_conv_last_wgrad_impl(dfeat, at<float>(tape, L.a[6]), part, g->conv[7].weight, B, T, F, ls)) return rc;
+    }
     VsProfScope ps(VS_PROF_BWD_EDGE, stream);
-    if (int rc = vs_conv_last_wgrad_impl(dfeat, at<float>(tape, L.a[6]), part, g->conv[7].weight, B, T, F, stream)) return rc;
     if (int rc = vs_conv_last_dgrad_impl(dfeat, p->conv[7].weight, gbuf[cur], B, T, F, stream)) return rc;
   }
   float* pack_tmp = at<float>(tape, L.pack_tmp);
+  bool wgrad_pending = false;         // a weight gradient on the side stream still reads the buffer the next data gradient writes
   for (int i = 5; i >= 0; --i) {
     const int l = i + 1;   // cnn(l+1), conv index l
     if (int rc = bn_bwd(l, gbuf[cur], at<float>(tape, L.z[l]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
     float* sc_bwd = at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * (8 + l);
+    if (wgrad_pending) {
+      VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+      wgrad_pending = false;
+    }
     {
       VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
       if (int rc = vs_conv64_layer_impl(d->math, gbuf[cur], p->conv[l].weight, pack_tmp, sc_bwd, 1,
                                         ones, zeros, gbuf[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, 1,
                                         nullptr, stream)) return rc;
     }
+    hipStream_t ws = stream;
+    if (side) {
+      VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+      VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+      ws = side->s;
+    }
     {
       // after the data gradient: in split-f16 mode it reuses the scale of dz that launch derived
       // (sc_bwd[0..1]) and the scale of the layer input the forward derived (slot l)
-      VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
+      VsProfScope ps(VS_PROF_BWD_WGRAD + i, ws);
       if (d->math != VS_MATH_FP32) {
         if (int rc = vs_conv64_wgrad_f16x3_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), sc_bwd, at<float>(tape, L.conv_scales) + VS_SCALE_SLOT_FLOATS * l,
-                                                part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream, d->math)) return rc;
+                                                part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, ws, d->math)) return rc;
       } else {
         if (int rc = vs_conv64_wgrad_impl(gbuf[cur], at<float>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F,
-                                          kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+                                          kMid[i].kt, kMid[i].kf, kMid[i].dil, ws)) return rc;
       }
     }
+    if (side) {
+      VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+      wgrad_pending = true;
+    }
     cur ^= 1;
+  }
+  // cnn2's weight gradient reads gbuf[cur ^ 1], which cnn1's backward uses as scratch -- and the caller's stream has
+  // to see everything the side stream produced: join here
+  if (side) {
+    VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+    VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
   }
   if (F < 4 || (long long)T * F >= (1 << 24)) {   // packs spanning >2 frames / float frame index: unfused path
     if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;
