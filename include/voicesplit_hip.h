@@ -144,6 +144,21 @@ int vs_forward(const vs_dims* dims, const vs_params* params, const float* x, con
                int conv_act, int bn_mode, void* workspace, size_t workspace_bytes,
                float* mask, void* stream);
 
+/* ---- eval-mode forward with the weight-only work done once ------------------------------------
+ * validation() / serving call the model again and again with unchanged weights
+ * (utils/generic_utils.py:476-558: sample by sample, B = 1).  vs_forward re-derives on every call what
+ * depends on the parameters alone (~40 small launches: BatchNorm folded into scale/shift, conv weights
+ * packed in MFMA fragment order with their power-of-two scale, W_ih split into f16 halves, W_hh packed);
+ * vs_prepare_weights does it once into a caller-owned buffer (vs_prepared_bytes(dims): depends on F, E,
+ * H and dims.math, not on B or T; 256-byte aligned) and vs_forward_prepared reads it.  The caller
+ * re-prepares whenever a parameter, a BatchNorm running statistic or dims.math changes -- the library
+ * cannot see that.  Results are bit-identical to vs_forward(..., VS_BN_EVAL, ...). */
+size_t vs_prepared_bytes(const vs_dims* dims);
+int vs_prepare_weights(const vs_dims* dims, const vs_params* params, void* prepared, size_t prepared_bytes, void* stream);
+int vs_forward_prepared(const vs_dims* dims, const vs_params* params, const void* prepared, size_t prepared_bytes,
+                        const float* x, const float* dvec, int conv_act, void* workspace, size_t workspace_bytes,
+                        float* mask, void* stream);
+
 /* ---- stages (each is what vs_forward runs, in order) --------------------------------------- */
 /* self.conv(x.unsqueeze(1)) + transpose/view: models/voicesplit/model.py:68-74 -> feat [B][T][8F] */
 int vs_conv_stack_fwd(const vs_dims* dims, const vs_params* params, const float* x, int conv_act,

@@ -197,3 +197,52 @@ def test_exact_long_form_equals_a_whole_clip_pass():
     assert _rel(restart.numpy(), ref.numpy()) > 10 * REL_TOL
     with pytest.raises(RuntimeError):
         m.train().long_form_stages()
+
+
+@pytest.mark.parametrize("cls_name", ["VoiceSplit", "VoiceFilter"])
+@pytest.mark.parametrize("math", ["f16x3", "fp32", "bf16"])
+def test_prepared_weights_forward_is_bit_identical_and_tracks_the_parameters(cls_name, math):
+    """Eval-mode calls go through vs_prepare_weights (once) + vs_forward_prepared: the same kernels on the same
+    operands as vs_forward, so the mask is bit-identical; the prepared buffer is reused while the parameters are
+    untouched and rebuilt as soon as one changes in place, is replaced, or a running statistic moves."""
+    import voicesplit_amd as V
+    from voicesplit_amd import ops
+    dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=48, fc1_dim=64, fc2_dim=601)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 11), 6.0)
+    prev = ops.get_conv_math()
+    ops.set_conv_math(math)
+    try:
+        m = getattr(V, cls_name)(V.default_config(601, 256, 48, 64, 601))
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        x, dvec = R.synthetic_inputs(2, 40, dims_d, 3)
+        xc, dc = x.cuda(), dvec.cuda()
+
+        def direct():
+            t = {k: v.detach() for k, v in m._tensors().items()}
+            return ops.forward(t, xc, dc, m._dims(2, 40), m.conv_act, training=False)
+
+        with torch.no_grad():
+            y1 = m(xc, dc)
+            prep1 = m.__dict__["_prepared"]
+            assert torch.equal(y1, direct())
+            y2 = m(xc, dc)
+            assert m.__dict__["_prepared"] is prep1 and torch.equal(y1, y2)          # reused
+            y3 = m(xc[:1, :17].contiguous(), dc[:1])                                   # another B, T: same buffer
+            assert m.__dict__["_prepared"] is prep1 and y3.shape == (1, 17, 601)
+            m.conv[1].weight.mul_(1.5)                                                 # in-place update (optimizer step)
+            y4 = m(xc, dc)
+            assert m.__dict__["_prepared"] is not prep1
+            assert torch.equal(y4, direct()) and not torch.equal(y4, y1)
+            prep2 = m.__dict__["_prepared"]
+            m.conv[2].running_var.add_(0.25)                                           # a BatchNorm buffer
+            y5 = m(xc, dc)
+            assert m.__dict__["_prepared"] is not prep2 and torch.equal(y5, direct()) and not torch.equal(y5, y4)
+            m.load_state_dict(sd, strict=True)                                         # copy_ into the same storage
+            assert torch.equal(m(xc, dc), y1)
+        m.train()
+        assert "_prepared" not in m.__dict__                                           # dropped when training starts
+        m(xc, dc)
+        assert "_prepared" not in m.__dict__                                           # training calls never build it
+    finally:
+        ops.set_conv_math(prev)

@@ -91,6 +91,9 @@ SIGNATURES = {
     "vs_workspace_layout": (c_int, [POINTER(VsDims), POINTER(VsWsLayout)]),
     "vs_workspace_bytes": (c_size_t, [POINTER(VsDims)]),
     "vs_forward": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_int, c_int, _P, c_size_t, _P, _P]),
+    "vs_prepared_bytes": (c_size_t, [POINTER(VsDims)]),
+    "vs_prepare_weights": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, c_size_t, _P]),
+    "vs_forward_prepared": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, c_size_t, _P, _P, c_int, _P, c_size_t, _P, _P]),
     "vs_conv_stack_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, c_int, c_int, _P, c_size_t, _P, _P]),
     "vs_bilstm_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, _P, c_size_t, _P, _P]),
     "vs_head_fwd": (c_int, [POINTER(VsDims), POINTER(VsParams), _P, _P, c_size_t, _P, _P, _P]),

@@ -98,6 +98,61 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
   return 0;
 }
 
+// ---- prepared weights (vs_prepare_weights / vs_forward_prepared): everything an eval-mode forward derives from
+// the parameters alone -- BatchNorm folded into per-channel scale/shift, conv weights in MFMA fragment order with
+// their power-of-two scale, W_ih split into f16 halves with its scale, W_hh in fragment order.  Independent of B, T.
+struct PrepLayout {
+  size_t bn_scale, bn_shift, conv_packed[6], conv_wscale, gemm_wscale, wih_hi, wih_lo, lstm_packed, total_bytes;
+};
+struct Prep {
+  float *bn_scale, *bn_shift;
+  void* conv_packed[6];
+  float* conv_wscale;     // [6][8]: scale2 of layer i's weights at [8i .. 8i+1], |max| scratch at 8i+4
+  float* gemm_wscale;     // [8]: scale2 of W_ih at [0..1], |max| scratch at [4]
+  _Float16 *wih_hi, *wih_lo;
+  float* lstm_packed;
+};
+
+int prep_layout(const vs_dims* d, PrepLayout* L) {
+  if (int rc = check_dims(d)) return rc;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  L->bn_scale = take(8 * 64 * 4);
+  L->bn_shift = take(8 * 64 * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
+  L->conv_wscale = take(6 * 8 * 4);
+  L->gemm_wscale = take(8 * 4);
+  const size_t Kp = ((size_t)8 * d->F + 31) / 32 * 32;
+  L->wih_hi = take((size_t)8 * d->H * Kp * 2);
+  L->wih_lo = take((size_t)8 * d->H * Kp * 2);
+  L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
+  L->total_bytes = off;
+  return 0;
+}
+
+int prep_pointers(const vs_dims* d, const void* blob, size_t bytes, Prep* P) {
+  PrepLayout L;
+  if (int rc = prep_layout(d, &L)) return rc;
+  VS_REQUIRE(blob != nullptr, "prepared weights: NULL buffer");
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 255) == 0, "prepared weights: buffer must be 256-byte aligned");
+  VS_REQUIRE(bytes >= L.total_bytes, "prepared weights: buffer too small: %zu < %zu bytes", bytes, L.total_bytes);
+  void* b = const_cast<void*>(blob);
+  P->bn_scale = at<float>(b, L.bn_scale);
+  P->bn_shift = at<float>(b, L.bn_shift);
+  for (int i = 0; i < 6; ++i) P->conv_packed[i] = at<char>(b, L.conv_packed[i]);
+  P->conv_wscale = at<float>(b, L.conv_wscale);
+  P->gemm_wscale = at<float>(b, L.gemm_wscale);
+  P->wih_hi = at<_Float16>(b, L.wih_hi);
+  P->wih_lo = at<_Float16>(b, L.wih_lo);
+  P->lstm_packed = at<float>(b, L.lstm_packed);
+  return 0;
+}
+
+int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
+                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep);
+int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
+                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep);
+
 }  // namespace
 
 int vs_check_dims_impl(const vs_dims* d) { return check_dims(d); }
@@ -125,31 +180,49 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
 // training).  When it can hold both operands split into f16 hi/lo arrays (vs_gemm_presplit_bytes),
 // the split is a pass of its own and the GEMM streams halves; otherwise (tiny batches: the split
 // weights alone are 62 MB) the GEMM converts fp32 tiles while it stages them.
+// the split-f16 / bf16 image of W_ih[:, :K] of both directions: scale2 (2 floats), then hi and lo halves [8H][Kp]
+int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int H, int K, int KE, unsigned* amax1,
+                           float* w_scale2, _Float16* Wh, _Float16* Wl, hipStream_t stream) {
+  const size_t Kp = (size_t)(K + 31) / 32 * 32;
+  VS_CHECK_HIP(hipMemsetAsync(amax1, 0, sizeof(unsigned), stream));
+  if (int rc = vs_absmax_accum_impl(w_ih0, (long long)4 * H * KE, amax1, stream)) return rc;
+  if (int rc = vs_absmax_accum_impl(w_ih1, (long long)4 * H * KE, amax1, stream)) return rc;
+  if (int rc = vs_scale_from_absmax_impl(amax1, 1, w_scale2, stream)) return rc;
+  if (!Wh) return 0;
+  if (int rc = vs_split_rows_impl(w_ih0, 4 * H, K, KE, w_scale2, Wh, Wl, 0, stream, math)) return rc;
+  return vs_split_rows_impl(w_ih1, 4 * H, K, KE, w_scale2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream, math);
+}
+
+// prep_* != NULL: W_ih arrives prepared (vs_prepare_weights): its scale and split halves are read, not rebuilt
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
-                            hipStream_t stream) {
+                            hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl) {
   if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
     if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
-    VS_CHECK_HIP(hipMemsetAsync(amax + 1, 0, sizeof(unsigned), stream));
-    if (int rc = vs_absmax_accum_impl(w_ih0, (long long)4 * H * KE, amax + 1, stream)) return rc;
-    if (int rc = vs_absmax_accum_impl(w_ih1, (long long)4 * H * KE, amax + 1, stream)) return rc;
-    if (int rc = vs_scale_from_absmax_impl(amax + 1, 1, gs + 2, stream)) return rc;
-    if (scratch && scratch_bytes >= vs_gemm_presplit_bytes(M, 8 * H, K) && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0) {
-      const size_t Kp = (size_t)(K + 31) / 32 * 32;
-      const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
-      char* base = static_cast<char*>(scratch);
-      _Float16* Ah = reinterpret_cast<_Float16*>(base);
-      _Float16* Al = reinterpret_cast<_Float16*>(base + na);
-      _Float16* Wh = reinterpret_cast<_Float16*>(base + 2 * na);
-      _Float16* Wl = reinterpret_cast<_Float16*>(base + 2 * na + nw);
-      if (2 * na + 2 * nw <= scratch_bytes) {
+    const size_t Kp = (size_t)(K + 31) / 32 * 32;
+    const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
+    const bool aligned = scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0;
+    char* base = static_cast<char*>(scratch);
+    _Float16* Ah = reinterpret_cast<_Float16*>(base);
+    _Float16* Al = reinterpret_cast<_Float16*>(base + na);
+    if (prep_wscale2) {
+      if (aligned && 2 * na <= scratch_bytes) {
         if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc;
-        if (int rc = vs_split_rows_impl(w_ih0, 4 * H, K, KE, gs + 2, Wh, Wl, 0, stream, math)) return rc;
-        if (int rc = vs_split_rows_impl(w_ih1, 4 * H, K, KE, gs + 2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream, math)) return rc;
-        return vs_gemm_presplit_impl(Ah, Al, Wh, Wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
-                                     VS_ACT_NONE, 0, gs, gs + 2, stream, math);
+        return vs_gemm_presplit_impl(Ah, Al, prep_wh, prep_wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
+                                     VS_ACT_NONE, 0, gs, prep_wscale2, stream, math);
       }
+      return vs_gemm_f16x3_impl(0, 0, feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T,
+                                nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, prep_wscale2, stream, math);
+    }
+    const bool presplit = aligned && scratch_bytes >= vs_gemm_presplit_bytes(M, 8 * H, K) && 2 * na + 2 * nw <= scratch_bytes;
+    _Float16* Wh = reinterpret_cast<_Float16*>(base + 2 * na);
+    _Float16* Wl = reinterpret_cast<_Float16*>(base + 2 * na + nw);
+    if (int rc = vs_lstm_split_wih_impl(math, w_ih0, w_ih1, H, K, KE, amax + 1, gs + 2, presplit ? Wh : nullptr, Wl, stream)) return rc;
+    if (presplit) {
+      if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc;
+      return vs_gemm_presplit_impl(Ah, Al, Wh, Wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
+                                   VS_ACT_NONE, 0, gs, gs + 2, stream, math);
     }
     return vs_gemm_f16x3_impl(0, 0, feat, K, w_ih0, w_ih1, 4 * H, KE, xg, 8 * H, M, 8 * H, K, nullptr, nullptr, rowbias, 8 * H, T,
                               nullptr, 0, 0, 0, VS_ACT_NONE, 0, gs, gs + 2, stream, math);
@@ -279,19 +352,27 @@ int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, 
 // ---------------------------------------------------------------------------------------------
 int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
                       void* ws, size_t ws_bytes, float* feat, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
   vs_ws_layout L;
   if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  return conv_stack_impl(d, p, x, conv_act, bn_mode, ws, L, feat, (hipStream_t)stream_, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
+                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep) {
   VS_REQUIRE(p && x, "conv_stack: NULL argument");
   VS_REQUIRE(conv_act == VS_ACT_MISH || conv_act == VS_ACT_RELU, "conv_stack: conv_act must be MISH or RELU");
   VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "conv_stack: unknown bn_mode %d", bn_mode);
   if (!feat) feat = at<float>(ws, L.feat);
   const int B = d->B, T = d->T, F = d->F;
   float* act[2] = {at<float>(ws, L.act0), at<float>(ws, L.act1)};
-  float* scale = at<float>(ws, L.bn_scale);
-  float* shift = at<float>(ws, L.bn_shift);
+  float* scale = prep ? prep->bn_scale : at<float>(ws, L.bn_scale);
+  float* shift = prep ? prep->bn_shift : at<float>(ws, L.bn_shift);
   double* stats = at<double>(ws, L.bn_stats);
   const bool train = bn_mode == VS_BN_TRAIN;
+  VS_REQUIRE(!(prep && train), "conv_stack: prepared weights are an eval-mode form (BatchNorm folded)");
 
   for (int l = 0; l < 8; ++l) {
     const vs_conv_layer& c = p->conv[l];
@@ -305,7 +386,9 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   //         statistics, normalisation and activation follow as a second pass which then
   //         overwrites the layer's slot with the batch scale/shift.
   const int layer_act = train ? VS_ACT_NONE : conv_act;
-  if (!train) {
+  if (prep) {
+    // folded by vs_prepare_weights
+  } else if (!train) {
     for (int l = 0; l < 8; ++l) {
       const vs_conv_layer& c = p->conv[l];
       if (int rc = vs_bn_fold_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, c.bias, kBnEps, Cl[l],
@@ -343,6 +426,18 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
     ProfScope ps(VS_PROF_CNN2 + i, stream);
     const bool fuse = train && f16;        // statistics of this layer accumulated by the conv epilogue
     if (fuse) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+    if (prep) {          // weights packed and scaled once; only the input's scale is derived here
+      float* slot = cs + VS_SCALE_SLOT_FLOATS * l;
+      if (f16) {
+        if (int rc = vs_scale_from_absmax_impl(vs_amax_slot(slot), VS_AMAX_SLOTS, slot, stream)) return rc;
+        if (int rc = vs_conv64_f16x3_fwd_impl(act[cur], static_cast<const _Float16*>(prep->conv_packed[i]), scale + 64 * l, shift + 64 * l,
+                                              slot, prep->conv_wscale + 8 * i, act[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil,
+                                              layer_act, amax_for(l + 1), stream, d->math, nullptr)) return rc;
+      } else {
+        if (int rc = vs_conv64_fwd_impl(act[cur], static_cast<const float*>(prep->conv_packed[i]), scale + 64 * l, shift + 64 * l,
+                                        act[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
+      }
+    } else
     if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, cs + VS_SCALE_SLOT_FLOATS * l, 1,
                                       scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
                                       kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, 0, train ? nullptr : amax_for(l + 1), stream,
@@ -365,15 +460,25 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
   }
   return 0;
 }
+}  // namespace
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------
 // stage 2: d-vector concat + BiLSTM, models/voicesplit/model.py:77-82
 // ---------------------------------------------------------------------------------------------
 int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
                   void* ws, size_t ws_bytes, float* lstm_out, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
   vs_ws_layout L;
   if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  return bilstm_impl(d, p, feat, dvec, ws, L, lstm_out, (hipStream_t)stream_, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
+                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep) {
   VS_REQUIRE(p && dvec, "bilstm: NULL argument");
   if (!feat) feat = at<float>(ws, L.feat);
   if (!lstm_out) lstm_out = at<float>(ws, L.lstm_out);
@@ -394,13 +499,18 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
   const size_t act_bytes = (size_t)B * 64 * T * d->F * sizeof(float);
   if (int rc = vs_lstm_input_gemm_impl(d->math, feat, K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
                                        at<float>(ws, L.gemm_scales), at<char>(ws, L.act0),
-                                       L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes, stream)) return rc;
+                                       L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes, stream,
+                                       prep ? prep->gemm_wscale : nullptr, prep ? prep->wih_hi : nullptr,
+                                       prep ? prep->wih_lo : nullptr)) return rc;
   }
-  float* packed = at<float>(ws, L.lstm_packed);
-  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
+  float* packed = prep ? prep->lstm_packed : at<float>(ws, L.lstm_packed);
+  if (!prep) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc; }
   ProfScope ps(VS_PROF_LSTM_REC, stream);
   return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, nullptr, nullptr, B, T, H, stream);
 }
+}  // namespace
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------
 // stage 3: head, models/voicesplit/model.py:83-87
@@ -436,6 +546,61 @@ int vs_forward(const vs_dims* d, const vs_params* p, const float* x, const float
   VS_REQUIRE(mask != nullptr, "forward: mask is NULL");
   if (int rc = vs_conv_stack_fwd(d, p, x, conv_act, bn_mode, ws, ws_bytes, nullptr, stream)) return rc;
   if (int rc = vs_bilstm_fwd(d, p, nullptr, dvec, ws, ws_bytes, nullptr, stream)) return rc;
+  return vs_head_fwd(d, p, nullptr, ws, ws_bytes, nullptr, mask, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// eval-mode forward with the weight-only work done once (validation / serving: weights do not change
+// between calls; utils/generic_utils.py:476-558 runs the model sample by sample at B = 1)
+// ---------------------------------------------------------------------------------------------
+size_t vs_prepared_bytes(const vs_dims* dims) {
+  PrepLayout L;
+  memset(&L, 0, sizeof(L));
+  if (prep_layout(dims, &L)) return 0;
+  return L.total_bytes;
+}
+
+int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, size_t prepared_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  Prep P;
+  if (int rc = prep_pointers(d, prepared, prepared_bytes, &P)) return rc;
+  VS_REQUIRE(p != nullptr, "prepare_weights: params is NULL");
+  const int Cl[8] = {64, 64, 64, 64, 64, 64, 64, 8};
+  for (int l = 0; l < 8; ++l) {
+    const vs_conv_layer& c = p->conv[l];
+    VS_REQUIRE(c.weight && c.bias && c.bn_weight && c.bn_bias && c.bn_running_mean && c.bn_running_var,
+               "prepare_weights: layer %d has a NULL parameter", l + 1);
+    if (int rc = vs_bn_fold_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, c.bias, kBnEps, Cl[l],
+                                 P.bn_scale + 64 * l, P.bn_shift + 64 * l, stream)) return rc;
+  }
+  for (int i = 0; i < 6; ++i) {
+    const float* w = p->conv[i + 1].weight;
+    if (d->math != VS_MATH_FP32) {
+      float* ws8 = P.conv_wscale + 8 * i;
+      if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0,
+                                           reinterpret_cast<unsigned*>(ws8 + 4), ws8, stream, d->math)) return rc;
+    } else {
+      if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+    }
+  }
+  for (int dir = 0; dir < 2; ++dir)
+    VS_REQUIRE(p->w_ih[dir] && p->w_hh[dir], "prepare_weights: NULL LSTM parameter (dir %d)", dir);
+  if (d->math != VS_MATH_FP32) {
+    if (int rc = vs_lstm_split_wih_impl(d->math, p->w_ih[0], p->w_ih[1], d->H, 8 * d->F, 8 * d->F + d->E,
+                                        reinterpret_cast<unsigned*>(P.gemm_wscale + 4), P.gemm_wscale, P.wih_hi, P.wih_lo, stream)) return rc;
+  }
+  return vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], P.lstm_packed, d->H, stream);
+}
+
+int vs_forward_prepared(const vs_dims* d, const vs_params* p, const void* prepared, size_t prepared_bytes,
+                        const float* x, const float* dvec, int conv_act, void* ws, size_t ws_bytes, float* mask, void* stream) {
+  VS_REQUIRE(mask != nullptr, "forward_prepared: mask is NULL");
+  Prep P;
+  if (int rc = prep_pointers(d, prepared, prepared_bytes, &P)) return rc;
+  vs_ws_layout L;
+  if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  if (int rc = conv_stack_impl(d, p, x, conv_act, VS_BN_EVAL, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
+  if (int rc = bilstm_impl(d, p, nullptr, dvec, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
   return vs_head_fwd(d, p, nullptr, ws, ws_bytes, nullptr, mask, stream);
 }
 

@@ -37,7 +37,10 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
 // training: [0..1] scale of feat, [2..3] scale of the two W_ih, [4..5] uint |max| scratch.
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gemm_scales,
-                            void* scratch, size_t scratch_bytes, hipStream_t);
+                            void* scratch, size_t scratch_bytes, hipStream_t, const float* prep_wscale2 = nullptr,
+                            const _Float16* prep_wh = nullptr, const _Float16* prep_wl = nullptr);
+int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int H, int K, int KE, unsigned* amax1,
+                           float* w_scale2, _Float16* Wh, _Float16* Wl, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
                             float* w_scale2, hipStream_t, int math = VS_MATH_CODE_F16X3);
 int vs_conv64_f16x3_fwd_impl(const float* in, const _Float16* wp, const float* scale, const float* shift,

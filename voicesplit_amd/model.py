@@ -103,12 +103,26 @@ class _MaskNet(nn.Module):
         sd.update({k: v for k, v in self.named_buffers()})
         return sd
 
+    def train(self, mode: bool = True):
+        if mode:
+            self.__dict__.pop("_prepared", None)     # the eval-mode weight cache is not kept through training
+        return super().train(mode)
+
     def _run(self, x, dvec):
         x = x.contiguous()
         dvec = dvec.contiguous()
         dims = self._dims(x.shape[0], x.shape[1])
         sd = {k: v.detach() for k, v in self._tensors().items()}
-        mask = ops.forward(sd, x.detach(), dvec.detach(), dims, self.conv_act, training=self.training)
+        if not self.training:
+            # eval mode (validation(), test.py, serving): the weight-only work of the forward is done once and
+            # kept until a parameter or a running statistic changes (tensor identity + version counters)
+            prep = self.__dict__.get("_prepared")
+            if prep is None or not prep.matches(sd, dims):
+                prep = ops.PreparedWeights(sd, dims)
+                self.__dict__["_prepared"] = prep
+            return ops.forward_prepared(sd, prep, x.detach(), dvec.detach(), dims, self.conv_act)
+        self.__dict__.pop("_prepared", None)
+        mask = ops.forward(sd, x.detach(), dvec.detach(), dims, self.conv_act, training=True)
         self._bump_bn_counters()
         return mask
 

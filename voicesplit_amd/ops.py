@@ -155,6 +155,50 @@ def forward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool = False,
     return mask
 
 
+class PreparedWeights:
+    """What an eval-mode forward derives from the parameters alone (vs_prepare_weights), kept on the device
+    together with the identity of the tensors it was derived from: ``matches(sd, dims)`` is False as soon as
+    any parameter / BatchNorm buffer was replaced or modified in place (optimizer step, load_state_dict,
+    ``.to()``), or the arithmetic changed."""
+
+    def __init__(self, sd, dims: VsDims):
+        lib = _lib.load()
+        some = next(iter(sd.values()))
+        nbytes = lib.vs_prepared_bytes(ctypes.byref(dims))
+        if nbytes == 0:
+            check(-1, "vs_prepared_bytes")
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=some.device)
+        self.key = self._key(sd, dims)
+        params = pack_params(sd)
+        with torch.cuda.device(some.device):
+            rc = lib.vs_prepare_weights(ctypes.byref(dims), ctypes.byref(params), _p(self.buf), self.buf.numel(), _stream())
+        check(rc, "vs_prepare_weights")
+
+    @staticmethod
+    def _key(sd, dims: VsDims):
+        return (dims.F, dims.E, dims.H, dims.FC1, dims.FC2, dims.math,
+                tuple((k, v.data_ptr(), v._version) for k, v in sorted(sd.items()) if not k.endswith("num_batches_tracked")))
+
+    def matches(self, sd, dims: VsDims) -> bool:
+        return self.key == self._key(sd, dims)
+
+
+def forward_prepared(sd, prepared: PreparedWeights, x, dvec, dims: VsDims, conv_act: str,
+                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Eval-mode mask = model(x, dvec) with the weight-only work read from ``prepared``; bit-identical to
+    ``forward(..., training=False)``."""
+    lib = _lib.load()
+    _check_inputs(x, dvec, dims)
+    params = pack_params(sd)
+    ws = workspace if workspace is not None else get_workspace(dims, x.device)
+    mask = torch.empty(dims.B, dims.T, dims.FC2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.vs_forward_prepared(ctypes.byref(dims), ctypes.byref(params), _p(prepared.buf), prepared.buf.numel(),
+                                     _p(x), _p(dvec), ACT_CODES[conv_act], _p(ws), ws.numel(), _p(mask), _stream())
+    check(rc, "vs_forward_prepared")
+    return mask
+
+
 def conv_stack(sd, x, dims: VsDims, conv_act: str, training: bool = False, workspace=None) -> torch.Tensor:
     lib = _lib.load()
     _dev_check(x, "x")
