@@ -45,11 +45,10 @@ PEAK_HBM_GBS = 8000.0
 def committed_pmc_traffic(tag, kernel_substr):
     """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/<tag>_rocprof/pmc_per_kernel.csv, written by tools/profile_gpu.sh + summarize_prof.py in
-    separate --pmc passes): FETCH_SIZE + WRITE_SIZE as reported, in GB.  The guide's x2 correction of
-    FETCH_SIZE on gfx950 is calibrated for 16 B/lane streaming reads; this kernel stages its window with
-    dword loads, for which the raw value matches the tile geometry (12 input rows x 36 columns per
-    8 x 32 outputs = 1.69 x the 2.96 GB input; raw FETCH_SIZE 4.6 GB), so it is left uncorrected.
-    bench.py itself cannot collect counters; None when the file is absent."""
+    separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE, in GB.  The x2 is calibrated, not assumed: a 1 GiB
+    read reports FETCH_SIZE = 0.5 GiB for dword and for 16-byte loads alike on this chip and tool version, and a
+    1 GiB write reports WRITE_SIZE = 1 GiB (profiles/r02_calibration/).  bench.py itself cannot collect
+    counters; None when the file is absent."""
     import csv
     path = os.path.join(ROOT, "profiles", f"{tag}_rocprof", "pmc_per_kernel.csv")
     if not os.path.isfile(path):
@@ -59,7 +58,7 @@ def committed_pmc_traffic(tag, kernel_substr):
         if kernel_substr in r["kernel"] and r.get("fetch_GB_x2") and r.get("write_GB"):
             n = int(r["dispatches"])
             if best is None or n > best[0]:
-                best = (n, float(r["fetch_GB_x2"]) / 2 + float(r["write_GB"]))
+                best = (n, float(r["fetch_GB_x2"]) + float(r["write_GB"]))
     return None if best is None else round(best[1], 2)
 
 
@@ -345,7 +344,7 @@ def main():
                 "frac": round(achieved / peak, 4),
                 "traffic": (committed_pmc_traffic("r02_train" if train else "r02_forward", "conv64_f16x3_pk_kernel")
                             if conv_math == "f16x3" and B == 64 else None),
-                "traffic_unit": "GB per launch: FETCH_SIZE + WRITE_SIZE from the committed --pmc passes of this command "
+                "traffic_unit": "GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
                                 "(profiles/r02_*_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
                                 "algorithmic bytes 5.9 GB",
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
@@ -354,14 +353,17 @@ def main():
         if train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
-            wname = ("conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, bf16 single pass, incl. its reduce)" if conv_math == "bf16" else
-                     "conv64_wgrad_ring_kernel<5,5> (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
+            wname = ("conv64_wgrad_ring4_kernel (weight gradient of cnn3..cnn7, bf16 single pass, incl. its reduce)" if conv_math == "bf16" else
+                     "conv64_wgrad_ring4_kernel (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
                      if conv_math == "f16x3" else
                      "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)")
             roof["second_kernel"] = {"kernel": wname,
                                      "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                      "frac": round(B * GFLOP_CONV5X5 / wg_mean / peak, 4),
-                                     "launch_ms": [round(v, 3) for v in wg]}
+                                     "launch_ms": [round(v, 3) for v in wg],
+                                     "note": ("timed on the library's side stream while the BatchNorm backward passes of the next layer run beside it "
+                                              "(vs_set_backward_overlap, DESIGN.md 6.7); alone (--serial-backward) a launch takes ~6.5 ms"
+                                              if not args.serial_backward else "serial schedule: the kernel alone")}
         line = {
             "metric": f"utterances/sec (3 s clips, B={B}/GPU) " + ("fwd+bwd, " if train else "forward, ") + MATH_LABEL,
             "value": round(value, 2), "unit": "utterances/s",
@@ -385,6 +387,9 @@ def main():
                                        f"batch-sharded x{world}, no data-path collective")},
             "roofline": roof,
             "stage_ms": {k: (round(v, 3) if v is not None else None) for k, v in stage_ms.items()},
+            "stage_ms_note": ("HIP-event time of each stage on the stream it was launched on; with the side-stream backward schedule the "
+                              "wgrad_* / bwd_bn / bwd_lstm_gemm / bwd_edge stages overlap in time and do not add up to the step"
+                              if train and not args.serial_backward else "stages run in order on one stream"),
             "model_tflops": round(value / world * GFLOP_FWD_TOTAL * (3 if train else 1) / 1e3, 2),
         }
         if fwd is not None:

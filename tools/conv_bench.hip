@@ -70,6 +70,38 @@ int main(int argc, char** argv) {
     printf("calib: 3 x (1 GiB dword read, 1 GiB dwordx4 read, 1 GiB dword write)\n");
     return 0;
   }
+  if (argc > 3 && !strcmp(argv[3], "mall")) {
+    // Does a buffer that was just streamed come back faster the second time (memory-side cache, 256 MB)?
+    // For each size: read the SAME region twice in a row vs read two DIFFERENT regions, 16-byte loads.
+    const long long total = 3LL << 30;      // 3 GiB arena (bytes)
+    float *x, *sink;
+    CK(hipMalloc(&x, total)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(x, 1, total));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (long long mb : {32LL, 64LL, 92LL, 128LL, 184LL, 256LL, 512LL}) {
+      const long long n4 = mb * 1024 * 1024 / 16;
+      auto run = [&](bool same) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          // flush: stream 1 GiB of something else
+          hipLaunchKernelGGL(calib_read_dwordx4, dim3(4096), dim3(256), 0, nullptr, (const float4*)(x + (2LL << 30) / 4), (1LL << 30) / 16, sink);
+          hipLaunchKernelGGL(calib_read_dwordx4, dim3(4096), dim3(256), 0, nullptr, (const float4*)x, n4, sink);
+          CK(hipEventRecord(e0));
+          hipLaunchKernelGGL(calib_read_dwordx4, dim3(4096), dim3(256), 0, nullptr, (const float4*)(same ? x : x + (1LL << 30) / 4), n4, sink);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          best = ms < best ? ms : best;
+        }
+        return best;
+      };
+      const float a = run(true), b = run(false);
+      printf("  %4lld MB: re-read %.3f ms (%.2f TB/s)   fresh region %.3f ms (%.2f TB/s)\n", mb, a, mb / 1024.0 / 1024.0 / a * 1e3 * 1.048576 * 1.048576 ,
+             b, mb / 1024.0 / 1024.0 / b * 1e3 * 1.048576 * 1.048576);
+    }
+    return 0;
+  }
   if (argc > 3 && !strcmp(argv[3], "wgrad")) {
     // weight-gradient ring kernel (5x5): default vs timing ablations, random and zero operands
     const int B = Bbig, T = 301, F = 601;
