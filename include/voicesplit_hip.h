@@ -309,7 +309,9 @@ int vs_set_lstm_kernel(int mode);
 /* vs_backward schedule: 1 (default) = the 64->64 weight gradients run on a second HIP stream of the library beside
  * the BatchNorm backward passes of the next layer (matrix-pipe kernel beside an HBM stream); 0 = everything in
  * order on the caller's stream.  Same kernels and summation order: results are bit-identical.  The caller's stream
- * is joined before vs_backward returns.  Returns 0, or -1 for any other value. */
+ * is joined before vs_backward returns.  The side stream and its events are shared by all callers of a device, so
+ * while this is on the ENQUEUE phase of concurrent vs_backward calls is serialized by a mutex (the GPU work is not).
+ * Returns 0, or -1 for any other value. */
 int vs_set_backward_overlap(int on);
 /* BatchNorm+activation backward over rows [R][L] with channel = r % C (NCHW: R = B*C, L = T*F;
  * cnn8 feature layout: R = B*T*8, L = F).  dz may alias da.  stats: 2*C doubles, coef: 3*C floats. */

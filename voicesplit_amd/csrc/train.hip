@@ -4,6 +4,7 @@
 //
 // Reference graph being differentiated: models/voicesplit/model.py:66-89 (forward) as driven by
 // train.py:94-110 (mask -> loss -> loss.backward()).
+#include <mutex>
 #include <string.h>
 
 #include "../../include/voicesplit_hip.h"
@@ -233,6 +234,9 @@ namespace {
 int g_bwd_overlap = 1;
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 SideStream g_side[16];
+// the side stream and its two events are shared by every caller on the device: one vs_backward enqueues at a time
+// (host threads driving different caller streams would otherwise re-record an event another call is about to wait on)
+std::mutex g_side_mutex;
 int side_stream(SideStream** out) {
   int dev = 0;
   VS_CHECK_HIP(hipGetDevice(&dev));
@@ -257,6 +261,8 @@ extern "C" int vs_set_backward_overlap(int on) {
 int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
                 void* tape, size_t tape_bytes, const float* mask, const float* dmask, const vs_grads* g, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  if (g_bwd_overlap) side_lock.lock();
   vs_tape_layout L;
   if (int rc = check_tape(d, tape, tape_bytes, &L)) return rc;
   if (int rc = check_params(p)) return rc;
