@@ -46,6 +46,14 @@ def test_workspace_layout_and_argument_errors():
     assert b"multiple of 8" in lib.vs_last_error()
     with pytest.raises(_lib.VoiceSplitHipError):
         ops.workspace_layout(bad)
+    # prepared eval-mode weights: a function of the model dimensions and the arithmetic, not of B or T
+    pb = lib.vs_prepared_bytes(ctypes.byref(d))
+    assert pb == lib.vs_prepared_bytes(ctypes.byref(ops.make_dims(1, 17, 601, 256, 400, 600, 601))) and pb % 256 == 0
+    kp = (8 * 601 + 31) // 32 * 32
+    assert 2 * 8 * 400 * kp * 2 < pb < 2 * 8 * 400 * kp * 2 + 16 * 2 ** 20        # the split W_ih halves dominate (62 MB)
+    assert lib.vs_prepared_bytes(ctypes.byref(bad)) == 0
+    assert lib.vs_prepare_weights(ctypes.byref(d), None, None, 0, None) != 0 and b"NULL" in lib.vs_last_error()
+    assert lib.vs_set_backward_overlap(2) == -1 and lib.vs_set_backward_overlap(1) == 0
     assert lib.vs_conv64_packed_floats(5, 5) == (8 * 25 + 4) * 512   # + 4 dummy taps for the prefetch overrun
     assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400
 
