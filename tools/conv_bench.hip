@@ -143,6 +143,8 @@ int main(int argc, char** argv) {
     timeit(228, 1, "  - every load from the slab's first 64 KB (L2-hot)");
     timeit(232, 1, "  - loads only + L2-hot");
     timeit(356, 1, "  - all staging pieces behind K block 3");
+    timeit(612, 1, "  - same bytes per step as ONE contiguous 28 KB piece (HBM-cold, one page)");
+    timeit(616, 1, "  - loads only + contiguous piece");
     timeit(101, 1, "  - fragments read once per step");
     timeit(102, 1, "  - no staging (loads, conversion, LDS writes)");
     timeit(108, 1, "  - no barriers");

@@ -1366,7 +1366,9 @@ void conv64_wgrad_ring_kernel(WgradRingArgs g) {
 // the hi windows come first and the lo windows reuse their registers.  Same staging, ring, barriers,
 // chunking and partial-sum layout as the eight-wave kernel; results agree to summation order.
 // ABL: timing ablations (results are garbage unless 0): 1 = fragments read once per step, 2 = no staging
-// (global loads, conversion, LDS writes), 8 = no barriers.
+// (global loads, conversion, LDS writes), 8 = no barriers, 4 = loads only, 16 = conversion only, 64 = every load out of
+// range, 128 = every load from the slab's first 64 KB, 256 = all staging behind K block 3, 512 = the step's bytes
+// as one contiguous piece (profiles/r02_wgrad_ablation.md).
 // =================================================================================================
 template <bool CK, bool BF = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1)
@@ -1487,10 +1489,15 @@ void conv64_wgrad_ring4_kernel(WgradRingArgs g) {
     const bool last_seg = o.f0 + kNF + KF - 1 - PADF > g.F;
     const unsigned base_d = (unsigned)((t * g.F + o.f0) * 4);
     if (!CK || ev.kind != 2) {
-      const bool risky = !(ABL & 192) && t == g.T - 1 && last_seg;
+      const bool risky = !(ABL & (192 | 512)) && t == g.T - 1 && last_seg;
+      // ablation 512: the same number of bytes per step, but as ONE contiguous 28 KB piece that walks through the
+      // slab (cold in L2, a single page) instead of 96 row pieces on 96 channel planes
+      const unsigned walk = (unsigned)(((unsigned)ev.col * 331u + (unsigned)k) % ((unsigned)(slab >> 15) - 2u)) << 15;
 #pragma unroll
       for (int i = 0; i < NID; ++i) {
         const int idx = tid + NTHR * i;
+        if (ABL & 512) R.sd[i] = fast16(rd, (int)(walk + idx * 16), true);
+        else
         if (!risky) R.sd[i] = fast16(rd, (int)((idx >> 4) * plane_bytes + base_d + (idx & 15) * 16), true);
         else R.sd[i] = load16(rd, (long long)(idx >> 4) * plane_bytes + base_d + (idx & 15) * 16, true);
       }
@@ -1502,11 +1509,14 @@ void conv64_wgrad_ring4_kernel(WgradRingArgs g) {
       const bool row_ok = m <= o.klast;
       const int tm = o.r + m * g.dil;
       const int base_a = (tm * g.F + o.f0 - PADF) * 4;          // may be negative at the very first pixels
-      const bool risky = !(ABL & 192) && ((tm == 0 && o.f0 < PADF) || (tm >= g.T - 1 && last_seg));
+      const bool risky = !(ABL & (192 | 512)) && ((tm == 0 && o.f0 < PADF) || (tm >= g.T - 1 && last_seg));
+      const unsigned walk_a = (unsigned)(((unsigned)ev.col * 331u + (unsigned)m) % ((unsigned)(slab >> 15) - 2u)) << 15;
 #pragma unroll
       for (int i = 0; i < NIA; ++i) {
         const int ch = chl + RPP * i;
         const bool live = row_ok && chl < RPP && ch < CH;
+        if (ABL & 512) R.sa[j][i] = fast16(ra, (int)(walk_a + 16384u + (unsigned)(ch * NQA + qa) * 16u), live);
+        else
         if (!risky) R.sa[j][i] = fast16(ra, (int)((hh * 32 + ch) * plane_bytes) + base_a + qa * 16, live);
         else R.sa[j][i] = load16(ra, (long long)(hh * 32 + ch) * plane_bytes + base_a + qa * 16, live);
       }
@@ -1840,7 +1850,7 @@ static int g_wgrad_kernel = 0;
 extern "C" int vs_set_wgrad_kernel(int mode) {
   // 3 = the four-wave 5x5 ring kernel (default where it applies), 1 = the eight-wave ring kernel, 2 = kt-split;
   // 100 + ABL: timing ablations of the four-wave kernel
-  if ((mode < 0 || mode > 3) && (mode < 100 || mode > 100 + 511)) return -1;
+  if ((mode < 0 || mode > 3) && (mode < 100 || mode > 100 + 1023)) return -1;
   g_wgrad_kernel = mode;
   return 0;
 }
@@ -1893,6 +1903,8 @@ int vs_conv64_wgrad_f16x3_impl(const float* dz, const float* in, const float* dz
           case 64: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 64>, 256); break;
           case 128: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 128>, 256); break;
           case 256: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 256>, 256); break;
+          case 512: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 512>, 256); break;
+          case 516: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 516>, 256); break;
           case 68: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 68>, 256); break;
           case 132: rc = launch(&conv64_wgrad_ring4_kernel<false, false, 132>, 256); break;
           default: rc = launch(&conv64_wgrad_ring4_kernel<false>, 256); break;
