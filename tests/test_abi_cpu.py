@@ -49,7 +49,7 @@ def test_workspace_layout_and_argument_errors():
     # prepared eval-mode weights: a function of the model dimensions and the arithmetic, not of B or T
     pb = lib.vs_prepared_bytes(ctypes.byref(d))
     assert pb == lib.vs_prepared_bytes(ctypes.byref(ops.make_dims(1, 17, 601, 256, 400, 600, 601))) and pb % 256 == 0
-    kp = (8 * 601 + 31) // 32 * 32
+    kp = (8 * 601 + 63) // 64 * 64          # VS_GEMM_KPAD
     assert 2 * 8 * 400 * kp * 2 < pb < 2 * 8 * 400 * kp * 2 + 16 * 2 ** 20        # the split W_ih halves dominate (62 MB)
     assert lib.vs_prepared_bytes(ctypes.byref(bad)) == 0
     assert lib.vs_prepare_weights(ctypes.byref(d), None, None, 0, None) != 0 and b"NULL" in lib.vs_last_error()

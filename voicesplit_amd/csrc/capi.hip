@@ -122,7 +122,7 @@ int prep_layout(const vs_dims* d, PrepLayout* L) {
   for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
   L->conv_wscale = take(6 * 8 * 4);
   L->gemm_wscale = take(8 * 4);
-  const size_t Kp = ((size_t)8 * d->F + 31) / 32 * 32;
+  const size_t Kp = ((size_t)8 * d->F + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
   L->wih_hi = take((size_t)8 * d->H * Kp * 2);
   L->wih_lo = take((size_t)8 * d->H * Kp * 2);
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
@@ -183,7 +183,7 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
 // the split-f16 / bf16 image of W_ih[:, :K] of both directions: scale2 (2 floats), then hi and lo halves [8H][Kp]
 int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int H, int K, int KE, unsigned* amax1,
                            float* w_scale2, _Float16* Wh, _Float16* Wl, hipStream_t stream) {
-  const size_t Kp = (size_t)(K + 31) / 32 * 32;
+  const size_t Kp = (size_t)(K + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
   VS_CHECK_HIP(hipMemsetAsync(amax1, 0, sizeof(unsigned), stream));
   if (int rc = vs_absmax_accum_impl(w_ih0, (long long)4 * H * KE, amax1, stream)) return rc;
   if (int rc = vs_absmax_accum_impl(w_ih1, (long long)4 * H * KE, amax1, stream)) return rc;
@@ -200,7 +200,7 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
   if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
     if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
-    const size_t Kp = (size_t)(K + 31) / 32 * 32;
+    const size_t Kp = (size_t)(K + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
     const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
     const bool aligned = scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0;
     char* base = static_cast<char*>(scratch);

@@ -301,8 +301,11 @@ void launch_layout(const Gemm16Args& g, bool vec, dim3 grid, hipStream_t stream,
 // global b128 -> register -> ds_write_b128, no conversion, and a lane's fragment (8 consecutive k)
 // is ONE ds_read_b128 (row pitch 80 B: 5 x 16 B, conflict-free for b128 with lane = row).
 // ---------------------------------------------------------------------------------------------
-constexpr int PBK = 32;                 // K block in halves
-constexpr int PPW = 20;                 // LDS row pitch in dwords (32 halves + 8 pad)
+constexpr int PBK = VS_GEMM_KPAD;       // K block in halves: 64 (one barrier pair per 48 MFMAs of a wave; 32 measured 10 % slower)
+constexpr int PPW = PBK / 2 + 4;        // LDS row pitch in dwords (64 halves + 8 pad = 144 B: conflict-free b128 reads, lane = row)
+constexpr int PCPR = PBK / 8;           // 16-byte chunks per row of a tile
+constexpr int PRPP = 256 / PCPR;        // rows one pass of the workgroup stages
+constexpr int PNP = 128 / PRPP;         // passes per 128-row tile
 
 // src [rows][ld] fp32 (K valid columns) -> hi, lo [rows][Kp] f16 of src * scale[0]
 __global__ __launch_bounds__(256)
@@ -348,9 +351,9 @@ struct GemmPreArgs {
   int tiles_m, tiles_n;
 };
 
-// C (+)= act((Ah+Al)(Wh+Wl)^T / (sA*sW) + bias terms): 128x128x32 tile, 4 waves (2x2) of 64x64
+// C (+)= act((Ah+Al)(Wh+Wl)^T / (sA*sW) + bias terms): 128x128x64 tile, 4 waves (2x2) of 64x64
 template <bool BF>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, 2)
 void gemm_pre_kernel(GemmPreArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned sAh[BM * PPW], sAl[BM * PPW], sWh[BN * PPW], sWl[BN * PPW];
   const int tid = threadIdx.x;
@@ -379,33 +382,33 @@ void gemm_pre_kernel(GemmPreArgs g) {
   };
   const __amdgpu_buffer_rsrc_t rAh = desc(g.Ah, (size_t)g.M * g.Kp), rAl = desc(g.Al, (size_t)g.M * g.Kp);
   const __amdgpu_buffer_rsrc_t rWh = desc(g.Wh, (size_t)g.N * g.Kp), rWl = desc(g.Wl, (size_t)g.N * g.Kp);
-  const int srow = tid >> 2, sq = tid & 3;                       // (row, 16-byte chunk) staged by this thread
-  unsigned offA[2], offW[2];
+  const int srow = tid / PCPR, sq = tid % PCPR;                  // (row, 16-byte chunk) staged by this thread, per pass
+  unsigned offA[PNP], offW[PNP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = srow + 64 * i;
+  for (int i = 0; i < PNP; ++i) {
+    const int row = srow + PRPP * i;
     offA[i] = (m0 + row < g.M) ? (unsigned)(((size_t)(m0 + row) * g.Kp + 8 * sq) * 2) : kOob;
     offW[i] = (n0 + row < g.N) ? (unsigned)(((size_t)(n0 + row) * g.Kp + 8 * sq) * 2) : kOob;
   }
-  u4v ra[2][2], rw[2][2];      // [row half][hi, lo]
+  u4v ra[PNP][2], rw[PNP][2];      // [pass][hi, lo]
   auto tile_load = [&](int k0) {
     const unsigned so = (unsigned)k0 * 2u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PNP; ++i) {
       ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rAh, offA[i], so, 0);
       ra[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rAl, offA[i], so, 0);
       rw[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rWh, offW[i], so, 0);
       rw[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rWl, offW[i], so, 0);
     }
   };
-  const int st = srow * PPW + 4 * sq;                           // dword index of this thread's chunk, row half 0
+  const int st = srow * PPW + 4 * sq;                           // dword index of this thread's chunk, pass 0
   auto tile_store = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u4v*>(&sAh[st + 64 * i * PPW]) = ra[i][0];
-      *reinterpret_cast<u4v*>(&sAl[st + 64 * i * PPW]) = ra[i][1];
-      *reinterpret_cast<u4v*>(&sWh[st + 64 * i * PPW]) = rw[i][0];
-      *reinterpret_cast<u4v*>(&sWl[st + 64 * i * PPW]) = rw[i][1];
+    for (int i = 0; i < PNP; ++i) {
+      *reinterpret_cast<u4v*>(&sAh[st + PRPP * i * PPW]) = ra[i][0];
+      *reinterpret_cast<u4v*>(&sAl[st + PRPP * i * PPW]) = ra[i][1];
+      *reinterpret_cast<u4v*>(&sWh[st + PRPP * i * PPW]) = rw[i][0];
+      *reinterpret_cast<u4v*>(&sWl[st + PRPP * i * PPW]) = rw[i][1];
     }
   };
   // fragment of 32-row block x, k-step ks: dwords [row*PPW + 8*ks + 4*half .. +3]
@@ -526,7 +529,7 @@ int vs_split_rows_impl(const float* x, int rows, int K, int ld, const float* sca
 }
 
 // C[M][N] (+)= act(A W^T + bias terms) over operands already split by vs_split_rows_impl (Kp = K
-// rounded up to 32; scales as used for the split)
+// rounded up to VS_GEMM_KPAD; scales as used for the split)
 int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, int Kp,
                           float* C, int ldc, int M, int N, const float* bias1, const float* bias2,
                           const float* rowbias, int ldrb, int group, int act, int accumulate,

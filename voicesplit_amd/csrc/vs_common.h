@@ -111,6 +111,7 @@ __device__ __forceinline__ float vs_act_rt(float v, int act) {
 // +40 ms per training step when tried) and a plain load first skips the atomic when it cannot
 // raise the slot (a stale value only costs a redundant atomic).  out == nullptr: no-op.
 // partial-sum slots of the BatchNorm statistics the conv epilogues accumulate ([slot][64 channels][2] doubles)
+#define VS_GEMM_KPAD 64        /* rows of pre-split GEMM operands are zero-padded to a multiple of the GEMM's K block (gemm_f16x3.hip) */
 #define VS_BN_STAT_SLOTS 64
 #define VS_AMAX_SLOTS 1024
 __device__ __forceinline__ void vs_absmax_commit(float m, unsigned* out) {
