@@ -1,4 +1,8 @@
 set -u
 export TMPDIR=/tmp
-echo "=== gemm / lstm / forward tests"; timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_forward.py tests/test_gpu_kernels.py tests/test_gpu_bf16.py -m gpu -q -x -k "gemm or bilstm or module or golden or stages or prepared or bf16" 2>&1 | grep -E "passed|failed|error" | cut -c1-200
-timeout 300 python bench.py --no-cpu-baseline --steps 6 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); s=d['stage_ms']; print(d['value'], d['ms_per_step'], 'lstm_gemm', s['lstm_gemm'], 'fwd', d['forward']['value'])"
+REPO=$PWD
+mkdir -p gpurun_out/gq
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/gq -o t -f csv -- python $REPO/bench.py --mode forward --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/gq/log.txt 2>&1
+grep -E "gemm_pre|split_rows|pk_kernel|lstm_persistent" $REPO/gpurun_out/gq/t_kernel_stats.csv | cut -d, -f1-4 | cut -c1-160
+find $REPO/gpurun_out/gq -type f ! -name "*stats.csv" -delete
