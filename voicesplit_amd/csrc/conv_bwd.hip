@@ -1389,7 +1389,6 @@ void conv64_wgrad_ring4_kernel(WgradRingArgs g) {
   constexpr bool DB = KF == 5;                     // double-buffered LDS: ring of KT+1 slots, two dz buffers
   constexpr int NS = DB ? KT + 1 : KT;             // ring slots
   constexpr int NDZ = DB ? 2 : 1;
-  constexpr int D = DB ? 1 : 2;                    // steps in flight in registers
   unsigned* const sD = smem;                       // [NDZ][hi, lo][64 rows][kPW]
   unsigned* const sA = smem + NDZ * 2 * 64 * kPW;  // [NS slots][hi, lo][CH rows][kPW]
 
@@ -1630,18 +1629,6 @@ void conv64_wgrad_ring4_kernel(WgradRingArgs g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = (kf & 1) ? __builtin_amdgcn_alignbit(w[m + q + 1], w[m + q], 16) : w[m + q];
     return __builtin_bit_cast(h8, r);
-  };
-  auto window = [&](int slot, int kb, unsigned (&wh)[6], unsigned (&wl)[6]) {
-    const unsigned* ph = sA + (size_t)(slot * 2) * CH * kPW + rowa + 8 * kb;
-    const unsigned* pl = ph + CH * kPW;
-    const u4 a = *reinterpret_cast<const u4*>(ph);
-    const u4 c = *reinterpret_cast<const u4*>(pl);
-    wh[0] = a[0]; wh[1] = a[1]; wh[2] = a[2]; wh[3] = a[3];
-    wl[0] = c[0]; wl[1] = c[1]; wl[2] = c[2]; wl[3] = c[3];
-    const u2v a2 = *reinterpret_cast<const u2v*>(ph + 4);
-    const u2v c2 = *reinterpret_cast<const u2v*>(pl + 4);
-    wh[4] = a2[0]; wh[5] = a2[1];
-    wl[4] = c2[0]; wl[5] = c2[1];
   };
   auto slot_of = [&](int m) { return ((m % NS) + NS) % NS; };
   // half-window reader: the hi (part 0) or lo (part 1) image of a ring slot, 12 halves of the lane's row
