@@ -192,6 +192,17 @@ int vs_conv64_pack_f16(const float* w, void* packed, int KT, int KF, int transpo
 int vs_conv64_f16x3_fwd(const float* in, const void* packed, const float* scale, const float* shift,
                         const float* in_scale2, const float* w_scale2, float* out,
                         int B, int T, int F, int KT, int KF, int dil, int act, void* stream);
+/* ---- channels-last bf16 form of the same layers: what VS_MATH_BF16 (BASELINE configs[2]) runs -----------------
+ * Activations [B][T][F][64] bf16 (a pixel's 64 channels contiguous), fp32 accumulate, bf16 store.
+ * vs_nhwc_conv_pack: weights [64][64][KT][KF] fp32 -> register-fragment order (vs_nhwc_conv_packed_bytes bytes);
+ * transpose_flip = 1 packs the data-gradient weights.  vs_nhwc_conv: out = act(conv(in) * scale[co] + shift[co])
+ * with 'same' zero padding and time dilation `dil`, (KT,KF) in {(7,1),(5,5)}; bn_stats (or NULL) = per-channel
+ * {sum, sum of squares} of the outputs accumulated into [64 slots][64 channels][2] doubles the caller zeroed
+ * (train-mode BatchNorm statistics; act must be VS_ACT_NONE then).  All buffers 16-byte aligned. */
+size_t vs_nhwc_conv_packed_bytes(int KT, int KF);
+int vs_nhwc_conv_pack(const float* w, void* packed, int KT, int KF, int transpose_flip, void* stream);
+int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const float* shift, void* out,
+                 int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream);
 /* cnn8: [B][64][T][F] -> [B][T][8][F], weight [8][64][1][1] */
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift,
                      float* out, int B, int T, int F, int act, void* stream);

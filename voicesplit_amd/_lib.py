@@ -102,6 +102,9 @@ SIGNATURES = {
     "vs_conv64_packed_floats": (c_size_t, [c_int, c_int]),
     "vs_conv64_pack": (c_int, [_P, _P, c_int, c_int, _P]),
     "vs_conv64_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv_packed_bytes": (c_size_t, [c_int, c_int]),
+    "vs_nhwc_conv_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_conv_last_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vs_conv64_packed_f16_floats": (c_size_t, [c_int, c_int]),
     "vs_pow2_scale": (c_int, [_P, c_longlong, _P, _P, _P]),

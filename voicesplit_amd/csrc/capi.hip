@@ -327,6 +327,19 @@ int vs_conv64_f16x3_fwd(const float* in, const void* packed, const float* scale,
                                   B, T, F, KT, KF, dil, act, nullptr, (hipStream_t)stream);
 }
 
+// ---- channels-last bf16 kernels of the VS_MATH_BF16 path (csrc/conv_nhwc.hip) -----------------------------
+size_t vs_nhwc_conv_packed_bytes(int KT, int KF) { return vs_nhwc_packed_bytes(KT, KF); }
+
+int vs_nhwc_conv_pack(const float* w, void* packed, int KT, int KF, int transpose_flip, void* stream) {
+  return vs_nhwc_pack_impl(w, packed, KT, KF, transpose_flip, (hipStream_t)stream);
+}
+
+int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const float* shift, void* out,
+                 int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream) {
+  VS_REQUIRE(in != out, "nhwc_conv: in-place is not supported");
+  return vs_nhwc_conv_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, bn_stats, (hipStream_t)stream);
+}
+
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int T, int F, int act, void* stream) {
   return vs_conv_last_fwd_impl(in, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);

@@ -1,0 +1,429 @@
+// 64 -> 64 convolution of the conv stack in the bf16 configuration (BASELINE configs[2], VS_MATH_BF16):
+// cnn2 (7x1) and cnn3..cnn7 (5x5, time dilation 1..16) of models/voicesplit/model.py:21-48, forward and data
+// gradient (the data gradient is the same kernel over weights packed transposed + tap-flipped).
+//
+// Layout: activations are CHANNELS-LAST bf16, [B][T][F][64] -- a pixel's 64 channels are 128 contiguous bytes.
+// That is the B operand of v_mfma_f32_16x16x32_bf16 as it lies in memory (a lane's 8 consecutive k = 8
+// consecutive channels of one pixel = one 16-byte piece), so the operand goes HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) and LDS -> register by one ds_read_b128 with no conversion, no transpose and no
+// VALU in between.  (The fp32 / split-f16 path keeps [B][64][T][F] fp32 and converts while staging:
+// conv_f16x3_pk.hip.)
+//
+// Decomposition.  A dilated layer is `dil` residue classes of t, each a dense conv along the class rows
+// k (t = cls + k*dil).  Work item = (utterance, class, 32-column strip, segment of class rows); a persistent
+// workgroup (one per CU, 4 waves, one per SIMD) walks its items in GROUPS of R = 8 output rows:
+//   * weights stay in REGISTERS for the whole launch: wave q owns output channels [16q, 16q+16) and holds the
+//     A fragments of all KT*KF taps x 2 k-chunks (5x5: 50 fragments = 200 VGPRs).  No weight traffic in the loop,
+//     no cross-wave reduction, every wave reads the same pixels from LDS;
+//   * the R + KT - 1 input rows a group needs sit in an LDS ring of 2 (R + KT - 1) rows (16-byte pieces
+//     XOR-swizzled on the SOURCE address so that the fragment reads are (nearly) conflict-free); the DMA of the
+//     NEXT group's R new rows -- or of all rows of the next item's first group -- is issued when a group starts,
+//     i.e. a whole group (5x5: 800 MFMAs per wave, ~13k cycles) ahead; out-of-image columns and rows come from a
+//     zero page; one s_waitcnt vmcnt(0) + one s_barrier per group;
+//   * a group is one straight-line block: for window row i, tap column df, k-chunk, column block: ONE fragment read,
+//     multiplied with the <= KT taps dt that send it to output row i - dt of the group (0.3 LDS reads per MFMA;
+//     no MFMA is issued for a (row, tap) pair outside the group, so nothing is wasted at group edges).  The R x 2
+//     accumulators are born and die inside the block: no loop-carried accumulators, no register rotation.
+//     Output row r is complete after window row r + KT - 1: its epilogue (scale/shift, activation, bf16 rounding,
+//     8-byte stores of 4 channels of one pixel) sits right there, under the MFMAs of the following window rows;
+//     lanes / rows outside the image store to a dump page instead of branching;
+//   * train mode: per-channel sum / sum of squares of the outputs are accumulated per lane over the whole launch
+//     and flushed once (shuffle over the 16 pixels of a fragment, one fp64 atomic per channel and wave).
+// Every input element is read from HBM once per strip (+12.5 % halo columns for 5x5, + KT-1 halo rows per segment),
+// every output written once.
+#include <utility>
+
+#include "vs_internal.h"
+
+namespace {
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(3))) const u4v lds_u4v;
+
+__device__ u4v g_zero_page[4];      // 64 zero bytes: source of every out-of-image piece
+__device__ u2v g_dump_page[256];    // where the stores of out-of-image lanes / rows go (one slot per thread)
+
+constexpr int STRIP = 32;           // output columns per strip = 2 MFMA column blocks of 16
+constexpr int NB = STRIP / 16;
+constexpr int R = 8;                // output rows per group
+#ifndef VS_NHWC_SGB
+#define VS_NHWC_SGB 0
+#endif
+
+struct NhwcConvArgs {
+  const unsigned short* in;         // [B][T][F][64] bf16
+  const unsigned short* wpk;        // [4 waves][taps][2 k-chunks][64 lanes][8] bf16 (vs_nhwc_pack_impl)
+  const float* scale;               // [64]  out = act(acc * scale + shift)
+  const float* shift;               // [64]
+  unsigned short* out;              // [B][T][F][64] bf16
+  double* bn_stats;                 // [VS_BN_STAT_SLOTS][64][2] or NULL
+  int B, T, F, dil;
+  int nstrip, nseg, seg_rows, n_items;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int KT, int KF>
+struct Geo {
+  static constexpr int P = KT / 2, PF = KF / 2, H = KT - 1;
+  static constexpr int NTAP = KT * KF;
+  static constexpr int RWPX = STRIP + 2 * PF;            // staged pixels per row (36 / 32)
+  static constexpr int CPR = (RWPX * 8 + 63) / 64;       // 1 KiB DMA chunks per row (5 / 4); the last may be part padding
+  static constexpr int ROWB = CPR * 1024;                // bytes per ring row
+  static constexpr int WIN = R + H;                      // input rows of a group
+  static constexpr int NR = 2 * WIN;                     // ring rows
+  static constexpr int LDS_BYTES = NR * ROWB;
+};
+
+struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
+
+template <int KT, int KF, int ACT, bool STATS>
+struct ConvWalk {
+  using G = Geo<KT, KF>;
+  static constexpr int P = G::P, PF = G::PF, H = G::H, NTAP = G::NTAP;
+
+  const NhwcConvArgs& a;
+  int lane, wave, n, g;
+  vs_bf16x8 wf[NTAP][2];
+  float sc[4], sh[4], s1[4], s2[4];
+  int boff[KF];
+  unsigned lds0;
+  const lds_byte* smem;
+
+  __device__ __forceinline__ ConvWalk(const NhwcConvArgs& a_, const lds_byte* smem_) : a(a_), smem(smem_) {
+    const int tid = threadIdx.x;
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    n = lane & 15;
+    g = lane >> 4;
+    lds0 = (unsigned)(uintptr_t)smem_;
+    const u4v* wp = reinterpret_cast<const u4v*>(a.wpk) + (size_t)wave * NTAP * 2 * 64 + lane;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) wf[tap][kc] = __builtin_bit_cast(vs_bf16x8, wp[(tap * 2 + kc) * 64]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = a.scale[wave * 16 + g * 4 + r];
+      sh[r] = a.shift[wave * 16 + g * 4 + r];
+      s1[r] = 0.f;
+      s2[r] = 0.f;
+    }
+#pragma unroll
+    for (int df = 0; df < KF; ++df) {
+      const int p = n + df;
+      boff[df] = p * 128 + ((g ^ ((p >> 1) & 7)) << 4);    // k-chunk 1: ^ 64; column block nb: + 2048 (the swizzle is 16-periodic in p)
+    }
+  }
+
+  __device__ __forceinline__ bool decode(int it, Item& r) const {
+    r.strip = it % a.nstrip;
+    const int t1 = it / a.nstrip;
+    const int seg = t1 % a.nseg;
+    const int t2 = t1 / a.nseg;
+    r.cls = t2 % a.dil;
+    r.b = t2 / a.dil;
+    const int nk = r.cls < a.T ? (a.T - r.cls + a.dil - 1) / a.dil : 0;
+    r.o0 = seg * a.seg_rows;
+    r.o1 = min(nk, r.o0 + a.seg_rows);
+    if (r.o0 >= r.o1) return false;
+    r.in_end = nk;
+    r.ngroups = (r.o1 - r.o0 + R - 1) / R;
+    return true;
+  }
+
+  // LDS-DMA of `nrows` class rows of item x starting at row w_first into ring positions pos_first.. (mod NR).
+  // A row is CPR chunks of 1 KiB (64 lanes x 16 bytes); chunk c goes to wave c % 4.  Branch-free per lane: a piece
+  // outside the image (row or column) or in the padding of a row reads the zero page.
+  __device__ __forceinline__ void issue(const Item& x, int w_first, int nrows, int pos_first) const {
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
+    const long long rel0 = reinterpret_cast<const unsigned char*>(a.in) - zp;
+    const long long row0 = (long long)x.b * a.T + x.cls;
+    const int nchunks = nrows * G::CPR;
+    for (int c = wave; c < nchunks; c += 4) {
+      const int row = c / G::CPR, part = c - row * G::CPR;
+      const int w = w_first + row;
+      int pos = pos_first + row;
+      if (pos >= G::NR) pos -= G::NR;
+      const int px = part * 8 + (lane >> 3);                              // pixel of the staged row
+      const int col = x.strip * STRIP - PF + px;
+      const bool ok = (w >= 0) & (w < x.in_end) & (px < G::RWPX) & (col >= 0) & (col < a.F);
+      const int sw = ((lane & 7) ^ ((px >> 1) & 7)) << 4;                 // LDS piece q of pixel px holds channel piece q ^ f(px)
+      const long long off = rel0 + ((((row0 + (long long)w * a.dil) * a.F + col) << 7) + sw);
+      const unsigned char* src = zp + (off & -(long long)ok);
+      const unsigned dst = lds0 + (unsigned)(pos * G::ROWB + part * 1024);
+      glds16(src, (unsigned)__builtin_amdgcn_readfirstlane(dst));
+    }
+  }
+
+  // One group: output rows ro .. ro+RV-1 of item x (RV = R, or the even tail of the item; rows >= x.o1 are computed and
+  // dropped), window rows at ring positions cq .. cq+RV+H-1 (mod NR).  gstep<RV, GI> is fragment GI of the block: its
+  // read two fragments ahead and its MFMAs.  The instruction order is pinned (sched_barrier after every MFMA): hipcc's
+  // own order reads a fragment, waits for it and issues two MFMAs, and its sched_group_barrier solver needs 17 minutes
+  // for this block.  The epilogue of output row r (complete after window row r + H) is cut into micro-ops -- one
+  // channel value, or one 8-byte store -- and one micro-op follows each of the first MFMAs of window row r + H + 1,
+  // so it issues in the shadow of the matrix pipe; only the last row's epilogue runs behind the block.
+  template <int RV>
+  struct GroupState {
+    f32x4 acc[RV][NB];
+    vs_bf16x8 bq[3];
+    float y[NB][4];
+    int ro, cq;
+  };
+  static constexpr int NMICRO = NB * 4 + NB;
+
+  template <int RV>
+  __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
+    const int nb = gi % NB, kc = (gi / NB) % 2, df = (gi / (2 * NB)) % KF, i = gi / (2 * NB * KF);
+    int pos = st.cq + i;
+    if (pos >= G::NR) pos -= G::NR;
+    return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(smem + pos * G::ROWB + nb * 2048 + (boff[df] ^ (kc << 6))));
+  }
+
+  // micro-op q of the epilogue of output row r of the group
+  template <int RV, int r, int q>
+  __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
+    if constexpr (q < NB * 4) {
+      constexpr int nb2 = q / 4, c = q % 4;
+      st.y[nb2][c] = vs_act_fast<ACT>(fmaf(st.acc[r][nb2][c], sc[c], sh[c]));
+    } else {
+      constexpr int nb2 = q - NB * 4;
+      const int k = st.ro + r;
+      const int col = x.strip * STRIP + nb2 * 16 + n;
+      const bool ok = (k < x.o1) & (col < a.F);
+      if (STATS) {
+        const float m = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float ym = st.y[nb2][c] * m; s1[c] += ym; s2[c] = fmaf(ym, st.y[nb2][c], s2[c]); }
+      }
+      const u2v pk = {vs_pack_bf16(st.y[nb2][0], st.y[nb2][1]), vs_pack_bf16(st.y[nb2][2], st.y[nb2][3])};
+      const size_t pix = ((size_t)x.b * a.T + (x.cls + k * a.dil)) * a.F + col;
+      unsigned char* dst = ok ? reinterpret_cast<unsigned char*>(a.out) + (pix << 7) + (wave * 32 + g * 8)
+                              : reinterpret_cast<unsigned char*>(g_dump_page) + threadIdx.x * 8;
+      *reinterpret_cast<u2v*>(dst) = pk;
+    }
+  }
+
+  template <int RV, int GI, int MM>
+  __device__ __forceinline__ void gmfma(const Item& x, GroupState<RV>& st) {
+    constexpr int nb = GI % NB, kc = (GI / NB) % 2, df = (GI / (2 * NB)) % KF, i = GI / (2 * NB * KF), ls = GI % (2 * NB * KF);
+    constexpr int r_lo = i - (KT - 1) > 0 ? i - (KT - 1) : 0, r_hi = i < RV - 1 ? i : RV - 1;
+    constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
+    constexpr int r = r_lo + MM;                            // tap dt = i - r
+    st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
+    constexpr int q = ls * nm + MM;                         // MFMAs issued since window row i started
+    if constexpr (i >= H + 1 && q < NMICRO) micro<RV, i - H - 1, q>(x, st);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  template <int RV, int GI, int... MMs>
+  __device__ __forceinline__ void gmfmas(const Item& x, GroupState<RV>& st, std::integer_sequence<int, MMs...>) {
+    (gmfma<RV, GI, MMs>(x, st), ...);
+  }
+
+  template <int RV, int GI>
+  __device__ __forceinline__ void gstep(const Item& x, GroupState<RV>& st) {
+    constexpr int NG = (RV + H) * KF * 2 * NB;              // fragment reads of the group
+    constexpr int i = GI / (2 * NB * KF);
+    constexpr int r_lo = i - (KT - 1) > 0 ? i - (KT - 1) : 0, r_hi = i < RV - 1 ? i : RV - 1;
+    if constexpr (GI + 2 < NG) st.bq[(GI + 2) % 3] = frag<RV>(st, GI + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    gmfmas<RV, GI>(x, st, std::make_integer_sequence<int, r_hi - r_lo + 1>());
+  }
+
+  template <int RV, int... GIs>
+  __device__ __forceinline__ void gsteps(const Item& x, GroupState<RV>& st, std::integer_sequence<int, GIs...>) {
+    (gstep<RV, GIs>(x, st), ...);
+  }
+
+  template <int RV, int... Qs>
+  __device__ __forceinline__ void last_row(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Qs...>) {
+    (micro<RV, RV - 1, Qs>(x, st), ...);
+  }
+
+  template <int RV>
+  __device__ __forceinline__ void group(const Item& x, int ro, int cq) {
+    GroupState<RV> st;
+    st.ro = ro;
+    st.cq = cq;
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) st.acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st.bq[0] = frag<RV>(st, 0);
+    st.bq[1] = frag<RV>(st, 1);
+    gsteps<RV>(x, st, std::make_integer_sequence<int, (RV + H) * KF * 2 * NB>());
+    last_row<RV>(x, st, std::make_integer_sequence<int, NMICRO>());
+  }
+
+  __device__ __forceinline__ void flush_stats() {
+    if (!STATS || a.bn_stats == nullptr) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1[r] += __shfl_xor(s1[r], o, 64);
+        s2[r] += __shfl_xor(s2[r], o, 64);
+      }
+    }
+    if (n == 0) {
+      double* dst = a.bn_stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + (wave * 16 + g * 4) * 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(dst + 2 * r, (double)s1[r]);
+        atomicAdd(dst + 2 * r + 1, (double)s2[r]);
+      }
+    }
+  }
+};
+
+template <int KT, int KF, int ACT, bool STATS>
+__global__ __launch_bounds__(256, 1)
+void nhwc_conv_kernel(NhwcConvArgs a) {
+  using G = Geo<KT, KF>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];      // the only LDS object of the kernel
+  ConvWalk<KT, KF, ACT, STATS> wk(a, (const lds_byte*)smem);
+
+  // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
+  Item pf;
+  int pf_it = (int)blockIdx.x, pf_g = 0;
+  bool pf_live = false;
+  auto pf_seek = [&]() {           // first item at or after pf_it that decodes
+    pf_live = false;
+    while (pf_it < a.n_items) {
+      if (wk.decode(pf_it, pf)) { pf_g = 0; pf_live = true; return; }
+      pf_it += (int)gridDim.x;
+    }
+  };
+  int wp = 0;                      // ring position the next DMA'd row goes to
+  auto pf_issue = [&]() {          // DMA the rows of group (pf, pf_g) that are not in the ring yet; advance the cursor
+    const int ro = pf.o0 + pf_g * R;
+    const int first = pf_g == 0 ? 0 : G::H;               // later groups share their first H window rows with the previous one
+    const int nrows = G::WIN - first;
+    wk.issue(pf, ro - G::P + first, nrows, wp);
+    wp += nrows;
+    if (wp >= G::NR) wp -= G::NR;
+    if (++pf_g >= pf.ngroups) { pf_it += (int)gridDim.x; pf_seek(); }
+  };
+  pf_seek();
+  if (pf_live) pf_issue();
+
+  Item cur;
+  int cq = 0;                      // ring position of the first window row of the group being computed
+  for (int it = (int)blockIdx.x; it < a.n_items; it += (int)gridDim.x) {
+    if (!wk.decode(it, cur)) continue;
+    for (int gidx = 0; gidx < cur.ngroups; ++gidx) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the window have landed (and its stores retired)
+      __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done with the previous window
+      const int wp_before = wp;
+      const bool pf_new_item = pf_live && pf_g == 0;
+      if (pf_live) pf_issue();
+      const int ro = cur.o0 + gidx * R;
+      const int left = cur.o1 - ro;                           // > 0
+      if (left > 6) wk.template group<8>(cur, ro, cq);
+      else if (left > 4) wk.template group<6>(cur, ro, cq);
+      else if (left > 2) wk.template group<4>(cur, ro, cq);
+      else wk.template group<2>(cur, ro, cq);
+      // next group: same item -> its window starts R rows further; next item -> where its first group was just written
+      if (gidx + 1 < cur.ngroups) { cq += R; if (cq >= G::NR) cq -= G::NR; }
+      else if (pf_new_item) cq = wp_before;
+    }
+  }
+  wk.flush_stats();
+}
+
+// w [co][ci][KT][KF] fp32 -> per-wave A fragments: [q][tap][kc][lane][j] = w'[16q + (lane&15)][32kc + 8(lane>>4) + j][tap]
+// (transpose_flip: w'[m][k][dt][df] = w[k][m][KT-1-dt][KF-1-df], the data gradient's weights)
+__global__ void nhwc_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int KT, int KF, int transpose_flip) {
+  const int ntap = KT * KF;
+  const int total = 4 * ntap * 2 * 64 * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, kc = (i >> 9) & 1;
+    const int tap = (i >> 10) % ntap, q = (i >> 10) / ntap;
+    const int m = 16 * q + (lane & 15), k = 32 * kc + 8 * (lane >> 4) + j;
+    const int dt = tap / KF, df = tap - dt * KF;
+    const float v = transpose_flip ? w[((size_t)(k * 64 + m) * KT + (KT - 1 - dt)) * KF + (KF - 1 - df)]
+                                   : w[((size_t)(m * 64 + k) * KT + dt) * KF + df];
+    out[i] = (unsigned short)(vs_pack_bf16(v, 0.f) & 0xffffu);
+  }
+}
+
+int num_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  }
+  return cus[dev];
+}
+
+template <int KT, int KF>
+int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
+  const int nk_max = (a.T + a.dil - 1) / a.dil;
+  const long long base_items = (long long)a.B * a.dil * a.nstrip;
+  // enough items for the persistent grid to balance (>= ~16 per workgroup), segments no shorter than 16 rows
+  int nseg = (int)((4096 + base_items - 1) / base_items);
+  if (nseg > nk_max / 16) nseg = nk_max / 16;
+  if (nseg < 1) nseg = 1;
+  int seg_rows = (nk_max + nseg - 1) / nseg;
+  seg_rows = (seg_rows + R - 1) / R * R;
+  nseg = (nk_max + seg_rows - 1) / seg_rows;
+  a.nseg = nseg;
+  a.seg_rows = seg_rows;
+  const long long n_items = base_items * nseg;
+  VS_REQUIRE(n_items < (1LL << 30), "nhwc conv: too many work items");
+  a.n_items = (int)n_items;
+  const int cus = num_cus();
+  const dim3 grid((unsigned)(n_items < cus ? n_items : cus)), block(256);
+  const size_t lds = 0;   // static LDS: Geo::LDS_BYTES
+  const bool stats = a.bn_stats != nullptr;
+#define VS_NHWC_LAUNCH(A, S) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S>), grid, block, lds, stream, a)
+  if (stats) {
+    VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv: fused statistics go with no activation");
+    VS_NHWC_LAUNCH(VS_ACT_NONE, true);
+  } else if (act == VS_ACT_NONE) VS_NHWC_LAUNCH(VS_ACT_NONE, false);
+  else if (act == VS_ACT_MISH) VS_NHWC_LAUNCH(VS_ACT_MISH, false);
+  else if (act == VS_ACT_RELU) VS_NHWC_LAUNCH(VS_ACT_RELU, false);
+  else VS_REQUIRE(false, "nhwc conv: unsupported activation %d", act);
+#undef VS_NHWC_LAUNCH
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+size_t vs_nhwc_packed_bytes(int KT, int KF) { return (size_t)64 * 64 * KT * KF * 2; }
+
+int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t stream) {
+  VS_REQUIRE(w && packed, "nhwc pack: NULL argument");
+  VS_REQUIRE((KT == 5 && KF == 5) || (KT == 7 && KF == 1), "nhwc pack: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
+  hipLaunchKernelGGL(nhwc_pack_kernel, dim3(64), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(packed), KT, KF, transpose_flip);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[b][t][f][co] = act(scale[co] * sum_{ci,dt,df} w[co][ci][dt][df] in[b][t + (dt-KT/2) dil][f + df - KF/2][ci] + shift[co]),
+// zero padding; in/out channels-last bf16.  bn_stats: per-channel {sum, sum of squares} of the (fp32) outputs,
+// [VS_BN_STAT_SLOTS][64][2] doubles the caller zeroed (act must be VS_ACT_NONE then).
+int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
+                      int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t stream) {
+  VS_REQUIRE(in && packed && scale && shift && out, "nhwc conv: NULL argument");
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "nhwc conv: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nhwc conv: buffers must be 16-byte aligned");
+  NhwcConvArgs a{reinterpret_cast<const unsigned short*>(in), reinterpret_cast<const unsigned short*>(packed), scale, shift,
+                 reinterpret_cast<unsigned short*>(out), bn_stats, B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
+  if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
+  if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
+  VS_REQUIRE(false, "nhwc conv: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
+  return -1;
+}

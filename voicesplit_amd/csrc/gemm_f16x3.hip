@@ -26,6 +26,8 @@
 // at the bottom of this file (split pass + gemm_pre_kernel: 1.95 ms, MFMA pipe 46 % busy, 88M
 // instead of 697M VALU instructions per launch); the two backward contractions stay here: they
 // would need transposed split copies of dxg and feat (~0.45 ms) to save ~1 ms.
+#include <stdlib.h>
+
 #include "vs_common.h"
 
 namespace {
@@ -55,6 +57,7 @@ struct Gemm16Args {
   const float* a_scale;   // {s, 1/s}
   const float* w_scale;   // {s, 1/s}
   int tiles_m, tiles_n;
+  int band;               // tile rows per band of the workgroup -> tile map (gemm_tile_of)
 };
 
 // BF (VS_MATH_BF16): one bf16 rounding per element in the hi image, nothing in the lo image; the kernels
@@ -85,6 +88,26 @@ struct OperandView {
 };
 
 constexpr unsigned kOob = 0xFFFFFFF0u;    // beyond any descriptor (operands are < 4 GiB)
+
+// Workgroup id -> (m, n) tile.  XCD x (= workgroup id % 8, the dispatcher's round robin) owns the contiguous range
+// [x*per, (x+1)*per) of a BANDED tile list: bands of `band` tile rows (8; VOICESPLIT_GEMM_BAND overrides it for A/B timing, 0 = the row-major list), inside a band the m index runs fastest.
+// The ~64 workgroups an XCD has resident at a time then cover an 8 x 8 block of tiles: per K step they share 8 + 8
+// operand panels in that XCD's L2, where the row-major list (n fastest, 25 tiles per row in the LSTM input GEMM)
+// made them span 2.6 tile rows = 3 + 25 panels and re-stream all of W from the Infinity Cache for every row panel
+// (r02 counters: 9.87 GB fetched per launch against 0.68 GB of operands).
+__device__ __forceinline__ bool gemm_tile_of(int tiles_m, int tiles_n, int band_rows, int& tm, int& tn) {
+  const int per = (int)(gridDim.x >> 3);
+  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (t >= tiles_m * tiles_n) return false;
+  if (band_rows <= 0) { tm = t / tiles_n; tn = t - tm * tiles_n; return true; }   // row-major list (round 2), kept for A/B timing
+  const int band_tiles = band_rows * tiles_n;
+  const int band = t / band_tiles;
+  const int r = t - band * band_tiles;
+  const int rows = min(band_rows, tiles_m - band * band_rows);   // the last band may be shorter
+  tn = r / rows;
+  tm = band * band_rows + (r - tn * rows);
+  return true;
+}
 
 // One operand tile [128 rows][BK k] : global -> registers (RT floats per thread).  Every access
 // is a buffer load whose offset is pushed out of range when the row or k index is outside the
@@ -179,11 +202,9 @@ void gemm_f16x3_kernel(Gemm16Args g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  // XCD x takes tiles [x*per, (x+1)*per) of the row-major (m, n) tile list
-  const int per = gridDim.x >> 3;
-  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (tile >= g.tiles_m * g.tiles_n) return;
-  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  int tile_m, tile_n;
+  if (!gemm_tile_of(g.tiles_m, g.tiles_n, g.band, tile_m, tile_n)) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const float sa = g.a_scale[0], sw = g.w_scale[0];
   const float inv = g.a_scale[1] * g.w_scale[1];
 
@@ -349,6 +370,7 @@ struct GemmPreArgs {
   int act, accumulate;
   const float* a_scale; const float* w_scale;
   int tiles_m, tiles_n;
+  int band;
 };
 
 // C (+)= act((Ah+Al)(Wh+Wl)^T / (sA*sW) + bias terms): 128x128x64 tile, 4 waves (2x2) of 64x64
@@ -361,10 +383,9 @@ void gemm_pre_kernel(GemmPreArgs g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
-  const int per = gridDim.x >> 3;                                // XCD x owns tiles [x*per, (x+1)*per)
-  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (tile >= g.tiles_m * g.tiles_n) return;
-  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  int tile_m, tile_n;
+  if (!gemm_tile_of(g.tiles_m, g.tiles_n, g.band, tile_m, tile_n)) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const float inv = g.a_scale[1] * g.w_scale[1];
 
   f32x16 acc[2][2];
@@ -470,6 +491,14 @@ void gemm_pre_kernel(GemmPreArgs g) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int gemm_band() {
+  static const int band = [] {
+    const char* e = getenv("VOICESPLIT_GEMM_BAND");
+    return e ? atoi(e) : 8;
+  }();
+  return band;
+}
+
 }  // namespace
 
 int vs_pow2_scale_impl(const float* x, long long n, unsigned* amax_scratch, float* scale2, hipStream_t stream);
@@ -495,7 +524,7 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
   VS_REQUIRE(!layout_a || ((size_t)(K - 1) * lda + M) * 4 < (1ull << 32), "gemm_f16x3: K-major A above 4 GiB");
   VS_REQUIRE(!layout_w || ((size_t)(K - 1) * ldw + N) * 4 < (1ull << 32), "gemm_f16x3: K-major W above 4 GiB");
   Gemm16Args g{A, lda, W, ldw, W_hi, n_split, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1,
-               gate, ldg, a_relu, w_relu, act, accumulate, a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
+               gate, ldg, a_relu, w_relu, act, accumulate, a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN, gemm_band()};
   const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && (K % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
   VS_REQUIRE(layout_a || ((size_t)(M - 1) * lda + K) * 4 < (1ull << 32) - 64, "gemm_f16x3: A above 4 GiB");
   VS_REQUIRE(layout_w || ((size_t)(N - 1) * ldw + K) * 4 < (1ull << 32) - 64, "gemm_f16x3: W above 4 GiB");
@@ -539,7 +568,7 @@ int vs_gemm_presplit_impl(const _Float16* Ah, const _Float16* Al, const _Float16
   VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm_presplit: rowbias needs group>0 and ldrb>=N");
   VS_REQUIRE(aligned16(Ah) && aligned16(Al) && aligned16(Wh) && aligned16(Wl), "gemm_presplit: operands must be 16-byte aligned");
   GemmPreArgs g{Ah, Al, Wh, Wl, C, ldc, M, N, Kp, bias1, bias2, rowbias, ldrb, group > 0 ? group : 1, act, accumulate,
-                a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN};
+                a_scale2, w_scale2, (M + BM - 1) / BM, (N + BN - 1) / BN, gemm_band()};
   if (math == VS_MATH_CODE_BF16) hipLaunchKernelGGL(gemm_pre_kernel<true>, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
   else hipLaunchKernelGGL(gemm_pre_kernel<false>, dim3((unsigned)((g.tiles_m * g.tiles_n + 7) / 8 * 8)), dim3(256), 0, stream, g);
   VS_LAUNCH_CHECK();

@@ -65,6 +65,11 @@ int vs_conv64_layer_impl(int math, const float* in, const float* w, void* packed
                          int dil, int act, int transpose_flip, unsigned* amax_out, hipStream_t,
                          double* bn_stats = nullptr);   // split-f16 / bf16 only: fused train-mode BatchNorm statistics of `out`
 inline unsigned* vs_amax_slot(float* slot) { return reinterpret_cast<unsigned*>(slot + 8); }
+// conv_nhwc.hip: channels-last bf16 64->64 convs (VS_MATH_BF16)
+size_t vs_nhwc_packed_bytes(int KT, int KF);
+int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
+int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
+                      int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
 // conv_edge.hip
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
 int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, unsigned* amax_out, hipStream_t);

@@ -631,3 +631,27 @@ def colsum(x, groups: int, rows: int):
     out = torch.empty(groups, N, dtype=torch.float32, device=x.device)
     check(lib.vs_colsum(_p(x), N, groups, rows, N, _p(out), N, _stream()), "vs_colsum")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# channels-last bf16 kernels of the VS_MATH_BF16 path (csrc/conv_nhwc.hip); unit-test surface
+# ---------------------------------------------------------------------------------------------
+def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = False, stats: bool = False):
+    """x [B,T,F,64] bf16 (channels last), w [64,64,KT,KF] fp32 -> act(conv(x) * scale + shift) as [B,T,F,64] bf16,
+    'same' zero padding, time dilation `dil`.  stats: also return the per-channel {sum, sum of squares} of the
+    outputs, [64, 2] float64 (train-mode BatchNorm statistics; act must be "none")."""
+    lib = _lib.load()
+    _dev_check(x, "x", torch.bfloat16)
+    for n, t in (("w", w), ("scale", scale), ("shift", shift)):
+        _dev_check(t, n)
+    B, T, F, C = x.shape
+    if C != 64:
+        raise ValueError("nhwc_conv: 64 channels expected")
+    KT, KF = w.shape[2], w.shape[3]
+    packed = torch.empty(lib.vs_nhwc_conv_packed_bytes(KT, KF), dtype=torch.uint8, device=x.device)
+    check(lib.vs_nhwc_conv_pack(_p(w), _p(packed), KT, KF, int(transpose_flip), _stream()), "vs_nhwc_conv_pack")
+    out = torch.empty_like(x)
+    st = torch.zeros(64, 64, 2, dtype=torch.float64, device=x.device) if stats else None
+    check(lib.vs_nhwc_conv(_p(x), _p(packed), _p(scale), _p(shift), _p(out), B, T, F, KT, KF, dil, ACT_CODES[act],
+                           _p(st), _stream()), "vs_nhwc_conv")
+    return (out, st.sum(0)) if stats else out
