@@ -94,3 +94,31 @@ def test_nhwc_conv_one_hot_indexing():
         got = ops.nhwc_conv(x.to(torch.bfloat16).cuda(), w.cuda(), torch.ones(64).cuda(), torch.zeros(64).cuda(), dil, "none").float().cpu()
         ref = _ref_conv(x.to(torch.bfloat16), w, torch.ones(64), torch.zeros(64), dil, "none").float()
         assert torch.equal(got, ref.to(torch.bfloat16).float()), (t0, f0, ci, dil)
+
+
+# ---- the channels-last path inside the stage / whole-path calls (dims.math = VS_MATH_BF16) ------------------------
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("B,T,Fq", [(3, 45, 53), (2, 20, 601), (1, 301, 40)])
+def test_bf16_conv_stack_stage_vs_fp64_oracle(act, training, B, T, Fq):
+    """vs_conv_stack_fwd in bf16: cnn1 -> channels-last bf16 -> cnn2..cnn7 (conv_nhwc.hip) -> cnn8 -> feature layout,
+    eval (BatchNorm folded into the conv epilogues) and train mode (statistics from the epilogues + apply pass)."""
+    from oracle import reference_forward as R
+    from voicesplit_amd import ops
+    dims_d = dict(num_freq=Fq, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=Fq)
+    sd = R.build_state_dict(dims_d, 5)
+    x, _ = R.synthetic_inputs(B, T, dims_d, 5)
+    bn_out = {}
+    y = R.conv_stack(x.double(), {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, act, training, bn_out=bn_out)
+    ref = y.transpose(1, 2).reshape(B, T, -1)
+    sd_dev = {k: v.clone().cuda() for k, v in sd.items()}
+    dims = ops.make_dims(B, T, Fq, 24, 32, 44, Fq, math="bf16")
+    feat = ops.conv_stack(sd_dev, x.cuda(), dims, act, training=training)
+    err = ((feat.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 3e-2, f"bf16 conv stack ({act}, training={training}): {err:.3e} of the output range"
+    if training:      # running statistics updated from the epilogue sums (momentum 0.1)
+        for k in ("conv.2.running_mean", "conv.2.running_var", "conv.6.running_mean", "conv.6.running_var",
+                  "conv.26.running_mean", "conv.26.running_var"):
+            r = bn_out[k]
+            e = ((sd_dev[k].double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-6)).item()
+            assert e < 2e-2, (k, e)

@@ -413,6 +413,46 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
       VS_CHECK_HIP(hipMemcpyAsync(shift + 64 * l, p->conv[l].bias, sizeof(float) * Cl[l], hipMemcpyDeviceToDevice, stream));
   }
 
+  if (d->math == VS_MATH_BF16) {
+    // BASELINE configs[2]: channels-last bf16 activations [B][T][F][64] in the same ping-pong buffers (half their
+    // size), conv_nhwc.hip / nhwc_edge.hip kernels.  eval: BatchNorm + activation in the conv epilogue; train:
+    // z = conv + bias with statistics from the epilogue, then one apply pass in place.
+    void* abuf[2] = {at<void>(ws, L.act0), at<void>(ws, L.act1)};
+    const long long npix = (long long)B * T * F;
+    int c = 0;
+    auto bn_train = [&](int l, void* buf) -> int {
+      const vs_conv_layer& cl = p->conv[l];
+      if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, cl.bn_weight, cl.bn_bias, cl.bn_running_mean,
+                                       cl.bn_running_var, kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, nullptr, nullptr, stream)) return rc;
+      return vs_nhwc_bn_apply_impl(buf, buf, npix, conv_act, scale + 64 * l, shift + 64 * l, stream);
+    };
+    {
+      ProfScope ps(VS_PROF_CNN1, stream);
+      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+      if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, scale, shift, abuf[c], B, T, F, layer_act, train ? stats : nullptr, stream)) return rc;
+      if (train) { if (int rc = bn_train(0, abuf[c])) return rc; }
+    }
+    for (int i = 0; i < 6; ++i) {
+      const int l = i + 1;
+      ProfScope ps(VS_PROF_CNN2 + i, stream);
+      void* packed = prep ? prep->conv_packed[i] : at<void>(ws, L.conv_packed[i]);
+      if (!prep) { if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc; }
+      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+      if (int rc = vs_nhwc_conv_impl(abuf[c], packed, scale + 64 * l, shift + 64 * l, abuf[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf,
+                                     kMid[i].dil, layer_act, train ? stats : nullptr, stream)) return rc;
+      c ^= 1;
+      if (train) { if (int rc = bn_train(l, abuf[c])) return rc; }
+    }
+    ProfScope ps(VS_PROF_CNN8, stream);
+    if (int rc = vs_nhwc_conv_last_impl(abuf[c], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat, B, T, F, layer_act, stream)) return rc;
+    if (train) {
+      if (int rc = vs_bn_train_feat_impl(feat, feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
+                                         p->conv[7].bn_running_var, kBnEps, kBnMomentum, conv_act, stats,
+                                         scale + 64 * 7, shift + 64 * 7, nullptr, nullptr, stream)) return rc;
+    }
+    return 0;
+  }
+
   int cur = 0;
   // split-f16 convs: every producer of a conv operand folds its |max| into the consumer's slot
   float* cs = at<float>(ws, L.conv_scales);
@@ -588,7 +628,9 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
   }
   for (int i = 0; i < 6; ++i) {
     const float* w = p->conv[i + 1].weight;
-    if (d->math != VS_MATH_FP32) {
+    if (d->math == VS_MATH_BF16) {
+      if (int rc = vs_nhwc_pack_impl(w, P.conv_packed[i], kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+    } else if (d->math != VS_MATH_FP32) {
       float* ws8 = P.conv_wscale + 8 * i;
       if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0,
                                            reinterpret_cast<unsigned*>(ws8 + 4), ws8, stream, d->math)) return rc;

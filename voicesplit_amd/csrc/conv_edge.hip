@@ -324,6 +324,20 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
   return vs_bn_apply_impl(x, y, B, C, plane, act, scale, shift, amax_out, stream);
 }
 
+// Train-mode BatchNorm constants from accumulated statistics: stats = [slots][C][2] doubles {sum, sum of squares}
+// (slots > 1: partial sums of the conv epilogues, folded here) over `count` values per channel -> scale / shift of the
+// apply pass, mean / invstd for the backward pass, running buffers updated like nn.BatchNorm2d.
+int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float eps, float momentum,
+                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t stream) {
+  VS_REQUIRE(stats && C > 0 && count > 0, "bn_finalize: bad argument");
+  if (slots > 1) hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, slots);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, gamma, beta,
+                     eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 // y = act(x*scale[c] + shift[c]) over [B][C][plane]
 int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift,
                      unsigned* amax_out, hipStream_t stream) {

@@ -217,9 +217,18 @@ struct ConvWalk {
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
     st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
-    constexpr int q = ls * nm + MM;                         // MFMAs issued since window row i started
-    if constexpr (i >= H + 1 && q < NMICRO) micro<RV, i - H - 1, q>(x, st);
+    if constexpr (i >= H + 1) {
+      // MFMA number q of window row i carries micro-ops [q * per, (q + 1) * per) of the row completed before it; near
+      // the end of a group a window row has few MFMAs (7x1: 4), so several micro-ops may share one
+      constexpr int cap = 2 * NB * KF * nm, per = (NMICRO + cap - 1) / cap, q = ls * nm + MM;
+      micros<RV, i - H - 1, q * per>(x, st, std::make_integer_sequence<int, (q * per < NMICRO ? (NMICRO - q * per < per ? NMICRO - q * per : per) : 0)>());
+    }
     __builtin_amdgcn_sched_barrier(0);
+  }
+
+  template <int RV, int r, int Q0, int... Ds>
+  __device__ __forceinline__ void micros(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Ds...>) {
+    (micro<RV, r, Q0 + Ds>(x, st), ...);
   }
 
   template <int RV, int GI, int... MMs>

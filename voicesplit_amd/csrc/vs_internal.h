@@ -70,7 +70,16 @@ size_t vs_nhwc_packed_bytes(int KT, int KF);
 int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
+// nhwc_edge.hip: the HBM-bound kernels around them (cnn1, BatchNorm apply, cnn8)
+int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, const float* shift, void* out,
+                            int B, int T, int F, int act, double* bn_stats, hipStream_t);
+int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
+int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
+                           int B, int T, int F, int act, hipStream_t);
 // conv_edge.hip
+int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float eps, float momentum,
+                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
 int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, unsigned* amax_out, hipStream_t);
 int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
