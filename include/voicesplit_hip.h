@@ -203,6 +203,31 @@ size_t vs_nhwc_conv_packed_bytes(int KT, int KF);
 int vs_nhwc_conv_pack(const float* w, void* packed, int KT, int KF, int transpose_flip, void* stream);
 int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                  int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream);
+/* the memory-bound kernels around them.  cnn1: x [B][T][F] fp32 -> [B][T][F][64] bf16 (bn_stats as above);
+ * BatchNorm + activation apply a = act(z * scale[c] + shift[c]) over npix pixels (a may alias z); cnn8 + transpose/view:
+ * [B][T][F][64] bf16 -> [B][T][8][F] fp32. */
+int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
+                       int B, int T, int F, int act, double* bn_stats, void* stream);
+int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, void* stream);
+int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const float* shift, float* out,
+                      int B, int T, int F, int act, void* stream);
+/* backward.  Weight gradient of cnn2..cnn7: dz, in [B][T][F][64] bf16 -> dw [64][64][KT][KF] fp32; partials =
+ * vs_nhwc_conv_wgrad_partial_floats(KT, KF) floats of scratch.  BatchNorm + activation backward over npix pixels
+ * (dz may alias da; stats = 64*64*2 doubles, coef = 192 floats of scratch), and the same fused with cnn1's 1x7 weight
+ * gradient (dw [64][7], acc = 448 doubles; dz1 is never written).  cnn8 backward in one pass: dz8 [B][T][8][F] fp32,
+ * a7 [B][T][F][64] bf16 -> din (bf16, layout of a7) and dw [8][64]; partials = vs_nhwc_conv_last_bwd_blocks() * 512 floats. */
+size_t vs_nhwc_conv_wgrad_partial_floats(int KT, int KF);
+int vs_nhwc_conv_wgrad(const void* dz, const void* in, float* partials, float* dw, int B, int T, int F, int KT, int KF, int dil,
+                       void* stream);
+int vs_nhwc_bn_act_bwd(const void* da, const void* z, void* dz, long long npix, int act, int bn_mode,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream);
+int vs_nhwc_bn_act_bwd_first(const void* da, const void* z, const float* x, int B, int T, int F, int act, int bn_mode,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream);
+int vs_nhwc_conv_last_bwd_blocks(void);
+int vs_nhwc_conv_last_bwd(const float* dz8, const float* w, const void* a7, void* din, float* partials, float* dw,
+                          int B, int T, int F, void* stream);
 /* cnn8: [B][64][T][F] -> [B][T][8][F], weight [8][64][1][1] */
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift,
                      float* out, int B, int T, int F, int act, void* stream);

@@ -122,3 +122,152 @@ def test_bf16_conv_stack_stage_vs_fp64_oracle(act, training, B, T, Fq):
             r = bn_out[k]
             e = ((sd_dev[k].double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-6)).item()
             assert e < 2e-2, (k, e)
+
+
+# ---- memory-bound kernels and the backward kernels of the channels-last path ------------------------------------
+def _act(y, act):
+    if act == "relu":
+        return y.clamp_min(0)
+    if act == "mish":
+        return y * torch.tanh(F.softplus(y, threshold=20))
+    return y
+
+
+@pytest.mark.parametrize("act", ["none", "mish", "relu"])
+def test_nhwc_conv_first_bn_apply_conv_last(act):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, Fq = 2, 13, 75
+    x = torch.rand(B, T, Fq, generator=g)
+    w1 = torch.randn(64, 1, 1, 7, generator=g) * 0.4
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    ref = F.conv2d(x.double().unsqueeze(1), w1.double(), padding=(0, 3)) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = _act(ref, act).permute(0, 2, 3, 1).contiguous()
+    if act == "none":
+        got, st = ops.nhwc_conv_first(x.cuda(), w1.cuda(), scale.cuda(), shift.cuda(), act, stats=True)
+        assert torch.allclose(st[:, 0].cpu(), ref.sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st[:, 1].cpu(), (ref * ref).sum((0, 1, 2)), rtol=1e-4)
+    else:
+        got = ops.nhwc_conv_first(x.cuda(), w1.cuda(), scale.cuda(), shift.cuda(), act)
+    _close(got, ref, "nhwc cnn1")
+    # BatchNorm apply on the bf16 tensor
+    z = got
+    a = ops.nhwc_bn_apply(z, shift.cuda() * 0 + 1.3, scale.cuda() * 0.2, act)
+    _close(a, _act(z.double().cpu() * 1.3 + (scale.double() * 0.2), act), "nhwc bn apply")
+    # cnn8 + transpose/view
+    w8 = torch.randn(8, 64, 1, 1, generator=g) * 0.2
+    s8, h8 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.2
+    feat = ops.nhwc_conv_last(z, w8.cuda(), s8.cuda(), h8.cuda(), act)
+    zr = z.double().cpu()                                                  # [B,T,F,64]
+    y8 = torch.einsum("btfc,oc->btof", zr, w8.to(torch.bfloat16).double().view(8, 64)) * s8.double().view(1, 1, 8, 1) + h8.double().view(1, 1, 8, 1)
+    ref8 = _act(y8, act).reshape(B, T, 8 * Fq)
+    err = ((feat.double().cpu() - ref8).abs().max() / ref8.abs().max()).item()
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("B,T,Fq,KT,KF,dil", CASES)
+def test_nhwc_weight_gradient(B, T, Fq, KT, KF, dil):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(17 + T + dil)
+    dz = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    x = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    w = torch.zeros(64, 64, KT, KF, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=((KT // 2) * dil, KF // 2), dilation=(dil, 1))
+    y.backward(dz.double().permute(0, 3, 1, 2))
+    got = ops.nhwc_conv_wgrad(dz.cuda(), x.cuda(), KT, KF, dil).double().cpu()
+    ref = w.grad
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, f"nhwc wgrad {KT}x{KF} dil {dil}: {err:.3e}"       # exact bf16 products, fp32 accumulation
+
+
+def test_nhwc_weight_gradient_one_hot():
+    """dz and x one-hot: exactly one weight-gradient entry is 1."""
+    from voicesplit_amd import ops
+    for (t0, f0, co, t1, f1, ci, dil) in ((7, 9, 3, 7, 9, 5, 1), (20, 35, 63, 12, 36, 0, 4), (0, 0, 17, 4, 2, 40, 2), (39, 36, 40, 23, 34, 63, 8)):
+        dz = torch.zeros(1, 40, 37, 64)
+        x = torch.zeros(1, 40, 37, 64)
+        dz[0, t0, f0, co] = 1.0
+        x[0, t1, f1, ci] = 1.0
+        got = ops.nhwc_conv_wgrad(dz.to(torch.bfloat16).cuda(), x.to(torch.bfloat16).cuda(), 5, 5, dil).cpu()
+        ref = torch.zeros(64, 64, 5, 5)
+        dt, df = (t1 - t0) // dil + 2 if (t1 - t0) % dil == 0 else -1, f1 - f0 + 2
+        if 0 <= dt < 5 and 0 <= df < 5:
+            ref[co, ci, dt, df] = 1.0
+        assert torch.equal(got, ref), (t0, f0, co, t1, f1, ci, dil)
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+def test_nhwc_bn_act_backward(act, training):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, T, Fq = 2, 21, 45
+    z = (torch.randn(B, T, Fq, 64, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    da = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    zd = z.double().reshape(-1, 64).requires_grad_(True)
+    if training:
+        mean, var = zd.detach().mean(0), zd.detach().var(0, unbiased=False)
+    else:
+        mean, var = torch.randn(64, generator=g).double() * 0.1, (torch.rand(64, generator=g).double() + 0.5)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    if training:
+        m_ = zd.mean(0)
+        v_ = ((zd - m_) ** 2).mean(0)
+        y = (zd - m_) / torch.sqrt(v_ + 1e-5) * gd + bd
+    else:
+        y = (zd - mean) * invstd * gd + bd
+    if act == "relu":      # keep clear of the kink: bf16 z is exact, y is what the kernel recomputes in fp32
+        keep = y.detach().abs() > 1e-3
+    else:
+        keep = torch.ones_like(y, dtype=torch.bool)
+    a = _act(y, act)
+    a.backward(da.double().reshape(-1, 64) * keep)
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - mean * gamma.double() * invstd).float()
+    da_k = (da.double().reshape(-1, 64) * keep).reshape(B, T, Fq, 64).to(torch.bfloat16)
+    dz, dg, db, dbias = ops.nhwc_bn_act_bwd(da_k.cuda(), z.cuda(), act, training, scale.cuda(), shift.cuda(),
+                                            mean.float().cuda(), invstd.float().cuda())
+    ref = zd.grad.reshape(B, T, Fq, 64)
+    _close(dz, ref, f"nhwc bn backward dz ({act}, training={training})")
+    for got, r, nm in ((dg, gd.grad, "dgamma"), (db, bd.grad, "dbeta")):
+        e = ((got.double().cpu() - r).abs().max() / r.abs().max()).item()
+        assert e < 1e-4, (nm, e)
+
+
+def test_nhwc_cnn1_backward_and_cnn8_backward():
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(29)
+    B, T, Fq = 2, 11, 53
+    x = torch.rand(B, T, Fq, generator=g)
+    z = (torch.randn(B, T, Fq, 64, generator=g)).to(torch.bfloat16)
+    da = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    zd = z.double().reshape(-1, 64).requires_grad_(True)
+    m_ = zd.mean(0)
+    v_ = ((zd - m_) ** 2).mean(0)
+    invstd = 1.0 / torch.sqrt(v_.detach() + 1e-5)
+    y = (zd - m_) / torch.sqrt(v_ + 1e-5) * gamma.double() + beta.double()
+    _act(y, "mish").backward(da.double().reshape(-1, 64))
+    dz1 = zd.grad.reshape(B, T, Fq, 64)
+    xp = F.pad(x.double(), (3, 3))
+    ref_dw = torch.stack([torch.einsum("btfc,btf->c", dz1, xp[:, :, k:k + Fq]) for k in range(7)], dim=1)   # [64,7]
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - m_.detach() * gamma.double() * invstd).float()
+    dw, dg, db, dbias = ops.nhwc_bn_act_bwd_first(da.cuda(), z.cuda(), x.cuda(), "mish", True, scale.cuda(), shift.cuda(),
+                                                  m_.detach().float().cuda(), invstd.float().cuda())
+    e = ((dw.double().cpu() - ref_dw).abs().max() / ref_dw.abs().max()).item()
+    assert e < 2e-4, e
+    assert dbias.abs().max().item() == 0.0
+    # cnn8 backward
+    w8 = torch.randn(8, 64, 1, 1, generator=g) * 0.2
+    dz8 = torch.randn(B, T, 8 * Fq, generator=g)
+    a7 = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    din, dw8 = ops.nhwc_conv_last_bwd(dz8.cuda(), w8.cuda(), a7.cuda())
+    d8 = dz8.double().reshape(B, T, 8, Fq)
+    ref_din = torch.einsum("btof,oc->btfc", d8, w8.double().view(8, 64))
+    ref_dw8 = torch.einsum("btof,btfc->oc", d8, a7.double())
+    _close(din, ref_din, "nhwc cnn8 data gradient")
+    e = ((dw8.double().cpu() - ref_dw8).abs().max() / ref_dw8.abs().max()).item()
+    assert e < 2e-5, e

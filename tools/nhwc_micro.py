@@ -35,6 +35,8 @@ def main():
         for act, stats in (("none", False), ("none", True), ("mish", False)):
             ms = timed(lambda: ops.nhwc_conv(x, w, one, zero, dil, act, stats=stats))
             res[f"nhwc {KT}x{KF} dil{dil} act={act} stats={int(stats)}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
+        ms = timed(lambda: ops.nhwc_conv_wgrad(x, x, KT, KF, dil))
+        res[f"nhwc wgrad {KT}x{KF} dil{dil}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
     print(json.dumps(res, indent=1), flush=True)
 
 

@@ -340,6 +340,48 @@ int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const f
   return vs_nhwc_conv_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, bn_stats, (hipStream_t)stream);
 }
 
+int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
+                       int B, int T, int F, int act, double* bn_stats, void* stream) {
+  return vs_nhwc_conv_first_impl(x, w, scale, shift, out, B, T, F, act, bn_stats, (hipStream_t)stream);
+}
+
+int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, void* stream) {
+  return vs_nhwc_bn_apply_impl(z, a, npix, act, scale, shift, (hipStream_t)stream);
+}
+
+int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const float* shift, float* out,
+                      int B, int T, int F, int act, void* stream) {
+  return vs_nhwc_conv_last_impl(in, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);
+}
+
+size_t vs_nhwc_conv_wgrad_partial_floats(int KT, int KF) { return vs_nhwc_wgrad_partial_floats(KT, KF); }
+
+int vs_nhwc_conv_wgrad(const void* dz, const void* in, float* partials, float* dw, int B, int T, int F, int KT, int KF, int dil,
+                       void* stream) {
+  return vs_nhwc_wgrad_impl(dz, in, partials, dw, B, T, F, KT, KF, dil, (hipStream_t)stream);
+}
+
+int vs_nhwc_bn_act_bwd(const void* da, const void* z, void* dz, long long npix, int act, int bn_mode,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream) {
+  return vs_nhwc_bn_act_bwd_impl(da, z, dz, npix, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
+                                 stats, coef, (hipStream_t)stream);
+}
+
+int vs_nhwc_bn_act_bwd_first(const void* da, const void* z, const float* x, int B, int T, int F, int act, int bn_mode,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream) {
+  return vs_nhwc_bn_act_bwd_first_impl(da, z, x, B, T, F, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias,
+                                       dw, stats, coef, acc, (hipStream_t)stream);
+}
+
+int vs_nhwc_conv_last_bwd_blocks(void) { return VS_NHWC_LAST_BWD_BLOCKS; }
+
+int vs_nhwc_conv_last_bwd(const float* dz8, const float* w, const void* a7, void* din, float* partials, float* dw,
+                          int B, int T, int F, void* stream) {
+  return vs_nhwc_conv_last_bwd_impl(dz8, w, a7, din, partials, dw, B, T, F, (hipStream_t)stream);
+}
+
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int T, int F, int act, void* stream) {
   return vs_conv_last_fwd_impl(in, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);

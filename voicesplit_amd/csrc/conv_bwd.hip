@@ -635,6 +635,28 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   return 0;
 }
 
+namespace {
+__global__ void bn_bwd_fold_slots_kernel(double* __restrict__ stats, int n, int slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < slots; ++k) v += stats[(size_t)k * n + i];
+  stats[i] = v;
+}
+}  // namespace
+
+// stats: [slots][C][2] doubles {sum dy, sum dy*xhat} (slots > 1: folded into slot 0 first) -> parameter gradients and
+// the three per-channel coefficients of the apply pass
+int vs_bn_bwd_finalize_impl(double* stats, int slots, double count, int train, int C, const float* scale, const float* mean,
+                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t stream) {
+  VS_REQUIRE(stats && coef && C > 0 && count > 0, "bn_bwd_finalize: bad argument");
+  if (slots > 1) hipLaunchKernelGGL(bn_bwd_fold_slots_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, slots);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, train, C,
+                     scale, mean, invstd, dgamma, dbeta, dbias, coef);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 int vs_conv_last_dgrad_impl(const float* dz, const float* w, float* din, int B, int T, int F, hipStream_t stream) {
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && B <= 65535, "conv_last_dgrad: bad shape B=%d T=%d F=%d", B, T, F);
   hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3((T * F + 1023) / 1024, B), dim3(256), 0, stream, dz, w, din, T, F);

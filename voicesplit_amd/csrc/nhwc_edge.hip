@@ -155,6 +155,204 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
   }
 }
 
+// ---- BatchNorm + activation backward -----------------------------------------------------------------------------
+// dy = da * act'(z * scale + shift);  pass 1: per-channel sum dy, sum dy * xhat (xhat = (z - mean) * invstd);
+// pass 2: dz = cA * dy + cB * z + cC (coefficients from bn_bwd_finalize, conv_bwd.hip), bf16, may overwrite da.
+template <int ACT>
+__device__ __forceinline__ float nhwc_act_grad(float y) {
+  if (ACT == VS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (ACT == VS_ACT_MISH) return vs_mish_grad_fast(y);
+  return 1.f;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_bn_bwd_stats_kernel(const u4v* __restrict__ da, const u4v* __restrict__ z, long long npieces,
+                              const float* __restrict__ scale, const float* __restrict__ shift,
+                              const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ stats) {
+  __shared__ float red[4 * 2 * 64];
+  const int piece = threadIdx.x & 7;
+  float sc[8], sh[8], mu[8], is[8], acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = piece * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+    acc[0][j] = 0.f; acc[1][j] = 0.f;
+  }
+  const long long stride = (long long)gridDim.x * 256;
+  auto eat = [&](const u4v g, const u4v v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float z0 = bf_lo(v[q]), z1 = bf_hi(v[q]);
+      const float d0 = bf_lo(g[q]) * nhwc_act_grad<ACT>(fmaf(z0, sc[2 * q], sh[2 * q]));
+      const float d1 = bf_hi(g[q]) * nhwc_act_grad<ACT>(fmaf(z1, sc[2 * q + 1], sh[2 * q + 1]));
+      acc[0][2 * q] += d0;
+      acc[0][2 * q + 1] += d1;
+      acc[1][2 * q] = fmaf(d0, (z0 - mu[2 * q]) * is[2 * q], acc[1][2 * q]);
+      acc[1][2 * q + 1] = fmaf(d1, (z1 - mu[2 * q + 1]) * is[2 * q + 1], acc[1][2 * q + 1]);
+    }
+  };
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < npieces; i += 2 * stride) {
+    const u4v g0 = __builtin_nontemporal_load(da + i), v0 = __builtin_nontemporal_load(z + i);
+    const u4v g1 = __builtin_nontemporal_load(da + i + stride), v1 = __builtin_nontemporal_load(z + i + stride);
+    eat(g0, v0);
+    eat(g1, v1);
+  }
+  if (i < npieces) eat(__builtin_nontemporal_load(da + i), __builtin_nontemporal_load(z + i));
+  fold_channel_sums<2>(acc, stats, red);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_bn_bwd_apply_kernel(const u4v* da, const u4v* __restrict__ z, u4v* dz, long long npieces,
+                              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef) {
+  const int piece = threadIdx.x & 7;
+  float sc[8], sh[8], cA[8], cB[8], cC[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = piece * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; cA[j] = coef[c]; cB[j] = coef[64 + c]; cC[j] = coef[128 + c];
+  }
+  const long long stride = (long long)gridDim.x * 256;
+  auto apply = [&](const u4v g, const u4v v) {
+    u4v o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float z0 = bf_lo(v[q]), z1 = bf_hi(v[q]);
+      const float d0 = bf_lo(g[q]) * nhwc_act_grad<ACT>(fmaf(z0, sc[2 * q], sh[2 * q]));
+      const float d1 = bf_hi(g[q]) * nhwc_act_grad<ACT>(fmaf(z1, sc[2 * q + 1], sh[2 * q + 1]));
+      o[q] = vs_pack_bf16(fmaf(cA[2 * q], d0, fmaf(cB[2 * q], z0, cC[2 * q])),
+                          fmaf(cA[2 * q + 1], d1, fmaf(cB[2 * q + 1], z1, cC[2 * q + 1])));
+    }
+    return o;
+  };
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < npieces; i += 2 * stride) {
+    const u4v g0 = __builtin_nontemporal_load(da + i), v0 = __builtin_nontemporal_load(z + i);
+    const u4v g1 = __builtin_nontemporal_load(da + i + stride), v1 = __builtin_nontemporal_load(z + i + stride);
+    dz[i] = apply(g0, v0);
+    dz[i + stride] = apply(g1, v1);
+  }
+  if (i < npieces) dz[i] = apply(__builtin_nontemporal_load(da + i), __builtin_nontemporal_load(z + i));
+}
+
+// cnn1: pass 2 fused with the 1x7 weight gradient: dz1 = cA dy + cB z + cC is contracted with the 7 shifted inputs on
+// the spot (dz1 is never written): acc[c][k] += dz1[b][t][f][c] * x[b][t][f + k - 3]
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_bn_bwd_first_kernel(const u4v* __restrict__ da, const u4v* __restrict__ z, const float* __restrict__ x,
+                              long long npix, int F, const float* __restrict__ scale, const float* __restrict__ shift,
+                              const float* __restrict__ coef, double* __restrict__ acc_out /* [64][7] */) {
+  __shared__ float red[4 * 7 * 64];
+  const int piece = threadIdx.x & 7;
+  float sc[8], sh[8], cA[8], cB[8], cC[8], acc[7][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = piece * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; cA[j] = coef[c]; cB[j] = coef[64 + c]; cC[j] = coef[128 + c];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k][j] = 0.f;
+  }
+  const long long stride = (long long)gridDim.x * 32;
+  for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
+    const int f = (int)(p % F);
+    const float* xr = x + (p - f);
+    float xv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int ff = f + k - 3;
+      xv[k] = (ff >= 0 && ff < F) ? xr[ff] : 0.f;
+    }
+    const u4v g = __builtin_nontemporal_load(da + p * 8 + piece), v = __builtin_nontemporal_load(z + p * 8 + piece);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * q + e;
+        const float zv = e ? bf_hi(v[q]) : bf_lo(v[q]);
+        const float dy = (e ? bf_hi(g[q]) : bf_lo(g[q])) * nhwc_act_grad<ACT>(fmaf(zv, sc[j], sh[j]));
+        const float dzv = fmaf(cA[j], dy, fmaf(cB[j], zv, cC[j]));
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k][j] = fmaf(dzv, xv[k], acc[k][j]);
+      }
+    }
+  }
+  // fold: lanes sharing a channel piece, then the waves; one fp64 atomic per (channel, tap) and workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = acc[k][j];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 8) red[(wave * 7 + k) * 64 + lane * 8 + j] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 7 * 64; i += 256) {
+    const int k = i / 64, c = i - k * 64;
+    atomicAdd(acc_out + c * 7 + k, (double)(red[(0 * 7 + k) * 64 + c] + red[(1 * 7 + k) * 64 + c] + red[(2 * 7 + k) * 64 + c] + red[(3 * 7 + k) * 64 + c]));
+  }
+}
+
+__global__ void nhwc_cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
+// cnn8 backward in one pass over a7: din[b][t][f][ci] = sum_co w[co][ci] dz8[b][t][co][f]  (data gradient, bf16) and
+// dw[co][ci] = sum_pixels dz8[..][co][..] a7[..][ci]  (weight gradient: per-workgroup partial sums part[block][co][ci])
+__global__ __launch_bounds__(256)
+void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __restrict__ w, const u4v* __restrict__ a7,
+                               u4v* __restrict__ din, float* __restrict__ part, long long npix, int F) {
+  __shared__ float red[4 * 8 * 64];
+  const int piece = threadIdx.x & 7;
+  float wr[8][8], acc[8][8];            // [co][j], ci = 8 piece + j
+#pragma unroll
+  for (int co = 0; co < 8; ++co)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wr[co][j] = w[co * 64 + piece * 8 + j]; acc[co][j] = 0.f; }
+  const long long stride = (long long)gridDim.x * 32;
+  for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
+    const long long row = p / F;
+    const int f = (int)(p - row * F);
+    const float* dzr = dz8 + row * 8 * F + f;
+    float d[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) d[co] = dzr[(size_t)co * F];
+    const u4v av = __builtin_nontemporal_load(a7 + p * 8 + piece);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int co = 0; co < 8; ++co)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g[2 * q] = fmaf(wr[co][2 * q], d[co], g[2 * q]);
+        g[2 * q + 1] = fmaf(wr[co][2 * q + 1], d[co], g[2 * q + 1]);
+        acc[co][2 * q] = fmaf(d[co], bf_lo(av[q]), acc[co][2 * q]);
+        acc[co][2 * q + 1] = fmaf(d[co], bf_hi(av[q]), acc[co][2 * q + 1]);
+      }
+    din[p * 8 + piece] = u4v{vs_pack_bf16(g[0], g[1]), vs_pack_bf16(g[2], g[3]), vs_pack_bf16(g[4], g[5]), vs_pack_bf16(g[6], g[7])};
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int co = 0; co < 8; ++co)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = acc[co][j];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 8) red[(wave * 8 + co) * 64 + lane * 8 + j] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256)
+    part[(size_t)blockIdx.x * 512 + i] = red[i] + red[512 + i] + red[1024 + i] + red[1536 + i];
+}
+
 int stream_blocks(long long items_per_block_sweep, long long total) {
   long long nb = (total + items_per_block_sweep - 1) / items_per_block_sweep;
   if (nb > 2048) nb = 2048;
@@ -210,4 +408,70 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   else VS_REQUIRE(false, "nhwc conv_last: unsupported activation %d", act);
   VS_LAUNCH_CHECK();
   return 0;
+}
+
+// BatchNorm + activation backward over [npix][64] bf16 (dz may alias da): parameter gradients + dz
+int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            float* dgamma, float* dbeta, float* dbias, double* stats /* [VS_BN_STAT_SLOTS][64][2] */, float* coef,
+                            hipStream_t stream) {
+  VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef && npix > 0, "nhwc bn_act_bwd: bad argument");
+  const long long npieces = npix * 8;
+  const dim3 grid(stream_blocks(512, npieces)), block(256);
+  const u4v* g = reinterpret_cast<const u4v*>(da);
+  const u4v* zz = reinterpret_cast<const u4v*>(z);
+  VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+  else VS_REQUIRE(false, "nhwc bn_act_bwd: unsupported activation %d", act);
+  if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream)) return rc;
+  u4v* o = reinterpret_cast<u4v*>(dz);
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_bn_bwd_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, zz, o, npieces, scale, shift, coef);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_bn_bwd_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, zz, o, npieces, scale, shift, coef);
+  else hipLaunchKernelGGL(nhwc_bn_bwd_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, zz, o, npieces, scale, shift, coef);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn1: the same backward with pass 2 contracted against the input on the spot: dw [64][7] (dz1 is not written)
+int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x, int B, int T, int F, int act, int train,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc /* 448 */,
+                                  hipStream_t stream) {
+  VS_REQUIRE(da && z && x && dw && stats && coef && acc, "nhwc bn_act_bwd_first: NULL argument");
+  const long long npix = (long long)B * T * F, npieces = npix * 8;
+  const u4v* g = reinterpret_cast<const u4v*>(da);
+  const u4v* zz = reinterpret_cast<const u4v*>(z);
+  {
+    const dim3 grid(stream_blocks(512, npieces)), block(256);
+    VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+    if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+    else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+    else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_bn_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, zz, npieces, scale, shift, mean, invstd, stats);
+    else VS_REQUIRE(false, "nhwc bn_act_bwd_first: unsupported activation %d", act);
+  }
+  if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream)) return rc;
+  VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 448, stream));
+  const dim3 grid(stream_blocks(32, npix)), block(256);
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_bn_bwd_first_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, zz, x, npix, F, scale, shift, coef, acc);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_bn_bwd_first_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, zz, x, npix, F, scale, shift, coef, acc);
+  else hipLaunchKernelGGL(nhwc_bn_bwd_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, zz, x, npix, F, scale, shift, coef, acc);
+  hipLaunchKernelGGL(nhwc_cvt_f64_f32_kernel, dim3(2), dim3(256), 0, stream, acc, dw, 448);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn8 backward: dz8 [B][T][8][F] fp32, a7 [B][T][F][64] bf16 -> din (bf16, same layout as a7) and dw [8][64];
+// part: VS_NHWC_LAST_BWD_BLOCKS x 512 floats of scratch
+int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7, void* din, float* part, float* dw,
+                               int B, int T, int F, hipStream_t stream) {
+  VS_REQUIRE(dz8 && w && a7 && din && part && dw, "nhwc conv_last_bwd: NULL argument");
+  const long long npix = (long long)B * T * F;
+  long long nb = (npix + 31) / 32;
+  if (nb > VS_NHWC_LAST_BWD_BLOCKS) nb = VS_NHWC_LAST_BWD_BLOCKS;
+  hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dz8, w, reinterpret_cast<const u4v*>(a7),
+                     reinterpret_cast<u4v*>(din), part, npix, F);
+  VS_LAUNCH_CHECK();
+  return vs_reduce_partials_impl(part, (int)nb, 512, dw, stream);
 }

@@ -31,7 +31,8 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   const size_t B = d->B, T = d->T, F = d->F, H = d->H, M = B * T;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-  const size_t act = B * 64 * T * F * 4;
+  // conv activations: fp32 [B][64][T][F], or channels-last bf16 [B][T][F][64] in the bf16 configuration (half the bytes)
+  const size_t act = B * 64 * T * F * (d->math == VS_MATH_BF16 ? 2 : 4);
   for (int l = 0; l < 7; ++l) { L->z[l] = take(act); L->a[l] = take(act); }
   L->z8 = take(M * 8 * F * 4);
   L->feat = take(M * 8 * F * 4);
@@ -157,6 +158,46 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
                        : vs_bn_apply_impl(z, a, B, C, T * F, conv_act, sc, sh, amax, stream);
   };
 
+  const bool nhwc = d->math == VS_MATH_BF16;
+  if (nhwc) {
+    // BASELINE configs[2]: channels-last bf16 z / a (conv_nhwc.hip, nhwc_edge.hip); statistics from the conv epilogues
+    const long long npix = (long long)B * T * F;
+    auto bn16 = [&](int l) -> int {
+      VsProfScope ps(VS_PROF_FWD_BN, stream);
+      const vs_conv_layer& c = p->conv[l];
+      float *sc = scale + 64 * l, *sh = shift + 64 * l, *mu = mean + 64 * l, *is = invstd + 64 * l;
+      if (train) {
+        if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean,
+                                         c.bn_running_var, kBnEps, kBnMomentum, sc, sh, mu, is, stream)) return rc;
+      } else {
+        if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, 64, sc, sh, mu, is, stream)) return rc;
+      }
+      return vs_nhwc_bn_apply_impl(at<void>(tape, L.z[l]), at<void>(tape, L.a[l]), npix, conv_act, sc, sh, stream);
+    };
+    {
+      VsProfScope ps(VS_PROF_CNN1, stream);
+      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+      if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<void>(tape, L.z[0]), B, T, F, VS_ACT_NONE,
+                                           train ? stats : nullptr, stream)) return rc;
+    }
+    if (int rc = bn16(0)) return rc;
+    for (int i = 0; i < 6; ++i) {
+      const int l = i + 1;
+      void* packed = at<void>(tape, L.conv_packed[i]);
+      {
+        VsProfScope ps(VS_PROF_CNN2 + i, stream);
+        if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+        if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+        if (int rc = vs_nhwc_conv_impl(at<void>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<void>(tape, L.z[l]), B, T, F,
+                                       kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, train ? stats : nullptr, stream)) return rc;
+      }
+      if (int rc = bn16(l)) return rc;
+    }
+    {
+      VsProfScope ps(VS_PROF_CNN8, stream);
+      if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
+    }
+  } else {
   {
     VsProfScope ps(VS_PROF_CNN1, stream);
     if (int rc = vs_conv_first_fwd_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<float>(tape, L.z[0]), B, T, F, VS_ACT_NONE, nullptr, stream)) return rc;
@@ -181,6 +222,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     VsProfScope ps(VS_PROF_CNN8, stream);
     if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
   }
+  }
   if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
 
   // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
@@ -196,7 +238,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     // the backward pass's gradient buffers are idle during the forward pass
     if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
                                          at<float>(tape, L.gemm_scales), at<char>(tape, L.grad0),
-                                         (size_t)B * 64 * T * F * sizeof(float), stream)) return rc;
+                                         2 * (L.grad1 - L.grad0), stream)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
@@ -408,6 +450,65 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   };
   // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
   if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
+  if (d->math == VS_MATH_BF16) {
+    // BASELINE configs[2]: the conv stack backward on channels-last bf16 tensors (nhwc_edge.hip, conv_nhwc.hip,
+    // wgrad_nhwc.hip).  Same chain and the same side-stream schedule as below: layer l's weight gradient runs beside
+    // the BatchNorm backward of layer l-1.
+    const long long npix = (long long)B * T * F;
+    void* gb[2] = {at<void>(tape, L.grad0), at<void>(tape, L.grad1)};
+    int c = 0;
+    {
+      VsProfScope ps(VS_PROF_BWD_EDGE, stream);
+      // partial sums in the idle second gradient buffer: `part` may still be in use by the LSTM leaf GEMMs on the side stream
+      if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
+                                              g->conv[7].weight, B, T, F, stream)) return rc;
+    }
+    void* pack_t = at<void>(tape, L.pack_tmp);
+    bool pending = false;
+    for (int i = 5; i >= 0; --i) {
+      const int l = i + 1;
+      {
+        VsProfScope ps(VS_PROF_BWD_BN, stream);
+        if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
+                                             mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
+                                             stats, coef, stream)) return rc;
+      }
+      if (pending) {                 // the previous layer's weight gradient still reads the buffer this data gradient writes
+        VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+        pending = false;
+      }
+      {
+        VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
+        if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, pack_t, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
+        if (int rc = vs_nhwc_conv_impl(gb[c], pack_t, ones, zeros, gb[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE,
+                                       nullptr, stream)) return rc;
+      }
+      hipStream_t ws = stream;
+      if (side) {
+        VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+        VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+        ws = side->s;
+      }
+      {
+        VsProfScope ps(VS_PROF_BWD_WGRAD + i, ws);
+        if (int rc = vs_nhwc_wgrad_impl(gb[c], at<void>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf,
+                                        kMid[i].dil, ws)) return rc;
+      }
+      if (side) {
+        VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+        pending = true;
+      }
+      c ^= 1;
+    }
+    if (side) {
+      VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+      VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    }
+    VsProfScope ps(VS_PROF_BWD_BN, stream);
+    return vs_nhwc_bn_act_bwd_first_impl(gb[c], at<void>(tape, L.z[0]), x, B, T, F, conv_act, train, scale, shift, mean, invstd,
+                                         g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight, stats, coef,
+                                         at<double>(tape, L.first_acc), stream);
+  }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;
   {

@@ -70,12 +70,28 @@ size_t vs_nhwc_packed_bytes(int KT, int KF);
 int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
+// wgrad_nhwc.hip: their weight gradient (pairs of workgroups, one partial-sum slab per pair)
+#define VS_NHWC_WGRAD_MAX_PAIRS 128
+size_t vs_nhwc_wgrad_partial_floats(int KT, int KF);
+int vs_nhwc_wgrad_impl(const void* dz, const void* a_in, float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
 // nhwc_edge.hip: the HBM-bound kernels around them (cnn1, BatchNorm apply, cnn8)
 int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, const float* shift, void* out,
                             int B, int T, int F, int act, double* bn_stats, hipStream_t);
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t);
+int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);
+int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x, int B, int T, int F, int act, int train,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, hipStream_t);
+#define VS_NHWC_LAST_BWD_BLOCKS 1024
+int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7, void* din, float* part, float* dw,
+                               int B, int T, int F, hipStream_t);
+// conv_bwd.hip: coefficients of the BatchNorm backward apply pass from the folded sums
+int vs_bn_bwd_finalize_impl(double* stats, int slots, double count, int train, int C, const float* scale, const float* mean,
+                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t);
 // conv_edge.hip
 int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float eps, float momentum,

@@ -655,3 +655,91 @@ def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = Fal
     check(lib.vs_nhwc_conv(_p(x), _p(packed), _p(scale), _p(shift), _p(out), B, T, F, KT, KF, dil, ACT_CODES[act],
                            _p(st), _stream()), "vs_nhwc_conv")
     return (out, st.sum(0)) if stats else out
+
+
+def nhwc_conv_first(x, w, scale, shift, act: str, stats: bool = False):
+    """cnn1: x [B,T,F] fp32, w [64,1,1,7] -> act(conv * scale + shift) as [B,T,F,64] bf16 (+ [64,2] statistics)."""
+    lib = _lib.load()
+    for n, t in (("x", x), ("w", w), ("scale", scale), ("shift", shift)):
+        _dev_check(t, n)
+    B, T, F = x.shape
+    out = torch.empty(B, T, F, 64, dtype=torch.bfloat16, device=x.device)
+    st = torch.zeros(64, 64, 2, dtype=torch.float64, device=x.device) if stats else None
+    check(lib.vs_nhwc_conv_first(_p(x), _p(w), _p(scale), _p(shift), _p(out), B, T, F, ACT_CODES[act], _p(st), _stream()),
+          "vs_nhwc_conv_first")
+    return (out, st.sum(0)) if stats else out
+
+
+def nhwc_bn_apply(z, scale, shift, act: str):
+    lib = _lib.load()
+    _dev_check(z, "z", torch.bfloat16)
+    a = torch.empty_like(z)
+    check(lib.vs_nhwc_bn_apply(_p(z), _p(a), z.numel() // 64, ACT_CODES[act], _p(scale), _p(shift), _stream()), "vs_nhwc_bn_apply")
+    return a
+
+
+def nhwc_conv_last(x, w, scale, shift, act: str):
+    """cnn8 + transpose/view: x [B,T,F,64] bf16, w [8,64,1,1] -> [B,T,8F] fp32 (feature index c*F+f)."""
+    lib = _lib.load()
+    _dev_check(x, "x", torch.bfloat16)
+    B, T, F, _ = x.shape
+    out = torch.empty(B, T, 8 * F, dtype=torch.float32, device=x.device)
+    check(lib.vs_nhwc_conv_last(_p(x), _p(w), _p(scale), _p(shift), _p(out), B, T, F, ACT_CODES[act], _stream()), "vs_nhwc_conv_last")
+    return out
+
+
+def nhwc_conv_wgrad(dz, x, KT: int, KF: int, dil: int):
+    """dz, x [B,T,F,64] bf16 -> dw [64,64,KT,KF] fp32."""
+    lib = _lib.load()
+    _dev_check(dz, "dz", torch.bfloat16)
+    _dev_check(x, "x", torch.bfloat16)
+    B, T, F, _ = x.shape
+    part = torch.empty(lib.vs_nhwc_conv_wgrad_partial_floats(KT, KF), dtype=torch.float32, device=x.device)
+    dw = torch.empty(64, 64, KT, KF, dtype=torch.float32, device=x.device)
+    check(lib.vs_nhwc_conv_wgrad(_p(dz), _p(x), _p(part), _p(dw), B, T, F, KT, KF, dil, _stream()), "vs_nhwc_conv_wgrad")
+    return dw
+
+
+def nhwc_bn_act_bwd(da, z, act: str, training: bool, scale, shift, mean, invstd):
+    """da, z [.., 64] bf16 -> (dz bf16, dgamma, dbeta, dbias)."""
+    lib = _lib.load()
+    _dev_check(da, "da", torch.bfloat16)
+    _dev_check(z, "z", torch.bfloat16)
+    dev = z.device
+    dz = torch.empty_like(da)
+    dg, db, dbias = (torch.empty(64, dtype=torch.float32, device=dev) for _ in range(3))
+    stats = torch.empty(64 * 64 * 2, dtype=torch.float64, device=dev)
+    coef = torch.empty(192, dtype=torch.float32, device=dev)
+    check(lib.vs_nhwc_bn_act_bwd(_p(da), _p(z), _p(dz), z.numel() // 64, ACT_CODES[act], BN_TRAIN if training else BN_EVAL,
+                                 _p(scale), _p(shift), _p(mean), _p(invstd), _p(dg), _p(db), _p(dbias), _p(stats), _p(coef), _stream()),
+          "vs_nhwc_bn_act_bwd")
+    return dz, dg, db, dbias
+
+
+def nhwc_bn_act_bwd_first(da, z, x, act: str, training: bool, scale, shift, mean, invstd):
+    """cnn1: da, z [B,T,F,64] bf16, x [B,T,F] fp32 -> (dw [64,7], dgamma, dbeta, dbias)."""
+    lib = _lib.load()
+    dev = z.device
+    B, T, F = x.shape
+    dg, db, dbias = (torch.empty(64, dtype=torch.float32, device=dev) for _ in range(3))
+    dw = torch.empty(64, 7, dtype=torch.float32, device=dev)
+    stats = torch.empty(64 * 64 * 2, dtype=torch.float64, device=dev)
+    coef = torch.empty(192, dtype=torch.float32, device=dev)
+    acc = torch.empty(448, dtype=torch.float64, device=dev)
+    check(lib.vs_nhwc_bn_act_bwd_first(_p(da), _p(z), _p(x), B, T, F, ACT_CODES[act], BN_TRAIN if training else BN_EVAL,
+                                       _p(scale), _p(shift), _p(mean), _p(invstd), _p(dg), _p(db), _p(dbias), _p(dw), _p(stats),
+                                       _p(coef), _p(acc), _stream()), "vs_nhwc_bn_act_bwd_first")
+    return dw, dg, db, dbias
+
+
+def nhwc_conv_last_bwd(dz8, w, a7):
+    """dz8 [B,T,8F] fp32, w [8,64,1,1], a7 [B,T,F,64] bf16 -> (din [B,T,F,64] bf16, dw [8,64])."""
+    lib = _lib.load()
+    _dev_check(dz8, "dz8")
+    _dev_check(a7, "a7", torch.bfloat16)
+    B, T, F, _ = a7.shape
+    din = torch.empty_like(a7)
+    part = torch.empty(lib.vs_nhwc_conv_last_bwd_blocks() * 512, dtype=torch.float32, device=a7.device)
+    dw = torch.empty(8, 64, dtype=torch.float32, device=a7.device)
+    check(lib.vs_nhwc_conv_last_bwd(_p(dz8), _p(w), _p(a7), _p(din), _p(part), _p(dw), B, T, F, _stream()), "vs_nhwc_conv_last_bwd")
+    return din, dw
