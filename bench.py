@@ -1,30 +1,39 @@
 #!/usr/bin/env python
 """Throughput of the hot path on MI355X: utterances/s of the VoiceSplit mask-prediction path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--mode train|forward]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--mode train|forward|longform]
 
 Workload (BASELINE.json metric "utterances/sec (3 s clips, B=64) fwd+bwd"): B=64 synthetic
-[64,301,601] spectrograms + 256-d d-vectors per GPU, fp32, random-init weights of the reference
+[64,301,601] spectrograms + 256-d d-vectors per GPU, random-init weights of the reference
 architecture, batch-statistics BatchNorm (model.train(), train.py:84).  A "step" is what one
 iteration of train.py:85-111 does: forward (with the tape), the reference's SI-SNR loss through a
 GPU iSTFT (train.py:95-108, vs_sisnr_loss; --loss fixed replaces it by a fixed upstream gradient),
 backward, the gradient exchange (one flat-bucket all-reduce, a no-op at N=1) and the Adam update.  Inputs
-are resident in HBM before the timed region.  --mode forward times BASELINE configs[1]
-(forward only, eval-mode BatchNorm) instead.
-N>1 (launched by torch.distributed.run, one rank per GPU): data parallel, 64 utterances per rank
-("weak" scaling), one RCCL all-reduce of the 75.5 MB gradient bucket per step over xGMI.
+are resident in HBM before the timed region.  --mode forward times BASELINE configs[1] (forward only,
+eval-mode BatchNorm); --mode longform times configs[4] (30 s clips cut into 301-frame windows, 256 windows
+per forward batch, clips sharded over the ranks, no collective).
 
-Rank 0 prints ONE JSON line with the whole-job utterances/s plus
-  roofline     -- the dominant kernel, conv64_mfma_kernel<5,5> (cnn3..cnn7 forward and their data
-                  gradients: 10 launches per training step): algorithmic FLOPs per launch / mean
-                  launch time from HIP events recorded inside the timed region; the weight-
-                  gradient kernel is reported next to it
-  cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores.
+N>1: one rank per GPU over RCCL, data parallel, 64 utterances per rank ("weak" scaling), one all-reduce of the
+75.5 MB gradient bucket per step over xGMI.  The driver's `python -m torch.distributed.run ... bench.py --gpus N`
+runs the ranks directly; a plain `python bench.py --gpus N` (no RANK / WORLD_SIZE in the environment) launches the
+same command itself on 127.0.0.1 and fails loudly when fewer than N devices are visible.
+
+Rank 0 prints ONE JSON line (the last line on stdout) with the whole-job utterances/s of the default arithmetic
+(fp32 results from split-f16 MFMAs) plus
+  roofline     -- the dominant kernel (5x5 64->64 conv: cnn3..cnn7 forward and their data gradients, 10 launches
+                  per training step): algorithmic FLOPs per launch / mean launch time from HIP events recorded
+                  inside the timed region; the weight-gradient kernel next to it
+  forward      -- BASELINE configs[1] timed in the same process
+  bf16         -- BASELINE configs[2]: the same training step in the channels-last bf16 configuration
+                  (bf16 activations / tape, csrc/conv_nhwc.hip), with its own roofline figures
+  fp32_strict  -- the same step on the fp32 matrix cores (bitwise an fmaf chain), 3 steps
+  cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores, B=1 and B=4.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,10 +45,15 @@ import torch  # noqa: E402
 # algorithmic work per utterance at T=301, F=601; FLOP = 2*MAC
 T_FRAMES, N_FREQ, EMB = 301, 601, 256
 GFLOP_CONV5X5 = 2 * 64 * 64 * 25 * T_FRAMES * N_FREQ / 1e9       # 37.05 per layer per utterance
+GFLOP_LSTM_GEMM = 2 * 4808 * 3200 * T_FRAMES / 1e9                # 9.26 per utterance (d-vector columns folded away)
 GFLOP_FWD_TOTAL = 206.995
 PEAK_FP32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md chip table
 PEAK_F16_MFMA_TFLOPS = 2500.0                                      # dense f16/bf16 MFMA (same table)
 PEAK_HBM_GBS = 8000.0
+LONG_FRAMES = 3001                                                 # 30 s at hop 160 / 16 kHz
+
+MATH_LABEL = {"fp32": "fp32 MFMA", "f16x3": "fp32 I/O, split-f16 MFMA (3 f16 products per fp32 product)",
+              "bf16": "channels-last bf16 activations / tape, bf16 MFMA, fp32 accumulate / statistics / master weights"}
 
 
 def committed_pmc_traffic(tag, kernel_substr):
@@ -50,16 +64,19 @@ def committed_pmc_traffic(tag, kernel_substr):
     1 GiB write reports WRITE_SIZE = 1 GiB (profiles/r02_calibration/).  bench.py itself cannot collect
     counters; None when the file is absent."""
     import csv
-    path = os.path.join(ROOT, "profiles", f"{tag}_rocprof", "pmc_per_kernel.csv")
-    if not os.path.isfile(path):
-        return None
-    best = None
-    for r in csv.DictReader(open(path)):
-        if kernel_substr in r["kernel"] and r.get("fetch_GB_x2") and r.get("write_GB"):
-            n = int(r["dispatches"])
-            if best is None or n > best[0]:
-                best = (n, float(r["fetch_GB_x2"]) + float(r["write_GB"]))
-    return None if best is None else round(best[1], 2)
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_rocprof", "pmc_per_kernel.csv")
+        if not os.path.isfile(path):
+            continue
+        best = None
+        for r in csv.DictReader(open(path)):
+            if kernel_substr in r["kernel"] and r.get("fetch_GB_x2") and r.get("write_GB"):
+                n = int(r["dispatches"])
+                if best is None or n > best[0]:
+                    best = (n, float(r["fetch_GB_x2"]) + float(r["write_GB"]))
+        if best is not None:
+            return round(best[1], 2), rnd
+    return None, None
 
 
 def _pick_threads():
@@ -90,38 +107,63 @@ def _pick_threads():
     return best[0] or 1, avail
 
 
-def cpu_baseline(mode, seconds_budget=20.0):
-    """Oracle (reference restatement, torch CPU ops, nn.LSTM) on the host cores: forward, or
-    forward + autograd backward from the same fixed upstream gradient."""
+def cpu_baseline(mode, seconds_budget=14.0):
+    """Oracle (reference restatement, torch CPU ops, nn.LSTM) on the host cores: forward, or forward + autograd
+    backward from the same fixed upstream gradient, at B=1 (BASELINE configs[0]) and B=4."""
     from oracle import reference_backward as RB
     from oracle import reference_forward as R
     threads, avail = _pick_threads()
     torch.set_num_threads(threads)
     dims = R.default_dims()
     sd = R.build_state_dict(dims, 0)
-    x, dvec = R.synthetic_inputs(1, T_FRAMES, dims, 0)
-    w = RB.loss_weights(1, T_FRAMES, dims["fc2_dim"], 0)
-
-    def once():
-        if mode == "train":
-            RB.gradients(sd, x, dvec, w, act="mish", training=True)
-        else:
-            with torch.no_grad():
-                R.forward(sd, x, dvec, act="mish")
-
-    once()                                                     # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        once()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 30:
-            break
     what = "forward + autograd backward" if mode == "train" else "forward"
-    return {"value": round(n / el, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
-            "sample": f"{n} x {what} of one [1,301,601] utterance (B=1, fp32), "
-                      f"{el:.1f} s, torch {torch.__version__} CPU ops, {threads} threads "
+
+    def run(B, budget):
+        x, dvec = R.synthetic_inputs(B, T_FRAMES, dims, 0)
+        w = RB.loss_weights(B, T_FRAMES, dims["fc2_dim"], 0)
+
+        def once():
+            if mode == "train":
+                RB.gradients(sd, x, dvec, w, act="mish", training=True)
+            else:
+                with torch.no_grad():
+                    R.forward(sd, x, dvec, act="mish")
+
+        once()                                                     # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            once()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 30:
+                break
+        return n, el
+
+    n1, el1 = run(1, seconds_budget)
+    n4, el4 = run(4, seconds_budget * 0.6)
+    return {"value": round(n1 / el1, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
+            "value_b4": round(4 * n4 / el4, 4),
+            "sample": f"{n1} x {what} of one [1,301,601] utterance in {el1:.1f} s (value) and {n4} x the same at B=4 in "
+                      f"{el4:.1f} s (value_b4), fp32, torch {torch.__version__} CPU ops, {threads} threads "
                       f"(fastest of a 4..256 sweep; {avail} logical cores visible)"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run the driver's own command line on this node."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node -- refusing to run a smaller job "
+                         f"under the same name (one rank per GPU, no CPU fallback)")
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -129,27 +171,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
-    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--batch", type=int, default=None, help="utterances (windows) per GPU and forward batch: 64; 256 in longform mode")
+    ap.add_argument("--mode", default="train", choices=["train", "forward", "longform"])
+    ap.add_argument("--clips", type=int, default=128, help="longform mode: 30 s clips per GPU and step")
     ap.add_argument("--model", default="voicesplit", choices=["voicesplit", "voicefilter"])
     ap.add_argument("--conv-math", default=None, choices=["fp32", "f16x3", "bf16"],
-                    help="arithmetic of the 64->64 conv layers (default: the library default)")
+                    help="arithmetic / layout of the conv stack and the LSTM GEMMs (default: the library default, f16x3)")
     ap.add_argument("--loss", default="sisnr", choices=["sisnr", "powerlaw", "fixed"],
                     help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward / bf16 / fp32_strict sub-objects of the training line")
     ap.add_argument("--serial-backward", action="store_true",
                     help="weight gradients in order on the one stream (default: on the library's side stream, "
                          "beside the BatchNorm backward passes; same results)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 256 if args.mode == "longform" else 64
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -169,35 +219,36 @@ def main():
 
     B = args.batch
     train = args.mode == "train"
-    MATH_LABEL = {"fp32": "fp32 MFMA", "f16x3": "fp32 I/O, split-f16 MFMA (3 f16 products per fp32 product)",
-                  "bf16": "bf16 MFMA operands (single pass), fp32 accumulate / tape / statistics"}[conv_math]
-    torch.manual_seed(0)
     cls = V.VoiceSplit if args.model == "voicesplit" else V.VoiceFilter
-    model = cls(V.default_config())
-    model.train(train)
-    with torch.no_grad():                                           # non-trivial BN statistics
-        g = torch.Generator().manual_seed(1000)
-        for m in model.conv:
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
-                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
-                m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
-                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
-    model = model.to(dev)
+
+    def new_model(training):
+        torch.manual_seed(0)
+        m = cls(V.default_config())
+        m.train(training)
+        with torch.no_grad():                                           # non-trivial BN statistics
+            g_ = torch.Generator().manual_seed(1000)
+            for mod in m.conv:
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.copy_(torch.randn(mod.num_features, generator=g_) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.num_features, generator=g_) + 0.5)
+                    mod.weight.copy_(torch.rand(mod.num_features, generator=g_) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.num_features, generator=g_) * 0.1)
+        return m.to(dev)
+
+    model = new_model(train)
     g = torch.Generator().manual_seed(77 + rank)
-    spec = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)      # resident in HBM before timing
-    dvec = torch.randn(B, EMB, generator=g)
+    nb = B if args.mode != "longform" else 1
+    spec = torch.rand(nb, T_FRAMES, N_FREQ, generator=g).to(dev)      # resident in HBM before timing
+    dvec = torch.randn(nb, EMB, generator=g)
     dvec = (dvec / dvec.norm(dim=1, keepdim=True)).to(dev)
     # the rest of a training batch (train.py:85-92): target spectrogram, mixture phase, lengths
-    target = torch.rand(B, T_FRAMES, N_FREQ, generator=g).to(dev)
-    phase = ((torch.rand(B, T_FRAMES, N_FREQ, generator=g) - 0.5) * 6.2831853).to(dev)
-    seq_len = torch.full((B,), 160 * (T_FRAMES - 1), dtype=torch.int32, device=dev)
-    audio_cfg = {"n_fft": 1200, "hop_length": 160, "win_length": 400, "min_level_db": -100.0, "ref_level_db": 20.0}
+    target = torch.rand(nb, T_FRAMES, N_FREQ, generator=g).to(dev)
+    phase = ((torch.rand(nb, T_FRAMES, N_FREQ, generator=g) - 0.5) * 6.2831853).to(dev)
+    seq_len = torch.full((nb,), 160 * (T_FRAMES - 1), dtype=torch.int32, device=dev)
     # --loss fixed: a fixed d(loss)/d(mask) instead of the loss head
-    dmask = (torch.randn(B, T_FRAMES, N_FREQ, generator=g) / B).to(dev)
-    from voicesplit_amd import losses
+    dmask = (torch.randn(nb, T_FRAMES, N_FREQ, generator=g) / nb).to(dev)
 
-    if train:
+    def make_trainer(m):
         # the product's own training step (voicesplit_amd/trainer.py = train.py:86-117 per rank):
         # forward, criterion, backward, one flat gradient all-reduce, Adam, loss.item()
         from voicesplit_amd.trainer import Trainer
@@ -205,45 +256,65 @@ def main():
         cfg.loss["loss_name"] = {"sisnr": "si_snr", "powerlaw": "power_law_compression", "fixed": "si_snr"}[args.loss]
         cfg.train_config["learning_rate"] = 1e-4                    # random data: keep the weights finite
         fixed = (lambda mask, mixed, tgt, sl, ph: (mask * dmask).sum()) if args.loss == "fixed" else None
-        trainer = Trainer(model, cfg, rank, world, criterion=fixed)
+        return Trainer(m, cfg, rank, world, criterion=fixed)
+
+    units_per_step = B                                              # utterances (windows) per rank and step
+    if train:
+        trainer = make_trainer(model)
         bucket = trainer.bucket
         batch = (dvec, target, spec, seq_len, None, phase)
 
         def step():
             trainer.train_step(batch)
             return bucket.flat
-    else:
+    elif args.mode == "forward":
         def step():
             with torch.no_grad():
                 return model(spec, dvec)
+    else:
+        # BASELINE configs[4]: this rank's clips of the job (clips sharded over the ranks: voicesplit_amd/sharding.py)
+        from voicesplit_amd import sharding, streaming
+        lo, hi = sharding.shard_range(args.clips * world, rank, world)
+        n_clips = hi - lo
+        long_spec = torch.rand(n_clips, LONG_FRAMES, N_FREQ, generator=g).to(dev)
+        long_dvec = torch.randn(n_clips, EMB, generator=g)
+        long_dvec = (long_dvec / long_dvec.norm(dim=1, keepdim=True)).to(dev)
+        units_per_step = n_clips * sharding.chunk_windows(LONG_FRAMES, T_FRAMES)
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    if rank == 0:
-        rc = lib.vs_profile_begin(args.steps)
-        _lib.check(rc, "vs_profile_begin")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
+        def step():
+            return streaming.separate_long_many(model, long_spec, long_dvec, window=T_FRAMES, max_batch=B)
+
+    def timed(fn, steps, warmup, profile):
+        for _ in range(warmup):
+            out_ = fn()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        if profile and rank == 0:
+            _lib.check(lib.vs_profile_begin(steps * (6 if args.mode == "longform" else 1)), "vs_profile_begin")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out_ = fn()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert torch.isfinite(out_).all()
+        ms = calls = None
+        if profile and rank == 0:          # close the per-stage timers before anything else calls into the library
+            ms = (ctypes.c_float * _lib.PROF_SLOTS)()
+            calls = (ctypes.c_int * _lib.PROF_SLOTS)()
+            _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
+        return el, ms, calls
+
+    elapsed, ms, calls = timed(step, args.steps, args.warmup, True)
     if train:
         assert torch.isfinite(bucket.flat).all()
-    if rank == 0:                  # close the per-stage timers before anything else calls into the library
-        ms = (ctypes.c_float * _lib.PROF_SLOTS)()
-        calls = (ctypes.c_int * _lib.PROF_SLOTS)()
-        _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
 
     # ---- RCCL leg (outside the timed region) ---------------------------------------------------------
     # N > 1: every rank must hold the same bucket after the step's all-reduce (a checksum per rank, gathered).
@@ -277,56 +348,30 @@ def main():
                 assert torch.equal(bucket.flat, keep)
                 rccl = {"rccl_ranks": 1, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1),
                         "one_rank_allreduce_ms": round(e0.elapsed_time(e1) / 5, 3),
-                        "note": "one-rank ncclAllReduce of the gradient bucket on the device, outside the timed region; "
-                                "no multi-GPU node was available to the builder"}
+                        "note": "one-rank ncclAllReduce of the gradient bucket on the device, outside the timed region"}
                 tdist.destroy_process_group()
         except AssertionError:
             raise
         except Exception as exc:                      # RCCL unavailable on this box: report, do not fail the bench
             rccl = {"rccl_ranks": 0, "error": str(exc)[:200]}
 
-    # ---- BASELINE configs[1] next to the training line: forward only, eval-mode BatchNorm ---------------
-    fwd = None
-    if train:
-        model.eval()
-        with torch.no_grad():
-            for _ in range(2):
-                fo = model(spec, dvec)
-            torch.cuda.synchronize()
-            if dist:
-                dist.barrier()
-            FK = 10
-            tf0 = time.perf_counter()
-            for _ in range(FK):
-                fo = model(spec, dvec)
-            torch.cuda.synchronize()
-            if dist:
-                dist.barrier()
-            fel = time.perf_counter() - tf0
-        if dist:
-            t = torch.tensor([fel], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fel = float(t.item())
-        assert torch.isfinite(fo).all()
-        fwd = {"metric": f"utterances/sec (3 s clips, B={B}/GPU) forward only, eval BatchNorm (BASELINE configs[1]), " + MATH_LABEL,
-               "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
-               "ms_per_step": round(1e3 * fel / FK, 3)}
-        model.train()
+    def stage_table(ms_, calls_, steps_):
+        return {n: (ms_[i] / steps_ if calls_[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
 
-    if rank == 0:
-        # per training step: total ms of each slot / steps (a slot may be entered once per layer)
-        stage_ms = {n: (ms[i] / args.steps if calls[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
-        # dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training)
+    def conv_roofline(stage_ms, math, is_train, tag):
+        """The dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training)."""
         launches = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
-        if train:
+        if is_train:
             launches += [stage_ms[f"dgrad_cnn{i}"] for i in range(3, 8)]
+        launches = [v / (5 if args.mode == "longform" else 1) for v in launches]      # longform: 5 forward batches per step
         mean_launch_ms = sum(launches) / len(launches)
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
-        value = world * B * args.steps / elapsed
-        if conv_math == "bf16":
-            kname, peak = "conv64_f16x3_pk_kernel<NT=1> (bf16 single pass)", PEAK_F16_MFMA_TFLOPS
-            extra = {"mfma_pipe": "bf16 (v_mfma_f32_32x32x16_bf16), one MFMA product per product", "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS}
-        elif conv_math == "f16x3":
+        act_bytes = 2 if math == "bf16" else 4
+        if math == "bf16":
+            kname, peak = "nhwc_conv_kernel<5,5> (channels-last bf16, LDS-DMA ring, register-resident weights)", PEAK_F16_MFMA_TFLOPS
+            extra = {"mfma_pipe": "bf16 (v_mfma_f32_16x16x32_bf16), one MFMA product per product", "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS}
+            ksub = "nhwc_conv_kernel"
+        elif math == "f16x3":
             # every fp32 product is three f16 MFMA products (csrc/conv_f16x3.hip): the pipe-level
             # ceiling for ALGORITHMIC flops is the dense f16 MFMA peak / 3
             kname, peak = "conv64_f16x3_pk_kernel<5,5> (persistent pipeline)", PEAK_F16_MFMA_TFLOPS / 3.0
@@ -336,51 +381,138 @@ def main():
                      "empirical_ceiling": "a stream of nothing but this layer's MFMAs reaches 1659 TF on the f16 pipe with its real operand values "
                                           "(2345 TF on zero operands): the chip clocks down with operand toggling; 553 TF algorithmic = 0.66 of `peak` "
                                           "is the most any schedule of this arithmetic reaches on random data (profiles/r02_conv_ablation.md)"}
+            ksub = "conv64_f16x3_pk_kernel"
         else:
-            kname, peak, extra = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}
+            kname, peak, extra, ksub = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel"
+        traffic, rnd = committed_pmc_traffic(tag, ksub) if B == 64 else (None, None)
+        algo_gb = B * 2 * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
         roof = {"bound": "mfma",
-                "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if train else "") + ")",
+                "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if is_train else "") + ")",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": (committed_pmc_traffic("r02_train" if train else "r02_forward", "conv64_f16x3_pk_kernel")
-                            if conv_math == "f16x3" and B == 64 else None),
-                "traffic_unit": "GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
-                                "(profiles/r02_*_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
-                                "algorithmic bytes 5.9 GB",
+                "traffic": traffic,
+                "traffic_unit": f"GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
+                                f"(profiles/{rnd or 'rNN'}_{tag}_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
+                                f"algorithmic bytes {algo_gb:.2f} GB",
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
-                "hbm_frac_of_same_kernel": round((B * 2 * 64 * T_FRAMES * N_FREQ * 4 / 1e9) / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
+                "hbm_frac_of_same_kernel": round(algo_gb / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
         roof.update(extra)
-        if train:
+        if is_train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
-            wname = ("conv64_wgrad_ring4_kernel (weight gradient of cnn3..cnn7, bf16 single pass, incl. its reduce)" if conv_math == "bf16" else
-                     "conv64_wgrad_ring4_kernel (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)"
-                     if conv_math == "f16x3" else
-                     "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)")
+            wname = {"bf16": "nhwc_wgrad_kernel<5,5> (weight gradient of cnn3..cnn7: transposing LDS reads, incl. its reduce)",
+                     "f16x3": "conv64_wgrad_ring4_kernel (weight gradient of cnn3..cnn7, 3 f16 MFMA products per fp32 product, incl. its reduce)",
+                     "fp32": "conv64_wgrad_kernel<5> (weight gradient of cnn3..cnn7, fp32 MFMA, incl. its reduce)"}[math]
             roof["second_kernel"] = {"kernel": wname,
                                      "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                      "frac": round(B * GFLOP_CONV5X5 / wg_mean / peak, 4),
                                      "launch_ms": [round(v, 3) for v in wg],
                                      "note": ("timed on the library's side stream while the BatchNorm backward passes of the next layer run beside it "
-                                              "(vs_set_backward_overlap, DESIGN.md 6.7); alone (--serial-backward) a launch takes ~6.5 ms"
+                                              "(vs_set_backward_overlap, DESIGN.md 6.7)"
                                               if not args.serial_backward else "serial schedule: the kernel alone")}
+        if stage_ms.get("lstm_gemm"):
+            nl = 5 if args.mode == "longform" else 1
+            gemm_peak = PEAK_F16_MFMA_TFLOPS if math == "bf16" else PEAK_F16_MFMA_TFLOPS / 3.0 if math == "f16x3" else PEAK_FP32_MFMA_TFLOPS
+            lg = B * GFLOP_LSTM_GEMM / (stage_ms["lstm_gemm"] / nl)
+            roof["lstm_input_gemm"] = {"stage_ms": round(stage_ms["lstm_gemm"] / nl, 3), "achieved": round(lg, 1), "peak": round(gemm_peak, 1),
+                                       "unit": "TFLOP/s", "frac": round(lg / gemm_peak, 4),
+                                       "note": "x @ [W_ih; W_ih_reverse]^T (19264 x 3200 x 4808 at B=64) incl. the operand split passes and the d-vector fold"}
+        return roof
+
+    # ---- BASELINE configs[1] next to the training line: forward only, eval-mode BatchNorm ---------------
+    def forward_leg(m, math):
+        m.eval()
+        prev = ops.get_conv_math()
+        ops.set_conv_math(math)
+        try:
+            FK = 10
+
+            def f():
+                with torch.no_grad():
+                    return m(spec, dvec)
+            fel, _, _ = timed(f, FK, 2, False)
+        finally:
+            ops.set_conv_math(prev)
+            m.train()
+        return {"metric": f"utterances/sec (3 s clips, B={B}/GPU) forward only, eval BatchNorm (BASELINE configs[1]), " + MATH_LABEL[math],
+                "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
+                "ms_per_step": round(1e3 * fel / FK, 3)}
+
+    # ---- the same training step in another arithmetic (own model, own trainer, same inputs) ----------------
+    def train_leg(math, steps, warmup):
+        prev = ops.get_conv_math()
+        ops.set_conv_math(math)
+        try:
+            m2 = new_model(True)
+            tr2 = make_trainer(m2)
+
+            def st():
+                tr2.train_step(batch)
+                return tr2.bucket.flat
+            if rank == 0:
+                _lib.check(lib.vs_profile_begin(steps + warmup), "vs_profile_begin")
+            el, _, _ = timed(st, steps, warmup, False)
+            leg = {"metric": f"utterances/sec (3 s clips, B={B}/GPU) fwd+bwd, " + MATH_LABEL[math],
+                   "value": round(world * B * steps / el, 2), "unit": "utterances/s", "steps": steps, "warmup": warmup,
+                   "ms_per_step": round(1e3 * el / steps, 3)}
+            if rank == 0:
+                ms2 = (ctypes.c_float * _lib.PROF_SLOTS)()
+                calls2 = (ctypes.c_int * _lib.PROF_SLOTS)()
+                _lib.check(lib.vs_profile_end(ms2, calls2), "vs_profile_end")
+                st_ms = stage_table(ms2, calls2, steps + warmup)         # the timers also saw the warm-up steps
+                leg["roofline"] = conv_roofline(st_ms, math, True, "train_" + math)
+                leg["stage_ms"] = {k: (round(v, 3) if v is not None else None) for k, v in st_ms.items()}
+                leg["tape_gb"] = round(ops.tape_pool_bytes(dev) / 1e9, 2)
+            if math == "bf16":
+                leg["forward"] = forward_leg(m2, math)
+            del tr2, m2
+            ops.release_workspaces()
+            torch.cuda.empty_cache()
+            return leg
+        finally:
+            ops.set_conv_math(prev)
+
+    fwd = bf16 = strict = None
+    if train and not args.no_extras:
+        fwd = forward_leg(model, conv_math)
+        if conv_math == "f16x3":
+            ops.release_workspaces()
+            torch.cuda.empty_cache()
+            bf16 = train_leg("bf16", 5, 2)
+            strict = train_leg("fp32", 3, 1)
+
+    line = None
+    if rank == 0:
+        # per step: total ms of each slot / steps (a slot may be entered once per layer)
+        stage_ms = stage_table(ms, calls, args.steps)
+        value = world * units_per_step * args.steps / elapsed
+        roof = conv_roofline(stage_ms, conv_math, train, ("train" if train else "forward") + ("" if conv_math == "f16x3" else "_" + conv_math))
+        workload = {
+            "train": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
+                      "training step = forward (batch-stat BN) + "
+                      + {"sisnr": "SI-SNR loss through the GPU iSTFT (train.py:95-108)",
+                         "powerlaw": "power-law compressed loss (train.py:74-75,108)",
+                         "fixed": "fixed upstream gradient on the mask"}[args.loss]
+                      + " + backward + gradient all-reduce + Adam, random-init weights"),
+            "forward": (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
+                        f"{args.model} forward-only, eval BN, random-init weights"),
+            "longform": (f"BASELINE configs[4]: {args.clips} synthetic 30 s clips ([{LONG_FRAMES},601]) per GPU and step, each cut into "
+                         f"{-(-LONG_FRAMES // T_FRAMES)} independent 301-frame windows, {B} windows per forward batch, {args.model} forward, "
+                         "eval BN, clips sharded over the ranks, no collective"),
+        }[args.mode]
         line = {
-            "metric": f"utterances/sec (3 s clips, B={B}/GPU) " + ("fwd+bwd, " if train else "forward, ") + MATH_LABEL,
+            "metric": (f"utterances/sec (3 s clips, B={B}/GPU) " + {"train": "fwd+bwd, ", "forward": "forward, ",
+                                                                   "longform": "forward over 301-frame windows of 30 s clips, "}[args.mode]
+                       + MATH_LABEL[conv_math]),
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "fp32", "bf16": "bf16 (dense contractions: operands rounded to bf16, one bf16 MFMA product, fp32 accumulate; tape, BatchNorm, recurrence, head in fp32)",
+            "dtype": {"fp32": "fp32",
+                      "bf16": "bf16 (conv activations and tape stored as bf16, bf16 MFMA operands, fp32 accumulate; BatchNorm statistics, recurrence, head, master weights fp32)",
                       "f16x3": "fp32 (64->64 convs + LSTM GEMMs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)"}[conv_math],
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE metric config: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, {args.model} "
-                                    "training step = forward (batch-stat BN) + "
-                                    + {"sisnr": "SI-SNR loss through the GPU iSTFT (train.py:95-108)",
-                                       "powerlaw": "power-law compressed loss (train.py:74-75,108)",
-                                       "fixed": "fixed upstream gradient on the mask"}[args.loss]
-                                    + " + backward + gradient all-reduce + Adam, random-init weights") if train else
-                                   (f"BASELINE configs[1]: B={B}/GPU synthetic [B,301,601] spec + [B,256] dvec, "
-                                    f"{args.model} forward-only, eval BN, random-init weights"),
+            "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "frames": T_FRAMES, "num_freq": N_FREQ,
                        "conv_math": conv_math,
                        "parallelism": (f"dp{world}: one flat 75.5 MB fp32 gradient all-reduce per step" if train else
@@ -392,14 +524,18 @@ def main():
                               if train and not args.serial_backward else "stages run in order on one stream"),
             "model_tflops": round(value / world * GFLOP_FWD_TOTAL * (3 if train else 1) / 1e3, 2),
         }
+        if args.mode == "longform":
+            line["clips_per_s"] = round(world * args.clips * args.steps / elapsed, 2)
         if fwd is not None:
             line["forward"] = fwd
+        if bf16 is not None:
+            line["bf16"] = bf16
+        if strict is not None:
+            line["fp32_strict"] = strict
         if rccl is not None:
             line["rccl"] = rccl
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.mode)
-    else:
-        line = None
+            line["cpu_baseline"] = cpu_baseline("train" if train else "forward")
     if dist:
         dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a file:

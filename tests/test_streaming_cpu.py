@@ -89,3 +89,22 @@ def test_exact_plan_stays_inside_the_clip_and_keeps_frames_away_from_window_edge
                 assert st + wlen == n or k1 <= wlen - halo            # ... or the clip end
                 pos = st + k1
             assert pos == n
+
+
+def test_separate_long_many_equals_clip_by_clip():
+    """The batch form of BASELINE configs[4] (all windows of all clips in one list) == separate_long per clip."""
+    import torch
+    from voicesplit_amd import streaming
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(7, 7)
+
+    def model(x, emb):                       # any per-window function of (x, emb)
+        return torch.sigmoid(lin(x) + emb[:, :7].unsqueeze(1) + x.mean(dim=1, keepdim=True))
+
+    specs = torch.rand(5, 83, 7)
+    dvecs = torch.randn(5, 9)
+    many = streaming.separate_long_many(model, specs, dvecs, window=20, max_batch=6)
+    for i in range(5):
+        one = streaming.separate_long(model, specs[i], dvecs[i], window=20, halo=0, max_batch=4)
+        assert torch.allclose(many[i], one, atol=1e-6)
+    assert many.shape == (5, 83, 7)

@@ -265,9 +265,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
 #pragma unroll
               for (int hf = 0; hf < 2; ++hf) bq[s2 % 3][hf] = ds_read_tr16(a_frag_addr(r2, T0 + j2, hf));
             }
-            if (j < 4 && r + 1 < rv) {
+            // the next row's dz fragments: one co block per step of this row, whatever is left in its last step
+            // (a wave of the 7x1 layer has only 3 or 4 taps = steps per row)
+            if (r + 1 < rv) {
 #pragma unroll
-              for (int hf = 0; hf < 2; ++hf) zf[(r + 1) & 1][j][hf] = ds_read_tr16(z_frag_addr(r + 1, j, hf));
+              for (int cb = 0; cb < 4; ++cb) {
+                if (cb == j || (j == NTW - 1 && cb > j)) {
+#pragma unroll
+                  for (int hf = 0; hf < 2; ++hf) zf[(r + 1) & 1][cb][hf] = ds_read_tr16(z_frag_addr(r + 1, cb, hf));
+                }
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
             const vs_bf16x8 bfrag = frag_of(bq[s % 3][0], bq[s % 3][1]);

@@ -79,6 +79,31 @@ def separate_long(model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], s
 
 
 
+def separate_long_many(model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], specs: torch.Tensor,
+                       dvecs: torch.Tensor, window: int = 301, max_batch: int = 256) -> torch.Tensor:
+    """BASELINE configs[4] as a batch job: specs [N, T_long, F] (N clips of equal length), dvecs [N, E] ->
+    masks [N, T_long, F2].  Every clip is cut into independent `window`-frame items (the last one zero padded),
+    the windows of ALL clips form one list that goes through the model `max_batch` at a time (256 windows per
+    batch in the configuration), and the masks are cut back to T_long.  Same result as ``separate_long`` with
+    halo = 0 clip by clip; it exists so that a batch never runs half empty at a clip boundary."""
+    if specs.dim() != 3 or dvecs.dim() != 2 or specs.shape[0] != dvecs.shape[0]:
+        raise ValueError("specs must be [N, T, F] and dvecs [N, E]")
+    N, T_long, F = specs.shape
+    nw = -(-T_long // window)
+    pad = nw * window - T_long
+    x = torch.nn.functional.pad(specs, (0, 0, 0, pad)) if pad else specs
+    x = x.reshape(N * nw, window, F)
+    emb = dvecs.unsqueeze(1).expand(N, nw, dvecs.shape[1]).reshape(N * nw, -1)
+    out = None
+    with torch.no_grad():
+        for b0 in range(0, N * nw, max_batch):
+            mb = model(x[b0:b0 + max_batch].contiguous(), emb[b0:b0 + max_batch].contiguous())
+            if out is None:
+                out = mb.new_empty(N * nw, window, mb.shape[2])
+            out[b0:b0 + mb.shape[0]] = mb
+    return out.reshape(N, nw * window, -1)[:, :T_long]
+
+
 def plan_windows_exact(n_frames: int, window: int = 301, halo: int = CONV_RECEPTIVE_HALO) -> List[Tuple[int, int, int]]:
     """[(start, keep_lo, keep_hi)] for ``separate_long_exact``: every window lies INSIDE the clip (a frame
     outside the clip must stay a zero-padded activation in every conv layer, which a zero input frame
