@@ -342,6 +342,13 @@ int vs_set_conv_kernel(int mode);
  * (a workgroup of the launch was not resident): results are then invalid. */
 int vs_set_lstm_kernel(int mode);
 
+/* Did the persistent BiLSTM kernels of the last vs_forward_train / vs_backward on `tape` and / or the last vs_forward /
+ * vs_bilstm_fwd on `workspace` complete?  0 = yes, 1 = a bounded spin gave up (another process took CUs away while the
+ * launch ran; its output was overwritten with NaN so that no caller can use it by accident), < 0 = error.  Either
+ * buffer may be NULL.  Synchronises `stream`.  The launches themselves are cooperative: a grid that cannot be resident
+ * is refused by the runtime and the one-launch-per-step kernels run instead. */
+int vs_lstm_status(const vs_dims* dims, const void* tape, size_t tape_bytes, const void* workspace, size_t workspace_bytes, void* stream);
+
 /* vs_backward schedule: 1 (default) = the 64->64 weight gradients run on a second HIP stream of the library beside
  * the BatchNorm backward passes of the next layer (matrix-pipe kernel beside an HBM stream); 0 = everything in
  * order on the caller's stream.  Same kernels and summation order: results are bit-identical.  The caller's stream

@@ -139,6 +139,7 @@ SIGNATURES = {
     "vs_set_conv_kernel": (c_int, [c_int]),
     "vs_set_lstm_kernel": (c_int, [c_int]),
     "vs_set_backward_overlap": (c_int, [c_int]),
+    "vs_lstm_status": (c_int, [POINTER(VsDims), _P, c_size_t, _P, c_size_t, _P]),
     "vs_bn_act_bwd_first": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vs_bn_act_bwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vs_conv_last_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

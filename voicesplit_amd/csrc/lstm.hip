@@ -723,6 +723,26 @@ extern "C" int vs_set_lstm_kernel(int mode) {
   return 0;
 }
 
+namespace {
+// A persistent launch whose spin gave up (a workgroup was not resident: the error word is 1) has produced garbage.
+// The word is only read by callers that ask (vs_lstm_status), so the result itself is made unusable: NaN in the first
+// 64 outputs -> NaN mask / NaN gradients -> the training loop's loss guard (train.py:112-114) and every isfinite check
+// fire instead of training on wrong numbers.
+__global__ void lstm_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ out, int n) {
+  if (*err == 0u) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __uint_as_float(0x7fc00000u);
+}
+
+// Cooperative launch: the runtime checks the grid against the kernel's occupancy and refuses (instead of queueing
+// workgroups behind resident ones, where the flag protocol would spin until its bound) when it cannot be resident.
+template <class Args>
+hipError_t launch_resident(const void* kernel, dim3 grid, dim3 block, Args& a, hipStream_t stream) {
+  void* params[] = {&a};
+  return hipLaunchCooperativeKernel(kernel, grid, block, params, 0, stream);
+}
+}  // namespace
+
 // state: 3 * [2][H][Bpad] floats.  Step kernels: h ping, h pong, c, zeroed here (zero initial state).
 // Persistent kernel: h ping, h pong (fragment order), then the flag words + the error word.
 int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,
@@ -743,13 +763,24 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
   if (persistent) {
     unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * per);      // zeroed above
     unsigned* err = reinterpret_cast<unsigned*>(state + 3 * per);         // first of the 64 trailing words
+    bool launched = true;
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
       LstmPersistArgs a{xg, wp, hbuf[0], hbuf[1], flags, err, out, gates_save, c_save, B, T, H, Bpad, bt0};
-      hipLaunchKernelGGL(lstm_persistent_kernel, dim3(HQ * nbt, 2), dim3(256), 0, stream, a);
+      const hipError_t e = launch_resident(reinterpret_cast<const void*>(&lstm_persistent_kernel), dim3(HQ * nbt, 2), dim3(256), a, stream);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        // refused before anything ran (first launch): the step kernels below do the whole job; later: an error
+        VS_REQUIRE(bt0 == 0 && g_lstm_kernel != 2, "lstm: persistent recurrence could not be launched resident: %s", hipGetErrorString(e));
+        launched = false;
+        break;
+      }
     }
-    VS_LAUNCH_CHECK();
-    return 0;
+    if (launched) {
+      hipLaunchKernelGGL(lstm_poison_kernel, dim3(1), dim3(64), 0, stream, err, out, 64 < B * T * 2 * H ? 64 : B * T * 2 * H);
+      VS_LAUNCH_CHECK();
+      return 0;
+    }
   }
   float* c = state + 2 * per;
   dim3 grid(HQ * NBT, 2), block(256);
@@ -796,14 +827,25 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
   if (persistent) {
     unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * frag);      // 2*Bpad*H words available, 2*NBT*NUT*4 used
     unsigned* err = reinterpret_cast<unsigned*>(state + 2 * frag + (size_t)2 * Bpad * H);
+    bool launched = true;
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
       LstmBwdPersistArgs a{wpt, gbuf[0], gbuf[1], flags, err, gates, c_all, dout, B, T, H, Bpad, bt0};
-      hipLaunchKernelGGL(lstm_bwd_persistent_kernel, dim3(NUT * nbt, 2), dim3(512), 0, stream, a);
+      const hipError_t e = launch_resident(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        VS_REQUIRE(bt0 == 0 && g_lstm_kernel != 2, "lstm_bwd: persistent recurrence could not be launched resident: %s", hipGetErrorString(e));
+        launched = false;
+        break;
+      }
     }
-    VS_LAUNCH_CHECK();
-    return 0;
+    if (launched) {
+      hipLaunchKernelGGL(lstm_poison_kernel, dim3(1), dim3(64), 0, stream, err, gates, 64 < B * T * 8 * H ? 64 : B * T * 8 * H);
+      VS_LAUNCH_CHECK();
+      return 0;
+    }
   }
+  if (persistent) VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_bwd_state_floats(B, H) * sizeof(float), stream));
   float* dc = state + 2 * frag;
   dim3 grid(NUT * NBT, 2), block(512);
   for (int s = 0; s < T; ++s) {

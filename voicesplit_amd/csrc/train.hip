@@ -584,6 +584,32 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                   at<double>(tape, L.first_acc), stream);
 }
 
+// Did the persistent BiLSTM kernels of the last calls on these buffers complete?  (A launch that could not be resident
+// falls back to the step kernels before it starts; one whose bounded spin gave up anyway -- CUs taken away by another
+// process mid-launch -- sets a word in its state buffer and poisons its output with NaN.)  Synchronises `stream`.
+int vs_lstm_status(const vs_dims* d, const void* tape, size_t tape_bytes, const void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VS_REQUIRE(tape || workspace, "lstm_status: pass a tape and / or a workspace");
+  unsigned words[3] = {0u, 0u, 0u};
+  if (tape) {
+    vs_tape_layout L;
+    if (int rc = tape_layout(d, &L)) return rc;
+    VS_REQUIRE(tape_bytes >= L.total_bytes, "lstm_status: tape too small");
+    const char* t = static_cast<const char*>(tape);
+    VS_CHECK_HIP(hipMemcpyAsync(&words[0], t + L.lstm_state + (vs_lstm_state_floats(d->B, d->H) - 64) * sizeof(float), 4, hipMemcpyDeviceToHost, stream));
+    VS_CHECK_HIP(hipMemcpyAsync(&words[1], t + L.lstm_bwd_state + (vs_lstm_bwd_state_floats(d->B, d->H) - 64) * sizeof(float), 4, hipMemcpyDeviceToHost, stream));
+  }
+  if (workspace) {
+    vs_ws_layout W;
+    if (int rc = vs_workspace_layout(d, &W)) return rc;
+    VS_REQUIRE(workspace_bytes >= W.total_bytes, "lstm_status: workspace too small");
+    VS_CHECK_HIP(hipMemcpyAsync(&words[2], static_cast<const char*>(workspace) + W.lstm_state + (vs_lstm_state_floats(d->B, d->H) - 64) * sizeof(float), 4,
+                                hipMemcpyDeviceToHost, stream));
+  }
+  VS_CHECK_HIP(hipStreamSynchronize(stream));
+  return (words[0] == 1u || words[1] == 1u || words[2] == 1u) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // unit-test surface
 // ---------------------------------------------------------------------------------------------
