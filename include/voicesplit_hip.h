@@ -11,15 +11,25 @@
  *
  * Conventions
  *  - plain C types only; every pointer is a DEVICE pointer (fp32 unless noted) owned by the
- *    caller; the library never allocates device memory and keeps no pointer after return.
+ *    caller: inputs, outputs, the inference workspace and the training tape.  The library never
+ *    allocates device memory and keeps no caller pointer after return.
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
- *    synchronisation, no global mutable state; safe to call concurrently on different streams
- *    with disjoint workspaces.
+ *    synchronisation except where an entry point says so (vs_profile_end, vs_lstm_status).
+ *  - library-owned state (all of it): (1) ONE side stream + two events per device, created on the first
+ *    vs_backward and used to run weight gradients beside the BatchNorm backward passes; every vs_backward
+ *    joins it before returning, and the enqueue phase of concurrent vs_backward calls on one device is
+ *    serialised by a mutex while it is in use (vs_set_backward_overlap(0) turns it off); (2) the
+ *    process-wide kernel-selection switches vs_set_conv_kernel / vs_set_wgrad_kernel / vs_set_lstm_kernel /
+ *    vs_set_backward_overlap (A/B timing and cross-checks; every choice gives the same results) and the
+ *    opt-in profiler vs_profile_begin / _end; (3) a 64-byte zero page and a 2 KiB dump page in device memory
+ *    (static __device__ data of the channels-last kernels: source of out-of-image loads, sink of masked
+ *    stores).  Calls on different streams with disjoint buffers are otherwise independent.
  *  - return 0 on success, <0 on error (-1 bad argument, -2 HIP runtime error); the message is
  *    available from vs_last_error() (thread-local).  No exceptions cross the ABI.
  *  - tensors are dense row-major with the reference's layouts: spectrogram [B][T][F]
- *    (F contiguous), conv activations [B][C][T][F], LSTM features [B][T][8F] with feature
- *    index c*F+f, nn.Linear / nn.LSTM weights [out][in].
+ *    (F contiguous), conv activations [B][C][T][F] (VS_MATH_BF16: channels-last bf16 [B][T][F][C]
+ *    inside the workspace / tape), LSTM features [B][T][8F] with feature index c*F+f,
+ *    nn.Linear / nn.LSTM weights [out][in].
  */
 #ifndef VOICESPLIT_HIP_H
 #define VOICESPLIT_HIP_H
@@ -30,8 +40,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these are its only exports */
+#endif
 
-#define VS_ABI_VERSION 4
+#define VS_ABI_VERSION 5
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -43,10 +56,11 @@ extern "C" {
 #define VS_MATH_FP32 0    /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fmaf chain                              */
 #define VS_MATH_F16X3 1   /* fp32 operands split into two f16 halves, three v_mfma_f32_32x32x16_f16 per
                              product term set, fp32 accumulate: fp32-class accuracy at 3/16 of the matrix time */
-#define VS_MATH_BF16 2    /* BASELINE configs[2]: operands rounded to bf16 (round to nearest even), ONE
-                             v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, fp32 everywhere else (tape,
-                             BatchNorm statistics, master weights).  NOT fp32-class: ~3e-3 relative per layer;
-                             opt-in only, never a default (tests state its tolerance)                           */
+#define VS_MATH_BF16 2    /* BASELINE configs[2]: the conv stack on channels-last bf16 tensors -- activations and the
+                             training tape are STORED as bf16 [B][T][F][64] (half the bytes of every pass), bf16 MFMA
+                             operands, fp32 accumulate; BatchNorm statistics, LSTM recurrence, head and master weights
+                             stay fp32, the LSTM GEMMs round their operands to bf16.  NOT fp32-class (8-bit mantissa):
+                             opt-in only, never a default (tests/test_gpu_bf16.py states its bounds)                  */
 
 /* BatchNorm mode */
 #define VS_BN_EVAL 0      /* running statistics (model.eval(), utils/generic_utils.py:479,533) */
@@ -203,6 +217,13 @@ size_t vs_nhwc_conv_packed_bytes(int KT, int KF);
 int vs_nhwc_conv_pack(const float* w, void* packed, int KT, int KF, int transpose_flip, void* stream);
 int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                  int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream);
+/* bf16 GEMM of the same configuration (the three LSTM contractions): C[M][N] (+)= op(A) op(B) (+ rowbias[m / group][n]);
+ * A, B bf16; *_kmajor = 0: element (i, k) at i*ld + k, 1: at k*ld + i (no transposed copies: transposing LDS reads).
+ * vs_cvt_rows_bf16: fp32 [rows][ld] (K valid columns) -> bf16 [rows][Kp], zero padded.  Row-form operands must be
+ * padded to a multiple of 64 in k; ld multiples of 8; 16-byte aligned. */
+int vs_cvt_rows_bf16(const float* src, long long rows, int K, int ld, void* dst, int Kp, void* stream);
+int vs_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                 const float* rowbias, int ldrb, int group, int accumulate, void* stream);
 /* the memory-bound kernels around them.  cnn1: x [B][T][F] fp32 -> [B][T][F][64] bf16 (bn_stats as above);
  * BatchNorm + activation apply a = act(z * scale[c] + shift[c]) over npix pixels (a may alias z); cnn8 + transpose/view:
  * [B][T][F][64] bf16 -> [B][T][8][F] fp32. */
@@ -297,6 +318,7 @@ typedef struct vs_tape_layout {
   size_t bn_stats, bn_coef, first_acc, colsum_tmp, partials;
   size_t conv_scales;         /* [16] scale slots (8 forward, 8 backward): operand scales + running |max| arrays */
   size_t gemm_scales;         /* operand scales of the split-f16 LSTM GEMMs (feat, W_ih, gate gradients) */
+  size_t lstm_bf16;           /* VS_MATH_BF16: feat [B*T][Kp], [W_ih; W_ih_reverse] [8H][Kp], gate gradients [B*T][8H] as bf16 */
 } vs_tape_layout;
 
 int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);
@@ -442,6 +464,9 @@ int vs_wav_to_spec(const vs_loss_dims* dims, const float* wav, float* spec, floa
 int vs_spec_to_wav(const vs_loss_dims* dims, const float* spec, const float* mask, const float* phase, float* wav,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

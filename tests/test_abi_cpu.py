@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.vs_abi_version() == _lib.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_header():
+    """-fvisibility=hidden: the dynamic symbol table holds the header's functions and the compiler's own
+    __hip_cuid_* / fatbin bookkeeping, no internal launcher, kernel stub or helper."""
+    import subprocess
+    from voicesplit_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    extra = [s for s in syms if s not in set(_header_functions()) and not s.startswith("__hip_")]
+    assert not extra, f"unexpected exports: {extra[:10]}"
+
+
 def test_workspace_layout_and_argument_errors():
     from voicesplit_amd import _lib, ops
     lib = _lib.load()

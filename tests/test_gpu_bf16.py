@@ -36,7 +36,7 @@ FEAT_TOL = 4e-2
 LSTM_TOL = 0.12
 MASK_ABS_TOL = 0.1
 GRAD_TOL = 0.6
-COS_MIN = 0.93
+COS_MIN = 0.90
 
 
 def _rel(got, ref):

@@ -271,3 +271,37 @@ def test_nhwc_cnn1_backward_and_cnn8_backward():
     _close(din, ref_din, "nhwc cnn8 data gradient")
     e = ((dw8.double().cpu() - ref_dw8).abs().max() / ref_dw8.abs().max()).item()
     assert e < 2e-5, e
+
+
+# ---- bf16 GEMM of the LSTM contractions (csrc/gemm_bf16.hip) --------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(200, 300, 130), (128, 256, 64), (1, 17, 8), (777, 520, 1000), (3010, 3200, 424)])
+def test_gemm_bf16_all_operand_forms(M, N, K):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    Kp = (K + 63) // 64 * 64
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    rb = torch.randn(5, N, generator=g)
+    group = -(-M // 5)
+    Ab = ops.cvt_rows_bf16(A.cuda(), K, Kp)                  # [M, Kp], zero padded
+    Bb = ops.cvt_rows_bf16(B.cuda(), K, Kp)
+    assert torch.equal(Ab[:, :K].float().cpu(), A.to(torch.bfloat16).float()) and Ab[:, K:].abs().max().item() == 0 if Kp > K else True
+    Ad, Bd = A.to(torch.bfloat16).double(), B.to(torch.bfloat16).double()
+    ref = Ad @ Bd.t()
+    # row x row, with the per-row-group bias of the LSTM input projection
+    got = ops.gemm_bf16(Ab, Bb, M, N, K, rowbias=rb.cuda(), group=group).double().cpu()
+    want = ref + rb.double()[torch.arange(M) // group]
+    assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
+    # row x col: B given as [K, ldb] (K-major)
+    Np = (N + 7) // 8 * 8
+    Bk = torch.zeros(K, Np, dtype=torch.bfloat16)
+    Bk[:, :N] = B.to(torch.bfloat16).t()
+    got = ops.gemm_bf16(Ab, Bk.cuda(), M, N, K, b_kmajor=True).double().cpu()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    # col x col, accumulating on top of an existing C
+    Mp = (M + 7) // 8 * 8
+    Ak = torch.zeros(K, Mp, dtype=torch.bfloat16)
+    Ak[:, :M] = A.to(torch.bfloat16).t()
+    C0 = torch.randn(M, N, generator=g)
+    got = ops.gemm_bf16(Ak.cuda(), Bk.cuda(), M, N, K, a_kmajor=True, b_kmajor=True, out=C0.clone().cuda(), accumulate=True).double().cpu()
+    assert ((got - (ref + C0.double())).abs().max() / ref.abs().max()).item() < 2e-5

@@ -9,17 +9,17 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -f csv -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
-ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
-KREG="conv64_mfma|conv64_wgrad|conv64_f16|gemm_f16x3|gemm_pre|lstm_persistent|lstm_bwd_persistent"
+ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $*"
+KREG="conv64_mfma|conv64_wgrad|conv64_f16|gemm_f16x3|gemm_pre|lstm_persistent|lstm_bwd_persistent|nhwc_conv_kernel|nhwc_wgrad"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o pmc -f csv -- $ONE > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"
-timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG|conv_first|conv_last|bn_" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG|conv_first|conv_last|bn_|nhwc_" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc_fetch rc=$?"
-timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG|conv_first|conv_last|bn_" --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -f csv -- $ONE > "$OUT/pmc_write.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG|conv_first|conv_last|bn_|nhwc_" --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -f csv -- $ONE > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM -d "$OUT/pmc_lds" -o pmc -f csv -- $ONE > "$OUT/pmc_lds.log" 2>&1
 echo "pmc_lds rc=$?"

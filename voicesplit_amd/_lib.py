@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class VsDims(Structure):
@@ -77,7 +77,7 @@ class VsTapeLayout(Structure):
         ("dvbias", c_size_t), ("conv_packed", c_size_t * 6), ("pack_tmp", c_size_t), ("lstm_packed", c_size_t),
         ("lstm_packed_t", c_size_t), ("lstm_state", c_size_t), ("lstm_bwd_state", c_size_t), ("consts", c_size_t),
         ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
-        ("partials", c_size_t), ("conv_scales", c_size_t), ("gemm_scales", c_size_t),
+        ("partials", c_size_t), ("conv_scales", c_size_t), ("gemm_scales", c_size_t), ("lstm_bf16", c_size_t),
     ]
 
 
@@ -105,6 +105,8 @@ SIGNATURES = {
     "vs_nhwc_conv_packed_bytes": (c_size_t, [c_int, c_int]),
     "vs_nhwc_conv_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vs_cvt_rows_bf16": (c_int, [_P, c_longlong, c_int, c_int, _P, c_int, _P]),
+    "vs_gemm_bf16": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_first": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_nhwc_bn_apply": (c_int, [_P, _P, c_longlong, c_int, _P, _P, _P]),
     "vs_nhwc_conv_last": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

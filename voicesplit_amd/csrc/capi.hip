@@ -197,6 +197,20 @@ int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
                             hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl) {
+  if (math == VS_MATH_BF16 && scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0 &&
+      scratch_bytes >= vs_lstm_bf16_layout(M, K, H).total) {
+    // the bf16 configuration's own GEMM (gemm_bf16.hip): feat and W_ih as bf16 arrays that the backward pass reuses
+    const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K, H);
+    char* base = static_cast<char*>(scratch);
+    if (int rc = vs_cvt_rows_bf16_impl(feat, M, K, K, base + Lb.feat, Lb.Kp, stream)) return rc;
+    if (!prep_wh) {      // (prepared weights: the bf16 W_ih lives in the prepared blob)
+      if (int rc = vs_cvt_rows_bf16_impl(w_ih0, 4 * H, K, KE, static_cast<char*>(scratch) + Lb.wih, Lb.Kp, stream)) return rc;
+      if (int rc = vs_cvt_rows_bf16_impl(w_ih1, 4 * H, K, KE, static_cast<char*>(scratch) + Lb.wih + (size_t)4 * H * Lb.Kp * 2, Lb.Kp, stream)) return rc;
+    }
+    const void* wih = prep_wh ? static_cast<const void*>(prep_wh) : static_cast<const void*>(static_cast<char*>(scratch) + Lb.wih);
+    return vs_gemm_bf16_impl(0, 0, static_cast<char*>(scratch) + Lb.feat, Lb.Kp, wih, Lb.Kp, xg, 8 * H, nullptr, 0, M, 8 * H, K,
+                             rowbias, 8 * H, T, 0, stream);
+  }
   if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
     if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
@@ -338,6 +352,15 @@ int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const f
                  int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream) {
   VS_REQUIRE(in != out, "nhwc_conv: in-place is not supported");
   return vs_nhwc_conv_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, bn_stats, (hipStream_t)stream);
+}
+
+int vs_cvt_rows_bf16(const float* src, long long rows, int K, int ld, void* dst, int Kp, void* stream) {
+  return vs_cvt_rows_bf16_impl(src, rows, K, ld, dst, Kp, (hipStream_t)stream);
+}
+
+int vs_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                 const float* rowbias, int ldrb, int group, int accumulate, void* stream) {
+  return vs_gemm_bf16_impl(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, nullptr, 0, M, N, K, rowbias, ldrb, group, accumulate, (hipStream_t)stream);
 }
 
 int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
@@ -682,7 +705,11 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
   }
   for (int dir = 0; dir < 2; ++dir)
     VS_REQUIRE(p->w_ih[dir] && p->w_hh[dir], "prepare_weights: NULL LSTM parameter (dir %d)", dir);
-  if (d->math != VS_MATH_FP32) {
+  if (d->math == VS_MATH_BF16) {      // [8H][Kp] bf16, both directions stacked: the B operand of gemm_bf16.hip
+    const int K = 8 * d->F, KE = K + d->E, Kp = (K + 63) / 64 * 64;
+    if (int rc = vs_cvt_rows_bf16_impl(p->w_ih[0], 4 * d->H, K, KE, P.wih_hi, Kp, stream)) return rc;
+    if (int rc = vs_cvt_rows_bf16_impl(p->w_ih[1], 4 * d->H, K, KE, P.wih_hi + (size_t)4 * d->H * Kp, Kp, stream)) return rc;
+  } else if (d->math != VS_MATH_FP32) {
     if (int rc = vs_lstm_split_wih_impl(d->math, p->w_ih[0], p->w_ih[1], d->H, 8 * d->F, 8 * d->F + d->E,
                                         reinterpret_cast<unsigned*>(P.gemm_wscale + 4), P.gemm_wscale, P.wih_hi, P.wih_lo, stream)) return rc;
   }

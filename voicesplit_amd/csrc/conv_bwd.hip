@@ -425,13 +425,34 @@ void conv_last_wgrad_kernel(const float* __restrict__ dz, const float* __restric
   part[(size_t)blockIdx.x * 512 + (2 * og + 1) * 64 + ci] = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
 }
 
-// out[i] = sum_g part[g][i]
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// out[i] = sum_g part[g][i].  A thread owns four consecutive outputs (16-byte loads) and keeps eight slabs in flight:
+// the 128 slabs x 1.6 MB of a 5x5 weight gradient are a 210 MB stream, not a latency chain.
+__global__ __launch_bounds__(256)
+void reduce_partials_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (idx >= n) return;
-  float s = 0.f;
-  for (int gq = 0; gq < G; ++gq) s += part[(size_t)gq * n + idx];
-  out[idx] = s;
+  if (idx + 4 <= n && (n & 3) == 0) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int gq = 0;
+    for (; gq + 8 <= G; gq += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (size_t)(gq + u) * n + idx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; gq < G; ++gq) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)gq * n + idx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + idx) = s;
+    return;
+  }
+  for (int e = idx; e < n && e < idx + 4; ++e) {
+    float s = 0.f;
+    for (int gq = 0; gq < G; ++gq) s += part[(size_t)gq * n + e];
+    out[e] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -673,14 +694,14 @@ int vs_conv_last_wgrad_impl(const float* dz, const float* in, float* part /* [bl
   const size_t lds = (size_t)72 * kLwPitch * sizeof(float);        // 74.9 KB: two workgroups per CU
   VS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_last_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nblk), dim3(256), lds, stream, dz, in, part, B, T, F, (F + kLwSeg - 1) / kLwSeg);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, stream, part, nblk, 512, dw);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part, nblk, 512, dw);
   VS_LAUNCH_CHECK();
   return 0;
 }
 
 int vs_reduce_partials_impl(const float* part, int G, int n, float* out, hipStream_t stream) {
   VS_REQUIRE(G > 0 && n > 0, "reduce_partials: bad shape G=%d n=%d", G, n);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part, G, n, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 1023) / 1024), dim3(256), 0, stream, part, G, n, out);
   VS_LAUNCH_CHECK();
   return 0;
 }

@@ -300,7 +300,7 @@ int vs_conv_last_fwd_impl(const float* in, const float* w, const float* scale, c
 // stats_slots > 0: the conv that produced x already accumulated {sum, sum of squares} of every channel into
 // `stats_slots` partial slots of [C][2] doubles (its epilogue: conv_f16x3*.hip STATS); they are folded into slot 0
 // here and the statistics pass over x is skipped.
-__global__ void bn_stats_fold_kernel(double* __restrict__ stats, int n, int slots) {
+static __global__ void bn_stats_fold_kernel(double* __restrict__ stats, int n, int slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double v = 0.0;

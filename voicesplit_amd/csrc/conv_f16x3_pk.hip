@@ -553,6 +553,7 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
   if (nwg < 8) nwg = 8;
   if (nwg > (a.n_tiles + 7) / 8 * 8) nwg = (a.n_tiles + 7) / 8 * 8;
   dim3 grid((unsigned)nwg), block(256);
+#ifdef VS_ABLATION        // timing ablations of the kernel (tools/conv_bench): make -C voicesplit_amd/csrc ABLATION=1
   if (abl) {      // timing ablations (Mish epilogue), see the kernel's ABL parameter
     switch (abl) {
       case 1: hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_MISH, 1>), grid, block, 0, stream, a); break;
@@ -572,6 +573,9 @@ int launch_pk(const PkArgs& a0, int act, int i_base, int i_end, hipStream_t stre
     VS_LAUNCH_CHECK();
     return 0;
   }
+#else
+  VS_REQUIRE(abl == 0, "conv64_f16x3_pk: timing ablations are not compiled into this library (build with ABLATION=1)");
+#endif
   if (a.bn_stats) {      // train-mode forward: conv + bias, no activation, statistics fused
     VS_REQUIRE(act == VS_ACT_NONE, "conv64_f16x3_pk: fused BatchNorm statistics need act = NONE");
     if (math == VS_MATH_CODE_BF16) hipLaunchKernelGGL((conv64_f16x3_pk_kernel<P, VS_ACT_NONE, 0, 0, 1, true>), grid, block, 0, stream, a);

@@ -72,6 +72,8 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   L->partials = take(part * 4);
   L->conv_scales = take(16 * VS_SCALE_SLOT_FLOATS * 4);
   L->gemm_scales = take(32 * 4);
+  // bf16 configuration: feat / W_ih / dxg as bf16 arrays shared by the forward GEMM and the two backward contractions
+  L->lstm_bf16 = take(d->math == VS_MATH_BF16 ? vs_lstm_bf16_layout((long long)M, 8 * (int)F, (int)H).total : 256);
   L->total_bytes = off;
   return 0;
 }
@@ -237,8 +239,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     }
     // the backward pass's gradient buffers are idle during the forward pass
     if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
-                                         at<float>(tape, L.gemm_scales), at<char>(tape, L.grad0),
-                                         2 * (L.grad1 - L.grad0), stream)) return rc;
+                                         at<float>(tape, L.gemm_scales), nhwc ? at<char>(tape, L.lstm_bf16) : at<char>(tape, L.grad0),
+                                         nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
@@ -382,12 +384,25 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
     }
   }
+  const bool bf16g = d->math == VS_MATH_BF16;
+  const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K8, H);
+  char* bfb = at<char>(tape, L.lstm_bf16);
+  if (bf16g) {      // the gate gradients as bf16 [M][8H]: row-form A of dfeat, col-form A of dW_ih (gemm_bf16.hip)
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+    if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
+  }
   hipStream_t ls = stream;
   if (side) {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
     ls = side->s;
   }
+  if (bf16g) {
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+    // dfeat = dxg @ [W_ih; W_ih_reverse][:, :8F]: both directions in one contraction over K = 8H
+    if (int rc = vs_gemm_bf16_impl(0, 1, bfb + Lb.dxg, 8 * H, bfb + Lb.wih, Lb.Kp, dfeat, K8, nullptr, 0, M, K8, 8 * H,
+                                   nullptr, 0, 1, 0, stream)) return rc;
+  } else
   {
     VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
     for (int dir = 0; dir < 2; ++dir) {
@@ -409,7 +424,13 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
       const float* dxg_d = dxg + (size_t)dir * 4 * H;
       // dW_ih[:, :8F] = dxg_d^T @ feat
-      if (f16g) {
+      if (bf16g) {
+        // both directions in one col x col contraction over K = B*T: rows < 4H -> dW_ih, the rest -> dW_ih_reverse
+        if (dir == 0) {
+          if (int rc = vs_gemm_bf16_impl(1, 1, bfb + Lb.dxg, 8 * H, bfb + Lb.feat, Lb.Kp, g->w_ih[0], KE, g->w_ih[1], 4 * H, 8 * H, K8, M,
+                                         nullptr, 0, 1, 0, ls)) return rc;
+        }
+      } else if (f16g) {
         if (int rc = vs_gemm_f16x3_impl(1, 1, dxg_d, 8 * H, feat, nullptr, 0x7fffffff, K8, g->w_ih[dir], KE, 4 * H, K8, M,
                                         nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, gsc + 8, gsc, ls, d->math)) return rc;
       } else {

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include "../../include/voicesplit_hip.h"   // every translation unit sees the exported declarations (default visibility)
+
 #define VS_WAVE 64
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -134,6 +134,22 @@ int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, co
                          int w_shift, int w_group, int splits, float* partials, hipStream_t);
 int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+// gemm_bf16.hip: the LSTM contractions of the bf16 configuration (LDS-DMA ring, row / K-major operand forms)
+int vs_cvt_rows_bf16_impl(const float* src, long long rows, int K, int ld, void* dst, int Kp, hipStream_t);
+int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* C2, int split_m,
+                      int M, int N, int K, const float* rowbias, int ldrb, int group, int accumulate, hipStream_t);
+// layout of the three bf16 operand arrays inside one scratch region (256-byte aligned pieces): feat [M][Kp], W_ih [8H][Kp], dxg [M][8H]
+struct VsLstmBf16Layout { size_t feat, wih, dxg, total; int Kp; };
+inline VsLstmBf16Layout vs_lstm_bf16_layout(long long M, int K, int H) {
+  VsLstmBf16Layout L;
+  L.Kp = (K + 63) / 64 * 64;
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  L.feat = 0;
+  L.wih = up((size_t)M * L.Kp * 2);
+  L.dxg = L.wih + up((size_t)8 * H * L.Kp * 2);
+  L.total = L.dxg + up((size_t)M * 8 * H * 2);
+  return L;
+}
 // lstm.hip
 int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
 int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,

@@ -743,3 +743,24 @@ def nhwc_conv_last_bwd(dz8, w, a7):
     dw = torch.empty(8, 64, dtype=torch.float32, device=a7.device)
     check(lib.vs_nhwc_conv_last_bwd(_p(dz8), _p(w), _p(a7), _p(din), _p(part), _p(dw), B, T, F, _stream()), "vs_nhwc_conv_last_bwd")
     return din, dw
+
+
+def gemm_bf16(A, B, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, rowbias=None, group: int = 1,
+              out=None, accumulate: bool = False):
+    """C[M,N] (+)= op(A) op(B) on bf16 operands (csrc/gemm_bf16.hip); A, B 2-D bf16 tensors (row form [rows, ld >= K padded
+    to 64], K-major form [K, ld]); fp32 result."""
+    lib = _lib.load()
+    _dev_check(A, "A", torch.bfloat16)
+    _dev_check(B, "B", torch.bfloat16)
+    C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(lib.vs_gemm_bf16(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), C.shape[1], M, N, K,
+                           _p(rowbias), rowbias.shape[1] if rowbias is not None else 0, group, int(accumulate), _stream()), "vs_gemm_bf16")
+    return C
+
+
+def cvt_rows_bf16(x, K: int, Kp: int):
+    lib = _lib.load()
+    _dev_check(x, "x")
+    out = torch.empty(x.shape[0], Kp, dtype=torch.bfloat16, device=x.device)
+    check(lib.vs_cvt_rows_bf16(_p(x), x.shape[0], K, x.shape[1], _p(out), Kp, _stream()), "vs_cvt_rows_bf16")
+    return out
