@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE (oracle/): what bf16 STORAGE costs the parameter gradients of the path, independent of any
+kernel.  The reference forward (models/voicesplit/model.py:66-89: conv stack with batch-statistics BatchNorm, d-vector
+concat, BiLSTM, head) in fp64 autograd with bf16 rounding injected exactly where the VS_MATH_BF16 configuration rounds:
+the 64->64 conv weights, z = conv + bias, a = act(BN(z)), the gradients flowing back through those two, and the operands
+of the LSTM input GEMM and of its two backward contractions.  Accumulation, statistics, recurrence and head are exact.
+The difference between these gradients and the unrounded ones is the envelope a correct bf16 implementation lives in;
+tests/test_gpu_bf16.py holds the HIP path to it.  (tools/bf16_error_sources.py prints the breakdown by rounding point.)"""
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import reference_forward as R
+
+
+class _RoundSTE(torch.autograd.Function):
+    """forward: round to bf16 (or pass through); backward: round the gradient to bf16 (or pass through)."""
+
+    @staticmethod
+    def forward(ctx, x, rf, rg):
+        ctx.rg = rg
+        return x.to(torch.bfloat16).to(x.dtype) if rf else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.rg else g), None, None
+
+
+def _rnd(x, fwd: bool, bwd: bool = False):
+    return _RoundSTE.apply(x, bool(fwd), bool(bwd)) if (fwd or bwd) else x
+
+
+def gradients(sd: Dict[str, torch.Tensor], x: torch.Tensor, dvec: torch.Tensor, w: torch.Tensor, act: str = "mish",
+              bf16: bool = True) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+    """d(sum(mask * w))/d(parameter) in fp64, training-mode BatchNorm; bf16=True injects the storage roundings of the
+    bf16 configuration, bf16=False is the exact reference.  Returns (gradients by state_dict key, mask)."""
+    P = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    x, dvec, w = x.double(), dvec.double(), w.double()
+    B, T, _ = x.shape
+    h = x.unsqueeze(1)
+    for i, spec in enumerate(R.CONV_TABLE):
+        wt = P[f"conv.{spec.conv_idx}.weight"]
+        if bf16 and 1 <= i <= 6:
+            wt = _rnd(wt, True)
+        z = F.conv2d(h, wt, P[f"conv.{spec.conv_idx}.bias"], padding=((spec.kt // 2) * spec.dil_t, spec.kf // 2), dilation=(spec.dil_t, 1))
+        if i < 7:
+            z = _rnd(z, bf16, bf16)
+        m = z.mean((0, 2, 3), keepdim=True)
+        v = ((z - m) ** 2).mean((0, 2, 3), keepdim=True)
+        y = (z - m) / torch.sqrt(v + R.BN_EPS) * P[f"conv.{spec.bn_idx}.weight"].view(1, -1, 1, 1) + P[f"conv.{spec.bn_idx}.bias"].view(1, -1, 1, 1)
+        h = R.activation(y, act)
+        if i < 7:
+            h = _rnd(h, bf16, bf16)
+    feat = h.transpose(1, 2).reshape(B, T, -1)
+    K = feat.shape[2]
+    outs = []
+    for sfx, rev in (("", False), ("_reverse", True)):
+        w_ih, w_hh = P["lstm.weight_ih_l0" + sfx], P["lstm.weight_hh_l0" + sfx]
+        bias = P["lstm.bias_ih_l0" + sfx] + P["lstm.bias_hh_l0" + sfx]
+        fa, wa = (_rnd(feat, True), _rnd(w_ih[:, :K], True)) if bf16 else (feat, w_ih[:, :K])
+        xg = fa @ wa.t() + (dvec @ w_ih[:, K:].t()).unsqueeze(1) + bias
+        xg = _rnd(xg, False, bf16)                       # the gate gradients are rounded for the two backward contractions
+        H = w_hh.shape[1]
+        hh, c = xg.new_zeros(B, H), xg.new_zeros(B, H)
+        out = [None] * T
+        for t in (range(T - 1, -1, -1) if rev else range(T)):
+            g = xg[:, t] + hh @ w_hh.t()
+            i_, f_, gg, o_ = g.split(H, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
+            hh = torch.sigmoid(o_) * torch.tanh(c)
+            out[t] = hh
+        outs.append(torch.stack(out, 1))
+    lo = torch.relu(torch.cat(outs, 2))
+    h1 = torch.relu(F.linear(lo, P["fc1.weight"], P["fc1.bias"]))
+    mask = torch.sigmoid(F.linear(h1, P["fc2.weight"], P["fc2.bias"]))
+    (mask * w).sum().backward()
+    return {k: p.grad for k, p in P.items() if p.grad is not None}, mask.detach()

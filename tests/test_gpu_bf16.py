@@ -143,37 +143,43 @@ def test_bf16_metric_configuration_vs_upstream_golden():
     assert not bad, bad            # `not <`: a NaN gradient is a failure, not a pass
 
 
-def test_bf16_gradients_on_default_gain_weights():
-    """The stress fixtures above scale the recurrent / head weights up (gain 6) so that fp32-class errors become
-    visible; bf16's 8-bit operands then show 0.15-0.4 of a gradient tensor's maximum.  This is the same comparison
-    on the reference's DEFAULT initialisation (randomised BatchNorm parameters only), batch-statistics BatchNorm,
-    mid-size tensors: what the arithmetic itself costs.  Bounds: cosine >= 0.99, max error <= 0.1 of the tensor max."""
+def test_bf16_gradients_sit_inside_the_ideal_bf16_envelope():
+    """How much of the gradient error above is the arithmetic's and how much the kernels'?  oracle/bf16_model.py is the
+    reference in fp64 with bf16 rounding injected at the storage points of this configuration and NOTHING else changed:
+    its gradients already differ from the exact ones by 0.3-0.6 of a tensor's maximum at cosine 0.94-0.99 on this
+    (default-initialised, batch-statistics) fixture -- `sum(mask * w)` adds 10^5 terms of either sign, so its gradient is
+    badly conditioned.  The HIP path must not be worse than that ideal by more than a rounding-order margin."""
     import voicesplit_amd as V
-    dims_d = dict(num_freq=201, emb_dim=64, lstm_dim=96, fc1_dim=128, fc2_dim=201)
-    B, T = 4, 151
+    from oracle import bf16_model
+    dims_d = dict(num_freq=101, emb_dim=16, lstm_dim=24, fc1_dim=40, fc2_dim=101)
+    B, T = 4, 80
     sd = R.build_state_dict(dims_d, 31)
     x, dvec = R.synthetic_inputs(B, T, dims_d, 31)
-    w = RB.loss_weights(B, T, 201, 31)
-    m = V.VoiceSplit(V.default_config(201, 64, 96, 128, 201))
+    w = RB.loss_weights(B, T, 101, 31)
+    exact, mask_exact = bf16_model.gradients(sd, x, dvec, w, bf16=False)
+    ideal, _ = bf16_model.gradients(sd, x, dvec, w, bf16=True)
+    m = V.VoiceSplit(V.default_config(101, 16, 24, 40, 101))
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train(True)
     with _math("bf16"):
         mask = m(x.cuda(), dvec.cuda())
         (mask * w.cuda()).sum().backward()
-    stages = {}
-    ref = RB.gradients(sd, x, dvec, w, act="mish", training=True, dtype=torch.float64, lstm_impl="loop", stages=stages)
-    table = {"fwd/mask_abs": float((mask.detach().double().cpu() - stages["mask"]).abs().max()),
-             "fwd/mask_mse": float(((mask.detach().double().cpu() - stages["mask"]) ** 2).mean())}
     zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}
+    table = {"fwd/mask_mse": float(((mask.detach().double().cpu() - mask_exact) ** 2).mean())}
     for k, p in m.named_parameters():
         if k in zero:
             continue
-        table["grad/" + k] = _rel(p.grad, ref[k])
-        table["cos/" + k] = _cos(p.grad, ref[k])
-    _dump("default_gain", table)
-    assert table["fwd/mask_mse"] < 1e-4, table
-    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v <= 0.1) or (k.startswith("cos/") and not v >= 0.99)}
-    assert not bad, bad
+        table["hip_err/" + k], table["hip_cos/" + k] = _rel(p.grad, exact[k]), _cos(p.grad, exact[k])
+        table["ideal_err/" + k], table["ideal_cos/" + k] = _rel(ideal[k], exact[k]), _cos(ideal[k], exact[k])
+    _dump("ideal_envelope", table)
+    hip_err = max(v for k, v in table.items() if k.startswith("hip_err/"))
+    ideal_err = max(v for k, v in table.items() if k.startswith("ideal_err/"))
+    hip_cos = min(v for k, v in table.items() if k.startswith("hip_cos/"))
+    ideal_cos = min(v for k, v in table.items() if k.startswith("ideal_cos/"))
+    assert table["fwd/mask_mse"] < 1e-4
+    assert hip_err == hip_err and hip_cos == hip_cos                      # no NaN
+    assert hip_err <= 1.5 * ideal_err + 0.05, (hip_err, ideal_err)
+    assert hip_cos >= ideal_cos - 0.03, (hip_cos, ideal_cos)
 
 
 def test_bf16_is_never_the_default():

@@ -289,3 +289,27 @@ def test_oracle_reproduces_upstream_mask_on_a_real_clip():
     assert np.array_equal(out["mask"].numpy(), g["mask"])
     assert np.array_equal(out["logits"].numpy()[:, ::4], g["logits"])
     assert g["mask"].min() < 0.05 and g["mask"].max() > 0.95        # a mask that actually separates
+
+
+def test_bf16_storage_model_is_the_pinned_oracle_plus_roundings():
+    """oracle/bf16_model.py (the envelope tests/test_gpu_bf16.py holds the bf16 HIP path to): with the roundings off it IS
+    the pinned backward oracle (1e-12); with them on, the parameter gradients of `sum(mask * w)` move by tenths of a
+    tensor's maximum although every rounding is 2^-9 relative -- the loss is badly conditioned, not the arithmetic."""
+    import torch
+    from oracle import bf16_model
+    from oracle import reference_backward as RB
+    from oracle import reference_forward as R
+    dims_d = dict(num_freq=53, emb_dim=16, lstm_dim=24, fc1_dim=40, fc2_dim=53)
+    sd = R.build_state_dict(dims_d, 31)
+    x, dvec = R.synthetic_inputs(3, 40, dims_d, 31)
+    w = RB.loss_weights(3, 40, 53, 31)
+    exact, mask = bf16_model.gradients(sd, x, dvec, w, bf16=False)
+    ref = RB.gradients(sd, x, dvec, w, act="mish", training=True, dtype=torch.float64, lstm_impl="loop")
+    zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}
+    for k, v in exact.items():
+        if k not in zero:
+            assert ((v - ref[k].double()).abs().max() / ref[k].abs().max()).item() < 1e-10, k
+    ideal, mask16 = bf16_model.gradients(sd, x, dvec, w, bf16=True)
+    worst = max(((ideal[k] - exact[k]).abs().max() / exact[k].abs().max()).item() for k in exact if k not in zero)
+    assert 0.02 < worst < 1.5, worst                     # far above 2^-9, far below "wrong"
+    assert float(((mask16 - mask) ** 2).mean()) < 1e-5   # while the mask itself barely moves

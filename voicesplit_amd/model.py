@@ -51,6 +51,7 @@ class _MaskForward(torch.autograd.Function):
         mask = ops.forward_train(sd, x, dvec_c, dims, module.conv_act, module.training, tape)
         module._bump_bn_counters()
         ctx.module, ctx.dims, ctx.tape = module, dims, tape
+        module.__dict__["_last_tape"] = (tape, dims)
         ctx.training = module.training
         ctx.names = [n for n, _ in module.named_parameters()]
         ctx.save_for_backward(x, dvec_c, mask)
@@ -132,6 +133,19 @@ class _MaskNet(nn.Module):
                 for m in self.conv:
                     if isinstance(m, nn.BatchNorm2d):
                         m.num_batches_tracked += 1           # running_mean/var were updated in place by the library
+                        # ... through raw pointers, which torch cannot see: advance their version counters so that every
+                        # cache keyed on them (ops.PreparedWeights) knows (no kernel launch)
+                        torch.autograd.graph.increment_version(m.running_mean)
+                        torch.autograd.graph.increment_version(m.running_var)
+
+    def lstm_status(self) -> int:
+        """0 when the persistent BiLSTM kernels of the last training forward / backward completed, 1 when one gave up
+        (its output was NaN-poisoned; see vs_lstm_status).  Synchronises."""
+        last = self.__dict__.get("_last_tape")
+        if last is None:
+            return 0
+        tape, dims = last
+        return ops.lstm_status(dims, tape=tape)
 
     def long_form_stages(self):
         """(conv_stage, sequence_stage) for ``streaming.separate_long_exact``: the conv stack on a batch

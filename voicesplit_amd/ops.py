@@ -764,3 +764,14 @@ def cvt_rows_bf16(x, K: int, Kp: int):
     out = torch.empty(x.shape[0], Kp, dtype=torch.bfloat16, device=x.device)
     check(lib.vs_cvt_rows_bf16(_p(x), x.shape[0], K, x.shape[1], _p(out), Kp, _stream()), "vs_cvt_rows_bf16")
     return out
+
+
+def lstm_status(dims: VsDims, tape: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> int:
+    """vs_lstm_status: 0 = the persistent BiLSTM kernels that last ran on these buffers completed, 1 = one gave up
+    (output NaN-poisoned).  Synchronises the current stream."""
+    lib = _lib.load()
+    rc = lib.vs_lstm_status(ctypes.byref(dims), _p(tape), tape.numel() if tape is not None else 0,
+                            _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
+    if rc < 0:
+        check(rc, "vs_lstm_status")
+    return rc

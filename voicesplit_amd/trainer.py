@@ -188,6 +188,13 @@ class Trainer:
         # :115-117, in the reference's order: the update has been applied and counted when the guard
         # fires, so step numbering and checkpoint cadence after an explosion match train.py
         if value > 1e8 or math.isnan(value):
+            # a persistent BiLSTM launch that lost its CUs mid-flight poisons its output with NaN: say so instead of
+            # reporting a numerical explosion (the host is synchronised here anyway)
+            status = getattr(self.model, "lstm_status", None)
+            if callable(status) and status() != 0:
+                raise RuntimeError("the persistent BiLSTM kernel gave up waiting for a peer workgroup (another process is using "
+                                   "the GPU?): this step's results were NaN-poisoned; rerun, or select the per-step kernels "
+                                   "with vs_set_lstm_kernel(1)")
             raise LossExploded("Loss exploded to %.02f at step %d!" % (value, self.step))
         return value
 
@@ -199,6 +206,8 @@ class Trainer:
         self.model.eval()
         tot, cnt = 0.0, 0
         for emb, target, mixed, seq_len, _tw, phase in batches:
+            if emb is None or len(emb) == 0:          # every item of this batch was filtered by the collate (utils/dataset.py:93-95):
+                continue                              # nothing to score; the (sum, count) all-reduce below copes with unequal counts
             dev = self.device
             emb, target, mixed, phase = (t.to(dev) for t in (emb, target, mixed, phase))
             if seq_len is not None:
