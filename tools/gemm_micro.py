@@ -38,6 +38,30 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 3
             res[f"{name} [{math}]"] = {"ms": round(ms, 3), "tflops": round(flops[name.split()[0]] / ms / 1e9, 1)}
+    # the bf16 configuration's own GEMM (csrc/gemm_bf16.hip) on the same three contractions
+    Kp = (K8 + 63) // 64 * 64
+    feat_bf = ops.cvt_rows_bf16(feat, K8, Kp)
+    wih_bf = ops.cvt_rows_bf16(w[:, :K8].contiguous(), K8, Kp)
+    dxg_bf = ops.cvt_rows_bf16(dxg, 2 * H4, 2 * H4)
+    bf_cases = {
+        "xg (row x row) [bf16 gemm]": (lambda: ops.gemm_bf16(feat_bf, wih_bf, M, 2 * H4, K8), 2.0 * M * 2 * H4 * K8),
+        "dfeat (row x col, K=3200) [bf16 gemm]": (lambda: ops.gemm_bf16(dxg_bf, wih_bf, M, K8, 2 * H4, b_kmajor=True), 2.0 * M * K8 * 2 * H4),
+        "dW_ih (col x col, K=19264) [bf16 gemm]": (lambda: ops.gemm_bf16(dxg_bf, feat_bf, 2 * H4, K8, M, a_kmajor=True, b_kmajor=True), 2.0 * 2 * H4 * K8 * M),
+        "cvt feat -> bf16": (lambda: ops.cvt_rows_bf16(feat, K8, Kp), 0.0),
+    }
+    for name, (fn, fl) in bf_cases.items():
+        if only and only not in ("bf16", name.split()[0]):
+            continue
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        res[name] = {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1)}
     print(json.dumps(res, indent=1), flush=True)
 
 

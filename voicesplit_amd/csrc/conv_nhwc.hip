@@ -69,6 +69,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// XOR swizzle of the 16-byte pieces of a staged pixel (128 bytes = half a bank row; pixel parity picks the half): a
+// ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} ... that mix two k-groups, and the 16 pixels of a group
+// start at tap column df = 0..4.  ((p >> 1) & 3) << 1 puts every such group on 16 distinct 16-byte slots for every df
+// (exhaustive search over the GF(2)-linear maps of the pixel index; the first choice, (p >> 1) & 7, was conflict-free for
+// even df only: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.375 in profiles/r03_train_bf16_rocprof).
+__device__ __forceinline__ int swz(int p) { return ((p >> 1) & 3) << 1; }
+
 template <int KT, int KF>
 struct Geo {
   static constexpr int P = KT / 2, PF = KF / 2, H = KT - 1;
@@ -118,7 +125,7 @@ struct ConvWalk {
 #pragma unroll
     for (int df = 0; df < KF; ++df) {
       const int p = n + df;
-      boff[df] = p * 128 + ((g ^ ((p >> 1) & 7)) << 4);    // k-chunk 1: ^ 64; column block nb: + 2048 (the swizzle is 16-periodic in p)
+      boff[df] = p * 128 + ((g ^ swz(p)) << 4);            // k-chunk 1: ^ 64; column block nb: + 2048 (the swizzle is 8-periodic in p)
     }
   }
 
@@ -154,7 +161,7 @@ struct ConvWalk {
       const int px = part * 8 + (lane >> 3);                              // pixel of the staged row
       const int col = x.strip * STRIP - PF + px;
       const bool ok = (w >= 0) & (w < x.in_end) & (px < G::RWPX) & (col >= 0) & (col < a.F);
-      const int sw = ((lane & 7) ^ ((px >> 1) & 7)) << 4;                 // LDS piece q of pixel px holds channel piece q ^ f(px)
+      const int sw = ((lane & 7) ^ swz(px)) << 4;                          // LDS piece q of pixel px holds channel piece q ^ swz(px)
       const long long off = rel0 + ((((row0 + (long long)w * a.dil) * a.F + col) << 7) + sw);
       const unsigned char* src = zp + (off & -(long long)ok);
       const unsigned dst = lds0 + (unsigned)(pos * G::ROWB + part * 1024);

@@ -8,12 +8,16 @@
 // what lies in memory: two ds_read_b64_tr_b16, as in wgrad_nhwc.hip).  So xg is row x row, dfeat row x col, dW_ih
 // col x col, and no transposed copy of anything is ever written.
 //
-// Structure: persistent workgroups (one per CU, 4 waves = 2 x 2, wave tile 64 x 128, workgroup tile 128 x 256, K step
-// 64), tiles walked in bands of 8 tile rows per XCD (gemm_f16x3.hip's map); both operand tiles of a K step go
-// HBM/L2 -> LDS by LDS-DMA into a ring of three stages, two steps ahead of the step that reads them (counted vmcnt,
-// raw s_barrier: nothing drains early); XOR swizzles on the source address make the fragment reads conflict-free;
-// per K step a wave issues 24 fragment reads and 64 MFMAs in a pinned order (reads one k-half ahead).  fp32
-// accumulate, fp32 output (+ optional per-row-group bias, or accumulate into C).
+// Structure: persistent workgroups (one per CU, 4 waves = 2 x 2, wave tile 128 x 128 = 64 accumulator tiles = 256
+// registers, workgroup tile 256 x 256, K step 64), tiles walked in bands of 8 tile rows per XCD (gemm_f16x3.hip's
+// map); both operand tiles of a K step go L2 -> LDS by LDS-DMA into the other of two stages while the current one is
+// multiplied (a step is 128 MFMAs per wave = 2048 matrix-pipe cycles: the DMA has that long to land; one
+// s_waitcnt vmcnt(0) + one raw s_barrier per step); XOR swizzles on the source address make the fragment reads
+// conflict-free; per K step a wave issues 32 fragment reads and 128 MFMAs in a pinned order (reads one k-half
+// ahead).  The 256 x 256 tile is what the L2 allows: a 128 x 256 tile (first version) moved 48 KB per 1024 pipe
+// cycles and workgroup -- 25 TB/s over the chip at full MFMA rate, beyond the L2s -- and measured 0.93-1.0 ms
+// (600-640 TF) on the three contractions; this one moves 64 KB per 2048 cycles.  fp32 accumulate, fp32 output
+// (+ optional per-row-group bias, or accumulate into C).
 #include "vs_internal.h"
 
 namespace {
@@ -26,11 +30,12 @@ typedef __attribute__((address_space(3))) const u4v lds_u4v;
 
 __device__ u4v g_gemm_zero_page[4];
 
-constexpr int TM = 128, TN = 256, BK = 64;      // workgroup tile, K step
-constexpr int A_BYTES = TM * BK * 2;            // 16 KiB
+constexpr int TM = 256, TN = 256, BK = 64;      // workgroup tile, K step
+constexpr int A_BYTES = TM * BK * 2;            // 32 KiB
 constexpr int B_BYTES = TN * BK * 2;            // 32 KiB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 48 KiB
-constexpr int NSTAGE = 3;
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 64 KiB
+constexpr int NSTAGE = 2;
+constexpr int WA = 8, WB = 8;                   // 16 x 16 accumulator tiles of a wave: 128 x 128
 
 struct GemmBf16Args {
   const unsigned short* A; int lda;   // row form: [M][lda], col form: [K][lda]
@@ -63,51 +68,68 @@ __device__ __forceinline__ s4v ds_read_tr16(unsigned addr) {
 //   u ^ ((k & 3) | ((k >> 3) & 1) << 2): the 8 lines {c..c+3, c+8..c+11} a transposing read touches differ in it
 template <bool KMAJOR, int R>
 struct Operand {
-  // DMA of one K step: R*64 halves = R*8 pieces; piece e of the tile -> LDS byte 16 e (lane-linear), source swizzled
-  static constexpr int PIECES = R * 8;
-  __device__ static __forceinline__ void issue(const unsigned short* base, int ld, int rows /* matrix extent along R */, int kext,
-                                               int r0, int k0, unsigned lds_dst, int wave, int lane) {
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_gemm_zero_page);
-    const long long rel0 = reinterpret_cast<const unsigned char*>(base) - zp;
-#pragma unroll
-    for (int c = 0; c < PIECES / 256; ++c) {
-      const int e = (c * 4 + wave) * 64 + lane;            // chunk (c, wave) = 64 consecutive pieces = 1 KiB
-      long long off;
-      bool ok;
-      if (!KMAJOR) {
-        const int r = e >> 3, q = e & 7;
-        const int kp = q ^ ((r >> 1) & 7);
-        ok = (r0 + r < rows) & (k0 + kp * 8 < kext);
-        off = ((long long)(r0 + r) * ld + k0 + kp * 8) * 2;
-      } else {
-        constexpr int PPL = R / 8;                         // pieces per k line
-        const int k = e / PPL, q = e - k * PPL;
-        const int u = (k & 3) | (((k >> 3) & 1) << 2);
-        const int src = q ^ (u << 1);                      // piece index inside the line (pairs of pieces = 32-byte units)
-        ok = (k0 + k < kext) & (r0 + src * 8 < rows);
-        off = ((long long)(k0 + k) * ld + r0 + src * 8) * 2;
-      }
-      const unsigned char* src_p = zp + ((rel0 + off) & -(long long)ok);
-      glds16(src_p, (unsigned)__builtin_amdgcn_readfirstlane(lds_dst + (unsigned)((c * 4 + wave) * 1024)));
-    }
-  }
-  // fragment of the 16-row block starting at row rb (of the tile), k-half kh (32 k): lane (i = lane & 15, g = lane >> 4)
-  __device__ static __forceinline__ vs_bf16x8 frag(unsigned img, int rb, int kh, int lane) {
-    const int i = lane & 15, g = lane >> 4;
+  // DMA of one K step: R*64 halves = R*8 pieces = R/8 chunks of 1 KiB; chunk ch = 4 c + wave, piece e = 64 ch + lane
+  // lands at LDS byte 16 e.  What depends on the lane is computed ONCE (LaneDma): with R = 256 the swizzle term of a
+  // piece does not depend on c (row form) or only on its parity (col form), so chunk c is the lane's base offset plus a
+  // wave-uniform multiple of the leading dimension -- a handful of registers instead of sixteen hoisted address pairs.
+  static_assert(R == 256, "the lane decomposition below is for 256-row operand tiles");
+  static constexpr int CHUNKS = R / 8 / 4;                 // per wave
+  struct LaneDma { unsigned off[2]; int line; int col[2]; };
+  __device__ static __forceinline__ LaneDma lane_dma(int ld, int wave, int lane) {
+    LaneDma L;
     if (!KMAJOR) {
-      const int r = rb + i;
-      const unsigned a = img + (unsigned)(r * 128 + (((kh * 4 + g) ^ ((r >> 1) & 7)) << 4));
-      return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(uintptr_t)a);
+      const int r = wave * 8 + (lane >> 3), q = lane & 7;  // + 32 c
+      const int kp = q ^ ((r >> 1) & 7);                   // (32 c >> 1) & 7 == 0
+      L.line = r;
+      L.col[0] = L.col[1] = kp * 8;
+      L.off[0] = L.off[1] = (unsigned)(r * ld + kp * 8) * 2u;
     } else {
-      s4v h[2];
+      const int k = 2 * wave + (lane >> 5), q = lane & 31; // + 8 c: (k & 3) unchanged, bit 3 of k = c & 1
+      L.line = k;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int k = kh * 32 + 8 * g + 4 * hf + (i >> 2);
-        const int u = (k & 3) | (((k >> 3) & 1) << 2);
-        const int unit = (rb >> 4) ^ u;                     // 32-byte unit = 16 rows of the matrix
-        h[hf] = ds_read_tr16(img + (unsigned)(k * (R * 2) + (unit << 5) + (i & 3) * 8));
+      for (int par = 0; par < 2; ++par) {
+        const int src = q ^ (((k & 3) | (par << 2)) << 1);
+        L.col[par] = src * 8;
+        L.off[par] = (unsigned)(k * ld + src * 8) * 2u;
       }
-      return frag_of(h[0], h[1]);
+    }
+    return L;
+  }
+  // chunk c (0 .. CHUNKS-1) of this wave for the tile at (r0, k0): one LDS-DMA instruction
+  __device__ static __forceinline__ void issue_chunk(const LaneDma& L, const unsigned short* base, int ld, int rows /* extent along R */, int kext,
+                                                     int r0, int k0, unsigned lds_dst, int wave, int c) {
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_gemm_zero_page);
+    // tile origin (wave-uniform): row form (r0, k0), col form (k0, r0)
+    const unsigned char* origin = reinterpret_cast<const unsigned char*>(base) + (KMAJOR ? ((long long)k0 * ld + r0) : ((long long)r0 * ld + k0)) * 2;
+    bool ok;
+    unsigned off;
+    if (!KMAJOR) {
+      ok = (r0 + 32 * c + L.line < rows) & (k0 + L.col[0] < kext);
+      off = L.off[0] + (unsigned)(32 * c) * (unsigned)ld * 2u;
+    } else {
+      ok = (k0 + 8 * c + L.line < kext) & (r0 + L.col[c & 1] < rows);
+      off = L.off[c & 1] + (unsigned)(8 * c) * (unsigned)ld * 2u;
+    }
+    const unsigned char* src_p = ok ? origin + off : zp;
+    glds16(src_p, (unsigned)__builtin_amdgcn_readfirstlane(lds_dst + (unsigned)((c * 4 + wave) * 1024)));
+  }
+  // Fragment of the 16-row block starting at row rb (of the tile), k-half kh (32 k), for lane (i = lane & 15, g = lane >> 4).
+  // The lane-dependent part of the address is ONE register (frag_base, + the stage offset); rb and kh enter as an XOR
+  // with a constant and an immediate offset, so that the 32 fragment addresses of a step are not 32 live registers:
+  //   row form: r = rb + i, swizzle (r >> 1) & 7 = (i >> 1) & 7 (rb is a multiple of 16); k-half 1 = address ^ 64
+  //   col form: k = 32 kh + 8 g + 4 hf + i/4, u(k) = (i/4 & 3) | (g & 1) << 2 does not depend on kh, hf; unit = (rb/16) ^ u
+  __device__ static __forceinline__ unsigned frag_base(int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (!KMAJOR) return (unsigned)(i * 128 + ((g ^ ((i >> 1) & 7)) << 4));
+    const int u = ((i >> 2) & 3) | ((g & 1) << 2);
+    return (unsigned)((8 * g + (i >> 2)) * (R * 2) + (u << 5) + (i & 3) * 8);
+  }
+  __device__ static __forceinline__ vs_bf16x8 frag(unsigned base /* LDS address of the image + frag_base */, int rb, int kh) {
+    if (!KMAJOR) {
+      return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(uintptr_t)((base ^ (unsigned)(kh << 6)) + (unsigned)(rb * 128)));
+    } else {
+      const unsigned a = base ^ (unsigned)((rb >> 4) << 5);
+      return frag_of(ds_read_tr16(a + (unsigned)((kh * 32) * (R * 2))), ds_read_tr16(a + (unsigned)((kh * 32 + 4) * (R * 2))));
     }
   }
 };
@@ -131,7 +153,7 @@ void gemm_bf16_kernel(GemmBf16Args g) {
   using OB = Operand<BK_, TN>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                 // wave tile: rows [64 wm, +64), columns [128 wn, +128)
+  const int wm = wave >> 1, wn = wave & 1;                 // wave tile: rows [128 wm, +128), columns [128 wn, +128)
   const unsigned lds0 = (unsigned)(uintptr_t)(const lds_byte*)smem;
   const int nk = (g.K + BK - 1) / BK;
 
@@ -147,75 +169,86 @@ void gemm_bf16_kernel(GemmBf16Args g) {
   int pj = 0, pk = 0, ptm = 0, ptn = 0;
   bool plive = tile_ok(0) && tile_of(g, tile_id(0), ptm, ptn);
   int pstage = 0;
-  auto pf_issue = [&]() {
+  const unsigned fbA = OA::frag_base(lane), fbB = OB::frag_base(lane);
+  const typename OA::LaneDma la = OA::lane_dma(g.lda, wave, lane);
+  const typename OB::LaneDma lb = OB::lane_dma(g.ldb, wave, lane);
+  // The DMA of a stage is 16 instructions per wave (8 A chunks, 8 B chunks) with ~15 scalar / vector instructions of
+  // address arithmetic each: issued in one go behind the barrier they cost ~1000 cycles of a 2048-cycle step with the
+  // matrix pipe idle, so they are spread over the step instead -- one chunk in front of each of its 16 MFMA rows.
+  auto pf_chunk = [&](int slot /* 0..15 */, bool live) {     // !live (end of the job): every piece reads the zero page, no branch
     const unsigned dst = lds0 + (unsigned)(pstage * STAGE_BYTES);
-    OA::issue(g.A, g.lda, g.M, g.K, ptm * TM, pk * BK, dst, wave, lane);
-    OB::issue(g.B, g.ldb, g.N, g.K, ptn * TN, pk * BK, dst + A_BYTES, wave, lane);
-    pstage = pstage + 1 == NSTAGE ? 0 : pstage + 1;
+    if (slot < 8) OA::issue_chunk(la, g.A, g.lda, live ? g.M : 0, g.K, ptm * TM, pk * BK, dst, wave, slot);
+    else OB::issue_chunk(lb, g.B, g.ldb, live ? g.N : 0, g.K, ptn * TN, pk * BK, dst + A_BYTES, wave, slot - 8);
+  };
+  auto pf_done = [&]() {
+    pstage ^= 1;
     if (++pk == nk) {
       pk = 0;
       ++pj;
       plive = tile_ok(pj) && tile_of(g, tile_id(pj), ptm, ptn);
     }
   };
-  constexpr int DMA_PER_STAGE = (OA::PIECES + OB::PIECES) / 256;      // per wave: 4 + 8 = 12
-  if (plive) pf_issue();
-  if (plive) pf_issue();
+  if (plive) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pf_chunk(c, true);
+    pf_done();
+  }
 
   int cstage = 0;
   for (int j = 0; tile_ok(j); ++j) {
     int tm, tn;
     if (!tile_of(g, tile_id(j), tm, tn)) break;
-    f32x4 acc[4][8];
+    f32x4 acc[WA][WB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < WA; ++a)
 #pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < nk; ++ks) {
-      // the stage of this step was issued two issues ago: at most the newest stage's DMAs may still be in flight.  (The
-      // epilogue's stores of the previous tile are older than both and complete with the same wait.)
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_STAGE) : "memory");
-      __builtin_amdgcn_s_barrier();
-      // every wave is past the previous step: its stage can be refilled (it is the stage three issues back)
-      if (plive) pf_issue();
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing issued now: the NEXT step's stage is then the newest one
-      const unsigned imgA = lds0 + (unsigned)(cstage * STAGE_BYTES), imgB = imgA + A_BYTES;
-      vs_bf16x8 af[2][4], bf[2][8];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the stage have landed (issued one step ago)
+      __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done reading the other stage
+      const bool pf_now = plive;                            // the next step's tiles (possibly of the next output tile) go into it,
+                                                            // one chunk in front of each MFMA row below
+      unsigned fa = lds0 + (unsigned)(cstage * STAGE_BYTES) + fbA, fb = lds0 + (unsigned)(cstage * STAGE_BYTES + A_BYTES) + fbB;
+      asm volatile("" : "+v"(fa), "+v"(fb));               // opaque: keeps the compiler from hoisting 32 derived addresses per stage out of the loop
+      // B fragments of a k-half stay in registers for its 8 accumulator rows; the A fragment of the next row and the B
+      // fragments of the other k-half are read while a row's 8 MFMAs issue
+      vs_bf16x8 bf[2][WB], afc, afn;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[0][a] = OA::frag(imgA, wm * 64 + a * 16, 0, lane);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) bf[0][b] = OB::frag(imgB, wn * 128 + b * 16, 0, lane);
+      for (int b = 0; b < WB; ++b) bf[0][b] = OB::frag(fb, wn * 128 + b * 16, 0);
+      afc = OA::frag(fa, wm * 128, 0);
+      afn = afc;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
-        if (kh == 0) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) af[1][a] = OA::frag(imgA, wm * 64 + a * 16, 1, lane);
+        for (int a = 0; a < WA; ++a) {
+          if (a + 1 < WA) afn = OA::frag(fa, wm * 128 + (a + 1) * 16, kh);
+          else if (kh == 0) afn = OA::frag(fa, wm * 128, 1);
+          if (kh == 0) bf[1][a] = OB::frag(fb, wn * 128 + a * 16, 1);
+          pf_chunk(kh * 8 + a, pf_now);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < 8; ++b) bf[1][b] = OB::frag(imgB, wn * 128 + b * 16, 1, lane);
+          for (int b = 0; b < WB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc, bf[kh][b], acc[a][b], 0, 0, 0);
+          afc = afn;
           __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 8; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][a], bf[kh][b], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
-      cstage = cstage + 1 == NSTAGE ? 0 : cstage + 1;
+      if (pf_now) pf_done();
+      cstage ^= 1;
     }
     // epilogue: lane holds C[m = 16a + 4 (lane>>4) + r][n = 16b + (lane&15)]
     const int i = lane & 15, gq = lane >> 4;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < WA; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = tm * TM + wm * 64 + a * 16 + 4 * gq + r;
+        const int m = tm * TM + wm * 128 + a * 16 + 4 * gq + r;
         if (m >= g.M) continue;
         float* crow = (g.C2 && m >= g.split_m) ? g.C2 + (size_t)(m - g.split_m) * g.ldc : g.C + (size_t)m * g.ldc;
         const float* rb = g.rowbias ? g.rowbias + (size_t)(m / g.group) * g.ldrb : nullptr;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < WB; ++b) {
           const int n = tn * TN + wn * 128 + b * 16 + i;
           if (n < g.N) {
             float v = acc[a][b][r];

@@ -12,7 +12,7 @@
 // Decomposition: the same walk as the forward kernel (conv_nhwc.hip) -- item = (utterance, class, 32-column strip,
 // row segment), groups of R = 8 rows, LDS rings for the a rows (R + KT - 1 per group, R new per group) and the dz rows,
 // DMA one group ahead, zero page for everything outside the image / the item.  The 64 x 64 x taps accumulators do
-// not fit one workgroup's registers, so a PAIR of workgroups shares every item: workgroup h = blockIdx & 1 owns input
+// not fit one workgroup's registers, so a PAIR of workgroups shares every item: workgroup h = (blockIdx >> 3) & 1 owns input
 // channels [32h, 32h+32) and stages only those 64 bytes of each a pixel.  Inside it wave (cbi, th) owns input-channel
 // block cbi (16) and one half of the taps: 4 (co blocks) x 13 (taps) = 52 accumulator tiles = 208 registers that live
 // for the whole launch.  Per output row: 4 dz fragments (shared by all its taps) + one a fragment per tap -> 4 MFMAs
@@ -89,7 +89,7 @@ struct WgradWalk {
   __device__ __forceinline__ WgradWalk(const WgradArgs& a_, const lds_byte* smem) : a(a_) {
     lane = threadIdx.x & 63;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    h = (int)(blockIdx.x & 1);
+    h = (int)((blockIdx.x >> 3) & 1);
     lds0 = (unsigned)(uintptr_t)smem;
   }
 
@@ -191,7 +191,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
 
   // prefetch cursor (the group after the one being computed)
   WItem pf;
-  const int pair = (int)(blockIdx.x >> 1), npairs = (int)(gridDim.x >> 1);
+  // the two workgroups of a pair read the same dz rows and the two halves of the same a lines: they are blocks b and
+  // b + 8, which the dispatcher places on the same XCD (block % 8), so the second read of a line is an L2 hit
+  // (pairs (2p, 2p+1) sat on different XCDs: 6.3 GB fetched per launch against 2.96 GB of operands)
+  const int pair = (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)), npairs = (int)(gridDim.x >> 1);
   int pf_it = pair, pf_g = 0;
   bool pf_live = false;
   auto pf_seek = [&]() {
@@ -342,10 +345,10 @@ int launch_wgrad(WgradArgs a, float* dw, hipStream_t stream) {
   VS_REQUIRE(n_items < (1LL << 30), "nhwc wgrad: too many work items");
   a.n_items = (int)n_items;
   static int cus = wg_num_cus();
-  long long pairs = cus / 2;
-  if (pairs > n_items) pairs = n_items;
+  long long pairs = cus / 16 * 8;                       // blocks come in groups of 16: 8 pairs (b, b + 8)
+  if (pairs > (n_items + 7) / 8 * 8) pairs = (n_items + 7) / 8 * 8;
   if (pairs > VS_NHWC_WGRAD_MAX_PAIRS) pairs = VS_NHWC_WGRAD_MAX_PAIRS;
-  if (pairs < 1) pairs = 1;
+  if (pairs < 8) pairs = 8;
   hipLaunchKernelGGL((nhwc_wgrad_kernel<KT, KF>), dim3((unsigned)(2 * pairs)), dim3(256), 0, stream, a);
   VS_LAUNCH_CHECK();
   return vs_reduce_partials_impl(a.part, (int)pairs, 64 * 64 * G::NTAP, dw, stream);
