@@ -249,6 +249,24 @@ int vs_nhwc_bn_act_bwd_first(const void* da, const void* z, const float* x, int 
 int vs_nhwc_conv_last_bwd_blocks(void);
 int vs_nhwc_conv_last_bwd(const float* dz8, const float* w, const void* a7, void* din, float* partials, float* dw,
                           int B, int T, int F, void* stream);
+/* The dy forms vs_backward chains: the kernel that produces a layer's input gradient da also applies the activation
+ * derivative of the layer below, dy = da * act'(z * bn_scale + bn_shift) (z = that layer's conv + bias output), stores
+ * dy instead of da and accumulates the per-channel {sum dy, sum dy * xhat} into bn_stats (64*64*2 doubles the caller
+ * zeroed) -- the first of the two passes of vs_nhwc_bn_act_bwd, without reading the tensor again.
+ * vs_nhwc_bn_bwd_from_dy / _first_from_dy are the second pass: parameter gradients + dz = cA dy + cB z + cC (dz may
+ * alias dy).  act in {VS_ACT_MISH, VS_ACT_RELU}. */
+int vs_nhwc_conv_dy(const void* dz, const void* packed, void* dy, const void* z, int act,
+                    const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_stats,
+                    int B, int T, int F, int KT, int KF, int dil, void* stream);
+int vs_nhwc_conv_last_bwd_dy(const float* dz8, const float* w, const void* a7, void* dy, float* partials, float* dw,
+                             const void* z7, int act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                             const float* bn_invstd, double* bn_stats, int B, int T, int F, void* stream);
+int vs_nhwc_bn_bwd_from_dy(const void* dy, const void* z, void* dz, long long npix, int bn_mode,
+                           const float* scale, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream);
+int vs_nhwc_bn_bwd_first_from_dy(const void* dy, const void* z, const float* x, int B, int T, int F, int bn_mode,
+                                 const float* scale, const float* mean, const float* invstd,
+                                 float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream);
 /* cnn8: [B][64][T][F] -> [B][T][8][F], weight [8][64][1][1] */
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift,
                      float* out, int B, int T, int F, int act, void* stream);

@@ -273,6 +273,118 @@ def test_nhwc_cnn1_backward_and_cnn8_backward():
     assert e < 2e-5, e
 
 
+# ---- the dy forms: the producer of a data gradient does the first BatchNorm-backward pass ---------------------------
+def _bn_consts(z, gamma, beta, g, training):
+    zd = z.double().reshape(-1, 64)
+    if training:
+        mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    else:
+        mean, var = torch.randn(64, generator=g).double() * 0.1, torch.rand(64, generator=g).double() + 0.5
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - mean * gamma.double() * invstd).float()
+    return mean, invstd, scale, shift
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("B,T,Fq,KT,KF,dil", [(2, 40, 37, 5, 5, 1), (1, 23, 70, 5, 5, 2), (1, 50, 20, 5, 5, 16), (1, 301, 40, 5, 5, 8),
+                                               (2, 40, 37, 7, 1, 1), (1, 9, 601, 7, 1, 1), (1, 1, 17, 5, 5, 1), (3, 17, 32, 7, 1, 1)])
+def test_nhwc_conv_dy_epilogue(B, T, Fq, KT, KF, dil, act):
+    """dy = dgrad(dz) * act'(z * scale + shift) and its BatchNorm-backward sums, against fp64 on the same operands."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(41 + T + dil + KT)
+    dz = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    z = (torch.randn(B, T, Fq, 64, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    mean, invstd, scale, shift = _bn_consts(z, gamma, beta, g, True)
+    da = _ref_conv(dz, w, torch.ones(64), torch.zeros(64), dil, "none", transpose_flip=True)
+    y = (z.double() * scale.double() + shift.double()).requires_grad_(True)
+    _act(y, act).backward(da)
+    ref = y.grad
+    xhat = (z.double() - mean) * invstd
+    packed = ops.nhwc_conv_pack(w.cuda(), transpose_flip=True)
+    dy, st = ops.nhwc_conv_dy(dz.cuda(), packed, z.cuda(), act, scale.cuda(), shift.cuda(), mean.float().cuda(), invstd.float().cuda(),
+                              KT, KF, dil)
+    _close(dy, ref, f"dy epilogue {KT}x{KF} dil {dil} {act}")
+    st = st.sum(0).cpu()
+    s1, s2 = ref.sum((0, 1, 2)), (ref * xhat).sum((0, 1, 2))
+    n = (ref * ref).sum((0, 1, 2)).sqrt()          # the scale of a sum of that many terms
+    assert ((st[:, 0] - s1).abs() <= 1e-3 * n + 1e-4 * s1.abs()).all(), (st[:, 0] - s1).abs().max()
+    assert ((st[:, 1] - s2).abs() <= 2e-3 * n + 1e-4 * s2.abs()).all(), (st[:, 1] - s2).abs().max()
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+def test_nhwc_cnn8_backward_dy_then_bn_backward(act, training):
+    """cnn8 backward (dy form) + the second BatchNorm pass = autograd through a7 = act(BN(z7)), out = cnn8(a7)."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, T, Fq = 2, 13, 53
+    z = (torch.randn(B, T, Fq, 64, generator=g) * 1.2 + 0.2).to(torch.bfloat16)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    w8 = torch.randn(8, 64, 1, 1, generator=g) * 0.2
+    dz8 = torch.randn(B, T, 8 * Fq, generator=g)
+    mean, invstd, scale, shift = _bn_consts(z, gamma, beta, g, training)
+    zd = z.double().reshape(-1, 64).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    if training:
+        m_ = zd.mean(0)
+        y = (zd - m_) / torch.sqrt(((zd - m_) ** 2).mean(0) + 1e-5) * gd + bd
+    else:
+        y = (zd - mean) * invstd * gd + bd
+    a7 = _act(y, act)
+    a7_bf = a7.detach().reshape(B, T, Fq, 64).to(torch.bfloat16)
+    d8 = dz8.double().reshape(B, T, 8, Fq)
+    out = torch.einsum("btfc,oc->btof", a7.reshape(B, T, Fq, 64), w8.double().view(8, 64))
+    out.backward(d8)
+    dy, dw8, st = ops.nhwc_conv_last_bwd_dy(dz8.cuda(), w8.cuda(), a7_bf.cuda(), z.cuda(), act, scale.cuda(), shift.cuda(),
+                                            mean.float().cuda(), invstd.float().cuda())
+    dz, dg, db, dbias = ops.nhwc_bn_bwd_from_dy(dy, z.cuda(), st, training, scale.cuda(), mean.float().cuda(), invstd.float().cuda())
+    ref = zd.grad.reshape(B, T, Fq, 64)
+    if act == "relu":                               # fp32 vs fp64 may disagree on the side of the kink for |y| ~ 0
+        ref = ref * (y.detach().abs() > 1e-4).reshape(B, T, Fq, 64)
+        dz = dz.double().cpu() * (y.detach().abs() > 1e-4).reshape(B, T, Fq, 64)
+    _close(dz, ref, f"cnn8 backward dy + bn pass ({act}, training={training})")
+    for got, r, nm in ((dg, gd.grad, "dgamma"), (db, bd.grad, "dbeta")):
+        e = ((got.double().cpu() - r).abs().max() / r.abs().max()).item()
+        assert e < 2e-3, (nm, e)                    # the sums are of bf16-rounded a7-side products: 2^-9 relative, averaged
+    ref_dw8 = torch.einsum("btof,btfc->oc", d8, a7_bf.double())
+    e = ((dw8.double().cpu() - ref_dw8).abs().max() / ref_dw8.abs().max()).item()
+    assert e < 2e-5, e
+
+
+def test_nhwc_cnn1_backward_from_dy():
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(37)
+    B, T, Fq = 2, 11, 53
+    x = torch.rand(B, T, Fq, generator=g)
+    z = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    dy = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    mean, invstd, scale, shift = _bn_consts(z, gamma, beta, g, True)
+    zd = z.double().reshape(-1, 64).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    m_ = zd.mean(0)
+    y = (zd - m_) / torch.sqrt(((zd - m_) ** 2).mean(0) + 1e-5) * gd + bd
+    y.backward(dy.double().reshape(-1, 64))
+    dz1 = zd.grad.reshape(B, T, Fq, 64)
+    xp = F.pad(x.double(), (3, 3))
+    ref_dw = torch.stack([torch.einsum("btfc,btf->c", dz1, xp[:, :, k:k + Fq]) for k in range(7)], dim=1)
+    xhat = (z.double() - mean) * invstd
+    st = torch.zeros(64, 64, 2, dtype=torch.float64)
+    st[5, :, 0] = dy.double().sum((0, 1, 2))        # any slot: the finalize folds them
+    st[9, :, 1] = (dy.double() * xhat).sum((0, 1, 2))
+    dw, dg, db, dbias = ops.nhwc_bn_bwd_first_from_dy(dy.cuda(), z.cuda(), x.cuda(), st.cuda(), True, scale.cuda(), mean.float().cuda(),
+                                                      invstd.float().cuda())
+    e = ((dw.double().cpu() - ref_dw).abs().max() / ref_dw.abs().max()).item()
+    assert e < 2e-4, e
+    for got, r, nm in ((dg, gd.grad, "dgamma"), (db, bd.grad, "dbeta")):
+        e = ((got.double().cpu() - r).abs().max() / r.abs().max()).item()
+        assert e < 1e-4, (nm, e)
+    assert dbias.abs().max().item() == 0.0
+
+
 # ---- bf16 GEMM of the LSTM contractions (csrc/gemm_bf16.hip) --------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(200, 300, 130), (128, 256, 64), (1, 17, 8), (777, 520, 1000), (3010, 3200, 424)])
 def test_gemm_bf16_all_operand_forms(M, N, K):

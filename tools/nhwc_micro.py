@@ -35,6 +35,14 @@ def main():
         for act, stats in (("none", False), ("none", True), ("mish", False)):
             ms = timed(lambda: ops.nhwc_conv(x, w, one, zero, dil, act, stats=stats))
             res[f"nhwc {KT}x{KF} dil{dil} act={act} stats={int(stats)}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
+        if os.environ.get("VS_MICRO_DY", "1") != "0" and dil in (1, 4):
+            packed = ops.nhwc_conv_pack(w, transpose_flip=True)
+            mean, invstd = zero, one
+            for act in ("mish", "relu"):
+                ms = timed(lambda: ops.nhwc_conv_dy(x, packed, x, act, one, zero, mean, invstd, KT, KF, dil))
+                res[f"nhwc {KT}x{KF} dil{dil} dy epilogue act'={act}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
+        if os.environ.get("VS_MICRO_WGRAD", "1") == "0":
+            continue
         ms = timed(lambda: ops.nhwc_conv_wgrad(x, x, KT, KF, dil))
         res[f"nhwc wgrad {KT}x{KF} dil{dil}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
     print(json.dumps(res, indent=1), flush=True)

@@ -116,6 +116,10 @@ SIGNATURES = {
     "vs_nhwc_bn_act_bwd_first": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vs_nhwc_conv_last_bwd_blocks": (c_int, []),
     "vs_nhwc_conv_last_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv_dy": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv_last_bwd_dy": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_nhwc_bn_bwd_from_dy": (c_int, [_P, _P, _P, c_longlong, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vs_nhwc_bn_bwd_first_from_dy": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vs_conv_last_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vs_conv64_packed_f16_floats": (c_size_t, [c_int, c_int]),
     "vs_pow2_scale": (c_int, [_P, c_longlong, _P, _P, _P]),

@@ -402,7 +402,38 @@ int vs_nhwc_conv_last_bwd_blocks(void) { return VS_NHWC_LAST_BWD_BLOCKS; }
 
 int vs_nhwc_conv_last_bwd(const float* dz8, const float* w, const void* a7, void* din, float* partials, float* dw,
                           int B, int T, int F, void* stream) {
-  return vs_nhwc_conv_last_bwd_impl(dz8, w, a7, din, partials, dw, B, T, F, (hipStream_t)stream);
+  return vs_nhwc_conv_last_bwd_impl(dz8, w, a7, din, partials, dw, B, T, F, nullptr, VS_ACT_NONE, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    (hipStream_t)stream);
+}
+
+// ---- the dy forms: the producer of a data gradient also does the first pass of the BatchNorm backward below it ----
+int vs_nhwc_conv_dy(const void* dz, const void* packed, void* dy, const void* z, int act,
+                    const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_stats,
+                    int B, int T, int F, int KT, int KF, int dil, void* stream) {
+  VS_REQUIRE(dz != dy, "nhwc_conv_dy: in-place is not supported");
+  return vs_nhwc_conv_dy_impl(dz, packed, dy, z, act, bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats, B, T, F, KT, KF, dil, (hipStream_t)stream);
+}
+
+int vs_nhwc_conv_last_bwd_dy(const float* dz8, const float* w, const void* a7, void* dy, float* partials, float* dw,
+                             const void* z7, int act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                             const float* bn_invstd, double* bn_stats, int B, int T, int F, void* stream) {
+  VS_REQUIRE(z7, "nhwc_conv_last_bwd_dy: NULL z7");
+  return vs_nhwc_conv_last_bwd_impl(dz8, w, a7, dy, partials, dw, B, T, F, z7, act, bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats,
+                                    (hipStream_t)stream);
+}
+
+int vs_nhwc_bn_bwd_from_dy(const void* dy, const void* z, void* dz, long long npix, int bn_mode,
+                           const float* scale, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, void* stream) {
+  return vs_nhwc_bn_bwd_from_dy_impl(dy, z, dz, npix, bn_mode == VS_BN_TRAIN, scale, mean, invstd, dgamma, dbeta, dbias, stats, coef,
+                                     (hipStream_t)stream);
+}
+
+int vs_nhwc_bn_bwd_first_from_dy(const void* dy, const void* z, const float* x, int B, int T, int F, int bn_mode,
+                                 const float* scale, const float* mean, const float* invstd,
+                                 float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, void* stream) {
+  return vs_nhwc_bn_bwd_first_from_dy_impl(dy, z, x, B, T, F, bn_mode == VS_BN_TRAIN, scale, mean, invstd, dgamma, dbeta, dbias, dw,
+                                           stats, coef, acc, (hipStream_t)stream);
 }
 
 int vs_conv_last_fwd(const float* in, const float* w, const float* scale, const float* shift, float* out,

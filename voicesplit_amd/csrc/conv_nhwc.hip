@@ -39,11 +39,12 @@ namespace {
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+constexpr float kLog2e = 1.44269504088896340736f;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(3))) const u4v lds_u4v;
 
 __device__ u4v g_zero_page[4];      // 64 zero bytes: source of every out-of-image piece
-__device__ u2v g_dump_page[256];    // where the stores of out-of-image lanes / rows go (one slot per thread)
 
 constexpr int STRIP = 32;           // output columns per strip = 2 MFMA column blocks of 16
 constexpr int NB = STRIP / 16;
@@ -59,6 +60,10 @@ struct NhwcConvArgs {
   const float* shift;               // [64]
   unsigned short* out;              // [B][T][F][64] bf16
   double* bn_stats;                 // [VS_BN_STAT_SLOTS][64][2] or NULL
+  // data-gradient epilogue of the backward pass (DY instances): the output pixel's z and the BatchNorm constants of the
+  // layer whose activation gradient this launch produces
+  const unsigned short* z2;         // [B][T][F][64] bf16
+  const float* bn2_scale; const float* bn2_shift; const float* bn2_mean; const float* bn2_invstd;   // [64] each
   int B, T, F, dil;
   int nstrip, nseg, seg_rows, n_items;
 };
@@ -90,7 +95,12 @@ struct Geo {
 
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 
-template <int KT, int KF, int ACT, bool STATS>
+// DY: the launch is a data gradient whose result da feeds a BatchNorm + activation backward: the epilogue turns it into
+// dy = da * act'(z * scale + shift) on the spot (z = the output pixel's pre-BatchNorm value, loaded two output rows ahead),
+// accumulates the two sums of the BatchNorm backward (sum dy, sum dy * xhat) like the STATS epilogue accumulates the
+// forward's, and stores dy: the separate statistics pass over (da, z) disappears and the apply pass needs no activation
+// derivative (dz = cA dy + cB z + cC).  ACT is then the activation whose derivative is taken.
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
 struct ConvWalk {
   using G = Geo<KT, KF>;
   static constexpr int P = G::P, PF = G::PF, H = G::H, NTAP = G::NTAP;
@@ -99,7 +109,10 @@ struct ConvWalk {
   int lane, wave, n, g;
   vs_bf16x8 wf[NTAP][2];
   float sc[4], sh[4], s1[4], s2[4];
+  f2v ksc[2], ksh[2], d1[2], d2[2];          // DY: scale / shift of this lane's 4 channels times log2(e), as channel pairs; sums
   int boff[KF];
+  unsigned vcol[NB];
+  __amdgpu_buffer_rsrc_t rout, rz;
   unsigned lds0;
   const lds_byte* smem;
 
@@ -121,6 +134,12 @@ struct ConvWalk {
       sh[r] = a.shift[wave * 16 + g * 4 + r];
       s1[r] = 0.f;
       s2[r] = 0.f;
+      if (DY) {
+        ksc[r >> 1][r & 1] = a.bn2_scale[wave * 16 + g * 4 + r] * kLog2e;
+        ksh[r >> 1][r & 1] = a.bn2_shift[wave * 16 + g * 4 + r] * kLog2e;
+        d1[r >> 1][r & 1] = 0.f;
+        d2[r >> 1][r & 1] = 0.f;
+      }
     }
 #pragma unroll
     for (int df = 0; df < KF; ++df) {
@@ -169,6 +188,26 @@ struct ConvWalk {
     }
   }
 
+  // Output-side addressing (the epilogue's stores, the dy form's z loads): a buffer descriptor over the item's utterance,
+  // a per-lane byte offset of its pixel (column block nb) and channel quad inside a row -- or an offset no row offset brings
+  // back into range when the column is outside the image -- and a wave-uniform row offset, likewise out of range for rows
+  // the item does not own.  The range check does the predication: no address arithmetic or branches in the epilogue.
+  static constexpr unsigned kOob = 0x7FFFFFF0u;
+  __device__ __forceinline__ void begin_item(const Item& x) {
+    const size_t ub = (size_t)x.b * a.T * a.F * 128;
+    const unsigned bytes = (unsigned)a.T * a.F * 128;
+    rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out) + ub, 0, bytes, 0x00020000);
+    if (DY) rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.z2)) + ub, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int nb2 = 0; nb2 < NB; ++nb2) {
+      const int col = x.strip * STRIP + nb2 * 16 + n;
+      vcol[nb2] = col < a.F ? (unsigned)(col * 128 + wave * 32 + g * 8) : kOob;
+    }
+  }
+  __device__ __forceinline__ unsigned row_offset(const Item& x, int k) const {
+    return k < x.o1 ? (unsigned)((x.cls + k * a.dil) * a.F) * 128u : kOob;
+  }
+
   // One group: output rows ro .. ro+RV-1 of item x (RV = R, or the even tail of the item; rows >= x.o1 are computed and
   // dropped), window rows at ring positions cq .. cq+RV+H-1 (mod NR).  gstep<RV, GI> is fragment GI of the block: its
   // read two fragments ahead and its MFMAs.  The instruction order is pinned (sched_barrier after every MFMA): hipcc's
@@ -181,9 +220,16 @@ struct ConvWalk {
     f32x4 acc[RV][NB];
     vs_bf16x8 bq[3];
     float y[NB][4];
+    u2v zq[3][NB];                     // DY: z of the output row being finished and the next two (4 channels of one pixel each)
+    float cok[NB], mk[NB];             // DY: 1 for a column inside the image, else 0; the same for the row being finished
+    f2v tz, ty, tu, tn, tr, tw;        // DY: one channel pair in flight through the stages of the activation derivative
     int ro, cq;
   };
-  static constexpr int NMICRO = NB * 4 + NB;
+  // micro-ops of one output row.  Plain: NB*4 values + NB stores.  DY: z loads of a later row, NB*2 channel pairs x NSTAGE
+  // stages (packed fp32 math: one v_pk_* per two channels; at most three of them or one transcendental per micro-op, which
+  // is what fits behind one MFMA without holding up the next), NB stores.
+  static constexpr int NSTAGE = 9;
+  static constexpr int NMICRO = DY ? 1 + NB * 2 * NSTAGE + NB : NB * 4 + NB;
 
   template <int RV>
   __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
@@ -193,27 +239,99 @@ struct ConvWalk {
     return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(smem + pos * G::ROWB + nb * 2048 + (boff[df] ^ (kc << 6))));
   }
 
+  // DY: z of output row r of the group (both column blocks) -> zq[r % 3].  Issued two output rows (about 1.5 us of
+  // MFMAs) before its first use: one row ahead the epilogue waited on HBM latency.
+  template <int RV>
+  __device__ __forceinline__ void load_z(const Item& x, GroupState<RV>& st, int r) {
+    const unsigned so = row_offset(x, st.ro + r);
+#pragma unroll
+    for (int nb2 = 0; nb2 < NB; ++nb2)
+      st.zq[r % 3][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rz, vcol[nb2], so, 0));      // out of range: zeros
+  }
+
+  template <int RV>
+  __device__ __forceinline__ void store_px(const Item& x, GroupState<RV>& st, int r, int nb2) {
+    const int k = st.ro + r;
+    const int col = x.strip * STRIP + nb2 * 16 + n;
+    const bool ok = (k < x.o1) & (col < a.F);
+    if (STATS && !DY) {
+      const float m = ok ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float ym = st.y[nb2][c] * m; s1[c] += ym; s2[c] = fmaf(ym, st.y[nb2][c], s2[c]); }
+    }
+    const u2v pk = {vs_pack_bf16(st.y[nb2][0], st.y[nb2][1]), vs_pack_bf16(st.y[nb2][2], st.y[nb2][3])};
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rout, vcol[nb2], row_offset(x, k), 0);                               // out of range: dropped
+  }
+
   // micro-op q of the epilogue of output row r of the group
   template <int RV, int r, int q>
   __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
-    if constexpr (q < NB * 4) {
-      constexpr int nb2 = q / 4, c = q % 4;
-      st.y[nb2][c] = vs_act_fast<ACT>(fmaf(st.acc[r][nb2][c], sc[c], sh[c]));
-    } else {
-      constexpr int nb2 = q - NB * 4;
-      const int k = st.ro + r;
-      const int col = x.strip * STRIP + nb2 * 16 + n;
-      const bool ok = (k < x.o1) & (col < a.F);
-      if (STATS) {
-        const float m = ok ? 1.f : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const float ym = st.y[nb2][c] * m; s1[c] += ym; s2[c] = fmaf(ym, st.y[nb2][c], s2[c]); }
+    if constexpr (!DY) {
+      if constexpr (q < NB * 4) {
+        constexpr int nb2 = q / 4, c = q % 4;
+        st.y[nb2][c] = vs_act_fast<ACT>(fmaf(st.acc[r][nb2][c], sc[c], sh[c]));
+      } else {
+        store_px<RV>(x, st, r, q - NB * 4);
       }
-      const u2v pk = {vs_pack_bf16(st.y[nb2][0], st.y[nb2][1]), vs_pack_bf16(st.y[nb2][2], st.y[nb2][3])};
-      const size_t pix = ((size_t)x.b * a.T + (x.cls + k * a.dil)) * a.F + col;
-      unsigned char* dst = ok ? reinterpret_cast<unsigned char*>(a.out) + (pix << 7) + (wave * 32 + g * 8)
-                              : reinterpret_cast<unsigned char*>(g_dump_page) + threadIdx.x * 8;
-      *reinterpret_cast<u2v*>(dst) = pk;
+    } else {
+      // dy = da * act'(y), y = z * scale + shift.  Mish'(y) with u = e^y, n = u (u + 2), r = 1 / (n + 2):
+      //   tanh(softplus y) = n r,  1 - tanh^2 = 4 (n + 1) r^2 = 4 (u + 1)^2 r^2,  sigmoid = u / (u + 1)
+      //   =>  Mish' = r (n + 4 y u (u + 1) r)       (one exp2, one rcp; y clamped at 20, where the expression is 1 to fp32)
+      // computed on y log2(e) (folded into the constants).  The sums are of dy and dy * z; flush_stats turns the second
+      // into the sum of dy * xhat.
+      if constexpr (q == 0) {
+        if constexpr (r + 2 < RV) load_z<RV>(x, st, r + 2);
+#pragma unroll
+        for (int nb2 = 0; nb2 < NB; ++nb2) st.mk[nb2] = (st.ro + r < x.o1) ? st.cok[nb2] : 0.f;
+      } else if constexpr (q <= NB * 2 * NSTAGE) {
+        constexpr int v = (q - 1) / NSTAGE, sg = (q - 1) % NSTAGE, nb2 = v / 2, pr = v % 2;
+        constexpr bool mish = ACT == VS_ACT_MISH;
+        if constexpr (sg == 0) {
+          const unsigned u = st.zq[r % 3][nb2][pr];
+          st.tz = f2v{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+          st.ty = __builtin_elementwise_fma(st.tz, ksc[pr], ksh[pr]);
+        } else if constexpr (sg == 1) {
+          if constexpr (mish) {
+            st.ty = f2v{fminf(st.ty.x, 20.0f * kLog2e), fminf(st.ty.y, 20.0f * kLog2e)};
+            st.tu.x = __builtin_amdgcn_exp2f(st.ty.x);
+          }
+        } else if constexpr (sg == 2) {
+          if constexpr (mish) st.tu.y = __builtin_amdgcn_exp2f(st.ty.y);
+        } else if constexpr (sg == 3) {
+          if constexpr (mish) {
+            st.tn = st.tu * (st.tu + 2.0f);
+            st.tw = st.tn + 2.0f;
+          }
+        } else if constexpr (sg == 4) {
+          if constexpr (mish) st.tr.x = __builtin_amdgcn_rcpf(st.tw.x);
+        } else if constexpr (sg == 5) {
+          if constexpr (mish) st.tr.y = __builtin_amdgcn_rcpf(st.tw.y);
+        } else if constexpr (sg == 6) {
+          if constexpr (mish) {
+            st.tw = __builtin_elementwise_fma(st.tu, st.tu, st.tu);           // u (u + 1)
+            st.tw = st.tw * st.ty;
+            st.tu = st.tr * (4.0f * 0.69314718055994530942f);                   // 4 ln 2: y was scaled by log2(e)
+          }
+        } else if constexpr (sg == 7) {
+          const f2v da = {st.acc[r][nb2][2 * pr], st.acc[r][nb2][2 * pr + 1]};
+          if constexpr (mish) {
+            st.tn = __builtin_elementwise_fma(st.tw, st.tu, st.tn);
+            st.ty = da * (st.tr * st.tn);
+          } else if constexpr (ACT == VS_ACT_RELU) {
+            st.ty = f2v{st.ty.x > 0.f ? da.x : 0.f, st.ty.y > 0.f ? da.y : 0.f};
+          } else {
+            st.ty = da;
+          }
+        } else {
+          const f2v dm = st.ty * st.mk[nb2];
+          d1[pr] += dm;
+          d2[pr] = __builtin_elementwise_fma(dm, st.tz, d2[pr]);
+          st.y[nb2][2 * pr] = st.ty.x;
+          st.y[nb2][2 * pr + 1] = st.ty.y;
+        }
+      } else {
+        store_px<RV>(x, st, r, q - 1 - NB * 2 * NSTAGE);
+      }
     }
   }
 
@@ -224,11 +342,20 @@ struct ConvWalk {
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
     st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
+    if constexpr (DY && GI == 0 && MM == 0) {               // z of the group's first two rows
+      load_z<RV>(x, st, 0);
+      if constexpr (RV > 1) load_z<RV>(x, st, 1);
+    }
     if constexpr (i >= H + 1) {
-      // MFMA number q of window row i carries micro-ops [q * per, (q + 1) * per) of the row completed before it; near
-      // the end of a group a window row has few MFMAs (7x1: 4), so several micro-ops may share one
-      constexpr int cap = 2 * NB * KF * nm, per = (NMICRO + cap - 1) / cap, q = ls * nm + MM;
-      micros<RV, i - H - 1, q * per>(x, st, std::make_integer_sequence<int, (q * per < NMICRO ? (NMICRO - q * per < per ? NMICRO - q * per : per) : 0)>());
+      // The epilogue micro-ops of the row completed before window row i ride on its MFMAs: every stride-th MFMA
+      // carries `per` of them (stride > 1 when the row has more MFMAs than micro-ops: spread them out; per > 1 near
+      // the end of a group, where a window row has few MFMAs -- 7x1: 4 -- and several micro-ops must share one)
+      constexpr int cap = 2 * NB * KF * nm, q = ls * nm + MM;
+      constexpr int stride = cap >= NMICRO ? cap / NMICRO : 1, per = (NMICRO + cap - 1) / cap;
+      if constexpr (q % stride == 0) {
+        constexpr int m0 = (q / stride) * per;
+        micros<RV, i - H - 1, m0>(x, st, std::make_integer_sequence<int, (m0 < NMICRO ? (NMICRO - m0 < per ? NMICRO - m0 : per) : 0)>());
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -272,6 +399,10 @@ struct ConvWalk {
     for (int r = 0; r < RV; ++r)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) st.acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (DY) {
+#pragma unroll
+      for (int nb2 = 0; nb2 < NB; ++nb2) st.cok[nb2] = (x.strip * STRIP + nb2 * 16 + n < a.F) ? 1.f : 0.f;
+    }
     st.bq[0] = frag<RV>(st, 0);
     st.bq[1] = frag<RV>(st, 1);
     gsteps<RV>(x, st, std::make_integer_sequence<int, (RV + H) * KF * 2 * NB>());
@@ -279,7 +410,11 @@ struct ConvWalk {
   }
 
   __device__ __forceinline__ void flush_stats() {
-    if (!STATS || a.bn_stats == nullptr) return;
+    if (!(STATS || DY) || a.bn_stats == nullptr) return;
+    if (DY) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] = d1[r >> 1][r & 1]; s2[r] = d2[r >> 1][r & 1]; }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -292,19 +427,24 @@ struct ConvWalk {
       double* dst = a.bn_stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + (wave * 16 + g * 4) * 2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        atomicAdd(dst + 2 * r, (double)s1[r]);
-        atomicAdd(dst + 2 * r + 1, (double)s2[r]);
+        double t1 = (double)s1[r], t2 = (double)s2[r];
+        if (DY) {                      // sum dy * xhat = invstd * (sum dy * z - mean * sum dy)
+          const int ch = wave * 16 + g * 4 + r;
+          t2 = (double)a.bn2_invstd[ch] * (t2 - (double)a.bn2_mean[ch] * t1);
+        }
+        atomicAdd(dst + 2 * r, t1);
+        atomicAdd(dst + 2 * r + 1, t2);
       }
     }
   }
 };
 
-template <int KT, int KF, int ACT, bool STATS>
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
 __global__ __launch_bounds__(256, 1)
 void nhwc_conv_kernel(NhwcConvArgs a) {
   using G = Geo<KT, KF>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];      // the only LDS object of the kernel
-  ConvWalk<KT, KF, ACT, STATS> wk(a, (const lds_byte*)smem);
+  ConvWalk<KT, KF, ACT, STATS, DY> wk(a, (const lds_byte*)smem);
 
   // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
   Item pf;
@@ -334,6 +474,7 @@ void nhwc_conv_kernel(NhwcConvArgs a) {
   int cq = 0;                      // ring position of the first window row of the group being computed
   for (int it = (int)blockIdx.x; it < a.n_items; it += (int)gridDim.x) {
     if (!wk.decode(it, cur)) continue;
+    wk.begin_item(cur);
     for (int gidx = 0; gidx < cur.ngroups; ++gidx) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the window have landed (and its stores retired)
       __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done with the previous window
@@ -403,7 +544,12 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   const size_t lds = 0;   // static LDS: Geo::LDS_BYTES
   const bool stats = a.bn_stats != nullptr;
 #define VS_NHWC_LAUNCH(A, S) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S>), grid, block, lds, stream, a)
-  if (stats) {
+  if (a.z2) {            // data gradient with the activation-derivative epilogue: act = the activation whose derivative is taken
+    VS_REQUIRE(stats && a.bn2_scale && a.bn2_shift && a.bn2_mean && a.bn2_invstd, "nhwc conv: the dy epilogue needs statistics slots and BatchNorm constants");
+    if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, VS_ACT_MISH, false, true>), grid, block, lds, stream, a);
+    else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, VS_ACT_RELU, false, true>), grid, block, lds, stream, a);
+    else VS_REQUIRE(false, "nhwc conv: dy epilogue for activation %d", act);
+  } else if (stats) {
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv: fused statistics go with no activation");
     VS_NHWC_LAUNCH(VS_ACT_NONE, true);
   } else if (act == VS_ACT_NONE) VS_NHWC_LAUNCH(VS_ACT_NONE, false);
@@ -434,12 +580,35 @@ int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, co
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t stream) {
   VS_REQUIRE(in && packed && scale && shift && out, "nhwc conv: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "nhwc conv: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((long long)T * F * 128 < 0x7F000000LL, "nhwc conv: an utterance of %d x %d pixels does not fit the 31-bit offsets of the epilogue", T, F);
   VS_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nhwc conv: buffers must be 16-byte aligned");
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(in), reinterpret_cast<const unsigned short*>(packed), scale, shift,
-                 reinterpret_cast<unsigned short*>(out), bn_stats, B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
+                 reinterpret_cast<unsigned short*>(out), bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
+  return -1;
+}
+
+// The data gradient of a layer fused with the first half of the BatchNorm + activation backward of the layer below it:
+// da = conv(dz, packed (transposed + flipped weights)) is turned into dy = da * act'(z * bn_scale + bn_shift) in the
+// epilogue, dy is stored (bf16) and bn_stats receives per-channel {sum dy, sum dy * xhat} ([VS_BN_STAT_SLOTS][64][2]
+// doubles the caller zeroed).  z: the lower layer's conv + bias output, channels-last bf16.
+int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const void* z, int act,
+                         const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_stats,
+                         int B, int T, int F, int KT, int KF, int dil, hipStream_t stream) {
+  VS_REQUIRE(dz && packed && dy && z && bn_scale && bn_shift && bn_mean && bn_invstd && bn_stats, "nhwc conv dy: NULL argument");
+  VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "nhwc conv dy: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
+  VS_REQUIRE((long long)T * F * 128 < 0x7F000000LL, "nhwc conv dy: an utterance of %d x %d pixels does not fit the 31-bit offsets of the epilogue", T, F);
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(dz) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 7) == 0, "nhwc conv dy: buffer alignment");
+  NhwcConvArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(packed), bn_scale, bn_shift,
+                 reinterpret_cast<unsigned short*>(dy), bn_stats, reinterpret_cast<const unsigned short*>(z), bn_scale, bn_shift, bn_mean, bn_invstd,
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
+  if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
+  if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
+  VS_REQUIRE(false, "nhwc conv dy: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
   return -1;
 }

@@ -18,6 +18,8 @@
 // cycles and workgroup -- 25 TB/s over the chip at full MFMA rate, beyond the L2s -- and measured 0.93-1.0 ms
 // (600-640 TF) on the three contractions; this one moves 64 KB per 2048 cycles.  fp32 accumulate, fp32 output
 // (+ optional per-row-group bias, or accumulate into C).
+#include <stdlib.h>
+
 #include "vs_internal.h"
 
 namespace {
@@ -145,7 +147,9 @@ __device__ __forceinline__ bool tile_of(const GemmBf16Args& g, int t, int& tm, i
   return true;
 }
 
-template <bool AK, bool BK_>
+// DM: where the 16 LDS-DMA instructions of the next stage sit inside a step: 0 = all behind the barrier, 1 = two in front
+// of each of the first 8 MFMA rows, 2 = one in front of each of the 16 MFMA rows
+template <bool AK, bool BK_, int DM>
 __global__ __launch_bounds__(256, 1)
 void gemm_bf16_kernel(GemmBf16Args g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE_BYTES];
@@ -174,7 +178,9 @@ void gemm_bf16_kernel(GemmBf16Args g) {
   const typename OB::LaneDma lb = OB::lane_dma(g.ldb, wave, lane);
   // The DMA of a stage is 16 instructions per wave (8 A chunks, 8 B chunks) with ~15 scalar / vector instructions of
   // address arithmetic each: issued in one go behind the barrier they cost ~1000 cycles of a 2048-cycle step with the
-  // matrix pipe idle, so they are spread over the step instead -- one chunk in front of each of its 16 MFMA rows.
+  // matrix pipe idle, so they are spread over the FIRST half of the step -- two chunks in front of each of its first 8
+  // MFMA rows; the second half of the step is their time to land.  (Spread over all 16 rows, the col x col contraction,
+  // whose panels stream from HBM, waited for the late chunks: 0.63 -> 1.63 ms.)
   auto pf_chunk = [&](int slot /* 0..15 */, bool live) {     // !live (end of the job): every piece reads the zero page, no branch
     const unsigned dst = lds0 + (unsigned)(pstage * STAGE_BYTES);
     if (slot < 8) OA::issue_chunk(la, g.A, g.lda, live ? g.M : 0, g.K, ptm * TM, pk * BK, dst, wave, slot);
@@ -206,8 +212,11 @@ void gemm_bf16_kernel(GemmBf16Args g) {
     for (int ks = 0; ks < nk; ++ks) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the stage have landed (issued one step ago)
       __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done reading the other stage
-      const bool pf_now = plive;                            // the next step's tiles (possibly of the next output tile) go into it,
-                                                            // one chunk in front of each MFMA row below
+      const bool pf_now = plive;                            // the next step's tiles (possibly of the next output tile) go into it
+      if (DM == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) pf_chunk(c, pf_now);
+      }
       unsigned fa = lds0 + (unsigned)(cstage * STAGE_BYTES) + fbA, fb = lds0 + (unsigned)(cstage * STAGE_BYTES + A_BYTES) + fbB;
       asm volatile("" : "+v"(fa), "+v"(fb));               // opaque: keeps the compiler from hoisting 32 derived addresses per stage out of the loop
       // B fragments of a k-half stay in registers for its 8 accumulator rows; the A fragment of the next row and the B
@@ -225,7 +234,8 @@ void gemm_bf16_kernel(GemmBf16Args g) {
           if (a + 1 < WA) afn = OA::frag(fa, wm * 128 + (a + 1) * 16, kh);
           else if (kh == 0) afn = OA::frag(fa, wm * 128, 1);
           if (kh == 0) bf[1][a] = OB::frag(fb, wn * 128 + a * 16, 1);
-          pf_chunk(kh * 8 + a, pf_now);
+          if (DM == 1 && kh == 0) { pf_chunk(a, pf_now); pf_chunk(8 + a, pf_now); }
+          if (DM == 2) pf_chunk(kh * 8 + a, pf_now);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int b = 0; b < WB; ++b)
@@ -316,10 +326,25 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   if (nwg > (ntiles + 7) / 8 * 8) nwg = (ntiles + 7) / 8 * 8;
   if (nwg < 8) nwg = 8;
   const dim3 grid((unsigned)nwg), block(256);
-  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, g);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, g);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, g);
-  else VS_REQUIRE(false, "gemm_bf16: the col x row form is not used by the path");
+  // placement of the DMA instructions inside a step, per operand-form pair (measured, tools/gemm_micro.py; the
+  // VOICESPLIT_GEMM_DMA environment variable -- three digits: row x row, row x col, col x col -- overrides it for A/B timing)
+  static const int dm_cfg = [] {
+    const char* e = getenv("VOICESPLIT_GEMM_DMA");
+    int v = 200;                                         // row x row: spread over the step; the others: behind the barrier
+    if (e && e[0] && e[1] && e[2]) v = (e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0');
+    return v;
+  }();
+  const int form = (!a_kmajor && !b_kmajor) ? 0 : (!a_kmajor && b_kmajor) ? 1 : (a_kmajor && b_kmajor) ? 2 : 3;
+  VS_REQUIRE(form != 3, "gemm_bf16: the col x row form is not used by the path");
+  const int dm = form == 0 ? dm_cfg / 100 : form == 1 ? (dm_cfg / 10) % 10 : dm_cfg % 10;
+  VS_REQUIRE(dm >= 0 && dm <= 2, "gemm_bf16: VOICESPLIT_GEMM_DMA digit %d", dm);
+#define VS_GEMM_LAUNCH(AK_, BK2_, DM_) hipLaunchKernelGGL((gemm_bf16_kernel<AK_, BK2_, DM_>), grid, block, 0, stream, g)
+#define VS_GEMM_FORM(AK_, BK2_) do { if (dm == 0) VS_GEMM_LAUNCH(AK_, BK2_, 0); else if (dm == 1) VS_GEMM_LAUNCH(AK_, BK2_, 1); else VS_GEMM_LAUNCH(AK_, BK2_, 2); } while (0)
+  if (form == 0) VS_GEMM_FORM(false, false);
+  else if (form == 1) VS_GEMM_FORM(false, true);
+  else VS_GEMM_FORM(true, true);
+#undef VS_GEMM_FORM
+#undef VS_GEMM_LAUNCH
   VS_LAUNCH_CHECK();
   return 0;
 }

@@ -304,16 +304,34 @@ __global__ void nhwc_cvt_f64_f32_kernel(const double* __restrict__ src, float* _
 
 // cnn8 backward in one pass over a7: din[b][t][f][ci] = sum_co w[co][ci] dz8[b][t][co][f]  (data gradient, bf16) and
 // dw[co][ci] = sum_pixels dz8[..][co][..] a7[..][ci]  (weight gradient: per-workgroup partial sums part[block][co][ci])
+// DYACT >= 0: the data gradient is turned into dy = din * act'(z7 * scale + shift) before it is stored, and the
+// per-channel sums of dy and dy * xhat go to bn_stats (the first pass of cnn7's BatchNorm backward, fused)
+struct LastBwdBn {
+  const u4v* z;
+  const float *scale, *shift, *mean, *invstd;
+  double* stats;
+};
+
+template <int DYACT>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __restrict__ w, const u4v* __restrict__ a7,
-                               u4v* __restrict__ din, float* __restrict__ part, long long npix, int F) {
+                               u4v* __restrict__ din, float* __restrict__ part, long long npix, int F, LastBwdBn bn) {
   __shared__ float red[4 * 8 * 64];
   const int piece = threadIdx.x & 7;
   float wr[8][8], acc[8][8];            // [co][j], ci = 8 piece + j
+  float sc[8], sh[8], mu[8], is[8], bacc[2][8];
 #pragma unroll
   for (int co = 0; co < 8; ++co)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { wr[co][j] = w[co * 64 + piece * 8 + j]; acc[co][j] = 0.f; }
+  if (DYACT >= 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = piece * 8 + j;
+      sc[j] = bn.scale[c]; sh[j] = bn.shift[c]; mu[j] = bn.mean[c]; is[j] = bn.invstd[c];
+      bacc[0][j] = 0.f; bacc[1][j] = 0.f;
+    }
+  }
   const long long stride = (long long)gridDim.x * 32;
   for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
     const long long row = p / F;
@@ -335,7 +353,21 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
         acc[co][2 * q] = fmaf(d[co], bf_lo(av[q]), acc[co][2 * q]);
         acc[co][2 * q + 1] = fmaf(d[co], bf_hi(av[q]), acc[co][2 * q + 1]);
       }
+    if (DYACT >= 0) {
+      const u4v zv = __builtin_nontemporal_load(bn.z + p * 8 + piece);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float zj = (j & 1) ? bf_hi(zv[j >> 1]) : bf_lo(zv[j >> 1]);
+        g[j] *= nhwc_act_grad<(DYACT >= 0 ? DYACT : VS_ACT_NONE)>(fmaf(zj, sc[j], sh[j]));
+        bacc[0][j] += g[j];
+        bacc[1][j] = fmaf(g[j], (zj - mu[j]) * is[j], bacc[1][j]);
+      }
+    }
     din[p * 8 + piece] = u4v{vs_pack_bf16(g[0], g[1]), vs_pack_bf16(g[2], g[3]), vs_pack_bf16(g[4], g[5]), vs_pack_bf16(g[6], g[7])};
+  }
+  if (DYACT >= 0) {
+    fold_channel_sums<2>(bacc, bn.stats, red);
+    __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -434,6 +466,38 @@ int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long n
   return 0;
 }
 
+// The same with the first pass already done by the kernel that produced dy = da * act'(.) (conv_nhwc.hip's dy
+// epilogue, cnn8's backward below): stats holds the per-channel sums; parameter gradients + dz = cA dy + cB z + cC
+int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long long npix, int train,
+                                const float* scale, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream) {
+  VS_REQUIRE(dy && z && dz && scale && mean && invstd && stats && coef && npix > 0, "nhwc bn_bwd_from_dy: bad argument");
+  const long long npieces = npix * 8;
+  const dim3 grid(stream_blocks(512, npieces)), block(256);
+  if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream)) return rc;
+  hipLaunchKernelGGL(nhwc_bn_bwd_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, reinterpret_cast<const u4v*>(dy), reinterpret_cast<const u4v*>(z),
+                     reinterpret_cast<u4v*>(dz), npieces, scale, scale, coef);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn1, from dy: finalize + the pass that contracts dz1 with the input (dw [64][7])
+int vs_nhwc_bn_bwd_first_from_dy_impl(const void* dy, const void* z, const float* x, int B, int T, int F, int train,
+                                      const float* scale, const float* mean, const float* invstd,
+                                      float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc /* 448 */,
+                                      hipStream_t stream) {
+  VS_REQUIRE(dy && z && x && dw && stats && coef && acc, "nhwc bn_bwd_first_from_dy: NULL argument");
+  const long long npix = (long long)B * T * F;
+  if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream)) return rc;
+  VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 448, stream));
+  const dim3 grid(stream_blocks(32, npix)), block(256);
+  hipLaunchKernelGGL(nhwc_bn_bwd_first_kernel<VS_ACT_NONE>, grid, block, 0, stream, reinterpret_cast<const u4v*>(dy), reinterpret_cast<const u4v*>(z),
+                     x, npix, F, scale, scale, coef, acc);
+  hipLaunchKernelGGL(nhwc_cvt_f64_f32_kernel, dim3(2), dim3(256), 0, stream, acc, dw, 448);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
 // cnn1: the same backward with pass 2 contracted against the input on the spot: dw [64][7] (dz1 is not written)
 int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x, int B, int T, int F, int act, int train,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
@@ -464,14 +528,24 @@ int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x,
 
 // cnn8 backward: dz8 [B][T][8][F] fp32, a7 [B][T][F][64] bf16 -> din (bf16, same layout as a7) and dw [8][64];
 // part: VS_NHWC_LAST_BWD_BLOCKS x 512 floats of scratch
+// z7 != NULL: din is dy7 = da7 * act'(z7 * bn_scale + bn_shift) and bn_stats ([VS_BN_STAT_SLOTS][64][2] doubles, zeroed
+// by the caller) receives the sums the BatchNorm backward of cnn7 starts from (vs_nhwc_bn_bwd_from_dy_impl)
 int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7, void* din, float* part, float* dw,
-                               int B, int T, int F, hipStream_t stream) {
+                               int B, int T, int F, const void* z7, int act, const float* bn_scale, const float* bn_shift,
+                               const float* bn_mean, const float* bn_invstd, double* bn_stats, hipStream_t stream) {
   VS_REQUIRE(dz8 && w && a7 && din && part && dw, "nhwc conv_last_bwd: NULL argument");
+  VS_REQUIRE(!z7 || (bn_scale && bn_shift && bn_mean && bn_invstd && bn_stats), "nhwc conv_last_bwd: the dy form needs the BatchNorm constants and statistics slots");
   const long long npix = (long long)B * T * F;
   long long nb = (npix + 31) / 32;
   if (nb > VS_NHWC_LAST_BWD_BLOCKS) nb = VS_NHWC_LAST_BWD_BLOCKS;
-  hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dz8, w, reinterpret_cast<const u4v*>(a7),
-                     reinterpret_cast<u4v*>(din), part, npix, F);
+  const LastBwdBn bn{reinterpret_cast<const u4v*>(z7), bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats};
+  const dim3 grid((unsigned)nb), block(256);
+  const u4v* a = reinterpret_cast<const u4v*>(a7);
+  u4v* o = reinterpret_cast<u4v*>(din);
+  if (!z7) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<-1>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
+  else if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<VS_ACT_RELU>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
+  else VS_REQUIRE(false, "nhwc conv_last_bwd: dy form for activation %d", act);
   VS_LAUNCH_CHECK();
   return vs_reduce_partials_impl(part, (int)nb, 512, dw, stream);
 }

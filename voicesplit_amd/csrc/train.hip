@@ -478,11 +478,20 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     const long long npix = (long long)B * T * F;
     void* gb[2] = {at<void>(tape, L.grad0), at<void>(tape, L.grad1)};
     int c = 0;
+    // Every kernel that produces a layer's input gradient (cnn8's backward, the data-gradient convs) applies the
+    // activation derivative of the layer below on the spot and accumulates the BatchNorm backward sums (the dy forms):
+    // the BatchNorm backward proper is then finalize + one pass.
+    auto zero_stats = [&]() -> int {
+      VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+      return 0;
+    };
     {
       VsProfScope ps(VS_PROF_BWD_EDGE, stream);
+      if (int rc = zero_stats()) return rc;
       // partial sums in the idle second gradient buffer: `part` may still be in use by the LSTM leaf GEMMs on the side stream
       if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
-                                              g->conv[7].weight, B, T, F, stream)) return rc;
+                                              g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
+                                              mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
     }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
@@ -490,9 +499,9 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       const int l = i + 1;
       {
         VsProfScope ps(VS_PROF_BWD_BN, stream);
-        if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
-                                             mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                             stats, coef, stream)) return rc;
+        if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
+                                                 invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
+                                                 stats, coef, stream)) return rc;
       }
       if (pending) {                 // the previous layer's weight gradient still reads the buffer this data gradient writes
         VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
@@ -501,8 +510,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       {
         VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
         if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, pack_t, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
-        if (int rc = vs_nhwc_conv_impl(gb[c], pack_t, ones, zeros, gb[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE,
-                                       nullptr, stream)) return rc;
+        if (int rc = zero_stats()) return rc;
+        if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
+                                          shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
+                                          B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
       }
       hipStream_t ws = stream;
       if (side) {
@@ -526,9 +537,9 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
     }
     VsProfScope ps(VS_PROF_BWD_BN, stream);
-    return vs_nhwc_bn_act_bwd_first_impl(gb[c], at<void>(tape, L.z[0]), x, B, T, F, conv_act, train, scale, shift, mean, invstd,
-                                         g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight, stats, coef,
-                                         at<double>(tape, L.first_acc), stream);
+    return vs_nhwc_bn_bwd_first_from_dy_impl(gb[c], at<void>(tape, L.z[0]), x, B, T, F, train, scale, mean, invstd,
+                                             g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight, stats, coef,
+                                             at<double>(tape, L.first_acc), stream);
   }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;

@@ -88,7 +88,18 @@ int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x,
                                   float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, hipStream_t);
 #define VS_NHWC_LAST_BWD_BLOCKS 1024
 int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7, void* din, float* part, float* dw,
-                               int B, int T, int F, hipStream_t);
+                               int B, int T, int F, const void* z7, int act, const float* bn_scale, const float* bn_shift,
+                               const float* bn_mean, const float* bn_invstd, double* bn_stats, hipStream_t stream);
+int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const void* z, int act,
+                         const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_stats,
+                         int B, int T, int F, int KT, int KF, int dil, hipStream_t stream);
+int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long long npix, int train,
+                                const float* scale, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream);
+int vs_nhwc_bn_bwd_first_from_dy_impl(const void* dy, const void* z, const float* x, int B, int T, int F, int train,
+                                      const float* scale, const float* mean, const float* invstd,
+                                      float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc,
+                                      hipStream_t stream);
 // conv_bwd.hip: coefficients of the BatchNorm backward apply pass from the folded sums
 int vs_bn_bwd_finalize_impl(double* stats, int slots, double count, int train, int C, const float* scale, const float* mean,
                             const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t);

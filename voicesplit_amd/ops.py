@@ -657,6 +657,16 @@ def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = Fal
     return (out, st.sum(0)) if stats else out
 
 
+def nhwc_conv_pack(w, transpose_flip: bool = False):
+    """w [64,64,KT,KF] fp32 -> the register-fragment order vs_nhwc_conv / vs_nhwc_conv_dy take (uint8 tensor)."""
+    lib = _lib.load()
+    _dev_check(w, "w")
+    KT, KF = w.shape[2], w.shape[3]
+    packed = torch.empty(lib.vs_nhwc_conv_packed_bytes(KT, KF), dtype=torch.uint8, device=w.device)
+    check(lib.vs_nhwc_conv_pack(_p(w), _p(packed), KT, KF, int(transpose_flip), _stream()), "vs_nhwc_conv_pack")
+    return packed
+
+
 def nhwc_conv_first(x, w, scale, shift, act: str, stats: bool = False):
     """cnn1: x [B,T,F] fp32, w [64,1,1,7] -> act(conv * scale + shift) as [B,T,F,64] bf16 (+ [64,2] statistics)."""
     lib = _lib.load()
@@ -743,6 +753,65 @@ def nhwc_conv_last_bwd(dz8, w, a7):
     dw = torch.empty(8, 64, dtype=torch.float32, device=a7.device)
     check(lib.vs_nhwc_conv_last_bwd(_p(dz8), _p(w), _p(a7), _p(din), _p(part), _p(dw), B, T, F, _stream()), "vs_nhwc_conv_last_bwd")
     return din, dw
+
+
+def nhwc_conv_dy(dz, packed, z, act: str, bn_scale, bn_shift, bn_mean, bn_invstd, KT: int, KF: int, dil: int):
+    """Data gradient with the dy epilogue: dz [B,T,F,64] bf16, packed = transposed/flipped weights, z = the lower layer's
+    conv output -> (dy bf16, stats [64 slots, 64, 2] float64 with the per-channel sums of dy and dy * xhat)."""
+    lib = _lib.load()
+    _dev_check(dz, "dz", torch.bfloat16)
+    _dev_check(z, "z", torch.bfloat16)
+    B, T, F, _ = dz.shape
+    dy = torch.empty_like(dz)
+    stats = torch.zeros(64, 64, 2, dtype=torch.float64, device=dz.device)
+    check(lib.vs_nhwc_conv_dy(_p(dz), _p(packed), _p(dy), _p(z), ACT_CODES[act], _p(bn_scale), _p(bn_shift), _p(bn_mean), _p(bn_invstd),
+                              _p(stats), B, T, F, KT, KF, dil, _stream()), "vs_nhwc_conv_dy")
+    return dy, stats
+
+
+def nhwc_conv_last_bwd_dy(dz8, w, a7, z7, act: str, bn_scale, bn_shift, bn_mean, bn_invstd):
+    """cnn8 backward with the dy epilogue -> (dy7 bf16, dw [8,64], stats)."""
+    lib = _lib.load()
+    _dev_check(dz8, "dz8")
+    _dev_check(a7, "a7", torch.bfloat16)
+    _dev_check(z7, "z7", torch.bfloat16)
+    B, T, F, _ = a7.shape
+    dy = torch.empty_like(a7)
+    part = torch.empty(lib.vs_nhwc_conv_last_bwd_blocks() * 512, dtype=torch.float32, device=a7.device)
+    dw = torch.empty(8, 64, dtype=torch.float32, device=a7.device)
+    stats = torch.zeros(64, 64, 2, dtype=torch.float64, device=a7.device)
+    check(lib.vs_nhwc_conv_last_bwd_dy(_p(dz8), _p(w), _p(a7), _p(dy), _p(part), _p(dw), _p(z7), ACT_CODES[act], _p(bn_scale), _p(bn_shift),
+                                       _p(bn_mean), _p(bn_invstd), _p(stats), B, T, F, _stream()), "vs_nhwc_conv_last_bwd_dy")
+    return dy, dw, stats
+
+
+def nhwc_bn_bwd_from_dy(dy, z, stats, training: bool, scale, mean, invstd):
+    """Second pass of the BatchNorm backward from dy and its sums -> (dz bf16, dgamma, dbeta, dbias)."""
+    lib = _lib.load()
+    _dev_check(dy, "dy", torch.bfloat16)
+    _dev_check(z, "z", torch.bfloat16)
+    dev = z.device
+    dz = torch.empty_like(dy)
+    dg, db, dbias = (torch.empty(64, dtype=torch.float32, device=dev) for _ in range(3))
+    coef = torch.empty(192, dtype=torch.float32, device=dev)
+    check(lib.vs_nhwc_bn_bwd_from_dy(_p(dy), _p(z), _p(dz), z.numel() // 64, BN_TRAIN if training else BN_EVAL, _p(scale), _p(mean),
+                                     _p(invstd), _p(dg), _p(db), _p(dbias), _p(stats), _p(coef), _stream()), "vs_nhwc_bn_bwd_from_dy")
+    return dz, dg, db, dbias
+
+
+def nhwc_bn_bwd_first_from_dy(dy, z, x, stats, training: bool, scale, mean, invstd):
+    """cnn1, from dy -> (dw [64,7], dgamma, dbeta, dbias)."""
+    lib = _lib.load()
+    dev = z.device
+    B, T, F = x.shape
+    dg, db, dbias = (torch.empty(64, dtype=torch.float32, device=dev) for _ in range(3))
+    dw = torch.empty(64, 7, dtype=torch.float32, device=dev)
+    coef = torch.empty(192, dtype=torch.float32, device=dev)
+    acc = torch.empty(448, dtype=torch.float64, device=dev)
+    check(lib.vs_nhwc_bn_bwd_first_from_dy(_p(dy), _p(z), _p(x), B, T, F, BN_TRAIN if training else BN_EVAL, _p(scale), _p(mean),
+                                           _p(invstd), _p(dg), _p(db), _p(dbias), _p(dw), _p(stats), _p(coef), _p(acc), _stream()),
+          "vs_nhwc_bn_bwd_first_from_dy")
+    return dw, dg, db, dbias
 
 
 def gemm_bf16(A, B, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, rowbias=None, group: int = 1,
