@@ -108,8 +108,9 @@ struct ConvWalk {
   const NhwcConvArgs& a;
   int lane, wave, n, g;
   vs_bf16x8 wf[NTAP][2];
-  float sc[4], sh[4], s1[4], s2[4];
-  f2v ksc[2], ksh[2], d1[2], d2[2];          // DY: scale / shift of this lane's 4 channels times log2(e), as channel pairs; sums
+  // This lane's 4 output channels as two pairs (packed fp32 math in the epilogue).  csc / csh: the epilogue's scale and
+  // shift; DY: the BatchNorm scale / shift of the layer below, times log2(e).  a1 / a2: the two per-channel sums.
+  f2v csc[2], csh[2], a1[2], a2[2];
   int boff[KF];
   unsigned vcol[NB];
   __amdgpu_buffer_rsrc_t rout, rz;
@@ -130,16 +131,11 @@ struct ConvWalk {
       for (int kc = 0; kc < 2; ++kc) wf[tap][kc] = __builtin_bit_cast(vs_bf16x8, wp[(tap * 2 + kc) * 64]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sc[r] = a.scale[wave * 16 + g * 4 + r];
-      sh[r] = a.shift[wave * 16 + g * 4 + r];
-      s1[r] = 0.f;
-      s2[r] = 0.f;
-      if (DY) {
-        ksc[r >> 1][r & 1] = a.bn2_scale[wave * 16 + g * 4 + r] * kLog2e;
-        ksh[r >> 1][r & 1] = a.bn2_shift[wave * 16 + g * 4 + r] * kLog2e;
-        d1[r >> 1][r & 1] = 0.f;
-        d2[r >> 1][r & 1] = 0.f;
-      }
+      const int ch = wave * 16 + g * 4 + r;
+      csc[r >> 1][r & 1] = DY ? a.bn2_scale[ch] * kLog2e : a.scale[ch];
+      csh[r >> 1][r & 1] = DY ? a.bn2_shift[ch] * kLog2e : a.shift[ch];
+      a1[r >> 1][r & 1] = 0.f;
+      a2[r >> 1][r & 1] = 0.f;
     }
 #pragma unroll
     for (int df = 0; df < KF; ++df) {
@@ -219,7 +215,7 @@ struct ConvWalk {
   struct GroupState {
     f32x4 acc[RV][NB];
     vs_bf16x8 bq[3];
-    float y[NB][4];
+    f2v y[NB][2];                      // the finished row's values on their way to the store (channel pairs)
     u2v zq[3][NB];                     // DY: z of the output row being finished and the next two (4 channels of one pixel each)
     float cok[NB], mk[NB];             // DY: 1 for a column inside the image, else 0; the same for the row being finished
     f2v tz, ty, tu, tn, tr, tw;        // DY: one channel pair in flight through the stages of the activation derivative
@@ -228,8 +224,8 @@ struct ConvWalk {
   // micro-ops of one output row.  Plain: NB*4 values + NB stores.  DY: z loads of a later row, NB*2 channel pairs x NSTAGE
   // stages (packed fp32 math: one v_pk_* per two channels; at most three of them or one transcendental per micro-op, which
   // is what fits behind one MFMA without holding up the next), NB stores.
-  static constexpr int NSTAGE = 9;
-  static constexpr int NMICRO = DY ? 1 + NB * 2 * NSTAGE + NB : NB * 4 + NB;
+  static constexpr int NSTAGE = DY ? 9 : ACT == VS_ACT_MISH ? 7 : 1;
+  static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + NB;
 
   template <int RV>
   __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
@@ -252,14 +248,16 @@ struct ConvWalk {
   template <int RV>
   __device__ __forceinline__ void store_px(const Item& x, GroupState<RV>& st, int r, int nb2) {
     const int k = st.ro + r;
-    const int col = x.strip * STRIP + nb2 * 16 + n;
-    const bool ok = (k < x.o1) & (col < a.F);
     if (STATS && !DY) {
-      const float m = ok ? 1.f : 0.f;
+      const float m = ((k < x.o1) & (vcol[nb2] != kOob)) ? 1.f : 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { const float ym = st.y[nb2][c] * m; s1[c] += ym; s2[c] = fmaf(ym, st.y[nb2][c], s2[c]); }
+      for (int pr = 0; pr < 2; ++pr) {
+        const f2v ym = st.y[nb2][pr] * m;
+        a1[pr] += ym;
+        a2[pr] = __builtin_elementwise_fma(ym, st.y[nb2][pr], a2[pr]);
+      }
     }
-    const u2v pk = {vs_pack_bf16(st.y[nb2][0], st.y[nb2][1]), vs_pack_bf16(st.y[nb2][2], st.y[nb2][3])};
+    const u2v pk = {vs_pack_bf16(st.y[nb2][0].x, st.y[nb2][0].y), vs_pack_bf16(st.y[nb2][1].x, st.y[nb2][1].y)};
     __builtin_amdgcn_raw_buffer_store_b64(pk, rout, vcol[nb2], row_offset(x, k), 0);                               // out of range: dropped
   }
 
@@ -267,11 +265,32 @@ struct ConvWalk {
   template <int RV, int r, int q>
   __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
     if constexpr (!DY) {
-      if constexpr (q < NB * 4) {
-        constexpr int nb2 = q / 4, c = q % 4;
-        st.y[nb2][c] = vs_act_fast<ACT>(fmaf(st.acc[r][nb2][c], sc[c], sh[c]));
+      // out = act(acc * scale + shift).  Mish(y) = y n / (n + 2), n = u (u + 2), u = e^y (y clamped at 20, where n / (n + 2)
+      // is 1 to fp32): one exp2 and one rcp per channel, everything else packed, cut into stages like the dy form below
+      if constexpr (q < NB * 2 * NSTAGE) {
+        constexpr int v = q / NSTAGE, sg = q % NSTAGE, nb2 = v / 2, pr = v % 2;
+        if constexpr (sg == 0) {
+          const f2v acc2 = {st.acc[r][nb2][2 * pr], st.acc[r][nb2][2 * pr + 1]};
+          f2v y = __builtin_elementwise_fma(acc2, csc[pr], csh[pr]);
+          if constexpr (ACT == VS_ACT_RELU) y = f2v{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+          st.y[nb2][pr] = y;
+          if constexpr (ACT == VS_ACT_MISH) st.ty = f2v{fminf(y.x, 20.0f), fminf(y.y, 20.0f)} * kLog2e;
+        } else if constexpr (sg == 1) {
+          st.tu.x = __builtin_amdgcn_exp2f(st.ty.x);
+        } else if constexpr (sg == 2) {
+          st.tu.y = __builtin_amdgcn_exp2f(st.ty.y);
+        } else if constexpr (sg == 3) {
+          st.tn = st.tu * (st.tu + 2.0f);
+          st.tw = st.tn + 2.0f;
+        } else if constexpr (sg == 4) {
+          st.tr.x = __builtin_amdgcn_rcpf(st.tw.x);
+        } else if constexpr (sg == 5) {
+          st.tr.y = __builtin_amdgcn_rcpf(st.tw.y);
+        } else {
+          st.y[nb2][pr] = st.y[nb2][pr] * (st.tn * st.tr);
+        }
       } else {
-        store_px<RV>(x, st, r, q - NB * 4);
+        store_px<RV>(x, st, r, q - NB * 2 * NSTAGE);
       }
     } else {
       // dy = da * act'(y), y = z * scale + shift.  Mish'(y) with u = e^y, n = u (u + 2), r = 1 / (n + 2):
@@ -289,7 +308,7 @@ struct ConvWalk {
         if constexpr (sg == 0) {
           const unsigned u = st.zq[r % 3][nb2][pr];
           st.tz = f2v{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-          st.ty = __builtin_elementwise_fma(st.tz, ksc[pr], ksh[pr]);
+          st.ty = __builtin_elementwise_fma(st.tz, csc[pr], csh[pr]);
         } else if constexpr (sg == 1) {
           if constexpr (mish) {
             st.ty = f2v{fminf(st.ty.x, 20.0f * kLog2e), fminf(st.ty.y, 20.0f * kLog2e)};
@@ -324,10 +343,9 @@ struct ConvWalk {
           }
         } else {
           const f2v dm = st.ty * st.mk[nb2];
-          d1[pr] += dm;
-          d2[pr] = __builtin_elementwise_fma(dm, st.tz, d2[pr]);
-          st.y[nb2][2 * pr] = st.ty.x;
-          st.y[nb2][2 * pr + 1] = st.ty.y;
+          a1[pr] += dm;
+          a2[pr] = __builtin_elementwise_fma(dm, st.tz, a2[pr]);
+          st.y[nb2][pr] = st.ty;
         }
       } else {
         store_px<RV>(x, st, r, q - 1 - NB * 2 * NSTAGE);
@@ -411,10 +429,9 @@ struct ConvWalk {
 
   __device__ __forceinline__ void flush_stats() {
     if (!(STATS || DY) || a.bn_stats == nullptr) return;
-    if (DY) {
+    float s1[4], s2[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[r] = d1[r >> 1][r & 1]; s2[r] = d2[r >> 1][r & 1]; }
-    }
+    for (int r = 0; r < 4; ++r) { s1[r] = a1[r >> 1][r & 1]; s2[r] = a2[r >> 1][r & 1]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll

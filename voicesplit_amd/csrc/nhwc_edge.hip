@@ -91,27 +91,29 @@ __global__ __launch_bounds__(256)
 void nhwc_bn_apply_kernel(const u4v* __restrict__ z, u4v* __restrict__ a, const float* __restrict__ scale,
                           const float* __restrict__ shift, long long npieces) {
   const int piece = threadIdx.x & 7;
-  float sc[8], sh[8];
+  vs_f32x2 sc[4], sh[4];                                   // the lane's 8 channels as the 4 pairs its 32-bit words hold
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[piece * 8 + j]; sh[j] = shift[piece * 8 + j]; }
+  for (int q = 0; q < 4; ++q) {
+    sc[q] = vs_f32x2{scale[piece * 8 + 2 * q], scale[piece * 8 + 2 * q + 1]};
+    sh[q] = vs_f32x2{shift[piece * 8 + 2 * q], shift[piece * 8 + 2 * q + 1]};
+  }
   const long long stride = (long long)gridDim.x * 256;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   auto apply = [&](const u4v v) {
     u4v o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float lo = vs_act_fast<ACT>(fmaf(bf_lo(v[q]), sc[2 * q], sh[2 * q]));
-      const float hi = vs_act_fast<ACT>(fmaf(bf_hi(v[q]), sc[2 * q + 1], sh[2 * q + 1]));
-      o[q] = vs_pack_bf16(lo, hi);
+      const vs_f32x2 y = vs_act_fast2<ACT>(__builtin_elementwise_fma(vs_f32x2{bf_lo(v[q]), bf_hi(v[q])}, sc[q], sh[q]));
+      o[q] = vs_pack_bf16(y.x, y.y);
     }
     return o;
   };
   for (; i + stride < npieces; i += 2 * stride) {         // two pieces in flight per lane
     const u4v v0 = __builtin_nontemporal_load(z + i), v1 = __builtin_nontemporal_load(z + i + stride);
-    a[i] = apply(v0);
-    a[i + stride] = apply(v1);
+    __builtin_nontemporal_store(apply(v0), a + i);
+    __builtin_nontemporal_store(apply(v1), a + i + stride);
   }
-  if (i < npieces) a[i] = apply(__builtin_nontemporal_load(z + i));
+  if (i < npieces) __builtin_nontemporal_store(apply(__builtin_nontemporal_load(z + i)), a + i);
 }
 
 // ---- cnn8 + transpose/view ---------------------------------------------------------------------------------------
@@ -231,10 +233,10 @@ void nhwc_bn_bwd_apply_kernel(const u4v* da, const u4v* __restrict__ z, u4v* dz,
   for (; i + stride < npieces; i += 2 * stride) {
     const u4v g0 = __builtin_nontemporal_load(da + i), v0 = __builtin_nontemporal_load(z + i);
     const u4v g1 = __builtin_nontemporal_load(da + i + stride), v1 = __builtin_nontemporal_load(z + i + stride);
-    dz[i] = apply(g0, v0);
-    dz[i + stride] = apply(g1, v1);
+    __builtin_nontemporal_store(apply(g0, v0), dz + i);
+    __builtin_nontemporal_store(apply(g1, v1), dz + i + stride);
   }
-  if (i < npieces) dz[i] = apply(__builtin_nontemporal_load(da + i), __builtin_nontemporal_load(z + i));
+  if (i < npieces) __builtin_nontemporal_store(apply(__builtin_nontemporal_load(da + i), __builtin_nontemporal_load(z + i)), dz + i);
 }
 
 // cnn1: pass 2 fused with the 1x7 weight gradient: dz1 = cA dy + cB z + cC is contracted with the 7 shifted inputs on

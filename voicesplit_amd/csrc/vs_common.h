@@ -77,6 +77,25 @@ __device__ __forceinline__ float vs_mish_fast(float x) {
   return x > 20.0f ? x : y;
 }
 
+// Two channels at a time: on gfx950 v_pk_mul/add/fma_f32 do two fp32 lanes' worth per issue slot, so everything but the
+// exp2 / rcp of the pair costs half.  No select for x > 20: n / (n + 2) is exactly 1 in fp32 at the clamp.
+typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vs_f32x2 vs_mish_fast2(vs_f32x2 x) {
+  const vs_f32x2 e = vs_f32x2{fminf(x.x, 20.0f), fminf(x.y, 20.0f)} * 1.44269504088896340736f;
+  const vs_f32x2 u = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+  const vs_f32x2 n = u * (u + 2.0f);
+  const vs_f32x2 d = n + 2.0f;
+  const vs_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return x * (n * r);
+}
+
+template <int ACT>
+__device__ __forceinline__ vs_f32x2 vs_act_fast2(vs_f32x2 v) {
+  if (ACT == VS_ACT_MISH) return vs_mish_fast2(v);
+  if (ACT == VS_ACT_RELU) return vs_f32x2{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
+  return v;
+}
+
 template <int ACT>
 __device__ __forceinline__ float vs_act_fast(float v) {
   if (ACT == VS_ACT_MISH) return vs_mish_fast(v);

@@ -18,6 +18,7 @@
 // for the whole launch.  Per output row: 4 dz fragments (shared by all its taps) + one a fragment per tap -> 4 MFMAs
 // per a fragment (0.65 8-byte LDS reads per MFMA).  Partial sums go to part[pair][co][ci][tap]; vs_reduce_partials
 // adds the pairs.
+#include <cstdlib>
 #include <utility>
 
 #include "vs_internal.h"
@@ -39,6 +40,8 @@ struct WgradArgs {
   float* part;                      // [pairs][64 co][64 ci][taps]
   int B, T, F, dil;
   int nstrip, nseg, seg_rows, n_items;
+  int abl;                          // VS_ABLATION builds only (tools/wgrad_ablation.py): selects a timing-ablation instance
+                                    // (1 = no DMA after a workgroup's first groups, 2 = no LDS fragment reads, 4 = no MFMAs; results are wrong)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
@@ -154,31 +157,178 @@ struct WgradWalk {
   }
 };
 
+// Which (window row, column shift) fragments a wave reads and what it does with each.  A wave owns taps [T0, T0 + NTW) of
+// the row-major tap order, i.e. the time offsets dt in [DTLO, DTHI] (the first / last of them possibly for a subset of
+// the column shifts).  The a fragment of window row w, shift df is the operand of EVERY owned tap (dt, df) -- for output
+// row w - dt -- so the group is walked by window rows: one fragment read feeds up to DTN x 4 MFMAs (the walk by output
+// rows read it once per tap: 4 MFMAs, and the kernel sat on the LDS read port).  The dz fragments of the DTN output rows in
+// play stay in registers (ring of DTN + 1 rows x 4 co blocks).
 template <int KT, int KF, int TH>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* smem) {
+struct WSched {
   using G = WGeo<KT, KF>;
-  constexpr int P = G::P, H = G::H, NTAP = G::NTAP;
-  constexpr int T0 = TH ? G::NT0 : 0, NTW = TH ? NTAP - G::NT0 : G::NT0;     // first tap / number of taps of this wave
-  WgradWalk<KT, KF> wk(a, smem);
-  const int lane = wk.lane, g = lane >> 4, i = lane & 15, cbi = wk.wave & 1;
-  const unsigned lds0 = wk.lds0;
+  static constexpr int NTAP = G::NTAP, H = G::H;
+  static constexpr int T0 = TH ? G::NT0 : 0, NTW = TH ? NTAP - G::NT0 : G::NT0;
+  static constexpr int DTLO = T0 / KF, DTHI = (T0 + NTW - 1) / KF, DTN = DTHI - DTLO + 1, ZR = DTN + 1;
+  static constexpr bool owned(int dt, int df) { const int t = dt * KF + df; return dt >= DTLO && dt <= DTHI && t >= T0 && t < T0 + NTW; }
+  // does fragment (w, df) feed any MFMA of a group of RV output rows?
+  static constexpr bool valid(int RV, int w, int df) {
+    for (int dt = DTLO; dt <= DTHI; ++dt)
+      if (owned(dt, df) && w - dt >= 0 && w - dt < RV) return true;
+    return false;
+  }
+  static constexpr int nsteps(int RV) {
+    int n = 0;
+    for (int w = 0; w < RV + H; ++w)
+      for (int df = 0; df < KF; ++df) n += valid(RV, w, df) ? 1 : 0;
+    return n;
+  }
+  static constexpr int step_at(int RV, int s) {                   // w * KF + df of step s
+    int n = 0;
+    for (int w = 0; w < RV + H; ++w)
+      for (int df = 0; df < KF; ++df)
+        if (valid(RV, w, df)) { if (n == s) return w * KF + df; ++n; }
+    return -1;
+  }
+  static constexpr int steps_of_row(int RV, int w) { int n = 0; for (int df = 0; df < KF; ++df) n += valid(RV, w, df) ? 1 : 0; return n; }
+  static constexpr int rank_in_row(int RV, int w, int df) { int n = 0; for (int d = 0; d < df; ++d) n += valid(RV, w, d) ? 1 : 0; return n; }
+};
+
+template <int KT, int KF, int TH, int ABL>
+struct WgradCore {
+  using G = WGeo<KT, KF>;
+  using S = WSched<KT, KF, TH>;
+  static constexpr int NTW = S::NTW, T0 = S::T0, ZR = S::ZR;
 
   f32x4 acc[4][NTW];
+  unsigned aoff[KF][2], zoff[4][2];
+  unsigned lds0;
+  static constexpr int abl = ABL;      // VS_ABLATION instances: 1 = no DMA after the first groups, 2 = no fragment reads, 4 = no MFMAs
+
+  struct GroupRegs {
+    s4v bq[3][2];
+    s4v zf[ZR][4][2];
+    int cq, zq, rv;
+  };
+
+  __device__ __forceinline__ unsigned a_addr(const GroupRegs& gr, int w, int df, int hf) const {
+    int pos = gr.cq + w;
+    if (pos >= G::NRA) pos -= G::NRA;
+    return lds0 + (unsigned)(pos * G::AROWB) + aoff[df][hf];
+  }
+  __device__ __forceinline__ unsigned z_addr(const GroupRegs& gr, int r, int cb, int hf) const {
+    int pos = gr.zq + r;
+    if (pos >= G::NRZ) pos -= G::NRZ;
+    return lds0 + (unsigned)(G::A_BYTES + pos * G::ZROWB) + zoff[cb][hf];
+  }
+  template <int RV, int SI>
+  __device__ __forceinline__ void read_b(GroupRegs& gr) const {
+    constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
+    if constexpr (abl & 2) return;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) gr.bq[SI % 3][hf] = ds_read_tr16(a_addr(gr, w, df, hf));
+  }
+  template <int r, int cb>
+  __device__ __forceinline__ void read_z(GroupRegs& gr) const {
+    if constexpr (abl & 2) return;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) gr.zf[r % ZR][cb][hf] = ds_read_tr16(z_addr(gr, r, cb, hf));
+  }
+
+  // step SI of a group of RV rows: the read two steps ahead, this window row's share of the next output row's dz
+  // fragments, then the MFMAs of fragment SI
+  template <int RV, int SI>
+  __device__ __forceinline__ void step(GroupRegs& gr) {
+    constexpr int NS = S::nsteps(RV);
+    constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
+    if constexpr (SI + 2 < NS) read_b<RV, SI + 2>(gr);
+    // output row rn = w + 1 - DTLO is first used at window row w + 1: its 4 co blocks are spread over this row's steps
+    constexpr int rn = w + 1 - S::DTLO;
+    if constexpr (rn >= 1 && rn < RV) {
+      constexpr int nw = S::steps_of_row(RV, w), k = S::rank_in_row(RV, w, df);
+      if constexpr (0 % nw == k) read_z<rn, 0>(gr);
+      if constexpr (1 % nw == k) read_z<rn, 1>(gr);
+      if constexpr (2 % nw == k) read_z<rn, 2>(gr);
+      if constexpr (3 % nw == k) read_z<rn, 3>(gr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const vs_bf16x8 bfrag = frag_of(gr.bq[SI % 3][0], gr.bq[SI % 3][1]);
+    mfmas<RV, w, df>(gr, bfrag, std::make_integer_sequence<int, S::DTN>());
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int RV, int w, int df, int... Ds>
+  __device__ __forceinline__ void mfmas(GroupRegs& gr, const vs_bf16x8& bfrag, std::integer_sequence<int, Ds...>) {
+    (mfma4<RV, w, df, S::DTLO + Ds>(gr, bfrag), ...);
+  }
+  template <int RV, int w, int df, int dt>
+  __device__ __forceinline__ void mfma4(GroupRegs& gr, const vs_bf16x8& bfrag) {
+    constexpr int r = w - dt;
+    if constexpr (S::owned(dt, df) && r >= 0 && r < RV) {
+      constexpr int j = dt * KF + df - T0;
+      if (r < gr.rv && !(abl & 4)) {               // wave-uniform: the group's last rows may not exist (their dz rows are zeros either way)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(gr.zf[r % ZR][cb][0], gr.zf[r % ZR][cb][1]), bfrag, acc[cb][j], 0, 0, 0);
+      }
+    }
+  }
+  template <int RV, int... SIs>
+  __device__ __forceinline__ void steps(GroupRegs& gr, std::integer_sequence<int, SIs...>) {
+    (step<RV, SIs>(gr), ...);
+  }
+
+  // a group of rv <= R output rows (R, or the even tail of an item; a row past the item's end is a zero dz row).  ONE
+  // body with a wave-uniform guard per tap instead of one instance per row count: with several instances the
+  // accumulators, which live across groups, get a copy per instance (512 registers + spills).
+  __device__ __forceinline__ void group(int cq, int zq, int rv) {
+    constexpr int RV = R;
+    GroupRegs gr;
+    gr.cq = cq;
+    gr.zq = zq;
+    gr.rv = rv;
+    if constexpr (abl & 2) {          // no fragment reads: defined (not foldable) register contents instead
+      const short v = (short)(0x3c00 + (threadIdx.x & 7));
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { gr.bq[q][0] = s4v{v, v, v, v}; gr.bq[q][1] = s4v{v, v, v, v}; }
+#pragma unroll
+      for (int q = 0; q < ZR; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) { gr.zf[q][cb][0] = s4v{v, v, v, v}; gr.zf[q][cb][1] = s4v{v, v, v, v}; }
+    }
+    read_z<0, 0>(gr);
+    read_z<0, 1>(gr);
+    read_z<0, 2>(gr);
+    read_z<0, 3>(gr);
+    read_b<RV, 0>(gr);
+    if constexpr (S::nsteps(RV) > 1) read_b<RV, 1>(gr);
+    __builtin_amdgcn_sched_barrier(0);
+    steps<RV>(gr, std::make_integer_sequence<int, S::nsteps(RV)>());
+  }
+};
+
+template <int KT, int KF, int TH, int ABL>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* smem) {
+  using G = WGeo<KT, KF>;
+  constexpr int P = G::P, H = G::H;
+  WgradWalk<KT, KF> wk(a, smem);
+  WgradCore<KT, KF, TH, ABL> core;
+  constexpr int NTW = WgradCore<KT, KF, TH, ABL>::NTW, T0 = WgradCore<KT, KF, TH, ABL>::T0;
+  const int lane = wk.lane, g = lane >> 4, i = lane & 15, cbi = wk.wave & 1;
+  core.lds0 = wk.lds0;
+  int abl_groups = 0;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTW; ++t) core.acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane byte offsets of the transposing reads inside a row image, for both 4-pixel halves of a fragment.
   //   a image (64 bytes / pixel): pixel p = df + 8g + 4 half + i/4, unit (32 bytes) = cbi ^ bit3(p), + 8 (i%4)
   //   dz image (128 bytes / pixel): pixel p = 8g + 4 half + i/4, unit = cb ^ (bit1(p) | bit3(p) << 1), + 8 (i%4)
-  unsigned aoff[KF][2], zoff[4][2];
 #pragma unroll
   for (int df = 0; df < KF; ++df)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int p = df + 8 * g + 4 * hf + (i >> 2);
-      aoff[df][hf] = (unsigned)(p * 64 + ((cbi ^ ((p >> 3) & 1)) << 5) + (i & 3) * 8);
+      core.aoff[df][hf] = (unsigned)(p * 64 + ((cbi ^ ((p >> 3) & 1)) << 5) + (i & 3) * 8);
     }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
@@ -186,14 +336,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
     for (int hf = 0; hf < 2; ++hf) {
       const int p = 8 * g + 4 * hf + (i >> 2);
       const int u = ((p >> 1) & 1) | (((p >> 3) & 1) << 1);
-      zoff[cb][hf] = (unsigned)(p * 128 + ((cb ^ u) << 5) + (i & 3) * 8);
+      core.zoff[cb][hf] = (unsigned)(p * 128 + ((cb ^ u) << 5) + (i & 3) * 8);
     }
 
   // prefetch cursor (the group after the one being computed)
   WItem pf;
   // the two workgroups of a pair read the same dz rows and the two halves of the same a lines: they are blocks b and
   // b + 8, which the dispatcher places on the same XCD (block % 8), so the second read of a line is an L2 hit
-  // (pairs (2p, 2p+1) sat on different XCDs: 6.3 GB fetched per launch against 2.96 GB of operands)
+  // (pairs (2p, 2p+1) sat on different XCDs: 6.3 GB fetched per launch against 2.96 GB of operands; now 3.2 GB)
   const int pair = (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)), npairs = (int)(gridDim.x >> 1);
   int pf_it = pair, pf_g = 0;
   bool pf_live = false;
@@ -209,10 +359,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
     const int ro = pf.o0 + pf_g * R;
     const int first = pf_g == 0 ? 0 : H;
     const int nrows = G::WIN - first;
-    wk.issue_a(pf, ro - P + first, nrows, wp);
+    const bool dma = !(ABL & 1) || abl_groups++ < 2;
+    if (dma) wk.issue_a(pf, ro - P + first, nrows, wp);
     wp += nrows;
     if (wp >= G::NRA) wp -= G::NRA;
-    wk.issue_z(pf, ro, zwp);
+    if (dma) wk.issue_z(pf, ro, zwp);
     zwp += R;
     if (zwp >= G::NRZ) zwp -= G::NRZ;
     if (++pf_g >= pf.ngroups) { pf_it += npairs; pf_seek(); }
@@ -231,63 +382,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
       const bool pf_new_item = pf_live && pf_g == 0;
       if (pf_live) pf_issue();
       const int left = cur.o1 - (cur.o0 + gidx * R);
-      const int rv = left > 6 ? 8 : left > 4 ? 6 : left > 2 ? 4 : 2;     // rows of this group (even; a row past o1 is a zero dz row)
-
-      // ---- the group: rv output rows x NTW taps; pinned order: fragment reads two taps ahead, 4 MFMAs per tap ----
-      auto a_frag_addr = [&](int r, int tp, int hf) {       // a fragment of output row r, tap tp (compile-time r, tp)
-        const int dt = tp / KF, df = tp - dt * KF;
-        int pos = cq + r + dt;
-        if (pos >= G::NRA) pos -= G::NRA;
-        return lds0 + (unsigned)(pos * G::AROWB) + aoff[df][hf];
-      };
-      auto z_frag_addr = [&](int r, int cb, int hf) {
-        int pos = zq + r;
-        if (pos >= G::NRZ) pos -= G::NRZ;
-        return lds0 + (unsigned)(G::A_BYTES + pos * G::ZROWB) + zoff[cb][hf];
-      };
-      s4v bq[3][2];
-      s4v zf[2][4][2];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) zf[0][cb][hf] = ds_read_tr16(z_frag_addr(0, cb, hf));
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) bq[s][hf] = ds_read_tr16(a_frag_addr(s / NTW, T0 + s % NTW, hf));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r < rv) {
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            const int s = r * NTW + j;
-            // reads two taps ahead (possibly of the next row); the next row's dz fragments early in this row
-            const int s2 = s + 2, r2 = s2 / NTW, j2 = s2 - r2 * NTW;
-            if (r2 < rv) {
-#pragma unroll
-              for (int hf = 0; hf < 2; ++hf) bq[s2 % 3][hf] = ds_read_tr16(a_frag_addr(r2, T0 + j2, hf));
-            }
-            // the next row's dz fragments: one co block per step of this row, whatever is left in its last step
-            // (a wave of the 7x1 layer has only 3 or 4 taps = steps per row)
-            if (r + 1 < rv) {
-#pragma unroll
-              for (int cb = 0; cb < 4; ++cb) {
-                if (cb == j || (j == NTW - 1 && cb > j)) {
-#pragma unroll
-                  for (int hf = 0; hf < 2; ++hf) zf[(r + 1) & 1][cb][hf] = ds_read_tr16(z_frag_addr(r + 1, cb, hf));
-                }
-              }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const vs_bf16x8 bfrag = frag_of(bq[s % 3][0], bq[s % 3][1]);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-              acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(zf[r & 1][cb][0], zf[r & 1][cb][1]), bfrag, acc[cb][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
+      core.group(cq, zq, left > 6 ? 8 : left > 4 ? 6 : left > 2 ? 4 : 2);
       if (gidx + 1 < cur.ngroups) {
         cq += R; if (cq >= G::NRA) cq -= G::NRA;
       } else if (pf_new_item) {
@@ -307,18 +402,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = 16 * cb + 4 * g + q;
-        dst[((size_t)co * 64 + ci) * G::NTAP + T0 + j] = acc[cb][j][q];
+        dst[((size_t)co * 64 + ci) * G::NTAP + T0 + j] = core.acc[cb][j][q];
       }
 }
 
-template <int KT, int KF>
+template <int KT, int KF, int ABL = 0>
 __global__ __launch_bounds__(256, 1)
 void nhwc_wgrad_kernel(WgradArgs a) {
   using G = WGeo<KT, KF>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
   const int th = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
-  if (th == 0) wgrad_body<KT, KF, 0>(a, (const lds_byte*)smem);
-  else wgrad_body<KT, KF, 1>(a, (const lds_byte*)smem);
+  if (th == 0) wgrad_body<KT, KF, 0, ABL>(a, (const lds_byte*)smem);
+  else wgrad_body<KT, KF, 1, ABL>(a, (const lds_byte*)smem);
 }
 
 int wg_num_cus() {
@@ -349,7 +444,16 @@ int launch_wgrad(WgradArgs a, float* dw, hipStream_t stream) {
   if (pairs > (n_items + 7) / 8 * 8) pairs = (n_items + 7) / 8 * 8;
   if (pairs > VS_NHWC_WGRAD_MAX_PAIRS) pairs = VS_NHWC_WGRAD_MAX_PAIRS;
   if (pairs < 8) pairs = 8;
+#ifdef VS_ABLATION
+  switch (a.abl) {
+#define VS_WG_CASE(N) case N: hipLaunchKernelGGL((nhwc_wgrad_kernel<KT, KF, N>), dim3((unsigned)(2 * pairs)), dim3(256), 0, stream, a); break;
+    VS_WG_CASE(1) VS_WG_CASE(2) VS_WG_CASE(3) VS_WG_CASE(4) VS_WG_CASE(5) VS_WG_CASE(6)
+#undef VS_WG_CASE
+    default: hipLaunchKernelGGL((nhwc_wgrad_kernel<KT, KF>), dim3((unsigned)(2 * pairs)), dim3(256), 0, stream, a);
+  }
+#else
   hipLaunchKernelGGL((nhwc_wgrad_kernel<KT, KF>), dim3((unsigned)(2 * pairs)), dim3(256), 0, stream, a);
+#endif
   VS_LAUNCH_CHECK();
   return vs_reduce_partials_impl(a.part, (int)pairs, 64 * 64 * G::NTAP, dw, stream);
 }
@@ -365,7 +469,10 @@ int vs_nhwc_wgrad_impl(const void* dz, const void* a_in, float* part, float* dw,
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "nhwc wgrad: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((reinterpret_cast<uintptr_t>(dz) & 15) == 0 && (reinterpret_cast<uintptr_t>(a_in) & 15) == 0, "nhwc wgrad: operands must be 16-byte aligned");
   WgradArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(a_in), part, B, T, F, dil,
-              (F + STRIP - 1) / STRIP, 1, 0, 0};
+              (F + STRIP - 1) / STRIP, 1, 0, 0, 0};
+#ifdef VS_ABLATION
+  if (const char* e = getenv("VOICESPLIT_WGRAD_ABL")) a.abl = atoi(e);
+#endif
   if (KT == 5 && KF == 5) return launch_wgrad<5, 5>(a, dw, stream);
   if (KT == 7 && KF == 1) return launch_wgrad<7, 1>(a, dw, stream);
   VS_REQUIRE(false, "nhwc wgrad: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
