@@ -29,8 +29,6 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
-__device__ u4v g_wg_zero_page[4];
-
 constexpr int STRIP = 32;
 constexpr int R = 8;
 
@@ -44,10 +42,18 @@ struct WgradArgs {
                                     // (1 = no DMA after a workgroup's first groups, 2 = no LDS fragment reads, 4 = no MFMAs; results are wrong)
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// LDS-DMA through a buffer descriptor: lane i of the wave moves 16 bytes from desc.base + voff (+ soff) to LDS
+// m0 + 16 i, and a lane whose offset is outside [0, desc.num_records) moves zeros -- the image border and the rows an
+// item does not own cost no address arithmetic: a row is one descriptor (base = the row, num_records = its bytes, or 0
+// for a row that does not exist) and the per-lane offset is a launch constant plus a wave-uniform column term.
+__device__ __forceinline__ void blds16(u4v desc, unsigned voff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ u4v row_desc(const void* base, long long byte_off, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base) + (unsigned long long)byte_off;
+  return u4v{(unsigned)p, (unsigned)(p >> 32) & 0xffffu, bytes, 0x00020000u};
 }
 
 // transposing LDS read: the 16 lanes of a group supply the addresses of a [4 rows][16 columns] block of halves
@@ -73,9 +79,13 @@ struct WGeo {
   static constexpr int ZROWB = STRIP * 128;              // a dz row: 32 pixels x 64 channels = 4 chunks
   static constexpr int ZCPR = 4;
   static constexpr int WIN = R + H;
-  static constexpr int NRA = 2 * WIN;                    // a ring rows
-  static constexpr int NRZ = 2 * R;                      // dz ring rows
-  static constexpr int A_BYTES = NRA * AROWB, LDS_BYTES = A_BYTES + NRZ * ZROWB;
+  // LDS: two window buffers of WIN a rows and two of R dz rows.  A group's rows sit at FIXED offsets of its buffer (the
+  // H rows it shares with the previous group are fetched again -- L2 hits -- instead of being kept in a ring), so every
+  // fragment read is base register + immediate: one wave per SIMD issues one instruction per 4 cycles, an address add
+  // in front of each read (+ the dependency on it) cost more issue time than the read (tools/issue_probe.hip).
+  static constexpr int ABUF = WIN * AROWB, ZBUF = R * ZROWB;
+  static constexpr int A_BYTES = 2 * ABUF, LDS_BYTES = A_BYTES + 2 * ZBUF;
+  static constexpr int NROWS = WIN + R;                  // DMA rows of a group: a rows 0..WIN-1, then dz rows
 };
 
 struct WItem { int b, cls, strip, o0, o1, nk, ngroups; };
@@ -94,6 +104,14 @@ struct WgradWalk {
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     h = (int)((blockIdx.x >> 3) & 1);
     lds0 = (unsigned)(uintptr_t)smem;
+    {
+      const int px = lane >> 2, q = lane & 3;                       // a chunk: 16 pixels x 4 pieces of this workgroup's half
+      va_lane = (px - PF) * 128 + ((4 * h + (q ^ (((px >> 3) & 1) << 1))) << 4);
+    }
+    {
+      const int px = lane >> 3, q = lane & 7;                       // dz chunk: 8 pixels x 8 pieces (bit3(px) is added per chunk)
+      vz_lane = px * 128 + ((q ^ (((px >> 1) & 1) << 1)) << 4);
+    }
   }
 
   __device__ __forceinline__ bool decode(int it, WItem& r) const {
@@ -111,50 +129,78 @@ struct WgradWalk {
     return true;
   }
 
-  // a rows [w_first, w_first + nrows) of the item's class -> ring positions pos_first.. (mod NRA).  LDS piece q (16 bytes,
-  // 4 per pixel) of pixel px holds channel piece q ^ (2 * bit3(px)) of this workgroup's half: rows px and px + 8 of a
-  // transposing read land on different bank halves.
-  __device__ __forceinline__ void issue_a(const WItem& x, int w_first, int nrows, int pos_first) const {
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_wg_zero_page);
-    const long long rel0 = reinterpret_cast<const unsigned char*>(a.a) - zp;
-    const long long row0 = (long long)x.b * a.T + x.cls;
-    const int nchunks = nrows * G::ACPR;
-    for (int c = wave; c < nchunks; c += 4) {
-      const int row = c / G::ACPR, part = c - row * G::ACPR;
-      const int w = w_first + row;
-      int pos = pos_first + row;
-      if (pos >= G::NRA) pos -= G::NRA;
-      const int e = part * 64 + lane;
-      const int px = e >> 2, q = e & 3;
-      const int col = x.strip * STRIP - PF + px;
-      const bool ok = (w >= 0) & (w < x.nk) & (px < G::APX) & (col >= 0) & (col < a.F);
-      const int piece = 4 * h + (q ^ (((px >> 3) & 1) << 1));
-      const long long off = rel0 + ((((row0 + (long long)w * a.dil) * a.F + col) << 7) + (piece << 4));
-      const unsigned char* src = zp + (off & -(long long)ok);
-      glds16(src, (unsigned)__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(pos * G::AROWB + part * 1024)));
-    }
-  }
+  // ---- DMA of one group's rows, one ROW per unit ------------------------------------------------------------------------
+  // a rows w_first .. w_first + WIN - 1 of the item's class -> a buffer `buf`, dz rows k_first .. k_first + R - 1 -> dz
+  // buffer `buf`; rows outside the image / outside [o0, o1) are zeros (descriptor with no records), columns outside the
+  // image likewise (range check).  Row rho of the NROWS = WIN + R rows belongs to wave rho % 4; a row is ONE descriptor,
+  // ONE M0 and its 1 KiB chunks by immediate offset (which moves the memory and the LDS address alike,
+  // tools/lds_dma_offset_probe.hip).  LDS images: a piece q (16 bytes, 4 per pixel) of pixel px holds channel piece
+  // q ^ (2 * bit3(px)) of this workgroup's half (rows px and px + 8 of a transposing read land on different bank halves);
+  // dz piece q (8 per pixel) of pixel px holds channel piece q ^ (2 u(px)), u = bit1(px) | bit3(px) << 1.
+  struct Batch {
+    long long row0;                // b * T + cls
+    int nk, o0, o1;
+    int w_first, k_first, buf;
+    int live;                      // 0: nothing to fetch
+    unsigned va, vz0, vz1;         // per-lane source offsets inside a row: a; dz chunks 0 / 2 and 1 / 3 (bit3(px) flips piece bit 2)
+  };
+  int va_lane, vz_lane;            // launch constants of the per-lane source offsets (set by the constructor)
 
-  // dz rows [k_first, k_first + R) -> dz ring rows zpos_first.. ; rows outside [o0, o1) of the item are zero.
-  // LDS piece q (8 per pixel) of pixel px holds channel piece q ^ (2 u(px)), u = bit1(px) | bit3(px) << 1.
-  __device__ __forceinline__ void issue_z(const WItem& x, int k_first, int zpos_first) const {
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_wg_zero_page);
-    const long long rel0 = reinterpret_cast<const unsigned char*>(a.dz) - zp;
-    const long long row0 = (long long)x.b * a.T + x.cls;
-    for (int c = wave; c < R * G::ZCPR; c += 4) {
-      const int row = c / G::ZCPR, part = c - row * G::ZCPR;
-      const int k = k_first + row;
-      int pos = zpos_first + row;
-      if (pos >= G::NRZ) pos -= G::NRZ;
-      const int px = part * 8 + (lane >> 3), q = lane & 7;
-      const int col = x.strip * STRIP + px;
-      const bool ok = (k >= x.o0) & (k < x.o1) & (col < a.F);
-      const int u = ((px >> 1) & 1) | (((px >> 3) & 1) << 1);
-      const long long off = rel0 + ((((row0 + (long long)k * a.dil) * a.F + col) << 7) + ((q ^ (u << 1)) << 4));
-      const unsigned char* src = zp + (off & -(long long)ok);
-      glds16(src, (unsigned)__builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G::A_BYTES + pos * G::ZROWB + part * 1024)));
+  __device__ __forceinline__ void begin(Batch& bt, const WItem& x, int w_first, int k_first, int buf) const {
+    bt.row0 = (long long)x.b * a.T + x.cls;
+    bt.nk = x.nk; bt.o0 = x.o0; bt.o1 = x.o1;
+    bt.w_first = w_first; bt.k_first = k_first; bt.buf = buf;
+    bt.live = 1;
+    const int colb = (x.strip * STRIP) << 7;
+    bt.va = (unsigned)(va_lane + colb);
+    bt.vz0 = (unsigned)(vz_lane + colb);
+    bt.vz1 = (unsigned)((vz_lane ^ 64) + colb);
+  }
+  // unit j of this wave: row rho = wave + 4 j (j < UNITS)
+  static constexpr int UNITS = (G::NROWS + 3) / 4;
+  template <int J>
+  __device__ __forceinline__ void row_unit(const Batch& bt) const {
+    if (!bt.live) return;
+    const int rho = wave + 4 * J;
+    const unsigned rowbytes = (unsigned)a.F * 128u;
+    if (4 * J + 3 < G::WIN || rho < G::WIN) {              // an a row (compile-time for all J but the one straddling WIN)
+      if (4 * J >= G::WIN) return;
+      const int w = bt.w_first + rho;
+      const bool ok = (w >= 0) & (w < bt.nk);
+      const u4v d = row_desc(a.a, ((bt.row0 + (long long)w * a.dil) * a.F) << 7, ok ? rowbytes : 0u);
+      const unsigned dst = lds0 + (unsigned)(bt.buf * G::ABUF + rho * G::AROWB);
+      unsigned keep;
+      // chunk p: 16 pixels = 2 KiB of the tensor row, 1 KiB of the image (this half's 64 bytes per pixel): the immediate
+      // moves both addresses by 1 KiB, the other KiB of the memory step is in the offset register
+      static_assert(G::ACPR >= 1 && G::ACPR <= 3, "a row: 1..3 chunks");
+      if (G::ACPR == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %4, %2, 0 offen offset:1024 lds\n\tbuffer_load_dwordx4 %5, %2, 0 offen offset:2048 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(bt.va), "s"(d), "s"(dst), "v"(bt.va + 1024u), "v"(bt.va + 2048u) : "memory");
+      else if (G::ACPR == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %4, %2, 0 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(bt.va), "s"(d), "s"(dst), "v"(bt.va + 1024u) : "memory");
+      else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(bt.va), "s"(d), "s"(dst) : "memory");
+    } else {
+      const int r = rho - G::WIN;
+      if (r >= R) return;
+      const int k2 = bt.k_first + r;
+      const bool ok = (k2 >= bt.o0) & (k2 < bt.o1);
+      const u4v d = row_desc(a.dz, ((bt.row0 + (long long)k2 * a.dil) * a.F) << 7, ok ? rowbytes : 0u);
+      const unsigned dst = lds0 + (unsigned)(G::A_BYTES + bt.buf * G::ZBUF + r * G::ZROWB);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %4, %2, 0 offen offset:1024 lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %2, 0 offen offset:3072 lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(bt.vz0), "s"(d), "s"(dst), "v"(bt.vz1) : "memory");
     }
   }
+  template <int... Js>
+  __device__ __forceinline__ void all_units(const Batch& bt, std::integer_sequence<int, Js...>) const { (row_unit<Js>(bt), ...); }
+  __device__ __forceinline__ void fetch_all(const Batch& bt) const { all_units(bt, std::make_integer_sequence<int, UNITS>()); }
 };
 
 // Which (window row, column shift) fragments a wave reads and what it does with each.  A wave owns taps [T0, T0 + NTW) of
@@ -198,117 +244,169 @@ struct WgradCore {
   using G = WGeo<KT, KF>;
   using S = WSched<KT, KF, TH>;
   static constexpr int NTW = S::NTW, T0 = S::T0, ZR = S::ZR;
+  // a step at a group's edge has as few as 4 MFMAs (64 cycles); two steps ahead did not cover the LDS latency there
+  static constexpr int PD = 4;
 
   f32x4 acc[4][NTW];
-  unsigned aoff[KF][2], zoff[4][2];
+  unsigned aoff[KF][2], zoff[4][2];    // per-lane byte offsets of the transposing reads inside a row image (launch constants)
   unsigned lds0;
   static constexpr int abl = ABL;      // VS_ABLATION instances: 1 = no DMA after the first groups, 2 = no fragment reads, 4 = no MFMAs
 
   struct GroupRegs {
-    s4v bq[3][2];
+    s4v bq[PD + 1][2];                 // a fragments in flight: read PD steps ahead of their MFMAs
     s4v zf[ZR][4][2];
-    int cq, zq, rv;
+    unsigned ab[KF][2], zb[4][2];      // the read bases of this group's buffers; window row w / output row r are immediates
+    int rv;
   };
 
-  __device__ __forceinline__ unsigned a_addr(const GroupRegs& gr, int w, int df, int hf) const {
-    int pos = gr.cq + w;
-    if (pos >= G::NRA) pos -= G::NRA;
-    return lds0 + (unsigned)(pos * G::AROWB) + aoff[df][hf];
-  }
-  __device__ __forceinline__ unsigned z_addr(const GroupRegs& gr, int r, int cb, int hf) const {
-    int pos = gr.zq + r;
-    if (pos >= G::NRZ) pos -= G::NRZ;
-    return lds0 + (unsigned)(G::A_BYTES + pos * G::ZROWB) + zoff[cb][hf];
-  }
-  template <int RV, int SI>
+  __device__ __forceinline__ unsigned a_addr(const GroupRegs& gr, int w, int df, int hf) const { return gr.ab[df][hf] + (unsigned)(w * G::AROWB); }
+  __device__ __forceinline__ unsigned z_addr(const GroupRegs& gr, int r, int cb, int hf) const { return gr.zb[cb][hf] + (unsigned)(r * G::ZROWB); }
+  template <int RV, int SI, int hf>
   __device__ __forceinline__ void read_b(GroupRegs& gr) const {
     constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
     if constexpr (abl & 2) return;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) gr.bq[SI % 3][hf] = ds_read_tr16(a_addr(gr, w, df, hf));
+    gr.bq[SI % (PD + 1)][hf] = ds_read_tr16(a_addr(gr, w, df, hf));
   }
-  template <int r, int cb>
+  template <int r, int cb, int hf>
   __device__ __forceinline__ void read_z(GroupRegs& gr) const {
     if constexpr (abl & 2) return;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) gr.zf[r % ZR][cb][hf] = ds_read_tr16(z_addr(gr, r, cb, hf));
+    gr.zf[r % ZR][cb][hf] = ds_read_tr16(z_addr(gr, r, cb, hf));
   }
 
-  // step SI of a group of RV rows: the read two steps ahead, this window row's share of the next output row's dz
-  // fragments, then the MFMAs of fragment SI
-  template <int RV, int SI>
-  __device__ __forceinline__ void step(GroupRegs& gr) {
+  using Walk = WgradWalk<KT, KF>;
+  using Batch = typename Walk::Batch;
+
+  // Step SI of a group = the MFMAs of a fragment (w, df): every owned tap (dt, df) whose output row w - dt lies in the
+  // group, 4 co blocks each.  A wave issues in order, so whatever else the step has to do -- the DMA chunk, the two reads
+  // of the fragment PD steps ahead, this window row's share of the next output row's dz fragments -- only hides
+  // under the matrix pipe if it sits BETWEEN the MFMAs, one unit per MFMA (batched in front of them it cost 20-45 idle
+  // cycles per step: the weight gradient ran at MFMA-only time + read time + DMA time).
+  static constexpr int nvalid_dt(int RV, int w, int df) {
+    int n = 0;
+    for (int dt = S::DTLO; dt <= S::DTHI; ++dt) n += (S::owned(dt, df) && w - dt >= 0 && w - dt < RV) ? 1 : 0;
+    return n;
+  }
+  static constexpr int dt_at(int RV, int w, int df, int idx) {        // idx-th valid dt
+    int n = 0;
+    for (int dt = S::DTLO; dt <= S::DTHI; ++dt)
+      if (S::owned(dt, df) && w - dt >= 0 && w - dt < RV) { if (n == idx) return dt; ++n; }
+    return -1;
+  }
+  static constexpr int rmin(int RV, int w, int df) {                  // smallest output row the step touches
+    int m = 1 << 20;
+    for (int dt = S::DTLO; dt <= S::DTHI; ++dt)
+      if (S::owned(dt, df) && w - dt >= 0 && w - dt < RV && w - dt < m) m = w - dt;
+    return m;
+  }
+  // dz fragments read in step (w, df): co blocks cb with cb % (steps of window row w) == rank of df, of output row w + 1 - DTLO
+  static constexpr int nz_cb(int RV, int w, int df) {
+    const int rn = w + 1 - S::DTLO;
+    if (rn < 1 || rn >= RV) return 0;
+    const int nw = S::steps_of_row(RV, w), k = S::rank_in_row(RV, w, df);
+    int n = 0;
+    for (int cb = 0; cb < 4; ++cb) n += (cb % nw == k) ? 1 : 0;
+    return n;
+  }
+  static constexpr int z_cb_at(int RV, int w, int df, int idx) {
+    const int nw = S::steps_of_row(RV, w), k = S::rank_in_row(RV, w, df);
+    int n = 0;
+    for (int cb = 0; cb < 4; ++cb)
+      if (cb % nw == k) { if (n == idx) return cb; ++n; }
+    return -1;
+  }
+
+  // side unit U of step SI: 0 = DMA chunk, 1 / 2 = the halves of fragment SI + PD, 3.. = dz fragment halves
+  template <int RV, int SI, int U>
+  __device__ __forceinline__ void unit(GroupRegs& gr, const Walk& wk, const Batch& bt) {
     constexpr int NS = S::nsteps(RV);
     constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
-    if constexpr (SI + 2 < NS) read_b<RV, SI + 2>(gr);
-    // output row rn = w + 1 - DTLO is first used at window row w + 1: its 4 co blocks are spread over this row's steps
-    constexpr int rn = w + 1 - S::DTLO;
-    if constexpr (rn >= 1 && rn < RV) {
-      constexpr int nw = S::steps_of_row(RV, w), k = S::rank_in_row(RV, w, df);
-      if constexpr (0 % nw == k) read_z<rn, 0>(gr);
-      if constexpr (1 % nw == k) read_z<rn, 1>(gr);
-      if constexpr (2 % nw == k) read_z<rn, 2>(gr);
-      if constexpr (3 % nw == k) read_z<rn, 3>(gr);
+    if constexpr (U == 0) {
+      if constexpr (SI < Walk::UNITS) wk.template row_unit<SI>(bt);      // the next group's rows: one row per step
+    } else if constexpr (U <= 2) {
+      if constexpr (SI + PD < NS) read_b<RV, SI + PD, U - 1>(gr);
+    } else if constexpr (U < 3 + 2 * nz_cb(RV, w, df)) {
+      constexpr int cb = z_cb_at(RV, w, df, (U - 3) / 2);
+      read_z<w + 1 - S::DTLO, cb, (U - 3) % 2>(gr);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    const vs_bf16x8 bfrag = frag_of(gr.bq[SI % 3][0], gr.bq[SI % 3][1]);
-    mfmas<RV, w, df>(gr, bfrag, std::make_integer_sequence<int, S::DTN>());
+  }
+  template <int RV, int SI, int M>
+  __device__ __forceinline__ void mfma_unit(GroupRegs& gr, const Walk& wk, const Batch& bt, const vs_bf16x8& bfrag) {
+    constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
+    constexpr int dt = dt_at(RV, w, df, M / 4), cb = M % 4, r = w - dt, j = dt * KF + df - T0;
+    if constexpr (!(abl & 4))
+      acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(gr.zf[r % ZR][cb][0], gr.zf[r % ZR][cb][1]), bfrag, acc[cb][j], 0, 0, 0);
+    unit<RV, SI, M>(gr, wk, bt);
     __builtin_amdgcn_sched_barrier(0);
   }
-  template <int RV, int w, int df, int... Ds>
-  __device__ __forceinline__ void mfmas(GroupRegs& gr, const vs_bf16x8& bfrag, std::integer_sequence<int, Ds...>) {
-    (mfma4<RV, w, df, S::DTLO + Ds>(gr, bfrag), ...);
+  template <int RV, int SI, int... Ms>
+  __device__ __forceinline__ void mfma_units(GroupRegs& gr, const Walk& wk, const Batch& bt, const vs_bf16x8& bfrag, std::integer_sequence<int, Ms...>) {
+    (mfma_unit<RV, SI, Ms>(gr, wk, bt, bfrag), ...);
   }
-  template <int RV, int w, int df, int dt>
-  __device__ __forceinline__ void mfma4(GroupRegs& gr, const vs_bf16x8& bfrag) {
-    constexpr int r = w - dt;
-    if constexpr (S::owned(dt, df) && r >= 0 && r < RV) {
-      constexpr int j = dt * KF + df - T0;
-      if (r < gr.rv && !(abl & 4)) {               // wave-uniform: the group's last rows may not exist (their dz rows are zeros either way)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(gr.zf[r % ZR][cb][0], gr.zf[r % ZR][cb][1]), bfrag, acc[cb][j], 0, 0, 0);
-      }
+  template <int RV, int SI, int U0, int... Us>
+  __device__ __forceinline__ void tail_units(GroupRegs& gr, const Walk& wk, const Batch& bt, std::integer_sequence<int, Us...>) {
+    (unit<RV, SI, U0 + Us>(gr, wk, bt), ...);
+  }
+
+  template <int RV, int SI>
+  __device__ __forceinline__ void step(GroupRegs& gr, const Walk& wk, const Batch& bt) {
+    constexpr int code = S::step_at(RV, SI), w = code / KF, df = code % KF;
+    constexpr int NM = 4 * nvalid_dt(RV, w, df), NU = 3 + 2 * nz_cb(RV, w, df);
+    // wave-uniform: a step none of whose output rows exists in this (tail) group is skipped -- those steps form a suffix;
+    // inside an executed step rows past the group's end are zero dz rows
+    if (rmin(RV, w, df) < gr.rv) {
+      const vs_bf16x8 bfrag = frag_of(gr.bq[SI % (PD + 1)][0], gr.bq[SI % (PD + 1)][1]);
+      mfma_units<RV, SI>(gr, wk, bt, bfrag, std::make_integer_sequence<int, NM>());
+      if constexpr (NU > NM) tail_units<RV, SI, NM>(gr, wk, bt, std::make_integer_sequence<int, NU - NM>());
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   template <int RV, int... SIs>
-  __device__ __forceinline__ void steps(GroupRegs& gr, std::integer_sequence<int, SIs...>) {
-    (step<RV, SIs>(gr), ...);
+  __device__ __forceinline__ void steps(GroupRegs& gr, const Walk& wk, const Batch& bt, std::integer_sequence<int, SIs...>) {
+    (step<RV, SIs>(gr, wk, bt), ...);
   }
 
   // a group of rv <= R output rows (R, or the even tail of an item; a row past the item's end is a zero dz row).  ONE
   // body with a wave-uniform guard per tap instead of one instance per row count: with several instances the
   // accumulators, which live across groups, get a copy per instance (512 registers + spills).
-  __device__ __forceinline__ void group(int cq, int zq, int rv) {
+  __device__ __forceinline__ void group(const Walk& wk, const Batch& bt, int buf, int rv) {
     constexpr int RV = R;
+    static_assert(S::nsteps(R) >= Walk::UNITS, "every DMA row unit needs a step");
     GroupRegs gr;
-    gr.cq = cq;
-    gr.zq = zq;
     gr.rv = rv;
+#pragma unroll
+    for (int df = 0; df < KF; ++df)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) gr.ab[df][hf] = lds0 + (unsigned)(buf * G::ABUF) + aoff[df][hf];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) gr.zb[cb][hf] = lds0 + (unsigned)(G::A_BYTES + buf * G::ZBUF) + zoff[cb][hf];
     if constexpr (abl & 2) {          // no fragment reads: defined (not foldable) register contents instead
       const short v = (short)(0x3c00 + (threadIdx.x & 7));
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { gr.bq[q][0] = s4v{v, v, v, v}; gr.bq[q][1] = s4v{v, v, v, v}; }
+      for (int q = 0; q < PD + 1; ++q) { gr.bq[q][0] = s4v{v, v, v, v}; gr.bq[q][1] = s4v{v, v, v, v}; }
 #pragma unroll
       for (int q = 0; q < ZR; ++q)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) { gr.zf[q][cb][0] = s4v{v, v, v, v}; gr.zf[q][cb][1] = s4v{v, v, v, v}; }
     }
-    read_z<0, 0>(gr);
-    read_z<0, 1>(gr);
-    read_z<0, 2>(gr);
-    read_z<0, 3>(gr);
-    read_b<RV, 0>(gr);
-    if constexpr (S::nsteps(RV) > 1) read_b<RV, 1>(gr);
+    read_b<RV, 0, 0>(gr); read_b<RV, 0, 1>(gr);
+    read_z<0, 0, 0>(gr); read_z<0, 0, 1>(gr);
+    read_z<0, 1, 0>(gr); read_z<0, 1, 1>(gr);
+    read_z<0, 2, 0>(gr); read_z<0, 2, 1>(gr);
+    read_z<0, 3, 0>(gr); read_z<0, 3, 1>(gr);
+    if constexpr (PD > 1 && S::nsteps(RV) > 1) { read_b<RV, 1, 0>(gr); read_b<RV, 1, 1>(gr); }
+    if constexpr (PD > 2 && S::nsteps(RV) > 2) { read_b<RV, 2, 0>(gr); read_b<RV, 2, 1>(gr); }
+    if constexpr (PD > 3 && S::nsteps(RV) > 3) { read_b<RV, 3, 0>(gr); read_b<RV, 3, 1>(gr); }
     __builtin_amdgcn_sched_barrier(0);
-    steps<RV>(gr, std::make_integer_sequence<int, S::nsteps(RV)>());
+    steps<RV>(gr, wk, bt, std::make_integer_sequence<int, S::nsteps(RV)>());
   }
 };
 
 template <int KT, int KF, int TH, int ABL>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* smem) {
   using G = WGeo<KT, KF>;
-  constexpr int P = G::P, H = G::H;
+  constexpr int P = G::P;
   WgradWalk<KT, KF> wk(a, smem);
   WgradCore<KT, KF, TH, ABL> core;
   constexpr int NTW = WgradCore<KT, KF, TH, ABL>::NTW, T0 = WgradCore<KT, KF, TH, ABL>::T0;
@@ -354,41 +452,31 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const lds_byte* s
       pf_it += npairs;
     }
   };
-  int wp = 0, zwp = 0;               // ring positions the next DMA'd a row / dz row go to
-  auto pf_issue = [&]() {
+  typename WgradWalk<KT, KF>::Batch bt;
+  bt.live = 0;
+  int pbuf = 0;                      // buffer the next fetched group goes to
+  auto pf_begin = [&]() {            // describe the fetch of the group at the prefetch cursor (issued row by row), advance the cursor
     const int ro = pf.o0 + pf_g * R;
-    const int first = pf_g == 0 ? 0 : H;
-    const int nrows = G::WIN - first;
-    const bool dma = !(ABL & 1) || abl_groups++ < 2;
-    if (dma) wk.issue_a(pf, ro - P + first, nrows, wp);
-    wp += nrows;
-    if (wp >= G::NRA) wp -= G::NRA;
-    if (dma) wk.issue_z(pf, ro, zwp);
-    zwp += R;
-    if (zwp >= G::NRZ) zwp -= G::NRZ;
+    wk.begin(bt, pf, ro - P, ro, pbuf);
+    if ((ABL & 1) && abl_groups++ >= 2) bt.live = 0;
+    pbuf ^= 1;
     if (++pf_g >= pf.ngroups) { pf_it += npairs; pf_seek(); }
   };
   pf_seek();
-  if (pf_live) pf_issue();
+  if (pf_live) { pf_begin(); wk.fetch_all(bt); }
 
   WItem cur;
-  int cq = 0, zq = 0;
+  int cbuf = 0;
   for (int it = pair; it < a.n_items; it += npairs) {
     if (!wk.decode(it, cur)) continue;
     for (int gidx = 0; gidx < cur.ngroups; ++gidx) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int wp_before = wp;
-      const bool pf_new_item = pf_live && pf_g == 0;
-      if (pf_live) pf_issue();
+      bt.live = 0;
+      if (pf_live) pf_begin();
       const int left = cur.o1 - (cur.o0 + gidx * R);
-      core.group(cq, zq, left > 6 ? 8 : left > 4 ? 6 : left > 2 ? 4 : 2);
-      if (gidx + 1 < cur.ngroups) {
-        cq += R; if (cq >= G::NRA) cq -= G::NRA;
-      } else if (pf_new_item) {
-        cq = wp_before;
-      }
-      zq += R; if (zq >= G::NRZ) zq -= G::NRZ;
+      core.group(wk, bt, cbuf, left > 6 ? 8 : left > 4 ? 6 : left > 2 ? 4 : 2);
+      cbuf ^= 1;
     }
   }
 
