@@ -5,7 +5,7 @@
 // Layout: activations are CHANNELS-LAST bf16, [B][T][F][64] -- a pixel's 64 channels are 128 contiguous bytes.
 // That is the B operand of v_mfma_f32_16x16x32_bf16 as it lies in memory (a lane's 8 consecutive k = 8
 // consecutive channels of one pixel = one 16-byte piece), so the operand goes HBM -> LDS by LDS-DMA
-// (global_load_lds_dwordx4) and LDS -> register by one ds_read_b128 with no conversion, no transpose and no
+// (buffer_load_dwordx4 ... lds) and LDS -> register by one ds_read_b128 with no conversion, no transpose and no
 // VALU in between.  (The fp32 / split-f16 path keeps [B][64][T][F] fp32 and converts while staging:
 // conv_f16x3_pk.hip.)
 //
@@ -15,21 +15,28 @@
 //   * weights stay in REGISTERS for the whole launch: wave q owns output channels [16q, 16q+16) and holds the
 //     A fragments of all KT*KF taps x 2 k-chunks (5x5: 50 fragments = 200 VGPRs).  No weight traffic in the loop,
 //     no cross-wave reduction, every wave reads the same pixels from LDS;
-//   * the R + KT - 1 input rows a group needs sit in an LDS ring of 2 (R + KT - 1) rows (16-byte pieces
-//     XOR-swizzled on the SOURCE address so that the fragment reads are (nearly) conflict-free); the DMA of the
-//     NEXT group's R new rows -- or of all rows of the next item's first group -- is issued when a group starts,
-//     i.e. a whole group (5x5: 800 MFMAs per wave, ~13k cycles) ahead; out-of-image columns and rows come from a
-//     zero page; one s_waitcnt vmcnt(0) + one s_barrier per group;
+//   * the R + KT - 1 input rows of a group (its window) sit at FIXED offsets of one of two LDS window buffers (16-byte
+//     pieces XOR-swizzled on the SOURCE address: the fragment reads are conflict-free).  The window of the NEXT group is
+//     fetched while this one is computed, a whole group (5x5: 800 MFMAs per wave, ~13k cycles) ahead: each wave owns
+//     every fourth row and issues it as ONE unit -- a buffer descriptor for the tensor row, M0, and the row's 1 KiB
+//     chunks by immediate offset (buffer_load_dwordx4 ... lds) -- placed between two MFMAs.  Columns and rows outside
+//     the image are zeros by the descriptor's range check: no address arithmetic, no zero page.  The KT - 1 rows two
+//     consecutive groups share are fetched twice (the second time from L2) -- in exchange every fragment read is
+//     base register + immediate.  That matters because a wave alone on its SIMD issues one instruction per 4 cycles
+//     (tools/issue_probe.hip: between two 16-cycle MFMAs there is room for ~2 independent instructions; a dependent
+//     address add + read pair costs ~15 cycles): the ring version spent more issue slots on addresses than on reads.
+//     One s_waitcnt vmcnt(0) + one s_barrier per group;
 //   * a group is one straight-line block: for window row i, tap column df, k-chunk, column block: ONE fragment read,
 //     multiplied with the <= KT taps dt that send it to output row i - dt of the group (0.3 LDS reads per MFMA;
 //     no MFMA is issued for a (row, tap) pair outside the group, so nothing is wasted at group edges).  The R x 2
 //     accumulators are born and die inside the block: no loop-carried accumulators, no register rotation.
 //     Output row r is complete after window row r + KT - 1: its epilogue (scale/shift, activation, bf16 rounding,
 //     8-byte stores of 4 channels of one pixel) sits right there, under the MFMAs of the following window rows;
-//     lanes / rows outside the image store to a dump page instead of branching;
+//     lanes / rows outside the image are dropped by the store's buffer range check instead of branching;
 //   * train mode: per-channel sum / sum of squares of the outputs are accumulated per lane over the whole launch
 //     and flushed once (shuffle over the 16 pixels of a fragment, one fp64 atomic per channel and wave).
-// Every input element is read from HBM once per strip (+12.5 % halo columns for 5x5, + KT-1 halo rows per segment),
+// Every input element is read from HBM once per strip (+12.5 % halo columns for 5x5, + KT-1 halo rows per segment;
+// the re-fetched window rows are L2 hits),
 // every output written once.
 #include <utility>
 
@@ -44,7 +51,6 @@ constexpr float kLog2e = 1.44269504088896340736f;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(3))) const u4v lds_u4v;
 
-__device__ u4v g_zero_page[4];      // 64 zero bytes: source of every out-of-image piece
 
 constexpr int STRIP = 32;           // output columns per strip = 2 MFMA column blocks of 16
 constexpr int NB = STRIP / 16;
@@ -68,12 +74,6 @@ struct NhwcConvArgs {
   int nstrip, nseg, seg_rows, n_items;
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // XOR swizzle of the 16-byte pieces of a staged pixel (128 bytes = half a bank row; pixel parity picks the half): a
 // ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} ... that mix two k-groups, and the 16 pixels of a group
 // start at tap column df = 0..4.  ((p >> 1) & 3) << 1 puts every such group on 16 distinct 16-byte slots for every df
@@ -89,8 +89,13 @@ struct Geo {
   static constexpr int CPR = (RWPX * 8 + 63) / 64;       // 1 KiB DMA chunks per row (5 / 4); the last may be part padding
   static constexpr int ROWB = CPR * 1024;                // bytes per ring row
   static constexpr int WIN = R + H;                      // input rows of a group
-  static constexpr int NR = 2 * WIN;                     // ring rows
-  static constexpr int LDS_BYTES = NR * ROWB;
+  // LDS: two window buffers of WIN rows.  A group's rows sit at FIXED offsets of its buffer (the H rows it shares with the
+  // previous group are fetched again -- L2 hits -- instead of being kept in a ring), so a fragment read is a per-group base
+  // register + an immediate: with one wave per SIMD every instruction is a 4-cycle issue slot of the MFMA stream, and an
+  // address add in front of a read (plus the dependency on it) cost more than the read (tools/issue_probe.hip).
+  static constexpr int WBUF = WIN * ROWB;
+  static constexpr int LDS_BYTES = 2 * WBUF;
+  static constexpr int UNITS = (WIN + 3) / 4;            // DMA row units of a wave per group (row rho belongs to wave rho % 4)
 };
 
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
@@ -111,8 +116,9 @@ struct ConvWalk {
   // This lane's 4 output channels as two pairs (packed fp32 math in the epilogue).  csc / csh: the epilogue's scale and
   // shift; DY: the BatchNorm scale / shift of the layer below, times log2(e).  a1 / a2: the two per-channel sums.
   f2v csc[2], csh[2], a1[2], a2[2];
-  int boff[KF];
+  int boff[KF][2];                           // per-lane byte offset of the B fragment (column shift df, k-chunk kc) inside a row image
   unsigned vcol[NB];
+  int vdma;                                  // per-lane source offset of a DMA chunk inside a tensor row (launch constant)
   __amdgpu_buffer_rsrc_t rout, rz;
   unsigned lds0;
   const lds_byte* smem;
@@ -140,7 +146,12 @@ struct ConvWalk {
 #pragma unroll
     for (int df = 0; df < KF; ++df) {
       const int p = n + df;
-      boff[df] = p * 128 + ((g ^ swz(p)) << 4);            // k-chunk 1: ^ 64; column block nb: + 2048 (the swizzle is 8-periodic in p)
+      boff[df][0] = p * 128 + ((g ^ swz(p)) << 4);         // column block nb: + 2048 (the swizzle is 8-periodic in p)
+      boff[df][1] = boff[df][0] ^ 64;
+    }
+    {
+      const int px = lane >> 3;                            // chunk c of a row: pixel 8 c + lane / 8, LDS piece lane % 8 holds channel
+      vdma = (px - PF) * 128 + (((lane & 7) ^ swz(px)) << 4);     // piece (lane % 8) ^ swz(px) -- swz is 8-periodic: the same for every chunk
     }
   }
 
@@ -160,29 +171,51 @@ struct ConvWalk {
     return true;
   }
 
-  // LDS-DMA of `nrows` class rows of item x starting at row w_first into ring positions pos_first.. (mod NR).
-  // A row is CPR chunks of 1 KiB (64 lanes x 16 bytes); chunk c goes to wave c % 4.  Branch-free per lane: a piece
-  // outside the image (row or column) or in the padding of a row reads the zero page.
-  __device__ __forceinline__ void issue(const Item& x, int w_first, int nrows, int pos_first) const {
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
-    const long long rel0 = reinterpret_cast<const unsigned char*>(a.in) - zp;
-    const long long row0 = (long long)x.b * a.T + x.cls;
-    const int nchunks = nrows * G::CPR;
-    for (int c = wave; c < nchunks; c += 4) {
-      const int row = c / G::CPR, part = c - row * G::CPR;
-      const int w = w_first + row;
-      int pos = pos_first + row;
-      if (pos >= G::NR) pos -= G::NR;
-      const int px = part * 8 + (lane >> 3);                              // pixel of the staged row
-      const int col = x.strip * STRIP - PF + px;
-      const bool ok = (w >= 0) & (w < x.in_end) & (px < G::RWPX) & (col >= 0) & (col < a.F);
-      const int sw = ((lane & 7) ^ swz(px)) << 4;                          // LDS piece q of pixel px holds channel piece q ^ swz(px)
-      const long long off = rel0 + ((((row0 + (long long)w * a.dil) * a.F + col) << 7) + sw);
-      const unsigned char* src = zp + (off & -(long long)ok);
-      const unsigned dst = lds0 + (unsigned)(pos * G::ROWB + part * 1024);
-      glds16(src, (unsigned)__builtin_amdgcn_readfirstlane(dst));
-    }
+  // ---- LDS-DMA of a group's WIN window rows, one ROW per unit --------------------------------------------------------
+  // Class rows w_first .. w_first + WIN - 1 of item x -> window buffer `buf`.  Row rho belongs to wave rho % 4.  A row is
+  // one buffer descriptor (base = the tensor row, records = its bytes, or none for a row outside the image: the DMA then
+  // writes zeros, as it does for columns past the right edge), and its CPR chunks of 1 KiB (64 lanes x 16 bytes = 8
+  // pixels) by immediate offset, which moves the memory and the LDS address alike (tools/lds_dma_offset_probe.hip).
+  // Chunk 0 has its own offset register: in the first strip its first PF pixels lie left of the image -- a negative
+  // offset, out of range as it stands -- and an immediate must not be added to that.
+  struct Batch {
+    long long row0;                // b * T + cls
+    int in_end, w_first, buf, live;
+    unsigned v0, v1;               // per-lane source offsets: chunk 0; chunks 1.. (= chunk 0's + 1 KiB, by immediate from there)
+  };
+  Batch bt;                        // the fetch in progress: the window of the group after the one being computed
+  __device__ __forceinline__ void begin(Batch& bt, const Item& x, int w_first, int buf) const {
+    bt.row0 = (long long)x.b * a.T + x.cls;
+    bt.in_end = x.in_end; bt.w_first = w_first; bt.buf = buf; bt.live = 1;
+    bt.v0 = (unsigned)(vdma + ((x.strip * STRIP) << 7));
+    bt.v1 = bt.v0 + 1024u;
   }
+  template <int J>
+  __device__ __forceinline__ void row_unit(const Batch& bt) const {
+    const int rho = wave + 4 * J;
+    if (!bt.live || rho >= G::WIN) return;
+    const int w = bt.w_first + rho;
+    const bool ok = (w >= 0) & (w < bt.in_end);
+    const unsigned long long p = reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)(((bt.row0 + (long long)w * a.dil) * a.F) << 7);
+    const u4v d = {(unsigned)p, (unsigned)(p >> 32) & 0xffffu, ok ? (unsigned)a.F * 128u : 0u, 0x00020000u};
+    const unsigned dst = lds0 + (unsigned)(bt.buf * G::WBUF + rho * G::ROWB);
+    unsigned keep;
+    static_assert(G::CPR == 4 || G::CPR == 5, "a window row is 4 or 5 chunks");
+    if (G::CPR == 5)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                   "s_add_u32 m0, %3, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %4, %2, 0 offen offset:1024 lds\n\tbuffer_load_dwordx4 %4, %2, 0 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %2, 0 offen offset:3072 lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(bt.v0), "s"(d), "s"(dst), "v"(bt.v1) : "memory", "scc");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                   "s_add_u32 m0, %3, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %4, %2, 0 offen offset:1024 lds\n\tbuffer_load_dwordx4 %4, %2, 0 offen offset:2048 lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(bt.v0), "s"(d), "s"(dst), "v"(bt.v1) : "memory", "scc");
+  }
+  template <int... Js>
+  __device__ __forceinline__ void all_units(const Batch& bt, std::integer_sequence<int, Js...>) const { (row_unit<Js>(bt), ...); }
+  __device__ __forceinline__ void fetch_all(const Batch& bt) const { all_units(bt, std::make_integer_sequence<int, G::UNITS>()); }
 
   // Output-side addressing (the epilogue's stores, the dy form's z loads): a buffer descriptor over the item's utterance,
   // a per-lane byte offset of its pixel (column block nb) and channel quad inside a row -- or an offset no row offset brings
@@ -205,7 +238,7 @@ struct ConvWalk {
   }
 
   // One group: output rows ro .. ro+RV-1 of item x (RV = R, or the even tail of the item; rows >= x.o1 are computed and
-  // dropped), window rows at ring positions cq .. cq+RV+H-1 (mod NR).  gstep<RV, GI> is fragment GI of the block: its
+  // dropped), window rows 0 .. RV+H-1 of window buffer `buf`.  gstep<RV, GI> is fragment GI of the block: its
   // read two fragments ahead and its MFMAs.  The instruction order is pinned (sched_barrier after every MFMA): hipcc's
   // own order reads a fragment, waits for it and issues two MFMAs, and its sched_group_barrier solver needs 17 minutes
   // for this block.  The epilogue of output row r (complete after window row r + H) is cut into micro-ops -- one
@@ -219,7 +252,8 @@ struct ConvWalk {
     u2v zq[3][NB];                     // DY: z of the output row being finished and the next two (4 channels of one pixel each)
     float cok[NB], mk[NB];             // DY: 1 for a column inside the image, else 0; the same for the row being finished
     f2v tz, ty, tu, tn, tr, tw;        // DY: one channel pair in flight through the stages of the activation derivative
-    int ro, cq;
+    unsigned vb[KF][2];                // B-fragment read bases of this group's window buffer (column shift, k-chunk); row, column block: immediates
+    int ro;
   };
   // micro-ops of one output row.  Plain: NB*4 values + NB stores.  DY: z loads of a later row, NB*2 channel pairs x NSTAGE
   // stages (packed fp32 math: one v_pk_* per two channels; at most three of them or one transcendental per micro-op, which
@@ -230,9 +264,7 @@ struct ConvWalk {
   template <int RV>
   __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
     const int nb = gi % NB, kc = (gi / NB) % 2, df = (gi / (2 * NB)) % KF, i = gi / (2 * NB * KF);
-    int pos = st.cq + i;
-    if (pos >= G::NR) pos -= G::NR;
-    return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(smem + pos * G::ROWB + nb * 2048 + (boff[df] ^ (kc << 6))));
+    return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(uintptr_t)(st.vb[df][kc] + (unsigned)(i * G::ROWB + nb * 2048)));
   }
 
   // DY: z of output row r of the group (both column blocks) -> zq[r % 3].  Issued two output rows (about 1.5 us of
@@ -360,6 +392,7 @@ struct ConvWalk {
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
     st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
+    if constexpr (MM == 0 && GI % 4 == 0 && GI / 4 < G::UNITS) row_unit<GI / 4>(bt);      // the next group's window: one row per unit
     if constexpr (DY && GI == 0 && MM == 0) {               // z of the group's first two rows
       load_z<RV>(x, st, 0);
       if constexpr (RV > 1) load_z<RV>(x, st, 1);
@@ -409,10 +442,14 @@ struct ConvWalk {
   }
 
   template <int RV>
-  __device__ __forceinline__ void group(const Item& x, int ro, int cq) {
+  __device__ __forceinline__ void group(const Item& x, int ro, int buf) {
+    static_assert((RV + H) * KF * 2 * NB >= 4 * G::UNITS, "every DMA row unit needs a step");
     GroupState<RV> st;
     st.ro = ro;
-    st.cq = cq;
+#pragma unroll
+    for (int df = 0; df < KF; ++df)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) st.vb[df][kc] = lds0 + (unsigned)(buf * G::WBUF + boff[df][kc]);
 #pragma unroll
     for (int r = 0; r < RV; ++r)
 #pragma unroll
@@ -474,39 +511,33 @@ void nhwc_conv_kernel(NhwcConvArgs a) {
       pf_it += (int)gridDim.x;
     }
   };
-  int wp = 0;                      // ring position the next DMA'd row goes to
-  auto pf_issue = [&]() {          // DMA the rows of group (pf, pf_g) that are not in the ring yet; advance the cursor
-    const int ro = pf.o0 + pf_g * R;
-    const int first = pf_g == 0 ? 0 : G::H;               // later groups share their first H window rows with the previous one
-    const int nrows = G::WIN - first;
-    wk.issue(pf, ro - G::P + first, nrows, wp);
-    wp += nrows;
-    if (wp >= G::NR) wp -= G::NR;
+  int pbuf = 0;                    // window buffer the next fetched group goes to
+  auto pf_begin = [&]() {          // describe the fetch of group (pf, pf_g) -- its rows are issued one per unit inside the group being computed -- and advance the cursor
+    wk.begin(wk.bt, pf, pf.o0 + pf_g * R - G::P, pbuf);
+    pbuf ^= 1;
     if (++pf_g >= pf.ngroups) { pf_it += (int)gridDim.x; pf_seek(); }
   };
+  wk.bt.live = 0;
   pf_seek();
-  if (pf_live) pf_issue();
+  if (pf_live) { pf_begin(); wk.fetch_all(wk.bt); }
 
   Item cur;
-  int cq = 0;                      // ring position of the first window row of the group being computed
+  int cbuf = 0;                    // window buffer of the group being computed
   for (int it = (int)blockIdx.x; it < a.n_items; it += (int)gridDim.x) {
     if (!wk.decode(it, cur)) continue;
     wk.begin_item(cur);
     for (int gidx = 0; gidx < cur.ngroups; ++gidx) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the window have landed (and its stores retired)
-      __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done with the previous window
-      const int wp_before = wp;
-      const bool pf_new_item = pf_live && pf_g == 0;
-      if (pf_live) pf_issue();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's rows of the window have landed (and its stores retired)
+      __builtin_amdgcn_s_barrier();                         // ... every wave's have; every wave is done with the other buffer
+      wk.bt.live = 0;
+      if (pf_live) pf_begin();
       const int ro = cur.o0 + gidx * R;
       const int left = cur.o1 - ro;                           // > 0
-      if (left > 6) wk.template group<8>(cur, ro, cq);
-      else if (left > 4) wk.template group<6>(cur, ro, cq);
-      else if (left > 2) wk.template group<4>(cur, ro, cq);
-      else wk.template group<2>(cur, ro, cq);
-      // next group: same item -> its window starts R rows further; next item -> where its first group was just written
-      if (gidx + 1 < cur.ngroups) { cq += R; if (cq >= G::NR) cq -= G::NR; }
-      else if (pf_new_item) cq = wp_before;
+      if (left > 6) wk.template group<8>(cur, ro, cbuf);
+      else if (left > 4) wk.template group<6>(cur, ro, cbuf);
+      else if (left > 2) wk.template group<4>(cur, ro, cbuf);
+      else wk.template group<2>(cur, ro, cbuf);
+      cbuf ^= 1;
     }
   }
   wk.flush_stats();
