@@ -376,7 +376,7 @@ def main():
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
         act_bytes = 2 if math == "bf16" else 4
         if math == "bf16":
-            kname, peak = "nhwc_conv_kernel<5,5> (channels-last bf16, LDS-DMA ring, register-resident weights)", PEAK_F16_MFMA_TFLOPS
+            kname, peak = "nhwc_conv_kernel<5,5> (channels-last bf16, LDS-DMA window buffers, register-resident weights)", PEAK_F16_MFMA_TFLOPS
             extra = {"mfma_pipe": "bf16 (v_mfma_f32_16x16x32_bf16), one MFMA product per product", "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS}
             ksub = "nhwc_conv_kernel"
         elif math == "f16x3":

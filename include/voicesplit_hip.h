@@ -21,9 +21,9 @@
  *    serialised by a mutex while it is in use (vs_set_backward_overlap(0) turns it off); (2) the
  *    process-wide kernel-selection switches vs_set_conv_kernel / vs_set_wgrad_kernel / vs_set_lstm_kernel /
  *    vs_set_backward_overlap (A/B timing and cross-checks; every choice gives the same results) and the
- *    opt-in profiler vs_profile_begin / _end; (3) a 64-byte zero page and a 2 KiB dump page in device memory
- *    (static __device__ data of the channels-last kernels: source of out-of-image loads, sink of masked
- *    stores).  Calls on different streams with disjoint buffers are otherwise independent.
+ *    opt-in profiler vs_profile_begin / _end; (3) the error word of the persistent recurrence behind
+ *    vs_lstm_status and a 64-byte zero page in device memory (static __device__ data of the bf16 GEMM: source
+ *    of out-of-range operand pieces).  Calls on different streams with disjoint buffers are otherwise independent.
  *  - return 0 on success, <0 on error (-1 bad argument, -2 HIP runtime error); the message is
  *    available from vs_last_error() (thread-local).  No exceptions cross the ABI.
  *  - tensors are dense row-major with the reference's layouts: spectrogram [B][T][F]

@@ -1,18 +1,23 @@
-# Round-end GPU script (one gpurun call): full -m gpu suite, smoke(), the bench lines, both rocprofv3 profiles.
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/final_round.sh r02'
+# Round-end GPU script (one gpurun call): full -m gpu suite, smoke(), the bench lines, the probes, the rocprofv3 profile.
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/final_round.sh r03'
+# Results land in gpurun_out/final/; copy what is to be kept into profiles/ (tools/collect_final.sh <round>).
 set -u
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
 O=gpurun_out/final
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+timeout 1800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > $O/${R}_pytest_gpu.log; cat $O/${R}_pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 600 python bench.py 2> $O/bench_train.err | tail -1 > $O/${R}_bench_train.json; cut -c1-260 $O/${R}_bench_train.json
-timeout 300 python bench.py --mode forward 2> $O/bench_forward.err | tail -1 > $O/${R}_bench_forward.json; cut -c1-200 $O/${R}_bench_forward.json
-timeout 300 python bench.py --conv-math bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_bf16.json; cut -c1-200 $O/${R}_bench_train_bf16.json
-timeout 300 python bench.py --conv-math fp32 --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $O/${R}_bench_train_fp32math.json; cut -c1-200 $O/${R}_bench_train_fp32math.json
-timeout 300 python bench.py --serial-backward --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_serial_backward.json; cut -c1-200 $O/${R}_bench_train_serial_backward.json
-timeout 300 python bench.py --model voicefilter --loss powerlaw --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_voicefilter_powerlaw.json; cut -c1-200 $O/${R}_bench_train_voicefilter_powerlaw.json
-timeout 200 python bench.py --batch 2 --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_b2.json; cut -c1-200 $O/${R}_bench_train_b2.json
-bash tools/profile_gpu.sh ${R}_train 2>&1 | tail -2
-bash tools/profile_gpu.sh ${R}_forward --mode forward 2>&1 | tail -2
+timeout 900 python bench.py 2> $O/bench_train.err | tail -1 > $O/${R}_bench_train.json; cut -c1-300 $O/${R}_bench_train.json
+timeout 300 python bench.py --mode forward --no-cpu-baseline 2> $O/bench_forward.err | tail -1 > $O/${R}_bench_forward.json; cut -c1-200 $O/${R}_bench_forward.json
+timeout 300 python bench.py --mode forward --conv-math bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_forward_bf16.json; cut -c1-200 $O/${R}_bench_forward_bf16.json
+timeout 300 python bench.py --mode longform --conv-math bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_longform_bf16.json; cut -c1-200 $O/${R}_bench_longform_bf16.json
+timeout 300 python bench.py --mode longform --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_longform.json; cut -c1-200 $O/${R}_bench_longform.json
+timeout 300 python bench.py --serial-backward --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${R}_bench_train_serial_backward.json; cut -c1-200 $O/${R}_bench_train_serial_backward.json
+timeout 300 python bench.py --model voicefilter --loss powerlaw --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${R}_bench_train_voicefilter_powerlaw.json; cut -c1-200 $O/${R}_bench_train_voicefilter_powerlaw.json
+timeout 200 python bench.py --batch 2 --steps 30 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${R}_bench_train_b2.json; cut -c1-200 $O/${R}_bench_train_b2.json
+timeout 300 python tools/nhwc_micro.py > $O/${R}_nhwc_micro.json 2>/dev/null
+VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.json 2>/dev/null
+{ for p in issue_probe lds_tr_probe dma_fill_probe lds_dma_offset_probe buffer_oob_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
+[ -f voicesplit_amd/libvoicesplit_hip_abl.so ] && timeout 300 python tools/wgrad_ablation.py > $O/${R}_wgrad_ablation.json 2>/dev/null
+bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
