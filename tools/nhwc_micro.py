@@ -35,6 +35,10 @@ def main():
         for act, stats in (("none", False), ("none", True), ("mish", False)):
             ms = timed(lambda: ops.nhwc_conv(x, w, one, zero, dil, act, stats=stats))
             res[f"nhwc {KT}x{KF} dil{dil} act={act} stats={int(stats)}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
+        if dil == 4 or KF == 1:      # the same launch on all-zero activations: what the clock does without operand toggling
+            xz = torch.zeros_like(x)
+            ms = timed(lambda: ops.nhwc_conv(xz, w, one, zero, dil, "none"))
+            res[f"nhwc {KT}x{KF} dil{dil} act=none, zero activations"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
         if os.environ.get("VS_MICRO_DY", "1") != "0" and dil in (1, 4):
             packed = ops.nhwc_conv_pack(w, transpose_flip=True)
             mean, invstd = zero, one

@@ -40,6 +40,17 @@ __device__ __forceinline__ void fold_channel_sums(float (&v)[NV][8], double* __r
   }
 }
 
+// The 7 input samples x[f-3 .. f+3] of a pixel for all 8 lanes that share it (one lane per 8 channels): lane `piece`
+// loads sample `piece` (one load instruction per wave instead of seven mostly redundant ones) and the group exchanges
+// them by lane permutes.
+__device__ __forceinline__ void gather_x7(const float* xr, int f, int F, int piece, float (&xv)[7]) {
+  const int ff = f + piece - 3;
+  const float mine = (piece < 7 && ff >= 0 && ff < F) ? xr[ff] : 0.f;
+  const int base = (int)(threadIdx.x & 56u);               // first lane of the pixel's group inside the wave
+#pragma unroll
+  for (int k = 0; k < 7; ++k) xv[k] = __shfl(mine, base + k, 64);
+}
+
 // ---- cnn1 ---------------------------------------------------------------------------------------------------
 // out[b][t][f][co] = act(scale[co] * sum_j w[co][j] x[b][t][f+j-3] + shift[co]); STATS: sum / sum of squares of out
 template <int ACT, bool STATS>
@@ -61,15 +72,13 @@ void nhwc_conv_first_kernel(const float* __restrict__ x, const float* __restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
   const long long stride = (long long)gridDim.x * 32;     // pixels per sweep of the grid
-  for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
-    const int f = (int)(p % F);
-    const float* xr = x + (p - f);
+  const int sr = (int)(stride % F);                       // the column is carried along: one 64-bit division per launch, not per pixel
+  long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  int f = (int)(p % F);
+  for (; p < npix; p += stride, f += sr) {
+    if (f >= F) f -= F;
     float xv[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const int ff = f + k - 3;
-      xv[k] = (ff >= 0 && ff < F) ? xr[ff] : 0.f;
-    }
+    gather_x7(x + (p - f), f, F, piece, xv);
     float y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -140,9 +149,14 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
   const int blocks_per_row = (F + 15) >> 4;
   const long long nblk = nrows * blocks_per_row;
   const long long wstride = (long long)gridDim.x * 4;
-  for (long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += wstride) {
-    const long long row = blk / blocks_per_row;
-    const int f = (int)(blk - row * blocks_per_row) * 16 + n;
+  const long long sq = wstride / blocks_per_row;          // (row, block column) are carried along: one division per launch
+  const int sr = (int)(wstride - sq * blocks_per_row);
+  long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  long long row = blk / blocks_per_row;
+  int bc = (int)(blk - row * blocks_per_row);
+  for (; blk < nblk; blk += wstride, row += sq, bc += sr) {
+    if (bc >= blocks_per_row) { bc -= blocks_per_row; ++row; }
+    const int f = bc * 16 + n;
     const bool ok = f < F;
     const u4v* src = reinterpret_cast<const u4v*>(in + ((row * F + (ok ? f : 0)) << 6)) + g;
     const u4v b0 = ok ? src[0] : u4v{0u, 0u, 0u, 0u}, b1 = ok ? src[4] : u4v{0u, 0u, 0u, 0u};
@@ -257,15 +271,13 @@ void nhwc_bn_bwd_first_kernel(const u4v* __restrict__ da, const u4v* __restrict_
     for (int k = 0; k < 7; ++k) acc[k][j] = 0.f;
   }
   const long long stride = (long long)gridDim.x * 32;
-  for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
-    const int f = (int)(p % F);
-    const float* xr = x + (p - f);
+  const int sr = (int)(stride % F);
+  long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  int f = (int)(p % F);
+  for (; p < npix; p += stride, f += sr) {
+    if (f >= F) f -= F;
     float xv[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const int ff = f + k - 3;
-      xv[k] = (ff >= 0 && ff < F) ? xr[ff] : 0.f;
-    }
+    gather_x7(x + (p - f), f, F, piece, xv);
     const u4v g = __builtin_nontemporal_load(da + p * 8 + piece), v = __builtin_nontemporal_load(z + p * 8 + piece);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -335,9 +347,13 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
     }
   }
   const long long stride = (long long)gridDim.x * 32;
-  for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
-    const long long row = p / F;
-    const int f = (int)(p - row * F);
+  const int sr = (int)(stride % F);
+  const long long sq = stride / F;
+  long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  long long row = p / F;
+  int f = (int)(p - row * F);
+  for (; p < npix; p += stride, f += sr, row += sq) {
+    if (f >= F) { f -= F; ++row; }
     const float* dzr = dz8 + row * 8 * F + f;
     float d[8];
 #pragma unroll
