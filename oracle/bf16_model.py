@@ -2,7 +2,7 @@
 kernel.  The reference forward (models/voicesplit/model.py:66-89: conv stack with batch-statistics BatchNorm, d-vector
 concat, BiLSTM, head) in fp64 autograd with bf16 rounding injected exactly where the VS_MATH_BF16 configuration rounds:
 the 64->64 conv weights, z = conv + bias, a = act(BN(z)), the gradients flowing back through those two, and the operands
-of the LSTM input GEMM and of its two backward contractions.  Accumulation, statistics, recurrence and head are exact.
+of the LSTM input GEMM, of fc1 / fc2 and of their backward contractions.  Accumulation, statistics and the recurrence are exact.
 The difference between these gradients and the unrounded ones is the envelope a correct bf16 implementation lives in;
 tests/test_gpu_bf16.py holds the HIP path to it.  (tools/bf16_error_sources.py prints the breakdown by rounding point.)"""
 from typing import Dict, Tuple
@@ -71,7 +71,9 @@ def gradients(sd: Dict[str, torch.Tensor], x: torch.Tensor, dvec: torch.Tensor, 
             out[t] = hh
         outs.append(torch.stack(out, 1))
     lo = torch.relu(torch.cat(outs, 2))
-    h1 = torch.relu(F.linear(lo, P["fc1.weight"], P["fc1.bias"]))
-    mask = torch.sigmoid(F.linear(h1, P["fc2.weight"], P["fc2.bias"]))
+    # head: both operands of fc1 / fc2 rounded (forward and, through the saved tensors, the two backward contractions of
+    # each); the gradient arriving at each pre-activation is rounded as the operand of those contractions
+    h1 = torch.relu(_rnd(F.linear(_rnd(lo, bf16), _rnd(P["fc1.weight"], bf16), P["fc1.bias"]), False, bf16))
+    mask = torch.sigmoid(_rnd(F.linear(_rnd(h1, bf16), _rnd(P["fc2.weight"], bf16), P["fc2.bias"]), False, bf16))
     (mask * w).sum().backward()
     return {k: p.grad for k, p in P.items() if p.grad is not None}, mask.detach()

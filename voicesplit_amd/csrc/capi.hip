@@ -675,6 +675,8 @@ int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, voi
   float* h1 = at<float>(ws, L.fc1_out);
   const int M = d->B * d->T;
   ProfScope ps(VS_PROF_HEAD, stream);
+  // VS_MATH_BF16: bf16-rounded operands on the bf16 matrix instruction, fp32 accumulate and epilogue
+  const auto vs_gemm_nt_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_nt_bf16_impl : ::vs_gemm_nt_impl;
   // relu(lstm) -> fc1 -> relu
   if (int rc = vs_gemm_nt_impl(lstm_out, 2 * d->H, p->fc1_w, 2 * d->H, h1, d->FC1, M, d->FC1, 2 * d->H,
                                p->fc1_b, nullptr, nullptr, 0, 1, 1, VS_ACT_RELU, stream)) return rc;

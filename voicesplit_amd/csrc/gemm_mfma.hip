@@ -49,6 +49,16 @@ struct GemmArgs {
   long long c_split_stride;
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// 8 fp32 values -> the 8 bf16 of one v_mfma_f32_32x32x16_bf16 operand (RNE, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 to_bf16x8(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+  return r;
+}
+
 // 4 consecutive elements p[i..i+3] of a row of n valid elements, zero beyond
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* __restrict__ p, int i, int n) {
@@ -65,7 +75,10 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
-template <int LA, int LB, bool VEC>
+// BF: VS_MATH_BF16 instances -- same staging, same epilogue, but the fragments are rounded to bf16 on their way out of
+// LDS and multiplied by v_mfma_f32_32x32x16_bf16 (k = 16 ks + 8 half + j): 1/32 of the matrix-pipe time of the fp32
+// instruction; the head GEMMs of the bf16 configuration then run at the speed of their staging.
+template <int LA, int LB, bool VEC, bool BF = false>
 __global__ __launch_bounds__(256, 3)
 void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float sA[LDS_FLOATS];
@@ -139,6 +152,41 @@ void gemm_kernel(GemmArgs g) {
     sstore();
     __syncthreads();
     if (k0 + BK < ke) gload(k0 + BK);
+    if constexpr (BF) {
+      const float* fa8 = LA == 0 ? sA + (wm * 64 + l31) * PITCH + half * 8 : sA + (half * 8) * PITCH_T + wm * 64 + l31;
+      const float* fw8 = LB == 0 ? sW + (wn * 64 + l31) * PITCH + half * 8 : sW + (half * 8) * PITCH_T + wn * 64 + l31;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a8[2], b8[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          float t[8];
+          if (LA == 0) {
+            const float4 t0 = *reinterpret_cast<const float4*>(fa8 + x * 32 * PITCH + ks * 16);
+            const float4 t1 = *reinterpret_cast<const float4*>(fa8 + x * 32 * PITCH + ks * 16 + 4);
+            t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w; t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = fa8[(ks * 16 + j) * PITCH_T + x * 32];
+          }
+          a8[x] = to_bf16x8(t);
+          if (LB == 0) {
+            const float4 t0 = *reinterpret_cast<const float4*>(fw8 + x * 32 * PITCH + ks * 16);
+            const float4 t1 = *reinterpret_cast<const float4*>(fw8 + x * 32 * PITCH + ks * 16 + 4);
+            t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w; t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = fw8[(ks * 16 + j) * PITCH_T + x * 32];
+          }
+          b8[x] = to_bf16x8(t);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mb], b8[nb], acc[mb][nb], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       float a4[2][4], b4[2][4];
@@ -197,8 +245,11 @@ void gemm_kernel(GemmArgs g) {
 }
 
 template <int LA, int LB>
-void launch_layout(const GemmArgs& g, bool vec, dim3 grid, hipStream_t stream) {
-  if (vec) hipLaunchKernelGGL((gemm_kernel<LA, LB, true>), grid, dim3(256), 0, stream, g);
+void launch_layout(const GemmArgs& g, bool vec, bool bf, dim3 grid, hipStream_t stream) {
+  if (bf) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<LA, LB, true, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_kernel<LA, LB, false, true>), grid, dim3(256), 0, stream, g);
+  } else if (vec) hipLaunchKernelGGL((gemm_kernel<LA, LB, true>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_kernel<LA, LB, false>), grid, dim3(256), 0, stream, g);
 }
 
@@ -217,11 +268,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, long
 // General entry.  layout_a / layout_w: 0 = K contiguous (A[m][k], W[n][k]); 1 = K-major
 // (A[k][m], W[k][n]).  splits > 1: split-K through `partials` ([splits][M][N] floats), summed in
 // a fixed order into C (which must then be dense, ldc == N, and take no epilogue terms).
-int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
-                         int n_split, int ldw, float* C, int ldc, int M, int N, int K,
-                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
-                         const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
-                         int w_shift, int w_group, int splits, float* partials, hipStream_t stream) {
+static int gemm_general(bool bf, int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                        int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                        const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                        const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                        int w_shift, int w_group, int splits, float* partials, hipStream_t stream) {
   VS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VS_REQUIRE((layout_a == 0 || layout_a == 1) && (layout_w == 0 || layout_w == 1), "gemm: bad layout");
   VS_REQUIRE(lda >= (layout_a ? M : K) && ldw >= (layout_w ? N : K) && ldc >= N,
@@ -246,16 +297,35 @@ int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, co
              (long long)M * N};
   const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W) && aligned16(W_hi);
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
-  if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, grid, stream);
-  else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, grid, stream);
-  else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, grid, stream);
-  else launch_layout<1, 1>(g, vec, grid, stream);
+  if (layout_a == 0 && layout_w == 0) launch_layout<0, 0>(g, vec, bf, grid, stream);
+  else if (layout_a == 0 && layout_w == 1) launch_layout<0, 1>(g, vec, bf, grid, stream);
+  else if (layout_a == 1 && layout_w == 0) launch_layout<1, 0>(g, vec, bf, grid, stream);
+  else launch_layout<1, 1>(g, vec, bf, grid, stream);
   if (splits > 1) {
     const long long n = (long long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partials, splits, n, C);
   }
   VS_LAUNCH_CHECK();
   return 0;
+}
+
+int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                         int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                         const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                         int w_shift, int w_group, int splits, float* partials, hipStream_t stream) {
+  return gemm_general(false, layout_a, layout_w, A, lda, W, W_hi, n_split, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
+                      gate, ldg, a_relu, w_relu, act, accumulate, w_shift, w_group, splits, partials, stream);
+}
+
+// The same contraction with both operands rounded to bf16 (VS_MATH_BF16: the head of the bf16 configuration)
+int vs_gemm_general_bf16_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                              int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                              const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                              const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                              int w_shift, int w_group, int splits, float* partials, hipStream_t stream) {
+  return gemm_general(true, layout_a, layout_w, A, lda, W, W_hi, n_split, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
+                      gate, ldg, a_relu, w_relu, act, accumulate, w_shift, w_group, splits, partials, stream);
 }
 
 // C = act(opA(A) @ W^T + biases): both operands K-contiguous (the forward products).
@@ -265,6 +335,14 @@ int vs_gemm_nt2_impl(const float* A, int lda, const float* W, const float* W_hi,
                      int a_relu, int act, hipStream_t stream) {
   return vs_gemm_general_impl(0, 0, A, lda, W, W_hi, n_split, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
                               nullptr, 0, a_relu, 0, act, 0, 0, 0, 1, nullptr, stream);
+}
+
+// vs_gemm_nt_impl with bf16-rounded operands (VS_MATH_BF16 head)
+int vs_gemm_nt_bf16_impl(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                         int a_relu, int act, hipStream_t stream) {
+  return vs_gemm_general_bf16_impl(0, 0, A, lda, W, nullptr, 0x7fffffff, ldw, C, ldc, M, N, K, bias1, bias2, rowbias, ldrb, group,
+                                   nullptr, 0, a_relu, 0, act, 0, 0, 0, 1, nullptr, stream);
 }
 
 int vs_gemm_nt_impl(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,

@@ -254,6 +254,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   VsProfScope ps_head(VS_PROF_HEAD, stream);
   const int M = B * T;
   float* h1 = at<float>(tape, L.fc1_out);
+  const auto vs_gemm_nt_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_nt_bf16_impl : ::vs_gemm_nt_impl;
   if (int rc = vs_gemm_nt_impl(at<float>(tape, L.lstm_out), 2 * H, p->fc1_w, 2 * H, h1, d->FC1, M, d->FC1, 2 * H,
                                p->fc1_b, nullptr, nullptr, 0, 1, 1, VS_ACT_RELU, stream)) return rc;
   return vs_gemm_nt_impl(h1, d->FC1, p->fc2_w, d->FC1, mask, d->FC2, M, d->FC2, d->FC1,
@@ -336,6 +337,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* dlstm = at<float>(tape, L.dlstm_out);
   {
   VsProfScope ps(VS_PROF_BWD_HEAD, stream);
+  // VS_MATH_BF16: the four head contractions on bf16-rounded operands (fp32 accumulate, fp32 split-K partials)
+  const auto vs_gemm_general_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_general_bf16_impl : ::vs_gemm_general_impl;
   if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp, FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(tmp, FC2, 1, B, FC2, g->fc2_b, FC2, stream)) return rc;

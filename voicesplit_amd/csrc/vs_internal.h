@@ -143,7 +143,13 @@ int vs_gemm_general_impl(int layout_a, int layout_w, const float* A, int lda, co
                          const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
                          const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
                          int w_shift, int w_group, int splits, float* partials, hipStream_t);
+int vs_gemm_general_bf16_impl(int layout_a, int layout_w, const float* A, int lda, const float* W, const float* W_hi,
+                         int n_split, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* bias1, const float* bias2, const float* rowbias, int ldrb, int group,
+                         const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
+                         int w_shift, int w_group, int splits, float* partials, hipStream_t);
 int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+int vs_gemm_nt_bf16_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 // gemm_bf16.hip: the LSTM contractions of the bf16 configuration (LDS-DMA ring, row / K-major operand forms)
 int vs_cvt_rows_bf16_impl(const float* src, long long rows, int K, int ld, void* dst, int Kp, hipStream_t);
