@@ -44,7 +44,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these are its only exports */
 #endif
 
-#define VS_ABI_VERSION 5
+#define VS_ABI_VERSION 6
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -280,6 +280,16 @@ size_t vs_lstm_state_floats(int B, int H);
 int vs_lstm_pack(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, void* stream);
 int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, float* out,
                         int B, int T, int H, void* stream);
+/* The same with the arithmetic of the recurrent products h_{t-1} @ W_hh^T chosen by the caller -- what vs_forward* and
+ * vs_backward pass from dims.math (models/voicesplit/model.py:82, nn.LSTM's recurrent GEMV): VS_MATH_FP32 = fp32 MFMA
+ * (what the calls above use), VS_MATH_F16X3 = h and W_hh split into f16 hi + lo, three f16 MFMA products (fp32-class;
+ * the BPTT keeps the fp32 MFMA), VS_MATH_BF16 = h / W_hh rounded to f16 in the forward, gate gradients / W_hh^T rounded
+ * to bf16 in the BPTT, one product each.  Pack and recurrence must be given the same `math`; the packed buffers hold the
+ * fp32 fragment form (used by the one-launch-per-step kernels in every arithmetic) followed by the 16-bit form.
+ * gates_save / c_save may be NULL (inference). */
+int vs_lstm_pack_math(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, int math, void* stream);
+int vs_bilstm_recurrent_math(const float* xg, const float* packed_whh, float* state, float* out, float* gates_save, float* c_save,
+                             int B, int T, int H, int math, void* stream);
 
 /* =============================================================================================
  * Training: forward that keeps what backward needs + the backward pass itself.
@@ -375,8 +385,9 @@ int vs_set_wgrad_kernel(int mode);
  * the switch exists for A/B timing and the bitwise cross-check.  Process-wide. */
 int vs_set_conv_kernel(int mode);
 /* which BiLSTM recurrence / BPTT runs: 0 = default (the persistent kernels whenever all their workgroups
- * fit on the device at once, else one launch per time step), 1 = one launch per step, 2 = persistent
- * (error when the grid cannot be resident).  Both forms give bit-identical results.  Process-wide.
+ * fit on the device at once, else one launch per time step), 1 = one launch per step (always the fp32 MFMA products),
+ * 2 = persistent (error when the grid cannot be resident), 3 = persistent with the fp32 MFMA products whatever dims.math
+ * says (A/B of the f16 / bf16 products).  In VS_MATH_FP32 both forms give bit-identical results.  Process-wide.
  * The persistent kernels keep an error word in the caller's state buffer (the first of its last 64
  * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
  * (a workgroup of the launch was not resident): results are then invalid. */
@@ -434,6 +445,9 @@ size_t vs_lstm_bwd_state_floats(int B, int H);
 int vs_lstm_pack_t(const float* w_hh_fwd, const float* w_hh_bwd, float* packed_t, int H, void* stream);
 int vs_bilstm_recurrent_bwd(const float* packed_t, float* state, float* gates, const float* c_all,
                             const float* dout, int B, int T, int H, void* stream);
+int vs_lstm_pack_t_math(const float* w_hh_fwd, const float* w_hh_bwd, float* packed_t, int H, int math, void* stream);
+int vs_bilstm_recurrent_bwd_math(const float* packed_t, float* state, float* gates, const float* c_all,
+                                 const float* dout, int B, int T, int H, int math, void* stream);
 int vs_sigmoid_bwd(const float* dmask, const float* mask, float* dlogits, long long n, void* stream);
 /* out[g][n] = sum over the g-th block of `rows` rows of X [groups*rows][ld] */
 int vs_colsum(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, void* stream);

@@ -2,7 +2,8 @@
 kernel.  The reference forward (models/voicesplit/model.py:66-89: conv stack with batch-statistics BatchNorm, d-vector
 concat, BiLSTM, head) in fp64 autograd with bf16 rounding injected exactly where the VS_MATH_BF16 configuration rounds:
 the 64->64 conv weights, z = conv + bias, a = act(BN(z)), the gradients flowing back through those two, and the operands
-of the LSTM input GEMM, of fc1 / fc2 and of their backward contractions.  Accumulation, statistics and the recurrence are exact.
+of the LSTM input GEMM, of fc1 / fc2 and of their backward contractions.  The recurrent product is rounded as the kernels round it (h, W_hh to f16
+forward; gate gradients, W_hh^T to bf16 in the BPTT).  Accumulation, statistics and the gate arithmetic are exact.
 The difference between these gradients and the unrounded ones is the envelope a correct bf16 implementation lives in;
 tests/test_gpu_bf16.py holds the HIP path to it.  (tools/bf16_error_sources.py prints the breakdown by rounding point.)"""
 from typing import Dict, Tuple
@@ -24,6 +25,27 @@ class _RoundSTE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return (g.to(torch.bfloat16).to(g.dtype) if ctx.rg else g), None, None
+
+
+class _RecurrentProduct(torch.autograd.Function):
+    """h_{t-1} @ W_hh^T as the VS_MATH_BF16 recurrence computes it (csrc/lstm.hip, lstm16_*): forward operands rounded
+    to f16, the BPTT's product W_hh^T @ dgates and the dW_hh contraction on bf16-rounded operands."""
+
+    @staticmethod
+    def forward(ctx, h, w, on):
+        ctx.save_for_backward(h, w)
+        ctx.on = on
+        if on:
+            return h.to(torch.float16).to(h.dtype) @ w.to(torch.float16).to(w.dtype).t()
+        return h @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        if ctx.on:
+            gb = g.to(torch.bfloat16).to(g.dtype)
+            return gb @ w.to(torch.bfloat16).to(w.dtype), gb.t() @ h.to(torch.bfloat16).to(h.dtype), None
+        return g @ w, g.t() @ h, None
 
 
 def _rnd(x, fwd: bool, bwd: bool = False):
@@ -64,7 +86,7 @@ def gradients(sd: Dict[str, torch.Tensor], x: torch.Tensor, dvec: torch.Tensor, 
         hh, c = xg.new_zeros(B, H), xg.new_zeros(B, H)
         out = [None] * T
         for t in (range(T - 1, -1, -1) if rev else range(T)):
-            g = xg[:, t] + hh @ w_hh.t()
+            g = xg[:, t] + _RecurrentProduct.apply(hh, w_hh, bool(bf16))
             i_, f_, gg, o_ = g.split(H, dim=1)
             c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
             hh = torch.sigmoid(o_) * torch.tanh(c)

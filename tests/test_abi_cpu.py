@@ -66,7 +66,11 @@ def test_workspace_layout_and_argument_errors():
     assert lib.vs_prepare_weights(ctypes.byref(d), None, None, 0, None) != 0 and b"NULL" in lib.vs_last_error()
     assert lib.vs_set_backward_overlap(2) == -1 and lib.vs_set_backward_overlap(1) == 0
     assert lib.vs_conv64_packed_floats(5, 5) == (8 * 25 + 4) * 512   # + 4 dummy taps for the prefetch overrun
-    assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400
+    # fp32 fragment form + room for the two f16 planes of the math-selected recurrence + a 64-float header
+    assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400 + 2 * 1600 * 400 + 64
+    assert lib.vs_lstm_packed_t_floats(400) == 2 * 13 * 200 * 256 + 2 * 13 * 100 * 256 + 64
+    # h ping / pong / flags regions are sized for the 16-wide K chunks of the f16 form (H = 24 -> 32)
+    assert lib.vs_lstm_state_floats(3, 24) == 3 * 2 * 32 * 32 + 64 and lib.vs_lstm_state_floats(64, 400) == 3 * 2 * 400 * 64 + 64
 
 
 def test_missing_library_fails_loudly(tmp_path):

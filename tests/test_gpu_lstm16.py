@@ -1,0 +1,170 @@
+"""The BiLSTM recurrence / BPTT with the recurrent products on the f16 / bf16 matrix instructions (csrc/lstm.hip,
+lstm16_*: what dims.math = VS_MATH_F16X3 / VS_MATH_BF16 select) against autograd through the explicit recurrence in
+fp64 (nn.LSTM of models/voicesplit/model.py:57-61,82 and its backward under train.py:110).
+
+Bounds.  VS_MATH_F16X3 (h and W_hh as f16 hi + lo, three products): fp32-class, the SAME 3e-5 the fp32-MFMA kernels
+hold.  VS_MATH_BF16 (forward: h, W_hh rounded to f16; BPTT: gate gradients, W_hh^T rounded to bf16): an fp64 model
+with exactly those roundings injected (``_rounded_reference``) differs from the exact recurrence by 2-3.3e-4 (outputs)
+and 0.8-1.2e-3 (gate gradients) of the tensor range on these shapes; the kernels may not exceed 2x that model's error
++ 1e-4 and must stay inside 1e-3 / 4e-3 absolutely."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 3e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    ref = ref.detach().to(torch.float64).cpu()
+    got = got.detach().to(torch.float64).cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+class _Rec(torch.autograd.Function):
+    """h @ W^T with the roundings of the VS_MATH_BF16 recurrence: forward operands to f16, backward operands to bf16;
+    dW exact (the library computes it with a separate GEMM)."""
+
+    @staticmethod
+    def forward(ctx, h, W, rounded):
+        ctx.save_for_backward(h, W)
+        ctx.rounded = rounded
+        if rounded:
+            return h.to(torch.float16).to(h.dtype) @ W.to(torch.float16).to(W.dtype).t()
+        return h @ W.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        h, W = ctx.saved_tensors
+        if ctx.rounded:
+            return g.to(torch.bfloat16).to(g.dtype) @ W.to(torch.bfloat16).to(W.dtype), g.t() @ h, None
+        return g @ W, g.t() @ h, None
+
+
+def _rounded_reference(xg, whh, dout, rounded):
+    B, T, H8 = xg.shape
+    H = H8 // 8
+    xgd = xg.double().requires_grad_(True)
+    outs, gates, cs = [], [], []
+    for dirn in range(2):
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
+        out, gs, cc = [None] * T, [None] * T, [None] * T
+        for t in (range(T - 1, -1, -1) if dirn else range(T)):
+            pre = xgd[:, t, dirn * 4 * H:(dirn + 1) * 4 * H] + _Rec.apply(h, whh[dirn].double(), rounded)
+            i, f, gg, o = pre.split(H, dim=1)
+            i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            out[t], gs[t], cc[t] = h, torch.cat((i, f, gg, o), 1), c
+        outs.append(torch.stack(out, 1))
+        gates.append(torch.stack(gs, 1))
+        cs.append(torch.stack(cc, 1))
+    out = torch.cat(outs, 2)
+    (out * dout.double()).sum().backward()
+    return out.detach(), torch.cat(gates, 2).detach(), torch.cat(cs, 2).detach(), xgd.grad
+
+
+def _case(B, T, H, scale=1.5):
+    g = torch.Generator().manual_seed(B * 100 + T + 7 * H)
+    xg = torch.randn(B, T, 8 * H, generator=g)
+    whh = [torch.randn(4 * H, H, generator=g) * (scale / H ** 0.5) for _ in range(2)]
+    dout = torch.randn(B, T, 2 * H, generator=g)
+    return xg, whh, dout
+
+
+SHAPES = [(2, 9, 24), (5, 17, 32), (33, 6, 40), (3, 12, 400), (2, 101, 40), (1, 301, 400), (64, 5, 400), (70, 4, 16), (3, 7, 456)]
+
+
+@pytest.mark.parametrize("B,T,H", SHAPES)
+def test_split_f16_recurrence_is_fp32_class(B, T, H):
+    """VS_MATH_F16X3: outputs, saved gates and cell states of the training forward (and the inference entry) at the fp32
+    kernels' tolerance; the BPTT of this arithmetic is the fp32-MFMA kernel and must give the same gate gradients
+    from this forward's saved tensors.  H = 24 / 40 / 456 leave a half-empty last K chunk, H = 456 exceeds the
+    register-resident chunks, B = 70 needs a partly filled third batch tile."""
+    from voicesplit_amd import _lib, ops
+    xg, whh, dout = _case(B, T, H)
+    out_ref, gates_ref, c_ref, dxg_ref = _rounded_reference(xg, whh, dout, False)
+    d = dev()
+    out, gates, c = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_F16X3)
+    assert rel_err(out, out_ref) < KTOL
+    assert rel_err(gates, gates_ref) < KTOL
+    assert rel_err(c, c_ref) < KTOL
+    o_inf = ops.bilstm_recurrent(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_F16X3)
+    assert torch.equal(o_inf, out)
+    dxg = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_F16X3)
+    assert rel_err(dxg, dxg_ref) < KTOL
+
+
+def test_split_f16_recurrence_scales_with_the_weights():
+    """The split form derives one power-of-two scale from max|W_hh|: weights of very different magnitude (1e-3 .. 30x the
+    default init) keep the fp32-class bound.  (The 30x case runs two steps only: with |W_hh h| ~ 100 the recurrence is
+    chaotic and ANY fp32 arithmetic diverges from fp64 after a few steps -- the one recurrent product it does contain
+    is what exercises the scale.)"""
+    from voicesplit_amd import _lib, ops
+    d = dev()
+    for scale, T in ((1e-3, 13), (0.05, 13), (30.0, 2)):
+        xg, whh, dout = _case(4, T, 48, scale=scale)
+        out_ref, _, _, _ = _rounded_reference(xg, whh, dout, False)
+        out = ops.bilstm_recurrent(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_F16X3)
+        assert rel_err(out, out_ref) < KTOL, scale
+
+
+@pytest.mark.parametrize("B,T,H", SHAPES)
+def test_bf16_math_recurrence_and_bptt(B, T, H):
+    """VS_MATH_BF16: f16 products forward, bf16 products in the BPTT, against the exact fp64 recurrence, bounded by the
+    error of the fp64 model with the same roundings."""
+    from voicesplit_amd import _lib, ops
+    xg, whh, dout = _case(B, T, H)
+    out_ref, gates_ref, c_ref, dxg_ref = _rounded_reference(xg, whh, dout, False)
+    out_m, gates_m, c_m, dxg_m = _rounded_reference(xg, whh, dout, True)
+    d = dev()
+    out, gates, c = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    table = {}
+    for name, got, ref, model, cap in (("out", out, out_ref, out_m, 1e-3), ("gates", gates, gates_ref, gates_m, 1e-3),
+                                       ("c", c, c_ref, c_m, 1e-3)):
+        e, ideal = rel_err(got, ref), rel_err(model, ref)
+        table[name] = (e, ideal)
+        assert e < cap and e <= 2.0 * ideal + 1e-4, table
+    o_inf = ops.bilstm_recurrent(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    assert torch.equal(o_inf, out)
+    dxg = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    e, ideal = rel_err(dxg, dxg_ref), rel_err(dxg_m, dxg_ref)
+    assert torch.isfinite(dxg).all()
+    assert e < 4e-3 and e <= 2.0 * ideal + 1e-4, (e, ideal)
+    cosv = torch.nn.functional.cosine_similarity(dxg.double().cpu().flatten(), dxg_ref.flatten(), dim=0).item()
+    assert cosv > 0.99999, cosv
+
+
+def test_bf16_bptt_keeps_small_gradients():
+    """Gate gradients have no a-priori range: an upstream gradient of 1e-6 (a mean-reduced loss) must come out with the
+    same RELATIVE error as one of order 1 (bf16's 8-bit exponent; an f16 form would flush these)."""
+    from voicesplit_amd import _lib, ops
+    xg, whh, dout = _case(3, 21, 64)
+    d = dev()
+    out, gates, c = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    big = ops.bilstm_recurrent_bwd(gates, c, dout.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    small = ops.bilstm_recurrent_bwd(gates, c, (dout * 2.0 ** -20).to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    assert torch.allclose(small * 2.0 ** 20, big, rtol=1e-5, atol=0.0)          # powers of two commute with every rounding involved
+
+
+def test_fp32_selector_overrides_the_math():
+    """vs_set_lstm_kernel(3): persistent kernels with the fp32 MFMA products whatever math is passed (the A/B switch of
+    bench.py): bit-identical to the plain entry points."""
+    from voicesplit_amd import _lib, ops
+    lib = _lib.load()
+    xg, whh, dout = _case(5, 9, 40)
+    d = dev()
+    ref = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d))
+    try:
+        assert lib.vs_set_lstm_kernel(3) == 0
+        got = ops.bilstm_recurrent_train(xg.to(d), whh[0].to(d), whh[1].to(d), math=_lib.MATH_BF16)
+    finally:
+        lib.vs_set_lstm_kernel(0)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

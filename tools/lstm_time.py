@@ -17,14 +17,15 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for mode, name in ((1, "one launch per step"), (2, "persistent (one launch, flag hand-off)")):
+for mode, math, name in ((1, None, "one launch per step"), (2, None, "persistent, fp32 MFMA products"),
+                         (2, _lib.MATH_F16X3, "persistent, split-f16 fwd / fp32 BPTT"), (2, _lib.MATH_BF16, "persistent, f16 fwd / bf16 BPTT")):
     assert lib.vs_set_lstm_kernel(mode) == 0
-    out, gates, c = ops.bilstm_recurrent_train(xg, whh[0], whh[1])
-    f = timeit(lambda: ops.bilstm_recurrent(xg, whh[0], whh[1]))
-    ft = timeit(lambda: ops.bilstm_recurrent_train(xg, whh[0], whh[1]))
+    out, gates, c = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
+    f = timeit(lambda: ops.bilstm_recurrent(xg, whh[0], whh[1], math=math))
+    ft = timeit(lambda: ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math))
     def bwd():
         gg = gates.clone()
-        return ops.bilstm_recurrent_bwd(gg, c, dout, whh[0], whh[1])
+        return ops.bilstm_recurrent_bwd(gg, c, dout, whh[0], whh[1], math=math)
     clone = timeit(lambda: gates.clone())
     b = timeit(bwd) - clone
     print(f"B={B} {name:36s} forward {f:6.3f} ms ({f / T * 1e3:5.2f} us/step)  train fwd {ft:6.3f}  BPTT {b:6.3f} ms ({b / T * 1e3:5.2f} us/step)")

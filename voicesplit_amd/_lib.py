@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class VsDims(Structure):
@@ -131,6 +131,8 @@ SIGNATURES = {
     "vs_lstm_state_floats": (c_size_t, [c_int, c_int]),
     "vs_lstm_pack": (c_int, [_P, _P, _P, c_int, _P]),
     "vs_bilstm_recurrent": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_lstm_pack_math": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "vs_bilstm_recurrent_math": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     # training
     "vs_tape_layout_query": (c_int, [POINTER(VsDims), POINTER(VsTapeLayout)]),
     "vs_tape_bytes": (c_size_t, [POINTER(VsDims)]),
@@ -161,6 +163,8 @@ SIGNATURES = {
     "vs_lstm_bwd_state_floats": (c_size_t, [c_int, c_int]),
     "vs_lstm_pack_t": (c_int, [_P, _P, _P, c_int, _P]),
     "vs_bilstm_recurrent_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "vs_lstm_pack_t_math": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "vs_bilstm_recurrent_bwd_math": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vs_sisnr_workspace_bytes": (c_size_t, [POINTER(VsLossDims)]),
     "vs_sisnr_loss": (c_int, [POINTER(VsLossDims), _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P]),
     "vs_powerlaw_loss": (c_int, [_P, _P, _P, c_longlong, c_float, c_float, _P, _P, _P, _P]),

@@ -456,6 +456,35 @@ int vs_bilstm_recurrent(const float* xg, const float* packed_whh, float* state, 
   return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, nullptr, nullptr, B, T, H, (hipStream_t)stream);
 }
 
+// the same four calls with the arithmetic of the recurrent products chosen by the caller (what vs_forward* / vs_backward
+// pass from dims.math): pack and recurrence must be given the same value
+static int check_lstm_math(int math) {
+  VS_REQUIRE(math == VS_MATH_FP32 || math == VS_MATH_F16X3 || math == VS_MATH_BF16, "lstm: unknown math %d", math);
+  return 0;
+}
+int vs_lstm_pack_math(const float* w_hh_fwd, const float* w_hh_bwd, float* packed, int H, int math, void* stream) {
+  if (int rc = check_lstm_math(math)) return rc;
+  VS_REQUIRE(w_hh_fwd && w_hh_bwd && packed, "lstm_pack_math: NULL argument");
+  return vs_lstm_pack_impl(w_hh_fwd, w_hh_bwd, packed, H, (hipStream_t)stream, math);
+}
+int vs_bilstm_recurrent_math(const float* xg, const float* packed_whh, float* state, float* out, float* gates_save, float* c_save,
+                             int B, int T, int H, int math, void* stream) {
+  if (int rc = check_lstm_math(math)) return rc;
+  VS_REQUIRE(xg && packed_whh && state && out, "bilstm_recurrent_math: NULL argument");
+  return vs_bilstm_recurrent_impl(xg, packed_whh, state, out, gates_save, c_save, B, T, H, (hipStream_t)stream, math);
+}
+int vs_lstm_pack_t_math(const float* w_hh_fwd, const float* w_hh_bwd, float* packed_t, int H, int math, void* stream) {
+  if (int rc = check_lstm_math(math)) return rc;
+  VS_REQUIRE(w_hh_fwd && w_hh_bwd && packed_t, "lstm_pack_t_math: NULL argument");
+  return vs_lstm_pack_t_impl(w_hh_fwd, w_hh_bwd, packed_t, H, (hipStream_t)stream, math);
+}
+int vs_bilstm_recurrent_bwd_math(const float* packed_t, float* state, float* gates, const float* c_all, const float* dout,
+                                 int B, int T, int H, int math, void* stream) {
+  if (int rc = check_lstm_math(math)) return rc;
+  VS_REQUIRE(packed_t && state && gates && c_all && dout, "bilstm_recurrent_bwd_math: NULL argument");
+  return vs_bilstm_bwd_recurrent_impl(packed_t, state, gates, c_all, dout, B, T, H, (hipStream_t)stream, math);
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage 1: conv stack, models/voicesplit/model.py:68-74
 // ---------------------------------------------------------------------------------------------
@@ -653,9 +682,9 @@ int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const f
                                        prep ? prep->wih_lo : nullptr)) return rc;
   }
   float* packed = prep ? prep->lstm_packed : at<float>(ws, L.lstm_packed);
-  if (!prep) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc; }
+  if (!prep) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc; }
   ProfScope ps(VS_PROF_LSTM_REC, stream);
-  return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, nullptr, nullptr, B, T, H, stream);
+  return vs_bilstm_recurrent_impl(xg, packed, at<float>(ws, L.lstm_state), lstm_out, nullptr, nullptr, B, T, H, stream, d->math);
 }
 }  // namespace
 
@@ -746,7 +775,7 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
     if (int rc = vs_lstm_split_wih_impl(d->math, p->w_ih[0], p->w_ih[1], d->H, 8 * d->F, 8 * d->F + d->E,
                                         reinterpret_cast<unsigned*>(P.gemm_wscale + 4), P.gemm_wscale, P.wih_hi, P.wih_lo, stream)) return rc;
   }
-  return vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], P.lstm_packed, d->H, stream);
+  return vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], P.lstm_packed, d->H, stream, d->math);
 }
 
 int vs_forward_prepared(const vs_dims* d, const vs_params* p, const void* prepared, size_t prepared_bytes,

@@ -15,7 +15,7 @@
 // combined through LDS.  W_hh and h are both kept in MFMA fragment order (one coalesced dwordx4
 // per lane per 4 K-steps) and every load of a step is issued before its first MFMA, so a step
 // costs one L2 round trip + 13 x 4 MFMAs per wave; c stays [dir][H][Bpad].
-#include "vs_common.h"
+#include "vs_internal.h"
 
 namespace {
 
@@ -138,12 +138,12 @@ void lstm_step_kernel(LstmStepArgs a) {
   float hv[4], cnew[4], gact[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const float gi = vs_sigmoid(acc[0 + u] + xgv[0 + u]);
-    const float gf = vs_sigmoid(acc[4 + u] + xgv[4 + u]);
-    const float gg = vs_tanh(acc[8 + u] + xgv[8 + u]);
-    const float go = vs_sigmoid(acc[12 + u] + xgv[12 + u]);
+    const float gi = vs_sigmoid_fast(acc[0 + u] + xgv[0 + u]);
+    const float gf = vs_sigmoid_fast(acc[4 + u] + xgv[4 + u]);
+    const float gg = vs_tanh_fast(acc[8 + u] + xgv[8 + u]);
+    const float go = vs_sigmoid_fast(acc[12 + u] + xgv[12 + u]);
     const float cn = gf * cprev[u] + gi * gg;
-    hv[u] = go * vs_tanh(cn);
+    hv[u] = go * vs_tanh_fast(cn);
     cnew[u] = cn;
     gact[0][u] = gi; gact[1][u] = gf; gact[2][u] = gg; gact[3][u] = go;
     const int k = jg * 8 + 4 * half + u;
@@ -308,12 +308,12 @@ void lstm_persistent_kernel(LstmPersistArgs a) {
       float hv[4], cnew[4], gact[4][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float gi = vs_sigmoid(acc[0 + u] + xgv[0 + u]);
-        const float gf = vs_sigmoid(acc[4 + u] + xgv[4 + u]);
-        const float gg = vs_tanh(acc[8 + u] + xgv[8 + u]);
-        const float go = vs_sigmoid(acc[12 + u] + xgv[12 + u]);
+        const float gi = vs_sigmoid_fast(acc[0 + u] + xgv[0 + u]);
+        const float gf = vs_sigmoid_fast(acc[4 + u] + xgv[4 + u]);
+        const float gg = vs_tanh_fast(acc[8 + u] + xgv[8 + u]);
+        const float go = vs_sigmoid_fast(acc[12 + u] + xgv[12 + u]);
         const float cn = gf * cprev[u] + gi * gg;
-        hv[u] = go * vs_tanh(cn);
+        hv[u] = go * vs_tanh_fast(cn);
         cnew[u] = cn;
         cprev[u] = cn;
         gact[0][u] = gi; gact[1][u] = gf; gact[2][u] = gg; gact[3][u] = go;
@@ -485,7 +485,7 @@ void lstm_bwd_step_kernel(LstmBwdArgs a) {
   float di[4], df[4], dg[4], dO[4], dcn[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const float tc = vs_tanh(cc[u]);
+    const float tc = vs_tanh_fast(cc[u]);
     dO[u] = dh[u] * tc * go[u] * (1.f - go[u]);
     const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
     di[u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
@@ -656,7 +656,7 @@ void lstm_bwd_persistent_kernel(LstmBwdPersistArgs a) {
       float dg4[4][4];        // [gate i,f,g,o][unit]
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float tc = vs_tanh(cc[u]);
+        const float tc = vs_tanh_fast(cc[u]);
         dg4[3][u] = dh[u] * tc * go[u] * (1.f - go[u]);
         const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
         dg4[0][u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
@@ -700,25 +700,495 @@ void lstm_bwd_persistent_kernel(LstmBwdPersistArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The recurrent products on the f16 / bf16 matrix instructions (dims.math = VS_MATH_F16X3 / VS_MATH_BF16).
+//
+// v_mfma_f32_32x32x2_f32 retires 2 of K per 64 cycles, v_mfma_f32_32x32x16_{f16,bf16} 16 per 32: the 52 fp32 MFMAs a
+// wave issues per forward step (100 per BPTT step) are 1.5 us (3 us) of a 6.8 us (12.4 us) step whose other parts are
+// hand-off latency.  Same decomposition, flags and hand-off protocol as the kernels above; what changes is the operand
+// form of the exchanged vector and of the resident weights:
+//   * K runs in chunks of 16; lane (half, n) of a chunk holds k = 16c + 8*half + j, j = 0..7, as ONE 16-byte vector
+//     (A: rows = n, B: columns = n -- the same map on both sides, so the dot product is the plain one);
+//   * forward, NP = 1 (VS_MATH_BF16): h and W_hh rounded to f16 (11 significant bits; |h| < 1, no range problem) -- one
+//     product per chunk.  NP = 2 (VS_MATH_F16X3): both split into f16 hi + lo planes (h scaled by 2^10, W_hh by the
+//     power of two that puts max|W_hh| into [2^9, 2^10)), three products per chunk, the 2^-22 lo x lo term dropped:
+//     fp32-class, as in the split-f16 convs and GEMMs;
+//   * BPTT (VS_MATH_BF16 only): gate gradients and W_hh^T as bf16 -- gradients have no a-priori range, so the 8-bit
+//     exponent is the right 16-bit form; one product per chunk.  The fp32-class arithmetic keeps the fp32 MFMA BPTT.
+// A producer owns 8 consecutive k (8 hidden units / 8 gate rows x 32 batch columns) = exactly one half-chunk: after a
+// half-wave exchange each lane holds its column's 8 values, the lower half-wave stores the hi plane (16 B per lane),
+// the upper one the lo plane.  The exchange shrinks from 4 to 2 (x NP) bytes per value.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kHScale = 1024.f;     // h of the split form is exchanged as f16(h * 2^10)
+constexpr int kMaxC = 7;              // 16-wide K chunks per wave held in registers (H <= 448)
+
+// f16 forms of W_hh for the forward recurrence: [dir][jg = H/8][c = ceil(H/16)][p < NP][lane 64] x 16 bytes; element j:
+//   W_hh[dir][(i>>3)*H + jg*8 + (i&7)][16c + 8*(lane>>5) + j] * s,  i = lane & 31   (0 beyond H)
+// hdr: [1] = s (NP = 2: from vs_scale_from_absmax_impl; NP = 1: unused) -> [0] = what the accumulators are multiplied by
+template <int NP>
+__global__ void lstm_pack16_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_b, u32x4_t* __restrict__ wp,
+                                   float* __restrict__ hdr, int H) {
+  const int HQ = H / 8, NC = (H + 15) / 16;
+  const long long total = 2LL * HQ * NC * 64;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float s = NP == 2 ? hdr[1] : 1.f;
+  if (idx == 0) hdr[0] = NP == 2 ? hdr[2] * (1.f / kHScale) : 1.f;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  long long rest = idx >> 6;
+  const int c = rest % NC; rest /= NC;
+  const int jg = rest % HQ;
+  const int dir = rest / HQ;
+  const int i = lane & 31;
+  const int row = (i >> 3) * H + jg * 8 + (i & 7);
+  const int k0 = 16 * c + 8 * (lane >> 5);
+  const float* w = (dir ? whh_b : whh_f) + (size_t)row * H;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = k0 + j < H ? w[k0 + j] * s : 0.f;
+  u32x4_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (NP == 2) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]));
+      hi[j] = __builtin_bit_cast(unsigned, h);
+      lo[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * j] - (float)h[0], x[2 * j + 1] - (float)h[1]));
+    } else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 h = {(_Float16)x[2 * j], (_Float16)x[2 * j + 1]};
+      hi[j] = __builtin_bit_cast(unsigned, h);
+    }
+  }
+  u32x4_t* o = wp + ((size_t)((dir * HQ + jg) * NC + c) * NP) * 64 + lane;
+  o[0] = hi;
+  if (NP == 2) o[64] = lo;
+}
+
+// bf16 form of W_hh^T for the BPTT: [dir][ut = ceil(H/32)][c = H/4][lane 64] x 16 bytes; element j:
+//   W_hh[dir][r = 16c + 8*(lane>>5) + j][unit = 32*ut + (lane&31)]   (0 for unit >= H)
+__global__ void lstm_pack16_t_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_b, u32x4_t* __restrict__ wp, int H) {
+  const int NUT = (H + 31) / 32, NCt = H / 4;
+  const long long total = 2LL * NUT * NCt * 64;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  long long rest = idx >> 6;
+  const int c = rest % NCt; rest /= NCt;
+  const int ut = rest % NUT;
+  const int dir = rest / NUT;
+  const int unit = ut * 32 + (lane & 31);
+  const int r0 = 16 * c + 8 * (lane >> 5);
+  const float* w = dir ? whh_b : whh_f;
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)(unit < H ? w[(size_t)(r0 + j) * H + unit] : 0.f);
+  wp[idx] = __builtin_bit_cast(u32x4_t, v);
+}
+
+struct Lstm16Args {
+  const float* xg;
+  const u32x4_t* wp;    // lstm_pack16_kernel<NP>
+  const float* hdr;     // hdr[0]: accumulator scale
+  void* hbuf0;          // [2 dir][NBT][NC][NP][64 lane] x 16 bytes
+  void* hbuf1;
+  unsigned* flags;      // [2 dir][NBT][H/8] epoch words
+  unsigned* err;
+  float* out;
+  float* gates_save;
+  float* c_save;
+  int B, T, H, Bpad, bt0;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256)
+void lstm16_persistent_kernel(Lstm16Args a) {
+  __shared__ float sRed[3 * 16 * 64];
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HQ = a.H / 8;
+  const int NC = (a.H + 15) / 16;
+  const int NBT = a.Bpad / 32;
+  const int jg = blockIdx.x % HQ;
+  const int bt = a.bt0 + blockIdx.x / HQ;
+  const int dir = blockIdx.y;
+  const int b = bt * 32 + l31;
+  if (tid == 0) sDead = 0;
+
+  // W_hh slice: resident for the whole sequence
+  const u32x4_t* wq = a.wp + ((size_t)(dir * HQ + jg) * NC * NP) * 64 + lane;
+  f16x8 w[kMaxC][NP];
+#pragma unroll
+  for (int i = 0; i < kMaxC; ++i) {
+    const int c = wave + 4 * i;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      w[i][p] = __builtin_bit_cast(f16x8, c < NC ? wq[(size_t)(c * NP + p) * 64] : u32x4_t{0u, 0u, 0u, 0u});
+  }
+  const float inv = a.hdr[0];
+  const size_t group = (size_t)dir * NBT + bt;
+  const unsigned hbytes = (unsigned)((size_t)2 * NBT * NC * NP * 1024);
+  __amdgpu_buffer_rsrc_t hrs[2] = {__builtin_amdgcn_make_buffer_rsrc(a.hbuf0, 0, hbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.hbuf1, 0, hbytes, 0x00020000)};
+  unsigned* const gflags = a.flags + group * HQ;
+  float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? (a.T - 1 - s) : s;
+    float xgv[16];
+    if (wave == 0) {
+      const bool ok = b < a.B;
+      const float* xrow = a.xg + ((size_t)(ok ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xgv[r] = ok ? xrow[(r >> 2) * a.H + (r & 3)] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      if (wave == 0 && !sDead) {
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int j = lane; j < HQ; j += 64)
+            ok = ok && (__hip_atomic_load(gflags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) {
+            if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      const unsigned hoff = (unsigned)((group * NC * NP * 64 + lane) * 16);
+      f16x8 h[kMaxC][NP];
+#pragma unroll
+      for (int i = 0; i < kMaxC; ++i) {
+        const int c = wave + 4 * i;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          h[i][p] = __builtin_bit_cast(f16x8, c < NC ? __builtin_amdgcn_raw_buffer_load_b128(hrs[s & 1], hoff + (unsigned)(c * NP + p) * 1024u, 0, 16 /* sc1 */)
+                                                       : u32x4_t{0u, 0u, 0u, 0u});
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxC; ++i) {
+        if (wave + 4 * i < NC) {          // wave-uniform
+          if (NP == 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][NP - 1], h[i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][0], h[i][NP - 1], acc, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][0], h[i][0], acc, 0, 0, 0);
+        }
+      }
+      // hidden sizes beyond 4*kMaxC*16 = 448: remaining chunks, weights re-read from L2 each step
+      for (int c = wave + 4 * kMaxC; c < NC; c += 4) {
+        f16x8 wc[NP], hc[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          wc[p] = __builtin_bit_cast(f16x8, wq[(size_t)(c * NP + p) * 64]);
+          hc[p] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs[s & 1], hoff + (unsigned)(c * NP + p) * 1024u, 0, 16));
+        }
+        if (NP == 2) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[NP - 1], hc[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[0], hc[NP - 1], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[0], hc[0], acc, 0, 0, 0);
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sRed[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sRed[(w3 * 16 + r) * 64 + lane];
+      float hv[4], cnew[4], gact[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float gi = vs_sigmoid_fast(fmaf(acc[0 + u], inv, xgv[0 + u]));
+        const float gf = vs_sigmoid_fast(fmaf(acc[4 + u], inv, xgv[4 + u]));
+        const float gg = vs_tanh_fast(fmaf(acc[8 + u], inv, xgv[8 + u]));
+        const float go = vs_sigmoid_fast(fmaf(acc[12 + u], inv, xgv[12 + u]));
+        const float cn = gf * cprev[u] + gi * gg;
+        hv[u] = go * vs_tanh_fast(cn);
+        cnew[u] = cn;
+        cprev[u] = cn;
+        gact[0][u] = gi; gact[1][u] = gf; gact[2][u] = gg; gact[3][u] = go;
+      }
+      // this lane computed units 4*half .. 4*half+3 of the workgroup's 8 for batch column l31; after the half-wave
+      // exchange every lane holds all 8 = the half-chunk (chunk jg>>1, k-half jg&1) of its column
+      {
+        float full[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float o = __shfl_xor(hv[u], 32, 64);
+          full[u] = half ? o : hv[u];
+          full[4 + u] = half ? hv[u] : o;
+        }
+        u32x4_t v;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (NP == 2) {
+            const float x0 = full[2 * j] * kHScale, x1 = full[2 * j + 1] * kHScale;
+            const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+            const unsigned lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]));
+            v[j] = half ? lo : __builtin_bit_cast(unsigned, hh);
+          } else {
+            const h2 hh = {(_Float16)full[2 * j], (_Float16)full[2 * j + 1]};
+            v[j] = __builtin_bit_cast(unsigned, hh);
+          }
+        }
+        const unsigned plane = NP == 2 ? (unsigned)half : 0u;
+        const unsigned off = (unsigned)((((group * NC + (jg >> 1)) * NP + plane) * 64 + (jg & 1) * 32 + l31) * 16);
+        if (NP == 2 || half == 0)
+          __builtin_amdgcn_raw_buffer_store_b128(v, hrs[(s + 1) & 1], off, 0, 16 /* sc1: write-through */);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(gflags + jg, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b < a.B) {
+        float4* o = reinterpret_cast<float4*>(a.out + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+        *o = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (a.c_save) {
+          float4* cs = reinterpret_cast<float4*>(a.c_save + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+          *cs = make_float4(cnew[0], cnew[1], cnew[2], cnew[3]);
+        }
+        if (a.gates_save) {
+          float* grow = a.gates_save + ((size_t)b * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(grow + gq * a.H) = make_float4(gact[gq][0], gact[gq][1], gact[gq][2], gact[gq][3]);
+        }
+      }
+    }
+  }
+}
+
+struct Lstm16BwdArgs {
+  const u32x4_t* wpt;    // lstm_pack16_t_kernel
+  void* gbuf0;           // bf16 gate gradients [2 dir][NBT][H/4][64 lane] x 16 bytes
+  void* gbuf1;
+  unsigned* flags;       // [2 dir][NBT][NUT*4]
+  unsigned* err;
+  float* gates;
+  const float* c_all;
+  const float* dout;
+  int B, T, H, Bpad, bt0;
+};
+
+constexpr int kBwdRes16 = 13;   // 16-wide K chunks of W_hh^T per wave held in registers (4H <= 1664); the rest streams from L2
+
+__global__ __launch_bounds__(512)
+void lstm16_bwd_persistent_kernel(Lstm16BwdArgs a) {
+  __shared__ float sRed[8 * 16 * 64];
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int NCt = a.H / 4;
+  const int NUT = (a.H + 31) / 32;
+  const int NBT = a.Bpad / 32;
+  const int ut = blockIdx.x % NUT;
+  const int bt = a.bt0 + blockIdx.x / NUT;
+  const int dir = blockIdx.y;
+  if (tid == 0) sDead = 0;
+
+  const int b31 = tid & 31, ug = (tid >> 5) & 7;
+  const int b = bt * 32 + b31;
+  const int u0 = ut * 32 + 4 * ug;
+  const bool units_ok = tid < 256 && u0 < a.H;          // wave-uniform (H % 8 == 0)
+  const bool item = units_ok && b < a.B;
+
+  const u32x4_t* wq = a.wpt + ((size_t)(dir * NUT + ut) * NCt) * 64 + lane;
+  bf16x8 w[kBwdRes16];
+#pragma unroll
+  for (int i = 0; i < kBwdRes16; ++i) {
+    const int c = wave + 8 * i;
+    w[i] = __builtin_bit_cast(bf16x8, c < NCt ? wq[(size_t)c * 64] : u32x4_t{0u, 0u, 0u, 0u});
+  }
+  const size_t group = (size_t)dir * NBT + bt;
+  const unsigned gbytes = (unsigned)((size_t)2 * NBT * NCt * 1024);
+  __amdgpu_buffer_rsrc_t grs[2] = {__builtin_amdgcn_make_buffer_rsrc(a.gbuf0, 0, gbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.gbuf1, 0, gbytes, 0x00020000)};
+  const int nflag = NUT * 4;
+  unsigned* const gflags = a.flags + group * nflag;
+  float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? s : (a.T - 1 - s);
+    const int tp = dir ? t + 1 : t - 1;                 // forward-order predecessor (c_{t-1})
+    float4 gi4, gf4, gg4, go4, c4, cp4, dh4;
+    gi4 = gf4 = gg4 = go4 = c4 = cp4 = dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* grow = a.gates + ((size_t)(item ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + (item ? u0 : 0);
+    if (item) {
+      gi4 = *reinterpret_cast<const float4*>(grow);
+      gf4 = *reinterpret_cast<const float4*>(grow + a.H);
+      gg4 = *reinterpret_cast<const float4*>(grow + 2 * a.H);
+      go4 = *reinterpret_cast<const float4*>(grow + 3 * a.H);
+      const size_t so = ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + u0;
+      c4 = *reinterpret_cast<const float4*>(a.c_all + so);
+      dh4 = *reinterpret_cast<const float4*>(a.dout + so);
+      if (tp >= 0 && tp < a.T)
+        cp4 = *reinterpret_cast<const float4*>(a.c_all + ((size_t)b * a.T + tp) * (2 * a.H) + (size_t)dir * a.H + u0);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      if (wave == 0 && !sDead) {
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int j = lane; j < nflag; j += 64)
+            ok = ok && (__hip_atomic_load(gflags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit) {
+            if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      const unsigned goff = (unsigned)((group * NCt * 64 + lane) * 16);
+      bf16x8 g[kBwdRes16];
+#pragma unroll
+      for (int i = 0; i < kBwdRes16; ++i) {
+        const int c = wave + 8 * i;
+        g[i] = __builtin_bit_cast(bf16x8, c < NCt ? __builtin_amdgcn_raw_buffer_load_b128(grs[s & 1], goff + (unsigned)c * 1024u, 0, 16 /* sc1 */)
+                                                  : u32x4_t{0u, 0u, 0u, 0u});
+      }
+#pragma unroll
+      for (int i = 0; i < kBwdRes16; ++i) {
+        if (wave + 8 * i < NCt)        // wave-uniform
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i], g[i], acc, 0, 0, 0);
+      }
+      for (int c = wave + 8 * kBwdRes16; c < NCt; c += 8) {        // H > 416: weights re-read from L2 each step
+        const bf16x8 wc = __builtin_bit_cast(bf16x8, wq[(size_t)c * 64]);
+        const bf16x8 gc = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(grs[s & 1], goff + (unsigned)c * 1024u, 0, 16));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc, gc, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+      float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += sRed[(w8 * 16 + 4 * wave + u) * 64 + lane];
+      const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+      const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+      float dg4[4][4];        // [gate i,f,g,o][unit]
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float tc = vs_tanh_fast(cc[u]);
+        dg4[3][u] = dh[u] * tc * go[u] * (1.f - go[u]);
+        const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
+        dg4[0][u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
+        dg4[1][u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
+        dg4[2][u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
+        dcc[u] = dc * gf[u];
+      }
+      if (!item) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dg4[gate][u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dcc[u] = 0.f;
+      }
+      // next step's operand: rows gate*H + ut*32 + 8*wave .. +7 = one half-chunk; this lane computed 4*half .. 4*half+3 of them
+      if (units_ok) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+          bf16x8 v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float o = __shfl_xor(dg4[gate][u], 32, 64);
+            v[u] = (__bf16)(half ? o : dg4[gate][u]);
+            v[4 + u] = (__bf16)(half ? dg4[gate][u] : o);
+          }
+          const int r0 = gate * a.H + ut * 32 + 8 * wave;
+          const unsigned off = (unsigned)(((group * NCt + (r0 >> 4)) * 64 + ((r0 >> 3) & 1) * 32 + b31) * 16);
+          if (half == 0)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), grs[(s + 1) & 1], off, 0, 16 /* sc1 */);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(gflags + ut * 4 + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (item) {           // the batched GEMMs' operand, in place of the saved gates
+        *reinterpret_cast<float4*>(grow) = make_float4(dg4[0][0], dg4[0][1], dg4[0][2], dg4[0][3]);
+        *reinterpret_cast<float4*>(grow + a.H) = make_float4(dg4[1][0], dg4[1][1], dg4[1][2], dg4[1][3]);
+        *reinterpret_cast<float4*>(grow + 2 * a.H) = make_float4(dg4[2][0], dg4[2][1], dg4[2][2], dg4[2][3]);
+        *reinterpret_cast<float4*>(grow + 3 * a.H) = make_float4(dg4[3][0], dg4[3][1], dg4[3][2], dg4[3][3]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
-extern "C" size_t vs_lstm_packed_floats(int H) { return (size_t)2 * (H / 8) * (H / 8) * 256; }
+// packed recurrent weights: the fp32 fragment form (every arithmetic: the step kernels use it), then room for the f16
+// form of the math-selected persistent kernel (two planes), then a 64-float header (accumulator scale, weight scale, |max|)
+static size_t lstm_packed_fp32_floats(int H) { return (size_t)2 * (H / 8) * (H / 8) * 256; }
+static size_t lstm_packed_f16_floats(int H) { return (size_t)2 * (H / 8) * ((H + 15) / 16) * 2 * 256; }
+extern "C" size_t vs_lstm_packed_floats(int H) { return lstm_packed_fp32_floats(H) + lstm_packed_f16_floats(H) + 64; }
+// h ping, h pong, flags / c: three regions of 2 * Hp * Bpad floats (Hp = H rounded up to the f16 form's 16-wide K chunk)
 // + 64: the persistent kernel's error word lives in the last 64 floats (never touched by the step kernels)
-extern "C" size_t vs_lstm_state_floats(int B, int H) { return (size_t)3 * 2 * H * (((size_t)B + 31) / 32 * 32) + 64; }
+static size_t lstm_state_region(int B, int H) { return (size_t)2 * ((H + 15) / 16 * 16) * (((size_t)B + 31) / 32 * 32); }
+extern "C" size_t vs_lstm_state_floats(int B, int H) { return 3 * lstm_state_region(B, H) + 64; }
 
-int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream) {
+// math: the dims.math of the call the weights are packed for (VS_MATH_CODE_*); it selects the f16 form written behind
+// the fp32 one
+int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream, int math) {
   VS_REQUIRE(H > 0 && H % 8 == 0, "lstm: hidden size %d must be a multiple of 8", H);
-  const long long total = (long long)vs_lstm_packed_floats(H);
+  const long long total = (long long)lstm_packed_fp32_floats(H);
   hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, whh_f, whh_b, wp, H);
+  VS_LAUNCH_CHECK();
+  if (math == VS_MATH_CODE_FP32) return 0;
+  u32x4_t* w16 = reinterpret_cast<u32x4_t*>(wp + lstm_packed_fp32_floats(H));
+  float* hdr = wp + lstm_packed_fp32_floats(H) + lstm_packed_f16_floats(H);
+  const long long slots = 2LL * (H / 8) * ((H + 15) / 16) * 64;
+  if (math == VS_MATH_CODE_BF16) {
+    hipLaunchKernelGGL((lstm_pack16_kernel<1>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, whh_f, whh_b, w16, hdr, H);
+  } else {
+    // one power-of-two scale for both directions' W_hh: max|W_hh| * s in [2^9, 2^10)
+    unsigned* amax = reinterpret_cast<unsigned*>(hdr + 8);
+    VS_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), stream));
+    if (int rc = vs_absmax_accum_impl(whh_f, (long long)4 * H * H, amax, stream)) return rc;
+    if (int rc = vs_absmax_accum_impl(whh_b, (long long)4 * H * H, amax, stream)) return rc;
+    if (int rc = vs_scale_from_absmax_impl(amax, 1, hdr + 1, stream)) return rc;
+    hipLaunchKernelGGL((lstm_pack16_kernel<2>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, whh_f, whh_b, w16, hdr, H);
+  }
   VS_LAUNCH_CHECK();
   return 0;
 }
 
-// which recurrence runs: 0 = persistent when its grid is resident (default), 1 = one launch per step,
-// 2 = persistent (error if it cannot be).  Test / A-B switch, process-global.
+// which recurrence runs: 0 = persistent when its grid is resident (default), 1 = one launch per step (fp32 MFMA),
+// 2 = persistent (error if it cannot be), 3 = persistent with the fp32 MFMA products whatever dims.math says (A/B of
+// the f16 / bf16 products).  Test / A-B switch, process-global.
 static int g_lstm_kernel = 0;
 extern "C" int vs_set_lstm_kernel(int mode) {
-  VS_REQUIRE(mode >= 0 && mode <= 2, "vs_set_lstm_kernel: mode %d", mode);
+  VS_REQUIRE(mode >= 0 && mode <= 3, "vs_set_lstm_kernel: mode %d", mode);
   g_lstm_kernel = mode;
   return 0;
 }
@@ -746,10 +1216,11 @@ hipError_t launch_resident(const void* kernel, dim3 grid, dim3 block, Args& a, h
 // state: 3 * [2][H][Bpad] floats.  Step kernels: h ping, h pong, c, zeroed here (zero initial state).
 // Persistent kernel: h ping, h pong (fragment order), then the flag words + the error word.
 int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,
-                             int B, int T, int H, hipStream_t stream) {
+                             int B, int T, int H, hipStream_t stream, int math) {
   VS_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, "lstm: bad shape B=%d T=%d H=%d (H must be a multiple of 8)", B, T, H);
   const int Bpad = (B + 31) / 32 * 32;
-  const size_t per = (size_t)2 * H * Bpad;
+  const size_t per = lstm_state_region(B, H);
+  if (g_lstm_kernel == 3) math = VS_MATH_CODE_FP32;
   VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_state_floats(B, H) * sizeof(float), stream));
   float* hbuf[2] = {state, state + per};
   const int HQ = H / 8, NBT = Bpad / 32;
@@ -766,8 +1237,19 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
     bool launched = true;
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
-      LstmPersistArgs a{xg, wp, hbuf[0], hbuf[1], flags, err, out, gates_save, c_save, B, T, H, Bpad, bt0};
-      const hipError_t e = launch_resident(reinterpret_cast<const void*>(&lstm_persistent_kernel), dim3(HQ * nbt, 2), dim3(256), a, stream);
+      hipError_t e;
+      if (math == VS_MATH_CODE_FP32) {
+        LstmPersistArgs a{xg, wp, hbuf[0], hbuf[1], flags, err, out, gates_save, c_save, B, T, H, Bpad, bt0};
+        e = launch_resident(reinterpret_cast<const void*>(&lstm_persistent_kernel), dim3(HQ * nbt, 2), dim3(256), a, stream);
+      } else {
+        // the f16 form the weights were packed in (vs_lstm_pack_impl with the same math) and its header
+        const float* w16 = wp + lstm_packed_fp32_floats(H);
+        Lstm16Args a{xg, reinterpret_cast<const u32x4_t*>(w16), w16 + lstm_packed_f16_floats(H), hbuf[0], hbuf[1], flags, err, out,
+                     gates_save, c_save, B, T, H, Bpad, bt0};
+        e = math == VS_MATH_CODE_BF16
+                ? launch_resident(reinterpret_cast<const void*>(&lstm16_persistent_kernel<1>), dim3(HQ * nbt, 2), dim3(256), a, stream)
+                : launch_resident(reinterpret_cast<const void*>(&lstm16_persistent_kernel<2>), dim3(HQ * nbt, 2), dim3(256), a, stream);
+      }
       if (e != hipSuccess) {
         (void)hipGetLastError();
         // refused before anything ran (first launch): the step kernels below do the whole job; later: an error
@@ -792,17 +1274,25 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
   return 0;
 }
 
-extern "C" size_t vs_lstm_packed_t_floats(int H) { return (size_t)2 * ((H + 31) / 32) * (H / 2) * 256; }
+// W_hh^T in fp32 fragment form, then room for the bf16 form (VS_MATH_BF16's BPTT), then 64 spare floats
+static size_t lstm_packed_t_fp32_floats(int H) { return (size_t)2 * ((H + 31) / 32) * (H / 2) * 256; }
+static size_t lstm_packed_t_bf16_floats(int H) { return (size_t)2 * ((H + 31) / 32) * (H / 4) * 256; }
+extern "C" size_t vs_lstm_packed_t_floats(int H) { return lstm_packed_t_fp32_floats(H) + lstm_packed_t_bf16_floats(H) + 64; }
 // backward state: dgates fragments ping/pong [2][2][NBT][H/2][256] + dc carry [2][Bpad][H]
 extern "C" size_t vs_lstm_bwd_state_floats(int B, int H) {
   const size_t Bpad = ((size_t)B + 31) / 32 * 32;
   return 2 * (2 * (Bpad / 32) * (size_t)(H / 2) * 256) + 2 * Bpad * H + 64;   // + 64: error word of the persistent kernel
 }
 
-int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream) {
+int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H, hipStream_t stream, int math) {
   VS_REQUIRE(H > 0 && H % 8 == 0, "lstm: hidden size %d must be a multiple of 8", H);
-  const long long total = (long long)vs_lstm_packed_t_floats(H);
+  const long long total = (long long)lstm_packed_t_fp32_floats(H);
   hipLaunchKernelGGL(lstm_pack_whh_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, whh_f, whh_b, wp, H);
+  VS_LAUNCH_CHECK();
+  if (math != VS_MATH_CODE_BF16) return 0;
+  const long long slots = 2LL * ((H + 31) / 32) * (H / 4) * 64;
+  hipLaunchKernelGGL(lstm_pack16_t_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, whh_f, whh_b,
+                     reinterpret_cast<u32x4_t*>(wp + lstm_packed_t_fp32_floats(H)), H);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -811,8 +1301,9 @@ int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H
 // state: step kernels = dgates fragments ping/pong + dc carry; persistent kernel = the two fragment
 // buffers, then (in the dc region) the flag words and the error word.
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
-                                 int B, int T, int H, hipStream_t stream) {
+                                 int B, int T, int H, hipStream_t stream, int math) {
   VS_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, "lstm_bwd: bad shape B=%d T=%d H=%d (H must be a multiple of 8)", B, T, H);
+  if (g_lstm_kernel == 3) math = VS_MATH_CODE_FP32;
   const int Bpad = (B + 31) / 32 * 32;
   const size_t frag = (size_t)2 * (Bpad / 32) * (H / 2) * 256;
   VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_bwd_state_floats(B, H) * sizeof(float), stream));
@@ -830,8 +1321,15 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
     bool launched = true;
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
-      LstmBwdPersistArgs a{wpt, gbuf[0], gbuf[1], flags, err, gates, c_all, dout, B, T, H, Bpad, bt0};
-      const hipError_t e = launch_resident(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
+      hipError_t e;
+      if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
+        Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), gbuf[0], gbuf[1], flags, err, gates, c_all, dout,
+                        B, T, H, Bpad, bt0};
+        e = launch_resident(reinterpret_cast<const void*>(&lstm16_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
+      } else {
+        LstmBwdPersistArgs a{wpt, gbuf[0], gbuf[1], flags, err, gates, c_all, dout, B, T, H, Bpad, bt0};
+        e = launch_resident(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
+      }
       if (e != hipSuccess) {
         (void)hipGetLastError();
         VS_REQUIRE(bt0 == 0 && g_lstm_kernel != 2, "lstm_bwd: persistent recurrence could not be launched resident: %s", hipGetErrorString(e));

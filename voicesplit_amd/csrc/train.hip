@@ -243,11 +243,11 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
                                          nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
-  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream)) return rc;
+  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc;
   {
     VsProfScope ps(VS_PROF_LSTM_REC, stream);
     if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
-                                          at<float>(tape, L.cstate), B, T, H, stream)) return rc;
+                                          at<float>(tape, L.cstate), B, T, H, stream, d->math)) return rc;
   }
 
   // head
@@ -361,11 +361,11 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // ---- BiLSTM: BPTT, then the batched weight / input gradients ------------------------------
   float* dxg = at<float>(tape, L.gates);
   float* wpt = at<float>(tape, L.lstm_packed_t);
-  if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream)) return rc;
+  if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream, d->math)) return rc;
   {
     VsProfScope ps(VS_PROF_BWD_LSTM_REC, stream);
     if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
-                                              B, T, H, stream)) return rc;
+                                              B, T, H, stream, d->math)) return rc;
   }
   float* dsum = at<float>(tape, L.dsum);
   float* feat = at<float>(tape, L.feat);
@@ -444,7 +444,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       if (int rc = vs_gemm_general_impl(1, 1, dsum + (size_t)dir * 4 * H, 8 * H, dvec, nullptr, 0x7fffffff, E, g->w_ih[dir] + K8, KE,
                                         4 * H, E, B, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, ls)) return rc;
       // dW_hh = sum_t dgates_t^T h_{t-1}: the lstm_out rows shifted by one frame inside each utterance
-      if (int rc = vs_gemm_general_impl(1, 1, dxg_d, 8 * H, lstm_out + (size_t)dir * H, nullptr, 0x7fffffff, 2 * H, g->w_hh[dir], H,
+      // (VS_MATH_BF16: on bf16-rounded operands like the other contractions of this configuration)
+      if (int rc = (bf16g ? vs_gemm_general_bf16_impl : vs_gemm_general_impl)(1, 1, dxg_d, 8 * H, lstm_out + (size_t)dir * H, nullptr, 0x7fffffff, 2 * H, g->w_hh[dir], H,
                                         4 * H, H, M, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0,
                                         dir ? 1 : -1, T, kSplitK, part, ls)) return rc;
       if (g->dvec) {

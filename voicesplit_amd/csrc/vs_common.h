@@ -59,6 +59,21 @@ __device__ __forceinline__ float vs_sigmoid(float x) { return 1.0f / (1.0f + exp
 // ocml tanhf: accurate near 0 (a (1-e)/(1+e) form cancels there)
 __device__ __forceinline__ float vs_tanh(float x) { return tanhf(x); }
 
+// The recurrence's gate arithmetic sits on the step-to-step critical path of ONE wave (lstm.hip): 12 sigmoids and
+// 8 tanh per lane and step.  The ocml forms (expf + IEEE divide, tanhf) are ~20-25 dependent VALU each -- ~1 us per
+// step for a lone wave; these are 4 and 12: v_exp_f32 / v_rcp_f32 (1 ulp each).  sigmoid: <= ~3e-7 relative.  tanh: the
+// 1 - 2/(1+e^2x) form cancels near 0 (absolute error one ulp of 1), so |x| < 1/8 takes the odd series up to x^7
+// (truncation 62/2835 x^8 < 2e-9 relative there): <= ~1e-6 relative everywhere.
+__device__ __forceinline__ float vs_sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+__device__ __forceinline__ float vs_tanh_fast(float x) {
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f));
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+  return fabsf(x) < 0.125f ? small : big;
+}
+
 template <int ACT>
 __device__ __forceinline__ float vs_act(float v) {
   if (ACT == VS_ACT_RELU) return fmaxf(v, 0.0f);

@@ -168,12 +168,14 @@ inline VsLstmBf16Layout vs_lstm_bf16_layout(long long M, int K, int H) {
   return L;
 }
 // lstm.hip
-int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t);
+// math (VS_MATH_CODE_*): which products the persistent recurrences use -- fp32 MFMA, or (forward) split-f16 / f16 and
+// (BPTT, VS_MATH_BF16 only) bf16; the pack calls write the matching operand form behind the fp32 one
+int vs_lstm_pack_impl(const float*, const float*, float*, int, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, float* out, float* gates_save, float* c_save,
-                             int B, int T, int H, hipStream_t);
-int vs_lstm_pack_t_impl(const float*, const float*, float*, int, hipStream_t);
+                             int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
+int vs_lstm_pack_t_impl(const float*, const float*, float*, int, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
-                                 int B, int T, int H, hipStream_t);
+                                 int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
 // reduce.hip
 int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, long long n, hipStream_t);
 int vs_colsum_impl(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, hipStream_t);

@@ -324,18 +324,24 @@ def gemm_nt(A, W, bias1=None, bias2=None, rowbias=None, group: int = 1, a_relu: 
     return C
 
 
-def bilstm_recurrent(xg, w_hh_f, w_hh_b):
-    """xg [B,T,8H] (bias already added) -> [B,T,2H]."""
+def bilstm_recurrent(xg, w_hh_f, w_hh_b, math=None):
+    """xg [B,T,8H] (bias already added) -> [B,T,2H].  math: None = the fp32-MFMA entry points, else MATH_* through the
+    *_math entry points (the recurrent products on the f16 matrix instructions)."""
     lib = _lib.load()
     for n, t in (("xg", xg), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
         _dev_check(t, n)
     B, T, H8 = xg.shape
     H = H8 // 8
     packed = torch.empty(lib.vs_lstm_packed_floats(H), dtype=torch.float32, device=xg.device)
-    check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
     state = torch.empty(lib.vs_lstm_state_floats(B, H), dtype=torch.float32, device=xg.device)
     out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
-    check(lib.vs_bilstm_recurrent(_p(xg), _p(packed), _p(state), _p(out), B, T, H, _stream()), "vs_bilstm_recurrent")
+    if math is None:
+        check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
+        check(lib.vs_bilstm_recurrent(_p(xg), _p(packed), _p(state), _p(out), B, T, H, _stream()), "vs_bilstm_recurrent")
+    else:
+        check(lib.vs_lstm_pack_math(_p(w_hh_f), _p(w_hh_b), _p(packed), H, int(math), _stream()), "vs_lstm_pack_math")
+        check(lib.vs_bilstm_recurrent_math(_p(xg), _p(packed), _p(state), _p(out), None, None, B, T, H, int(math), _stream()),
+              "vs_bilstm_recurrent_math")
     _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent")
     return out
 
@@ -579,38 +585,48 @@ def gemm(A, W, M: int, N: int, K: int, layout_a: int = 0, layout_w: int = 0, bia
     return C
 
 
-def bilstm_recurrent_train(xg, w_hh_f, w_hh_b):
-    """xg [B,T,8H] -> (out [B,T,2H], gates [B,T,8H] activated, c [B,T,2H])."""
+def bilstm_recurrent_train(xg, w_hh_f, w_hh_b, math=None):
+    """xg [B,T,8H] -> (out [B,T,2H], gates [B,T,8H] activated, c [B,T,2H]).  math: see bilstm_recurrent."""
     lib = _lib.load()
     for n, t in (("xg", xg), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
         _dev_check(t, n)
     B, T, H8 = xg.shape
     H = H8 // 8
     packed = torch.empty(lib.vs_lstm_packed_floats(H), dtype=torch.float32, device=xg.device)
-    check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
     state = torch.empty(lib.vs_lstm_state_floats(B, H), dtype=torch.float32, device=xg.device)
     out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
     gates = xg.clone()
     c = torch.empty(B, T, 2 * H, dtype=torch.float32, device=xg.device)
-    check(lib.vs_bilstm_recurrent_train(_p(gates), _p(packed), _p(state), _p(out), _p(gates), _p(c), B, T, H, _stream()),
-          "vs_bilstm_recurrent_train")
+    if math is None:
+        check(lib.vs_lstm_pack(_p(w_hh_f), _p(w_hh_b), _p(packed), H, _stream()), "vs_lstm_pack")
+        check(lib.vs_bilstm_recurrent_train(_p(gates), _p(packed), _p(state), _p(out), _p(gates), _p(c), B, T, H, _stream()),
+              "vs_bilstm_recurrent_train")
+    else:
+        check(lib.vs_lstm_pack_math(_p(w_hh_f), _p(w_hh_b), _p(packed), H, int(math), _stream()), "vs_lstm_pack_math")
+        check(lib.vs_bilstm_recurrent_math(_p(gates), _p(packed), _p(state), _p(out), _p(gates), _p(c), B, T, H, int(math), _stream()),
+              "vs_bilstm_recurrent_math")
     _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent_train")
     return out, gates, c
 
 
-def bilstm_recurrent_bwd(gates, c, dout, w_hh_f, w_hh_b):
-    """BPTT: returns d(loss)/d(xg) [B,T,8H] (gates is not modified: works on a copy)."""
+def bilstm_recurrent_bwd(gates, c, dout, w_hh_f, w_hh_b, math=None):
+    """BPTT: returns d(loss)/d(xg) [B,T,8H] (gates is not modified: works on a copy).  math: see bilstm_recurrent."""
     lib = _lib.load()
     for n, t in (("gates", gates), ("c", c), ("dout", dout), ("w_hh_f", w_hh_f), ("w_hh_b", w_hh_b)):
         _dev_check(t, n)
     B, T, H8 = gates.shape
     H = H8 // 8
     packed_t = torch.empty(lib.vs_lstm_packed_t_floats(H), dtype=torch.float32, device=gates.device)
-    check(lib.vs_lstm_pack_t(_p(w_hh_f), _p(w_hh_b), _p(packed_t), H, _stream()), "vs_lstm_pack_t")
     state = torch.empty(lib.vs_lstm_bwd_state_floats(B, H), dtype=torch.float32, device=gates.device)
     dxg = gates.clone()
-    check(lib.vs_bilstm_recurrent_bwd(_p(packed_t), _p(state), _p(dxg), _p(c), _p(dout), B, T, H, _stream()),
-          "vs_bilstm_recurrent_bwd")
+    if math is None:
+        check(lib.vs_lstm_pack_t(_p(w_hh_f), _p(w_hh_b), _p(packed_t), H, _stream()), "vs_lstm_pack_t")
+        check(lib.vs_bilstm_recurrent_bwd(_p(packed_t), _p(state), _p(dxg), _p(c), _p(dout), B, T, H, _stream()),
+              "vs_bilstm_recurrent_bwd")
+    else:
+        check(lib.vs_lstm_pack_t_math(_p(w_hh_f), _p(w_hh_b), _p(packed_t), H, int(math), _stream()), "vs_lstm_pack_t_math")
+        check(lib.vs_bilstm_recurrent_bwd_math(_p(packed_t), _p(state), _p(dxg), _p(c), _p(dout), B, T, H, int(math), _stream()),
+              "vs_bilstm_recurrent_bwd_math")
     _lstm_check_err(state, state.numel() - 64, "vs_bilstm_recurrent_bwd")
     return dxg
 
