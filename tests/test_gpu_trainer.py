@@ -52,8 +52,13 @@ def test_trainer_step_equals_manual_loop_and_checkpoint_roundtrip(model_name, tm
         opt.step()
         assert abs(loss - rl.item()) <= 1e-6 * max(1.0, abs(rl.item()))
     for (n, p), q in zip(tr.model.named_parameters(), ref.parameters()):
-        # same kernels in the same order; only the fp64 atomics of the BN reductions are unordered
-        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+        # Same kernels in the same order: the gradients of the first step are bit-identical (tools/diag_trainer.py).  The
+        # two Adam implementations (one fused launch over the bucket views here, torch's default there) round the first
+        # update differently by an ulp (7e-9); through batch-statistics BatchNorm at B = 3 that becomes a 4e-6 (of the
+        # tensor maximum) gradient difference in step 2, and Adam normalises per element: an element whose gradient is
+        # 1e-3 of the maximum moves 0.4 % of a step (4e-6) differently.  A semantic difference (a missing zero_grad, a
+        # second step, another learning rate) moves parameters by a whole step, lr = 1e-3: the bound is 2 % of that.
+        assert torch.allclose(p, q, rtol=1e-5, atol=2e-5), n
     for a, b in zip(tr.model.buffers(), ref.buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-8)
     # checkpoint: the reference's four keys (train.py:127-132), resumable, state_dict keys intact

@@ -279,6 +279,18 @@ namespace {
 int g_bwd_overlap = 1;
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 SideStream g_side[16];
+// Every exit path of vs_backward after the fork -- the error returns included -- orders the caller's stream after what
+// the side stream has been given (it writes gradients and the shared partial-sum scratch), and leaves no unjoined fork
+// behind in a stream capture.  The normal path joins explicitly and disarms the guard.
+struct SideJoin {
+  SideStream* side = nullptr;
+  hipStream_t stream = nullptr;
+  bool forked = false;
+  ~SideJoin() {
+    if (!side || !forked) return;
+    if (hipEventRecord(side->join, side->s) == hipSuccess) (void)hipStreamWaitEvent(stream, side->join, 0);
+  }
+};
 // the side stream and its two events are shared by every caller on the device: one vs_backward enqueues at a time
 // (host threads driving different caller streams would otherwise re-record an event another call is about to wait on)
 std::mutex g_side_mutex;
@@ -383,7 +395,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
     // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
     // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
-    if (f16g) {
+    if (f16g && d->math != VS_MATH_BF16) {      // the bf16 contractions need no scale
       if (int rc = vs_pow2_scale_impl(dxg, (long long)M * 8 * H, reinterpret_cast<unsigned*>(gsc + 12), gsc + 8, stream)) return rc;
     }
   }
@@ -395,9 +407,13 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
   }
   hipStream_t ls = stream;
+  SideJoin side_join;
+  side_join.side = side;
+  side_join.stream = stream;
   if (side) {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    side_join.forked = true;
     ls = side->s;
   }
   if (bf16g) {
@@ -539,6 +555,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (side) {
       VS_CHECK_HIP(hipEventRecord(side->join, side->s));
       VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+      side_join.forked = false;
     }
     VsProfScope ps(VS_PROF_BWD_BN, stream);
     return vs_nhwc_bn_bwd_first_from_dy_impl(gb[c], at<void>(tape, L.z[0]), x, B, T, F, train, scale, mean, invstd,
@@ -606,6 +623,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   if (side) {
     VS_CHECK_HIP(hipEventRecord(side->join, side->s));
     VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    side_join.forked = false;
   }
   if (F < 4 || (long long)T * F >= (1 << 24)) {   // packs spanning >2 frames / float frame index: unfused path
     if (int rc = bn_bwd(0, gbuf[cur], at<float>(tape, L.z[0]), gbuf[cur], 64, (long long)B * 64, T * F)) return rc;

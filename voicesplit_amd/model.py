@@ -46,14 +46,14 @@ class _MaskForward(torch.autograd.Function):
         x = x.detach().contiguous()
         dvec_c = dvec.detach().contiguous()
         dims = module._dims(x.shape[0], x.shape[1])
-        sd = {k: v.detach() for k, v in module._tensors().items()}
+        sd = module._tensors()
         tape = ops.new_tape(dims, x.device)
         mask = ops.forward_train(sd, x, dvec_c, dims, module.conv_act, module.training, tape)
         module._bump_bn_counters()
         ctx.module, ctx.dims, ctx.tape = module, dims, tape
         module.__dict__["_last_tape"] = (tape, dims)
         ctx.training = module.training
-        ctx.names = [n for n, _ in module.named_parameters()]
+        ctx.names = [n for n, _ in module._named_params()]
         ctx.save_for_backward(x, dvec_c, mask)
         return mask
 
@@ -63,14 +63,16 @@ class _MaskForward(torch.autograd.Function):
         module = ctx.module
         if ctx.tape is None:
             raise RuntimeError("voicesplit_amd: backward called twice on the same forward (the tape was released)")
-        sd = {k: v.detach() for k, v in module._tensors().items()}
+        sd = module._tensors()
+        sink = module.__dict__.get("_grad_sink")
         grads = ops.backward(sd, x, dvec, ctx.dims, module.conv_act, ctx.training, ctx.tape, mask,
-                             grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2])
+                             grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2], sink=sink)
         ops.recycle_tape(ctx.tape)                           # 49 GB at B=64: back to the pool for the next forward
         ctx.tape = None
         out = [None, None, grads.get("speaker_embedding")]
         for i, name in enumerate(ctx.names):
-            out.append(grads[name] if ctx.needs_input_grad[3 + i] else None)
+            # a gradient the library wrote into the sink is already where .grad lives: nothing for autograd to accumulate
+            out.append(grads[name] if ctx.needs_input_grad[3 + i] and not (sink and name in sink) else None)
         return tuple(out)
 
 
@@ -100,9 +102,39 @@ class _MaskNet(nn.Module):
         return ops.make_dims(B, T, self.audio["num_freq"], m["emb_dim"], m["lstm_dim"], m["fc1_dim"], m["fc2_dim"])
 
     def _tensors(self):
-        sd = {k: v for k, v in self.named_parameters()}
-        sd.update({k: v for k, v in self.named_buffers()})
-        return sd
+        """{state_dict key: tensor} of every parameter and buffer.  The module tree is fixed after construction, so the walk
+        of named_parameters() / named_buffers() (~0.1 ms of host time in front of every step's first kernel) is done once:
+        what is kept is (key, owning dict, name), and the tensors are read from the owning modules' dicts on every call
+        -- load_state_dict, .to(), optimizer steps and parameter re-assignment are all seen."""
+        index = self.__dict__.get("_tensor_index")
+        if index is None:
+            index = []
+            for mod_name, mod in self.named_modules():
+                prefix = mod_name + "." if mod_name else ""
+                for n in mod._parameters:
+                    if mod._parameters[n] is not None:
+                        index.append((prefix + n, mod._parameters, n))
+                for n in mod._buffers:
+                    if mod._buffers[n] is not None and n not in mod._non_persistent_buffers_set:
+                        index.append((prefix + n, mod._buffers, n))
+            self.__dict__["_tensor_index"] = index
+        return {k: d[n] for k, d, n in index}
+
+    def set_gradient_sink(self, sink):
+        """sink: {state_dict key: tensor} or None.  With a sink, ``loss.backward()`` OVERWRITES these tensors with the
+        parameter gradients (vs_backward writes, it never accumulates) and hands autograd nothing for those parameters:
+        when they are the ``.grad`` tensors themselves (views into the trainer's all-reduce bucket,
+        sharding.GradientBucket) the 47 ``grad += new`` launches and the zeroing of a step disappear.  The caller owns
+        the zero_grad semantics: every backward replaces the contents (no accumulation over several backward calls)."""
+        if sink is None:
+            self.__dict__.pop("_grad_sink", None)
+        else:
+            self.__dict__["_grad_sink"] = dict(sink)
+
+    def _named_params(self):
+        """[(key, parameter)] in named_parameters() order, from the same index (no module-tree walk)."""
+        self._tensors() if "_tensor_index" not in self.__dict__ else None
+        return [(k, d[n]) for k, d, n in self.__dict__["_tensor_index"] if isinstance(d[n], nn.Parameter)]
 
     def train(self, mode: bool = True):
         if mode:
@@ -113,7 +145,7 @@ class _MaskNet(nn.Module):
         x = x.contiguous()
         dvec = dvec.contiguous()
         dims = self._dims(x.shape[0], x.shape[1])
-        sd = {k: v.detach() for k, v in self._tensors().items()}
+        sd = self._tensors()                      # only data pointers and version counters are read: no detach needed
         if not self.training:
             # eval mode (validation(), test.py, serving): the weight-only work of the forward is done once and
             # kept until a parameter or a running statistic changes (tensor identity + version counters)
@@ -170,8 +202,10 @@ class _MaskNet(nn.Module):
             raise NotImplementedError(
                 "voicesplit_amd: the gradient wrt the input spectrogram is not produced (the reference "
                 "never asks for it: x is data, train.py:85-94); detach x")
-        if torch.is_grad_enabled() and (speaker_embedding.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _MaskForward.apply(self, x, speaker_embedding, *self.parameters())
+        if torch.is_grad_enabled():
+            params = [p for _, p in self._named_params()]
+            if speaker_embedding.requires_grad or any(p.requires_grad for p in params):
+                return _MaskForward.apply(self, x, speaker_embedding, *params)
         return self._run(x, speaker_embedding)
 
 

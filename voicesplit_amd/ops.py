@@ -419,9 +419,10 @@ GRAD_KEYS_BN = (("bn_weight", "weight"), ("bn_bias", "bias"))
 
 
 def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor, mask, dmask,
-             want_dvec: bool = False) -> Dict[str, torch.Tensor]:
+             want_dvec: bool = False, sink: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """d(loss)/d(parameters) for dmask = d(loss)/d(mask); returns {state_dict key: gradient}
-    (+ 'speaker_embedding' when want_dvec)."""
+    (+ 'speaker_embedding' when want_dvec).  sink: {key: preallocated tensor} the library writes those gradients into
+    (overwriting, vs_backward never accumulates) instead of fresh tensors -- the trainer's flat all-reduce bucket."""
     lib = _lib.load()
     _dev_check(dmask, "grad_mask")
     _dev_check(mask, "mask")
@@ -430,7 +431,11 @@ def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: tor
     out: Dict[str, torch.Tensor] = {}
 
     def alloc(key):
-        t = torch.empty_like(sd[key])
+        t = sink.get(key) if sink else None
+        if t is None:
+            t = torch.empty_like(sd[key])
+        elif (t.shape != sd[key].shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != sd[key].device):
+            raise ValueError(f"gradient sink for {key}: expected a contiguous float32 {tuple(sd[key].shape)} tensor on {sd[key].device}")
         out[key] = t
         return t.data_ptr()
 

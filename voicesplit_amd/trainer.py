@@ -95,7 +95,11 @@ def make_criterion(c) -> Callable:
 def make_optimizer(c, params):
     """train.py:33-37."""
     if c.train_config["optimizer"] == "adam":
-        return torch.optim.Adam(params, lr=c.train_config["learning_rate"])
+        params = list(params)
+        # same update rule and state_dict as the reference's torch.optim.Adam(lr=...); on the device the whole step is
+        # one fused multi-tensor launch instead of 14 (0.4 -> 0.1 ms at the tail of every step)
+        fused = len(params) > 0 and all(p.is_cuda for p in params)
+        return torch.optim.Adam(params, lr=c.train_config["learning_rate"], fused=fused)
     raise Exception("The %s  not is a optimizer supported" % c.train_config["optimizer"])
 
 
@@ -112,6 +116,12 @@ class Trainer:
         self.criterion = criterion if criterion is not None else make_criterion(c)
         self.optimizer = optimizer if optimizer is not None else make_optimizer(c, model.parameters())
         self.bucket = GradientBucket(model.parameters(), group, extra=1).attach()
+        # the HIP modules write their gradients straight into the bucket's .grad views (no `grad += new` per parameter,
+        # no zeroing per step); any other module goes through autograd's accumulation into the zeroed bucket
+        self._sink = hasattr(model, "set_gradient_sink") and self.bucket.flat.is_cuda
+        if self._sink:
+            names = {id(p): n for n, p in model.named_parameters()}
+            model.set_gradient_sink({names[id(p)]: v for p, v in zip(self.bucket.params, self.bucket.views)})
         self.device = self.bucket.flat.device
         self.step = 0
         if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
@@ -175,10 +185,12 @@ class Trainer:
         emb, target, mixed, phase = (t.to(dev, non_blocking=True) for t in (emb, target, mixed, phase))
         if seq_len is not None:
             seq_len = seq_len.to(dev, non_blocking=True).reshape(-1)
-        self.model.train()
+        if not self.model.training:                                         # train.py:84 (once; the walk over the module tree
+            self.model.train()                                              # is 0.1 ms of host time with an idle device)
         mask = self.model(mixed, emb)                                       # train.py:94
         loss = self.criterion(mask, mixed, target, seq_len, phase)          # :95-108
-        self.bucket.zero()                                                  # optimizer.zero_grad()
+        if not self._sink:
+            self.bucket.zero()                                              # optimizer.zero_grad()
         loss.backward()                                                     # :110
         self.bucket.extra[0] = loss.detach()
         self.bucket.all_reduce(self.world)                                  # the one exchange step
