@@ -46,6 +46,30 @@ void fill_kernel(const unsigned char* __restrict__ src, long long bytes_per_wg, 
   if (sink && threadIdx.x == 0) sink[blockIdx.x] = *(volatile unsigned*)smem;
 }
 
+// L2-resident source: the workgroup re-reads a `wrap`-byte slab (its own, or -- shared -- one slab for the whole chip, as
+// the workgroups of a GEMM share operand panels), so after the first sweep every line is an L2 hit: the rate of the
+// L2 -> LDS path itself, which the HBM-streaming runs above cannot show.
+template <bool SHARED>
+__global__ __launch_bounds__(256, 1)
+void fill_l2_kernel(const unsigned char* __restrict__ src, long long bytes_per_wg, long long wrap, int depth, unsigned* sink) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[128 * 1024];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned char* base = SHARED ? src : src + (long long)blockIdx.x * wrap;
+  const long long round_bytes = (long long)depth * 4 * 1024;
+  const long long rounds = bytes_per_wg / round_bytes;
+  for (long long r = 0; r < rounds; ++r) {
+    for (int d = 0; d < depth; ++d) {
+      const long long chunk = (r * depth + d) * 4 + wave;
+      const unsigned char* p = base + ((chunk * 1024) & (wrap - 1)) + lane * 16;
+      glds16(p, lds0 + (unsigned)(((d * 4 + wave) * 1024) & (128 * 1024 - 1)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (sink && threadIdx.x == 0) sink[blockIdx.x] = *(volatile unsigned*)smem;
+}
+
 // `ahead` rounds in flight: round r waits only for round r - ahead (vmcnt counts this wave's later instructions)
 template <int DEPTH, int AHEAD>
 __global__ __launch_bounds__(256, 1)
@@ -120,6 +144,16 @@ int main() {
   run("LDS-DMA contiguous, 8 per round, 2 rounds ahead (96 KiB in flight)", [&] { hipLaunchKernelGGL((fill_ahead_kernel<8, 2>), dim3(cus), dim3(256), 0, 0, src, per_wg, sink); }, (double)total);
   run("LDS-DMA contiguous, 4 per round, 3 rounds ahead (64 KiB in flight)", [&] { hipLaunchKernelGGL((fill_ahead_kernel<4, 3>), dim3(cus), dim3(256), 0, 0, src, per_wg, sink); }, (double)total);
   run("LDS-DMA contiguous, 2 per round, 7 rounds ahead (64 KiB in flight)", [&] { hipLaunchKernelGGL((fill_ahead_kernel<2, 7>), dim3(cus), dim3(256), 0, 0, src, per_wg, sink); }, (double)total);
+  for (long long wrap : {64LL << 10, 1LL << 20}) {
+    for (int depth : {4, 8, 16, 32}) {
+      snprintf(name, sizeof name, "LDS-DMA from L2: own %lld KiB slab re-read, %d KiB in flight, drain per round", wrap >> 10, depth * 4);
+      run(name, [&] { hipLaunchKernelGGL(fill_l2_kernel<false>, dim3(cus), dim3(256), 0, 0, src, per_wg, wrap, depth, sink); }, (double)total);
+    }
+  }
+  for (int depth : {8, 16, 32}) {
+    snprintf(name, sizeof name, "LDS-DMA from L2: ONE 2 MiB slab shared by all workgroups, %d KiB in flight", depth * 4);
+    run(name, [&] { hipLaunchKernelGGL(fill_l2_kernel<true>, dim3(cus), dim3(256), 0, 0, src, per_wg, 2LL << 20, depth, sink); }, (double)total);
+  }
   for (int depth : {2, 4, 8}) {
     snprintf(name, sizeof name, "global_load_dwordx4 to registers, %d x 4 KiB per workgroup and round", depth);
     run(name, [&] { hipLaunchKernelGGL(reg_kernel, dim3(cus), dim3(256), 0, 0, (const u4v*)src, per_wg / 16, depth, sink); }, (double)total);
