@@ -115,6 +115,38 @@ struct Operand {
     const unsigned char* src_p = ok ? origin + off : zp;
     glds16(src_p, (unsigned)__builtin_amdgcn_readfirstlane(lds_dst + (unsigned)((c * 4 + wave) * 1024)));
   }
+  // The same chunk through a buffer descriptor (the conv kernels' form, conv_nhwc.hip): the descriptor covers the operand
+  // from the tile's origin at this K step to the end of its valid rows (row form) / k lines (col form), so rows / lines
+  // beyond the matrix are out of range and arrive as zeros without a compare or a select; what depends on the lane is the
+  // ONE offset register computed at kernel start (two in col form, by chunk parity), what depends on the chunk is a
+  // scalar offset and the LDS address in M0.  ~6 instructions per chunk where the pointer form above needs ~15 -- with 16
+  // chunks per wave and step beside 128 MFMAs that was the kernel's bound (profiles/r03_gemm_l2_prefetch.md).
+  __device__ static __forceinline__ u4v tile_desc(const unsigned short* base, int ld, int rows, int kext, int r0, int k0, bool live) {
+    unsigned long long p;
+    long long rec;
+    if (!KMAJOR) {
+      p = reinterpret_cast<unsigned long long>(base) + ((unsigned long long)r0 * (unsigned)ld + (unsigned)k0) * 2ull;
+      rec = ((long long)(rows - r0) * ld - k0) * 2;
+      if (k0 >= kext) rec = 0;
+    } else {
+      p = reinterpret_cast<unsigned long long>(base) + ((unsigned long long)k0 * (unsigned)ld + (unsigned)r0) * 2ull;
+      rec = ((long long)(kext - k0) * ld - r0) * 2;
+      if (r0 >= rows) rec = 0;
+    }
+    if (!live || rec < 0) rec = 0;
+    if (rec > 0xFFFFFFF0ll) rec = 0xFFFFFFF0ll;
+    return u4v{(unsigned)p, (unsigned)(p >> 32) & 0xffffu, (unsigned)rec, 0x00020000u};
+  }
+  // byte distance between consecutive chunks of a wave (wave-uniform): 32 rows (row form) / 8 k lines (col form)
+  __device__ static __forceinline__ unsigned chunk_pitch(int ld) { return (unsigned)(KMAJOR ? 8 : 32) * (unsigned)ld * 2u; }
+  __device__ static __forceinline__ void issue_chunk_desc(const LaneDma& L, u4v desc, unsigned pitch, unsigned lds_dst, int wave, int c) {
+    const unsigned voff = KMAJOR ? L.off[c & 1] : L.off[0];
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(pitch * (unsigned)c));
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + (unsigned)((c * 4 + wave) * 1024)));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(desc), "s"(dst), "s"(soff) : "memory");
+  }
   // Fragment of the 16-row block starting at row rb (of the tile), k-half kh (32 k), for lane (i = lane & 15, g = lane >> 4).
   // The lane-dependent part of the address is ONE register (frag_base, + the stage offset); rb and kh enter as an XOR
   // with a constant and an immediate offset, so that the 32 fragment addresses of a step are not 32 live registers:
@@ -181,10 +213,14 @@ void gemm_bf16_kernel(GemmBf16Args g) {
   // matrix pipe idle, so they are spread over the FIRST half of the step -- two chunks in front of each of its first 8
   // MFMA rows; the second half of the step is their time to land.  (Spread over all 16 rows, the col x col contraction,
   // whose panels stream from HBM, waited for the late chunks: 0.63 -> 1.63 ms.)
-  auto pf_chunk = [&](int slot /* 0..15 */, bool live) {     // !live (end of the job): every piece reads the zero page, no branch
+  // descriptors of the two operand tiles the prefetch cursor points at (wave-uniform: scalar registers), rebuilt when it moves
+  const unsigned pitchA = OA::chunk_pitch(g.lda), pitchB = OB::chunk_pitch(g.ldb);
+  u4v dA = OA::tile_desc(g.A, g.lda, g.M, g.K, ptm * TM, 0, plive), dB = OB::tile_desc(g.B, g.ldb, g.N, g.K, ptn * TN, 0, plive);
+  auto pf_chunk = [&](int slot /* 0..15 */, bool live) {     // !live (end of the job): empty descriptors, every piece lands as zeros, no branch
+    (void)live;
     const unsigned dst = lds0 + (unsigned)(pstage * STAGE_BYTES);
-    if (slot < 8) OA::issue_chunk(la, g.A, g.lda, live ? g.M : 0, g.K, ptm * TM, pk * BK, dst, wave, slot);
-    else OB::issue_chunk(lb, g.B, g.ldb, live ? g.N : 0, g.K, ptn * TN, pk * BK, dst + A_BYTES, wave, slot - 8);
+    if (slot < 8) OA::issue_chunk_desc(la, dA, pitchA, dst, wave, slot);
+    else OB::issue_chunk_desc(lb, dB, pitchB, dst + A_BYTES, wave, slot - 8);
   };
   auto pf_done = [&]() {
     pstage ^= 1;
@@ -193,6 +229,8 @@ void gemm_bf16_kernel(GemmBf16Args g) {
       ++pj;
       plive = tile_ok(pj) && tile_of(g, tile_id(pj), ptm, ptn);
     }
+    dA = OA::tile_desc(g.A, g.lda, g.M, g.K, ptm * TM, pk * BK, plive);
+    dB = OB::tile_desc(g.B, g.ldb, g.N, g.K, ptn * TN, pk * BK, plive);
   };
   if (plive) {
 #pragma unroll
@@ -330,7 +368,7 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   // VOICESPLIT_GEMM_DMA environment variable -- three digits: row x row, row x col, col x col -- overrides it for A/B timing)
   static const int dm_cfg = [] {
     const char* e = getenv("VOICESPLIT_GEMM_DMA");
-    int v = 200;                                         // row x row: spread over the step; the others: behind the barrier
+    int v = 122;                                         // measured with the descriptor form of the chunks (profiles/r03_gemm_l2_prefetch.md)
     if (e && e[0] && e[1] && e[2]) v = (e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0');
     return v;
   }();
