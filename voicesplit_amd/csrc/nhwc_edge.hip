@@ -129,10 +129,16 @@ void nhwc_bn_apply_kernel(const u4v* __restrict__ z, u4v* __restrict__ a, const 
 // out[b][t][co][f] = act(scale[co] * sum_ci w[co][ci] in[b][t][f][ci] + shift[co]), co < 8.  One wave = 16 pixels of a
 // row per step: the B operand of v_mfma_f32_16x16x32_bf16 is the pixels as they lie in memory (lane = (pixel, 8
 // channels) = one 16-byte load), A = the 8 x 64 weights zero-padded to 16 rows; C rows 0..7 -> 8 feature rows.
-template <int ACT>
+// STATS: the per-channel sum and sum of squares of what is stored (train-mode BatchNorm of cnn8: models/voicesplit/model.py:52)
+// accumulate per lane over the launch and flush once: stats[slot = block % VS_BN_STAT_SLOTS][8 channels][2] doubles
+// (vs_bn_finalize_impl folds the slots).  Replaces a pass over the 370 MB feature tensor.
+template <int ACT, bool STATS = false>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
-                           const float* __restrict__ shift, float* __restrict__ out, long long nrows /* B*T */, int F) {
+                           const float* __restrict__ shift, float* __restrict__ out, long long nrows /* B*T */, int F,
+                           double* __restrict__ stats) {
+  __shared__ float red[4 * 16];
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
   vs_bf16x8 wa[2];
 #pragma unroll
@@ -166,8 +172,27 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
     if (ok && g < 2) {
       float* o = out + (row * 8 + g * 4) * F + f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[(size_t)r * F] = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r]));
+      for (int r = 0; r < 4; ++r) {
+        const float v = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r]));
+        o[(size_t)r * F] = v;
+        if (STATS) { ssum[r] += v; ssq[r] = fmaf(v, v, ssq[r]); }
+      }
     }
+  }
+  if (STATS) {
+    // lanes (g, n): channel 4 g + r for g < 2; fold the 16 columns of a group, then the four waves
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = ssum[r], b = ssq[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (n == 0 && g < 2) { red[wave * 16 + (g * 4 + r) * 2] = a; red[wave * 16 + (g * 4 + r) * 2 + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+      atomicAdd(stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 16 + threadIdx.x,
+                (double)red[threadIdx.x] + (double)red[16 + threadIdx.x] + (double)red[32 + threadIdx.x] + (double)red[48 + threadIdx.x]);
   }
 }
 
@@ -445,16 +470,22 @@ int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const
 }
 
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
-                           int B, int T, int F, int act, hipStream_t stream) {
+                           int B, int T, int F, int act, hipStream_t stream, double* bn_stats) {
   VS_REQUIRE(in && w && scale && shift && out, "nhwc conv_last: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
   const dim3 grid(stream_blocks(4, nblk)), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
-  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_MISH>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_RELU>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F);
-  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_NONE>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F);
+  if (bn_stats) {      // train mode: z8 = conv + bias unactivated, statistics of it ([VS_BN_STAT_SLOTS][8][2] doubles, zeroed by the caller)
+    VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: statistics are those of the unactivated output");
+    hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_MISH>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_RELU>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_NONE>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
   else VS_REQUIRE(false, "nhwc conv_last: unsupported activation %d", act);
   VS_LAUNCH_CHECK();
   return 0;

@@ -197,7 +197,9 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     }
     {
       VsProfScope ps(VS_PROF_CNN8, stream);
-      if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
+      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 16, stream));
+      if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream,
+                                          train ? stats : nullptr)) return rc;
     }
   } else {
   {
@@ -225,7 +227,14 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
   }
   }
-  if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
+  if (nhwc && train) {
+    // cnn8's batch statistics came out of its own epilogue: finalize + the apply pass
+    VsProfScope ps(VS_PROF_FWD_BN, stream);
+    const vs_conv_layer& c = p->conv[7];
+    if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)B * T * F, 8, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
+                                     kBnEps, kBnMomentum, scale + 64 * 7, shift + 64 * 7, mean + 64 * 7, invstd + 64 * 7, stream)) return rc;
+    if (int rc = vs_bn_apply_feat_impl(at<float>(tape, L.z8), at<float>(tape, L.feat), B, T, F, conv_act, scale + 64 * 7, shift + 64 * 7, stream)) return rc;
+  } else if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
 
   // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
   const int K = 8 * F, KE = K + d->E;
