@@ -19,5 +19,9 @@ timeout 200 python bench.py --batch 2 --steps 30 --no-cpu-baseline --no-extras 2
 timeout 300 python tools/nhwc_micro.py > $O/${R}_nhwc_micro.json 2>/dev/null
 VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.json 2>/dev/null
 { for p in issue_probe lds_tr_probe dma_fill_probe lds_dma_offset_probe buffer_oob_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
+{ timeout 200 python tools/lstm_time.py 64; timeout 200 python tools/lstm_time.py 2; } 2>/dev/null | grep "B=" > $O/${R}_lstm_time.txt
 [ -f voicesplit_amd/libvoicesplit_hip_abl.so ] && timeout 300 python tools/wgrad_ablation.py > $O/${R}_wgrad_ablation.json 2>/dev/null
 bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
+# device idle gaps of one training step, from the kernel trace of the profile run
+F=$(find gpurun_out/prof_${R}_train_bf16/trace -name "*kernel_trace.csv" | head -1)
+[ -n "$F" ] && python tools/step_timeline.py $F > $O/${R}_step_timeline.txt && head -3 $O/${R}_step_timeline.txt
