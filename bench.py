@@ -520,7 +520,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "fp32",
-                      "bf16": "bf16 (conv activations and tape stored as bf16, bf16 MFMA operands, fp32 accumulate; BatchNorm statistics, recurrence, head, master weights fp32)",
+                      "bf16": "bf16 (conv activations and tape stored as bf16; bf16 MFMA operands in the convs, the LSTM / head contractions and the BPTT, f16 operands in the forward recurrence; fp32 accumulate, BatchNorm statistics, gate arithmetic / cell state, loss head, master weights)",
                       "f16x3": "fp32 (64->64 convs + LSTM GEMMs: fp32 operands as 2xf16 halves, 3 f16 MFMA products, fp32 accumulate)"}[conv_math],
             "data": "synthetic",
             "config": {"workload": workload,

@@ -232,6 +232,13 @@ int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const
 int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, void* stream);
 int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const float* shift, float* out,
                       int B, int T, int F, int act, void* stream);
+/* cnn8 straight on the un-normalised output z7 of cnn7 (train mode): a7 = pre_act(z7 * pre_scale + pre_shift) -- the
+ * BatchNorm + Mish/ReLU of models/voicesplit/model.py:47-48 -- is formed in registers, rounded to bf16 exactly as
+ * vs_nhwc_bn_apply would have stored it, and fed to the matrix pipe: no apply pass over cnn7's output and no a7 tensor.
+ * out = conv * scale + shift, unactivated; bn_stats (may be NULL): [64 slots][8][2] doubles, zeroed by the caller,
+ * receive the per-channel {sum, sum of squares} of out (cnn8's own train-mode BatchNorm). */
+int vs_nhwc_conv_last_pre(const void* z7, const float* pre_scale, const float* pre_shift, int pre_act, const float* w,
+                          const float* scale, const float* shift, float* out, double* bn_stats, int B, int T, int F, void* stream);
 /* backward.  Weight gradient of cnn2..cnn7: dz, in [B][T][F][64] bf16 -> dw [64][64][KT][KF] fp32; partials =
  * vs_nhwc_conv_wgrad_partial_floats(KT, KF) floats of scratch.  BatchNorm + activation backward over npix pixels
  * (dz may alias da; stats = 64*64*2 doubles, coef = 192 floats of scratch), and the same fused with cnn1's 1x7 weight
@@ -254,7 +261,8 @@ int vs_nhwc_conv_last_bwd(const float* dz8, const float* w, const void* a7, void
  * dy instead of da and accumulates the per-channel {sum dy, sum dy * xhat} into bn_stats (64*64*2 doubles the caller
  * zeroed) -- the first of the two passes of vs_nhwc_bn_act_bwd, without reading the tensor again.
  * vs_nhwc_bn_bwd_from_dy / _first_from_dy are the second pass: parameter gradients + dz = cA dy + cB z + cC (dz may
- * alias dy).  act in {VS_ACT_MISH, VS_ACT_RELU}. */
+ * alias dy).  act in {VS_ACT_MISH, VS_ACT_RELU}.  vs_nhwc_conv_last_bwd_dy: a7 may be NULL -- the layer input is then
+ * recomputed from z7 and the BatchNorm constants (the counterpart of vs_nhwc_conv_last_pre). */
 int vs_nhwc_conv_dy(const void* dz, const void* packed, void* dy, const void* z, int act,
                     const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_stats,
                     int B, int T, int F, int KT, int KF, int dil, void* stream);

@@ -417,3 +417,32 @@ def test_gemm_bf16_all_operand_forms(M, N, K):
     C0 = torch.randn(M, N, generator=g)
     got = ops.gemm_bf16(Ak.cuda(), Bk.cuda(), M, N, K, a_kmajor=True, b_kmajor=True, out=C0.clone().cuda(), accumulate=True).double().cpu()
     assert ((got - (ref + C0.double())).abs().max() / ref.abs().max()).item() < 2e-5
+
+
+# ---- cnn7's BatchNorm + activation applied by its consumer cnn8 (train mode: no apply pass over z7, no a7 tensor) --------------
+@pytest.mark.parametrize("act", ["mish", "relu"])
+def test_cnn8_applies_the_batchnorm_of_cnn7_itself(act):
+    """vs_nhwc_conv_last_pre(z7) == vs_nhwc_conv_last(vs_nhwc_bn_apply(z7)) bit for bit (the same formulas and the same bf16
+    rounding of a7, in registers instead of through memory), its statistics are those of what it wrote, and the backward
+    with a7 = NULL (recomputed from z7) == the backward that reads the stored a7, bit for bit."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, T, Fq = 3, 9, 75                       # 75 = 4 * 16 + 11: a partly filled last pixel block
+    z7 = (torch.randn(B, T, Fq, 64, generator=g) * 1.3 + 0.1).to(torch.bfloat16).cuda()
+    psc, psh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    w8 = (torch.randn(8, 64, 1, 1, generator=g) * 0.2).cuda()
+    ones, bias = torch.ones(8).cuda(), (torch.randn(8, generator=g) * 0.2).cuda()
+    a7 = ops.nhwc_bn_apply(z7, psc, psh, act)
+    ref = ops.nhwc_conv_last(a7, w8, ones, bias, "none")
+    got, st = ops.nhwc_conv_last_pre(z7, psc, psh, act, w8, ones, bias, stats=True)
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.nhwc_conv_last_pre(z7, psc, psh, act, w8, ones, bias), ref)
+    r = ref.double().reshape(B, T, 8, Fq)
+    assert torch.allclose(st[:, 0], r.sum((0, 1, 3)), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(st[:, 1], (r * r).sum((0, 1, 3)), rtol=1e-5)
+    # backward
+    dz8 = torch.randn(B, T, 8 * Fq, generator=g).cuda()
+    mean, invstd = (torch.randn(64, generator=g) * 0.1).cuda(), (torch.rand(64, generator=g) + 0.5).cuda()
+    dy0, dw0, st0 = ops.nhwc_conv_last_bwd_dy(dz8, w8, a7, z7, act, psc, psh, mean, invstd)
+    dy1, dw1, st1 = ops.nhwc_conv_last_bwd_dy(dz8, w8, None, z7, act, psc, psh, mean, invstd)
+    assert torch.equal(dy0, dy1) and torch.equal(dw0, dw1) and torch.equal(st0.sum(0), st1.sum(0))

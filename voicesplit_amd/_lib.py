@@ -110,6 +110,7 @@ SIGNATURES = {
     "vs_nhwc_conv_first": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_nhwc_bn_apply": (c_int, [_P, _P, c_longlong, c_int, _P, _P, _P]),
     "vs_nhwc_conv_last": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv_last_pre": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_wgrad_partial_floats": (c_size_t, [c_int, c_int]),
     "vs_nhwc_conv_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_nhwc_bn_act_bwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -377,6 +377,13 @@ int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const 
   return vs_nhwc_conv_last_impl(in, w, scale, shift, out, B, T, F, act, (hipStream_t)stream);
 }
 
+// cnn8 on the un-normalised output z7 of cnn7: BatchNorm + activation of cnn7 applied on the way into the matrix pipe
+int vs_nhwc_conv_last_pre(const void* z7, const float* pre_scale, const float* pre_shift, int pre_act, const float* w,
+                          const float* scale, const float* shift, float* out, double* bn_stats, int B, int T, int F, void* stream) {
+  VS_REQUIRE(pre_scale && pre_shift, "nhwc_conv_last_pre: NULL BatchNorm constants");
+  return vs_nhwc_conv_last_impl(z7, w, scale, shift, out, B, T, F, VS_ACT_NONE, (hipStream_t)stream, bn_stats, pre_scale, pre_shift, pre_act);
+}
+
 size_t vs_nhwc_conv_wgrad_partial_floats(int KT, int KF) { return vs_nhwc_wgrad_partial_floats(KT, KF); }
 
 int vs_nhwc_conv_wgrad(const void* dz, const void* in, float* partials, float* dw, int B, int T, int F, int KT, int KF, int dil,

@@ -132,14 +132,29 @@ void nhwc_bn_apply_kernel(const u4v* __restrict__ z, u4v* __restrict__ a, const 
 // STATS: the per-channel sum and sum of squares of what is stored (train-mode BatchNorm of cnn8: models/voicesplit/model.py:52)
 // accumulate per lane over the launch and flush once: stats[slot = block % VS_BN_STAT_SLOTS][8 channels][2] doubles
 // (vs_bn_finalize_impl folds the slots).  Replaces a pass over the 370 MB feature tensor.
-template <int ACT, bool STATS = false>
+// PRE >= 0: `in` is the UN-normalised output z7 of the layer below and the kernel applies that layer's BatchNorm +
+// activation PRE on its way into the matrix pipe (a7 = act(z7 * pre_scale + pre_shift), rounded to bf16 exactly as
+// nhwc_bn_apply_kernel would have stored it): cnn8 is an HBM-bound consumer with idle VALU, so the training step needs no
+// BatchNorm-apply pass for cnn7 and no a7 tensor at all (the backward recomputes it the same way).
+template <int ACT, bool STATS = false, int PRE = -1>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ out, long long nrows /* B*T */, int F,
-                           double* __restrict__ stats) {
+                           double* __restrict__ stats, const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
   __shared__ float red[4 * 16];
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  vs_f32x2 psc[2][4], psh[2][4];      // PRE: constants of this lane's 16 channels (k-chunk kc: 32 kc + 8 g + 2 q, + 1)
+  if (PRE >= 0) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = kc * 32 + g * 8 + 2 * q;
+        psc[kc][q] = vs_f32x2{pre_scale[ch], pre_scale[ch + 1]};
+        psh[kc][q] = vs_f32x2{pre_shift[ch], pre_shift[ch + 1]};
+      }
+  }
   vs_bf16x8 wa[2];
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc)
@@ -165,7 +180,16 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
     const int f = bc * 16 + n;
     const bool ok = f < F;
     const u4v* src = reinterpret_cast<const u4v*>(in + ((row * F + (ok ? f : 0)) << 6)) + g;
-    const u4v b0 = ok ? src[0] : u4v{0u, 0u, 0u, 0u}, b1 = ok ? src[4] : u4v{0u, 0u, 0u, 0u};
+    u4v b0 = ok ? src[0] : u4v{0u, 0u, 0u, 0u}, b1 = ok ? src[4] : u4v{0u, 0u, 0u, 0u};
+    if (PRE >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const vs_f32x2 y0 = vs_act_fast2<(PRE >= 0 ? PRE : VS_ACT_NONE)>(__builtin_elementwise_fma(vs_f32x2{bf_lo(b0[q]), bf_hi(b0[q])}, psc[0][q], psh[0][q]));
+        const vs_f32x2 y1 = vs_act_fast2<(PRE >= 0 ? PRE : VS_ACT_NONE)>(__builtin_elementwise_fma(vs_f32x2{bf_lo(b1[q]), bf_hi(b1[q])}, psc[1][q], psh[1][q]));
+        b0[q] = vs_pack_bf16(y0.x, y0.y);
+        b1[q] = vs_pack_bf16(y1.x, y1.y);
+      }
+    }
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], __builtin_bit_cast(vs_bf16x8, b0), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], __builtin_bit_cast(vs_bf16x8, b1), c, 0, 0, 0);
@@ -351,7 +375,30 @@ struct LastBwdBn {
   double* stats;
 };
 
-template <int DYACT>
+// activation and its derivative of one value; Mish: both from ONE exp2 and ONE rcp -- u, n, r as in vs_mish_fast2, so the
+// activation is bitwise what nhwc_bn_apply_kernel / the PRE form of nhwc_conv_last_kernel produce, and
+// Mish' = r (n + 4 y u (u + 1) r) (the identity derived at conv_nhwc.hip's dy epilogue)
+template <int ACT>
+__device__ __forceinline__ void nhwc_act_both(float y, float& a, float& d) {
+  if (ACT == VS_ACT_MISH) {
+    const float u = __builtin_amdgcn_exp2f(fminf(y, 20.0f) * 1.44269504088896340736f);
+    const float n = u * (u + 2.0f);
+    const float r = __builtin_amdgcn_rcpf(n + 2.0f);
+    a = y * (n * r);
+    const float dd = r * fmaf(4.0f * y * r, u * (u + 1.0f), n);
+    d = y > 20.0f ? 1.0f : dd;
+  } else if (ACT == VS_ACT_RELU) {
+    a = fmaxf(y, 0.0f);
+    d = y > 0.0f ? 1.0f : 0.0f;
+  } else {
+    a = y;
+    d = 1.0f;
+  }
+}
+
+// RECOMP: a7 is not read but recomputed from z7 (a7 = bf16(act(z7 * scale + shift)), the forward's own values: see
+// nhwc_conv_last_kernel's PRE form) -- one 1.48 GB operand stream less
+template <int DYACT, bool RECOMP = false>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __restrict__ w, const u4v* __restrict__ a7,
                                u4v* __restrict__ din, float* __restrict__ part, long long npix, int F, LastBwdBn bn) {
@@ -383,7 +430,22 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
     float d[8];
 #pragma unroll
     for (int co = 0; co < 8; ++co) d[co] = dzr[(size_t)co * F];
-    const u4v av = __builtin_nontemporal_load(a7 + p * 8 + piece);
+    u4v av, zv = {0u, 0u, 0u, 0u};
+    float zf[8], dact[8];
+    if (DYACT >= 0) {
+      zv = __builtin_nontemporal_load(bn.z + p * 8 + piece);
+      float aj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        zf[j] = (j & 1) ? bf_hi(zv[j >> 1]) : bf_lo(zv[j >> 1]);
+        nhwc_act_both<(DYACT >= 0 ? DYACT : VS_ACT_NONE)>(fmaf(zf[j], sc[j], sh[j]), aj[j], dact[j]);
+      }
+      if (RECOMP) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = vs_pack_bf16(aj[2 * q], aj[2 * q + 1]);
+      }
+    }
+    if (!RECOMP) av = __builtin_nontemporal_load(a7 + p * 8 + piece);
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
@@ -397,11 +459,10 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
         acc[co][2 * q + 1] = fmaf(d[co], bf_hi(av[q]), acc[co][2 * q + 1]);
       }
     if (DYACT >= 0) {
-      const u4v zv = __builtin_nontemporal_load(bn.z + p * 8 + piece);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float zj = (j & 1) ? bf_hi(zv[j >> 1]) : bf_lo(zv[j >> 1]);
-        g[j] *= nhwc_act_grad<(DYACT >= 0 ? DYACT : VS_ACT_NONE)>(fmaf(zj, sc[j], sh[j]));
+        const float zj = zf[j];
+        g[j] *= dact[j];
         bacc[0][j] += g[j];
         bacc[1][j] = fmaf(g[j], (zj - mu[j]) * is[j], bacc[1][j]);
       }
@@ -470,13 +531,25 @@ int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const
 }
 
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
-                           int B, int T, int F, int act, hipStream_t stream, double* bn_stats) {
+                           int B, int T, int F, int act, hipStream_t stream, double* bn_stats,
+                           const float* pre_scale, const float* pre_shift, int pre_act) {
   VS_REQUIRE(in && w && scale && shift && out, "nhwc conv_last: NULL argument");
+  VS_REQUIRE(!pre_scale == !pre_shift, "nhwc conv_last: pre_scale and pre_shift come together");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
   const dim3 grid(stream_blocks(4, nblk)), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
+  if (pre_scale) {     // `in` is z7: the layer below's BatchNorm + activation applied on the way in; output unactivated (+ statistics)
+    VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: the pre-activation form writes the unactivated output");
+    VS_REQUIRE(pre_act == VS_ACT_MISH || pre_act == VS_ACT_RELU, "nhwc conv_last: pre-activation %d", pre_act);
+#define VS_LAST_PRE(ST_, PRE_) hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, ST_, PRE_>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats, pre_scale, pre_shift)
+    if (bn_stats) { if (pre_act == VS_ACT_MISH) VS_LAST_PRE(true, VS_ACT_MISH); else VS_LAST_PRE(true, VS_ACT_RELU); }
+    else { if (pre_act == VS_ACT_MISH) VS_LAST_PRE(false, VS_ACT_MISH); else VS_LAST_PRE(false, VS_ACT_RELU); }
+#undef VS_LAST_PRE
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   if (bn_stats) {      // train mode: z8 = conv + bias unactivated, statistics of it ([VS_BN_STAT_SLOTS][8][2] doubles, zeroed by the caller)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: statistics are those of the unactivated output");
     hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats);
@@ -582,7 +655,8 @@ int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x,
 int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7, void* din, float* part, float* dw,
                                int B, int T, int F, const void* z7, int act, const float* bn_scale, const float* bn_shift,
                                const float* bn_mean, const float* bn_invstd, double* bn_stats, hipStream_t stream) {
-  VS_REQUIRE(dz8 && w && a7 && din && part && dw, "nhwc conv_last_bwd: NULL argument");
+  VS_REQUIRE(dz8 && w && din && part && dw, "nhwc conv_last_bwd: NULL argument");
+  VS_REQUIRE(a7 || z7, "nhwc conv_last_bwd: a7 may only be NULL in the dy form (it is then recomputed from z7)");
   VS_REQUIRE(!z7 || (bn_scale && bn_shift && bn_mean && bn_invstd && bn_stats), "nhwc conv_last_bwd: the dy form needs the BatchNorm constants and statistics slots");
   const long long npix = (long long)B * T * F;
   long long nb = (npix + 31) / 32;
@@ -592,6 +666,8 @@ int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7,
   const u4v* a = reinterpret_cast<const u4v*>(a7);
   u4v* o = reinterpret_cast<u4v*>(din);
   if (!z7) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<-1>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
+  else if (act == VS_ACT_MISH && !a7) hipLaunchKernelGGL((nhwc_conv_last_bwd_kernel<VS_ACT_MISH, true>), grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
+  else if (act == VS_ACT_RELU && !a7) hipLaunchKernelGGL((nhwc_conv_last_bwd_kernel<VS_ACT_RELU, true>), grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
   else if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
   else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_bwd_kernel<VS_ACT_RELU>, grid, block, 0, stream, dz8, w, a, o, part, npix, F, bn);
   else VS_REQUIRE(false, "nhwc conv_last_bwd: dy form for activation %d", act);

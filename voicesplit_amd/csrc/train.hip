@@ -182,6 +182,15 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<void>(tape, L.z[0]), B, T, F, VS_ACT_NONE,
                                            train ? stats : nullptr, stream)) return rc;
     }
+    // cnn7's BatchNorm + activation is applied by its consumer: cnn8 is an HBM-bound kernel with idle VALU (forward: on the
+    // way into its matrix pipe; backward: recomputed beside the derivative), so train mode has no apply pass over z7
+    // and no a7 tensor.  Everything else of bn16(6) -- finalize, running statistics, the constants -- stays.
+    auto bn16_consts = [&](int l) -> int {
+      VsProfScope ps(VS_PROF_FWD_BN, stream);
+      const vs_conv_layer& c = p->conv[l];
+      return vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
+                                 kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, mean + 64 * l, invstd + 64 * l, stream);
+    };
     if (int rc = bn16(0)) return rc;
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;
@@ -193,13 +202,16 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
         if (int rc = vs_nhwc_conv_impl(at<void>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<void>(tape, L.z[l]), B, T, F,
                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, train ? stats : nullptr, stream)) return rc;
       }
-      if (int rc = bn16(l)) return rc;
+      if (train && l == 6) { if (int rc = bn16_consts(l)) return rc; }
+      else if (int rc = bn16(l)) return rc;
     }
     {
       VsProfScope ps(VS_PROF_CNN8, stream);
-      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 16, stream));
-      if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream,
-                                          train ? stats : nullptr)) return rc;
+      if (train) {
+        VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 16, stream));
+        if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.z[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream,
+                                            stats, scale + 64 * 6, shift + 64 * 6, conv_act)) return rc;
+      } else if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
     }
   } else {
   {
@@ -518,7 +530,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       VsProfScope ps(VS_PROF_BWD_EDGE, stream);
       if (int rc = zero_stats()) return rc;
       // partial sums in the idle second gradient buffer: `part` may still be in use by the LSTM leaf GEMMs on the side stream
-      if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
+      // train mode: a7 was never written (see vs_forward_train): recomputed from z7 by the kernel
+      if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, train ? nullptr : at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
                                               g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
                                               mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
     }

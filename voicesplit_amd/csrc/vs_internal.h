@@ -79,7 +79,8 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
                             int B, int T, int F, int act, double* bn_stats, hipStream_t);
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
-                           int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr);
+                           int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr,
+                           const float* pre_scale = nullptr, const float* pre_shift = nullptr, int pre_act = VS_ACT_NONE);
 int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);

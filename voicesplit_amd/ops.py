@@ -719,6 +719,19 @@ def nhwc_conv_last(x, w, scale, shift, act: str):
     return out
 
 
+def nhwc_conv_last_pre(z7, pre_scale, pre_shift, pre_act: str, w, scale, shift, stats: bool = False):
+    """cnn8 on the un-normalised cnn7 output z7 [B,T,F,64] bf16 (its BatchNorm + activation applied on the way in)
+    -> [B,T,8F] fp32 unactivated (+ [8,2] float64 {sum, sum of squares} per output channel)."""
+    lib = _lib.load()
+    _dev_check(z7, "z7", torch.bfloat16)
+    B, T, F, _ = z7.shape
+    out = torch.empty(B, T, 8 * F, dtype=torch.float32, device=z7.device)
+    st = torch.zeros(64, 8, 2, dtype=torch.float64, device=z7.device) if stats else None
+    check(lib.vs_nhwc_conv_last_pre(_p(z7), _p(pre_scale), _p(pre_shift), ACT_CODES[pre_act], _p(w), _p(scale), _p(shift), _p(out), _p(st),
+                                    B, T, F, _stream()), "vs_nhwc_conv_last_pre")
+    return (out, st.sum(0)) if stats else out
+
+
 def nhwc_conv_wgrad(dz, x, KT: int, KF: int, dil: int):
     """dz, x [B,T,F,64] bf16 -> dw [64,64,KT,KF] fp32."""
     lib = _lib.load()
@@ -794,13 +807,14 @@ def nhwc_conv_last_bwd_dy(dz8, w, a7, z7, act: str, bn_scale, bn_shift, bn_mean,
     """cnn8 backward with the dy epilogue -> (dy7 bf16, dw [8,64], stats)."""
     lib = _lib.load()
     _dev_check(dz8, "dz8")
-    _dev_check(a7, "a7", torch.bfloat16)
+    if a7 is not None:                      # None: recomputed from z7 inside the kernel
+        _dev_check(a7, "a7", torch.bfloat16)
     _dev_check(z7, "z7", torch.bfloat16)
-    B, T, F, _ = a7.shape
-    dy = torch.empty_like(a7)
-    part = torch.empty(lib.vs_nhwc_conv_last_bwd_blocks() * 512, dtype=torch.float32, device=a7.device)
-    dw = torch.empty(8, 64, dtype=torch.float32, device=a7.device)
-    stats = torch.zeros(64, 64, 2, dtype=torch.float64, device=a7.device)
+    B, T, F, _ = z7.shape
+    dy = torch.empty_like(z7)
+    part = torch.empty(lib.vs_nhwc_conv_last_bwd_blocks() * 512, dtype=torch.float32, device=z7.device)
+    dw = torch.empty(8, 64, dtype=torch.float32, device=z7.device)
+    stats = torch.zeros(64, 64, 2, dtype=torch.float64, device=z7.device)
     check(lib.vs_nhwc_conv_last_bwd_dy(_p(dz8), _p(w), _p(a7), _p(dy), _p(part), _p(dw), _p(z7), ACT_CODES[act], _p(bn_scale), _p(bn_shift),
                                        _p(bn_mean), _p(bn_invstd), _p(stats), B, T, F, _stream()), "vs_nhwc_conv_last_bwd_dy")
     return dy, dw, stats
