@@ -196,13 +196,16 @@ int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int
 // prep_* != NULL: W_ih arrives prepared (vs_prepare_weights): its scale and split halves are read, not rebuilt
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
-                            hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl) {
+                            hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl,
+                            bool feat_bf16_ready) {
   if (math == VS_MATH_BF16 && scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0 &&
       scratch_bytes >= vs_lstm_bf16_layout(M, K, H).total) {
     // the bf16 configuration's own GEMM (gemm_bf16.hip): feat and W_ih as bf16 arrays that the backward pass reuses
     const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K, H);
     char* base = static_cast<char*>(scratch);
-    if (int rc = vs_cvt_rows_bf16_impl(feat, M, K, K, base + Lb.feat, Lb.Kp, stream)) return rc;
+    if (!feat_bf16_ready) {      // (the training forward's BatchNorm apply of cnn8 writes it itself)
+      if (int rc = vs_cvt_rows_bf16_impl(feat, M, K, K, base + Lb.feat, Lb.Kp, stream)) return rc;
+    }
     if (!prep_wh) {      // (prepared weights: the bf16 W_ih lives in the prepared blob)
       if (int rc = vs_cvt_rows_bf16_impl(w_ih0, 4 * H, K, KE, static_cast<char*>(scratch) + Lb.wih, Lb.Kp, stream)) return rc;
       if (int rc = vs_cvt_rows_bf16_impl(w_ih1, 4 * H, K, KE, static_cast<char*>(scratch) + Lb.wih + (size_t)4 * H * Lb.Kp * 2, Lb.Kp, stream)) return rc;

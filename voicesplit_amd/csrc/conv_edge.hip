@@ -213,6 +213,47 @@ void bn_apply_feat_kernel(const float* x, float* y, const float* __restrict__ sc
   }
 }
 
+// The same pass for the bf16 configuration's training forward: besides y it writes the bf16 row-form copy of the features
+// the LSTM input GEMM (and later dW_ih) reads -- [B*T][Kp], Kp >= 8F zero padded -- so no conversion pass re-reads the
+// 370 MB tensor.  One thread per 8 consecutive elements of a row (rows are 32 F bytes: 16-byte aligned): two float4 in,
+// two float4 + one 16-byte bf16 vector out; a group may straddle a channel boundary (F is odd).
+typedef unsigned edge_u4 __attribute__((ext_vector_type(4)));
+template <int ACT>
+__global__ __launch_bounds__(256)
+void bn_apply_feat_bf16_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned short* __restrict__ yb,
+                               const float* __restrict__ scale, const float* __restrict__ shift, int F, int Kp, long long rows) {
+  const int K = 8 * F, groups = Kp >> 3;
+  const long long total = rows * groups;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { sc[c] = scale[c]; sh[c] = shift[c]; }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / groups;
+    const int k0 = (int)(i - r * groups) * 8;
+    float v[8];
+    if (k0 < K) {                       // K is a multiple of 8: a group is entirely inside or entirely in the padding
+      const float4 a = *reinterpret_cast<const float4*>(x + r * K + k0), b = *reinterpret_cast<const float4*>(x + r * K + k0 + 4);
+      const float in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const int c0 = k0 / F, edge = (c0 + 1) * F;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + (k0 + e >= edge ? 1 : 0);
+        float s = sc[0], h = sh[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { s = c == q ? sc[q] : s; h = c == q ? sh[q] : h; }
+        v[e] = vs_act<ACT>(fmaf(in[e], s, h));
+      }
+      *reinterpret_cast<float4*>(y + r * K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(y + r * K + k0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    const edge_u4 o = {vs_pack_bf16(v[0], v[1]), vs_pack_bf16(v[2], v[3]), vs_pack_bf16(v[4], v[5]), vs_pack_bf16(v[6], v[7])};
+    *reinterpret_cast<edge_u4*>(yb + r * Kp + k0) = o;
+  }
+}
+
 // eval-mode BatchNorm applied to a raw conv output (bias already inside z): constants from the
 // running statistics, also kept as mean / invstd for the backward pass.
 __global__ void bn_eval_consts_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -363,6 +404,25 @@ int vs_bn_apply_feat_impl(const float* x, float* y, int B, int T, int F, int act
     case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_MISH>, dim3(ga), dim3(256), 0, stream, x, y, scale, shift, F, total); break;
     case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_feat_kernel<VS_ACT_NONE>, dim3(ga), dim3(256), 0, stream, x, y, scale, shift, F, total); break;
     default: VS_REQUIRE(false, "bn_apply_feat: unknown activation %d", act);
+  }
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = act(x*scale[c] + shift[c]) over the cnn8 feature layout, plus its bf16 row-form copy yb [B*T][Kp] (zero padded)
+int vs_bn_apply_feat_bf16_impl(const float* x, float* y, void* yb, int Kp, int B, int T, int F, int act, const float* scale, const float* shift,
+                               hipStream_t stream) {
+  VS_REQUIRE(x && y && yb && B > 0 && T > 0 && F > 0 && Kp >= 8 * F && Kp % 8 == 0, "bn_apply_feat_bf16: bad argument");
+  VS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(yb) & 15) == 0,
+             "bn_apply_feat_bf16: buffers must be 16-byte aligned");
+  const long long rows = (long long)B * T, total = rows * (Kp >> 3);
+  const int ga = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  unsigned short* o = reinterpret_cast<unsigned short*>(yb);
+  switch (act) {
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_apply_feat_bf16_kernel<VS_ACT_RELU>, dim3(ga), dim3(256), 0, stream, x, y, o, scale, shift, F, Kp, rows); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_apply_feat_bf16_kernel<VS_ACT_MISH>, dim3(ga), dim3(256), 0, stream, x, y, o, scale, shift, F, Kp, rows); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_apply_feat_bf16_kernel<VS_ACT_NONE>, dim3(ga), dim3(256), 0, stream, x, y, o, scale, shift, F, Kp, rows); break;
+    default: VS_REQUIRE(false, "bn_apply_feat_bf16: unknown activation %d", act);
   }
   VS_LAUNCH_CHECK();
   return 0;

@@ -239,13 +239,18 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     if (int rc = vs_conv_last_fwd_impl(at<float>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
   }
   }
+  bool feat_bf16_ready = false;
   if (nhwc && train) {
     // cnn8's batch statistics came out of its own epilogue: finalize + the apply pass
     VsProfScope ps(VS_PROF_FWD_BN, stream);
     const vs_conv_layer& c = p->conv[7];
     if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)B * T * F, 8, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
                                      kBnEps, kBnMomentum, scale + 64 * 7, shift + 64 * 7, mean + 64 * 7, invstd + 64 * 7, stream)) return rc;
-    if (int rc = vs_bn_apply_feat_impl(at<float>(tape, L.z8), at<float>(tape, L.feat), B, T, F, conv_act, scale + 64 * 7, shift + 64 * 7, stream)) return rc;
+    // ... which also writes the bf16 row-form copy of the features the LSTM GEMMs read
+    const VsLstmBf16Layout Lf = vs_lstm_bf16_layout((long long)B * T, 8 * F, H);
+    if (int rc = vs_bn_apply_feat_bf16_impl(at<float>(tape, L.z8), at<float>(tape, L.feat), at<char>(tape, L.lstm_bf16) + Lf.feat, Lf.Kp, B, T, F, conv_act,
+                                            scale + 64 * 7, shift + 64 * 7, stream)) return rc;
+    feat_bf16_ready = true;
   } else if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
 
   // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
@@ -261,7 +266,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     // the backward pass's gradient buffers are idle during the forward pass
     if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
                                          at<float>(tape, L.gemm_scales), nhwc ? at<char>(tape, L.lstm_bf16) : at<char>(tape, L.grad0),
-                                         nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream)) return rc;
+                                         nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream, nullptr, nullptr, nullptr,
+                                         feat_bf16_ready)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
   if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc;

@@ -38,7 +38,8 @@ int vs_gemm_f16x3_impl(int layout_a, int layout_w, const float* A, int lda, cons
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gemm_scales,
                             void* scratch, size_t scratch_bytes, hipStream_t, const float* prep_wscale2 = nullptr,
-                            const _Float16* prep_wh = nullptr, const _Float16* prep_wl = nullptr);
+                            const _Float16* prep_wh = nullptr, const _Float16* prep_wl = nullptr,
+                            bool feat_bf16_ready = false /* VS_MATH_BF16: the bf16 copy of feat is already in scratch */);
 int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int H, int K, int KE, unsigned* amax1,
                            float* w_scale2, _Float16* Wh, _Float16* Wl, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
@@ -120,6 +121,8 @@ int vs_bn_train_feat_impl(const float* x, float* y, int B, int T, int F, const f
                           float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
 int vs_bn_apply_impl(const float* x, float* y, int B, int C, int plane, int act, const float* scale, const float* shift, unsigned* amax_out, hipStream_t);
 int vs_bn_apply_feat_impl(const float* x, float* y, int B, int T, int F, int act, const float* scale, const float* shift, hipStream_t);
+int vs_bn_apply_feat_bf16_impl(const float* x, float* y, void* yb, int Kp, int B, int T, int F, int act, const float* scale, const float* shift,
+                               hipStream_t);
 int vs_bn_eval_consts_impl(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, int C,
                            float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
 // conv_bwd.hip
