@@ -101,11 +101,18 @@ class _MaskNet(nn.Module):
         m = self.config.model
         return ops.make_dims(B, T, self.audio["num_freq"], m["emb_dim"], m["lstm_dim"], m["fc1_dim"], m["fc2_dim"])
 
+    def __setattr__(self, name, value):
+        # a replaced sub-module / parameter invalidates the cached tensor index (see _tensors)
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            self.__dict__.pop("_tensor_index", None)
+        super().__setattr__(name, value)
+
     def _tensors(self):
         """{state_dict key: tensor} of every parameter and buffer.  The module tree is fixed after construction, so the walk
         of named_parameters() / named_buffers() (~0.1 ms of host time in front of every step's first kernel) is done once:
         what is kept is (key, owning dict, name), and the tensors are read from the owning modules' dicts on every call
-        -- load_state_dict, .to(), optimizer steps and parameter re-assignment are all seen."""
+        -- load_state_dict, .to(), optimizer steps and parameter re-assignment are all seen; assigning a new sub-module to
+        this module drops the index (``__setattr__``)."""
         index = self.__dict__.get("_tensor_index")
         if index is None:
             index = []
