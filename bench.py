@@ -340,17 +340,9 @@ def main():
                 assert same, "gradient buckets differ between ranks after the all-reduce"
                 rccl = {"rccl_ranks": world, "bucket_identical_on_all_ranks": True, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1)}
             else:
-                if launched and "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
-                    # started by torch.distributed.run with one rank: the rendezvous store is the launcher's (under
-                    # TORCHELASTIC_USE_AGENT_STORE every store is created as a CLIENT of the agent's, so a private tcp://
-                    # port would wait for a server that does not exist until the collective timeout): env:// it is
-                    tdist.init_process_group("nccl", device_id=dev)
-                else:
-                    import socket
-                    with socket.socket() as s_:
-                        s_.bind(("127.0.0.1", 0))
-                        port = s_.getsockname()[1]
-                    tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                # (under torch.distributed.run the group has to come from the launcher's store: see the helper)
+                from voicesplit_amd.sharding import init_single_rank_group
+                init_single_rank_group("nccl", device_id=dev)
                 keep = bucket.flat.clone()
                 bucket.all_reduce(1, force=True)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -125,3 +125,36 @@ def test_world2_gloo_gradient_bucket_allreduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_single_rank_group_under_the_launcher_and_alone(tmp_path):
+    """sharding.init_single_rank_group (bench.py's one-rank RCCL leg): as a plain process it builds a private tcp://
+    store; started by torch.distributed.run it must take the launcher's store (env://) -- a private store there is a
+    client without a server and waits for the collective timeout (found on the device: `torch.distributed.run
+    --nproc-per-node 1 bench.py --gpus 1` hung).  gloo stands in for RCCL; both must finish within seconds."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "one_rank.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from voicesplit_amd.sharding import init_single_rank_group\n"
+        "t0 = time.time()\n"
+        "how = init_single_rank_group('gloo')\n"
+        "x = torch.ones(4)\n"
+        "dist.all_reduce(x)\n"
+        "assert dist.get_world_size() == 1 and torch.equal(x, torch.ones(4))\n"
+        "dist.destroy_process_group()\n"
+        "print('HOW', how.split(':')[0], round(time.time() - t0, 1))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    alone = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert alone.returncode == 0 and "HOW tcp" in alone.stdout, alone.stdout + alone.stderr
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=180)
+    assert launched.returncode == 0 and "HOW env" in launched.stdout, launched.stdout + launched.stderr

@@ -6,6 +6,7 @@ the batch with replicated weights and no data-path collective.  The helpers here
 only: slice arithmetic, and an optional all-gather for callers that want every rank to hold the
 full mask (embarrassingly-parallel inference does not need it).
 """
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -130,3 +131,31 @@ def sync_buffers(module: torch.nn.Module, src: int = 0, group=None):
     import torch.distributed as dist
     for b in module.buffers():
         dist.broadcast(b, src=src, group=group)
+
+
+def init_single_rank_group(backend: str, device_id=None, env=None):
+    """A ONE-rank process group for this process (bench.py's RCCL leg at N = 1: the gradient bucket through a real
+    ncclAllReduce although the step's exchange is a no-op).  Two ways to get there, and the wrong one waits for minutes:
+
+    * started by ``torch.distributed.run`` (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment): under
+      ``TORCHELASTIC_USE_AGENT_STORE`` torch creates EVERY TCPStore as a client of the launcher's store, so a private
+      ``tcp://127.0.0.1:<free port>`` rendezvous waits for a server that does not exist until the timeout -- the group
+      has to come from ``env://`` (the launcher's store, rank 0 of 1);
+    * started as a plain process: a private ``tcp://`` store on a free local port (no environment needed).
+    """
+    import torch.distributed as dist
+    env = os.environ if env is None else env
+    kw = {"device_id": device_id} if device_id is not None else {}
+    launched = all(k in env for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if launched:
+        if int(env["WORLD_SIZE"]) != 1:
+            raise RuntimeError("init_single_rank_group: this process belongs to a job of %s ranks" % env["WORLD_SIZE"])
+        dist.init_process_group(backend, **kw)
+        return "env://"
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    method = f"tcp://127.0.0.1:{port}"
+    dist.init_process_group(backend, init_method=method, rank=0, world_size=1, **kw)
+    return method
