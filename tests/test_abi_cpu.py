@@ -69,6 +69,13 @@ def test_workspace_layout_and_argument_errors():
     # fp32 fragment form + room for the two f16 planes of the math-selected recurrence + a 64-float header
     assert lib.vs_lstm_packed_floats(400) == 2 * 1600 * 400 + 2 * 1600 * 400 + 64
     assert lib.vs_lstm_packed_t_floats(400) == 2 * 13 * 200 * 256 + 2 * 13 * 100 * 256 + 64
+    # the *_math entry points of the recurrence refuse an unknown arithmetic and NULL buffers before touching the device
+    assert lib.vs_lstm_pack_math(None, None, None, 400, 7, None) != 0 and b"unknown math" in lib.vs_last_error()
+    assert lib.vs_lstm_pack_math(None, None, None, 400, 2, None) != 0 and b"NULL" in lib.vs_last_error()
+    assert lib.vs_bilstm_recurrent_math(None, None, None, None, None, None, 1, 1, 8, 1, None) != 0 and b"NULL" in lib.vs_last_error()
+    assert lib.vs_bilstm_recurrent_bwd_math(None, None, None, None, None, 1, 1, 8, 9, None) != 0 and b"unknown math" in lib.vs_last_error()
+    assert lib.vs_nhwc_conv_last_pre(None, None, None, 2, None, None, None, None, None, 1, 1, 8, None) != 0 and b"NULL" in lib.vs_last_error()
+    assert lib.vs_set_lstm_kernel(3) == 0 and lib.vs_set_lstm_kernel(4) != 0 and lib.vs_set_lstm_kernel(0) == 0
     # h ping / pong / flags regions are sized for the 16-wide K chunks of the f16 form (H = 24 -> 32)
     assert lib.vs_lstm_state_floats(3, 24) == 3 * 2 * 32 * 32 + 64 and lib.vs_lstm_state_floats(64, 400) == 3 * 2 * 400 * 64 + 64
 
