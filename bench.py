@@ -28,7 +28,10 @@ reference, tests/test_gpu_bf16.py) -- plus
                   from split-f16 MFMAs, <= 1e-4 relative vs the reference); forward_bf16: the same in bf16
   fp32_class   -- the same training step in the fp32-class arithmetic (the headline of rounds 1-2), own roofline figures
   fp32_strict  -- the same step on the fp32 matrix cores (bitwise an fmaf chain), 3 steps
-  cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores, B=1 and B=4.
+  longform     -- BASELINE configs[4] as a short sub-leg (51 clips of 30 s = 510 windows per step, 256 windows per forward batch),
+                  in bf16 and in the fp32-class arithmetic (`--mode longform` is the full line of that configuration)
+  cpu_baseline -- the oracle (torch CPU restatement of the reference) timed on the host cores, B=1 and B=4; in training mode
+                  forward + autograd backward from a STAND-IN loss (a fixed d(loss)/d(mask)).
 --conv-math f16x3 makes the fp32-class step the line and bf16 the sub-object.
 """
 import argparse
@@ -58,21 +61,23 @@ MATH_LABEL = {"fp32": "fp32 MFMA", "f16x3": "fp32 I/O, split-f16 MFMA (3 f16 pro
               "bf16": "channels-last bf16 activations / tape, bf16 MFMA, fp32 accumulate / statistics / master weights"}
 
 
-def committed_pmc_traffic(tag, kernel_substr):
+def committed_pmc_traffic(tag, kernel_substr, instance=None):
     """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/<tag>_rocprof/pmc_per_kernel.csv, written by tools/profile_gpu.sh + summarize_prof.py in
     separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE, in GB.  The x2 is calibrated, not assumed: a 1 GiB
     read reports FETCH_SIZE = 0.5 GiB for dword and for 16-byte loads alike on this chip and tool version, and a
     1 GiB write reports WRITE_SIZE = 1 GiB (profiles/r02_calibration/).  bench.py itself cannot collect
-    counters; None when the file is absent."""
+    counters; None when the file is absent.  instance: a substring of the template arguments that picks ONE
+    instantiation of the kernel (the forward conv and the dy-form data gradient are two instances of nhwc_conv_kernel
+    with different traffic); without it the instance with the most dispatches."""
     import csv
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_rocprof", "pmc_per_kernel.csv")
         if not os.path.isfile(path):
             continue
         best = None
         for r in csv.DictReader(open(path)):
-            if kernel_substr in r["kernel"] and r.get("fetch_GB_x2") and r.get("write_GB"):
+            if kernel_substr in r["kernel"] and (instance is None or instance in r["kernel"]) and r.get("fetch_GB_x2") and r.get("write_GB"):
                 n = int(r["dispatches"])
                 if best is None or n > best[0]:
                     best = (n, float(r["fetch_GB_x2"]) + float(r["write_GB"]))
@@ -118,7 +123,7 @@ def cpu_baseline(mode, seconds_budget=14.0):
     torch.set_num_threads(threads)
     dims = R.default_dims()
     sd = R.build_state_dict(dims, 0)
-    what = "forward + autograd backward" if mode == "train" else "forward"
+    what = "forward + autograd backward from a stand-in loss (fixed d(loss)/d(mask), no iSTFT / SI-SNR head)" if mode == "train" else "forward"
 
     def run(B, budget):
         x, dvec = R.synthetic_inputs(B, T_FRAMES, dims, 0)
@@ -144,6 +149,8 @@ def cpu_baseline(mode, seconds_budget=14.0):
     n1, el1 = run(1, seconds_budget)
     n4, el4 = run(4, seconds_budget * 0.6)
     return {"value": round(n1 / el1, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
+            "metric": ("utterances/sec fwd+bwd with a stand-in loss (the model's share of the step: the SI-SNR head is not timed on the CPU)"
+                       if mode == "train" else "utterances/sec forward"),
             "value_b4": round(4 * n4 / el4, 4),
             "sample": f"{n1} x {what} of one [1,301,601] utterance in {el1:.1f} s (value) and {n4} x the same at B=4 in "
                       f"{el4:.1f} s (value_b4), fp32, torch {torch.__version__} CPU ops, {threads} threads "
@@ -392,6 +399,18 @@ def main():
             kname, peak, extra, ksub = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel"
         traffic, rnd = committed_pmc_traffic(tag, ksub) if B == 64 else (None, None)
         algo_gb = B * 2 * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
+        by_instance = None
+        if math == "bf16" and is_train:
+            # two instances of the kernel share the 10 launches: the forward conv (reads a, writes z: 2 tensors) and the dy-form
+            # data gradient (reads dz and the lower layer's z, writes dy: 3 tensors) -- each against ITS algorithmic bytes
+            one = B * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
+            t_f, r_f = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "true, false>") if B == 64 else (None, None)
+            t_d, r_d = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "false, true>") if B == 64 else (None, None)
+            by_instance = {"forward": {"launches_per_step": 5, "algorithmic_gb": round(2 * one, 2), "traffic_gb": t_f},
+                           "dy_form_data_gradient": {"launches_per_step": 5, "algorithmic_gb": round(3 * one, 2), "traffic_gb": t_d}}
+            algo_gb = 2.5 * one                                                 # mean over the 10 launches
+            if t_f is not None and t_d is not None:
+                traffic, rnd = round((t_f + t_d) / 2, 2), r_f
         roof = {"bound": "mfma",
                 "kernel": kname + " (cnn3..cnn7 forward" + (" + data gradient" if is_train else "") + ")",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -399,10 +418,12 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": f"GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
                                 f"(profiles/{rnd or 'rNN'}_{tag}_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
-                                f"algorithmic bytes {algo_gb:.2f} GB",
+                                f"algorithmic bytes {algo_gb:.2f} GB" + (" (mean over the two instances: traffic_by_instance)" if by_instance else ""),
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
                 "hbm_frac_of_same_kernel": round(algo_gb / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
         roof.update(extra)
+        if by_instance:
+            roof["traffic_by_instance"] = by_instance
         if is_train:
             wg = [stage_ms[f"wgrad_cnn{i}"] for i in range(3, 8)]
             wg_mean = sum(wg) / 5.0
@@ -444,6 +465,31 @@ def main():
                 "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
                 "ms_per_step": round(1e3 * fel / FK, 3)}
 
+    # ---- BASELINE configs[4] next to the training line: 30 s clips as independent 301-frame windows, 256 per forward batch ----
+    def longform_leg(m, math, clips=51, steps=2):
+        from voicesplit_amd import sharding, streaming
+        m.eval()
+        prev = ops.get_conv_math()
+        ops.set_conv_math(math)
+        try:
+            gl = torch.Generator().manual_seed(99 + rank)
+            ls = torch.rand(clips, LONG_FRAMES, N_FREQ, generator=gl).to(dev)
+            ld = torch.randn(clips, EMB, generator=gl)
+            ld = (ld / ld.norm(dim=1, keepdim=True)).to(dev)
+            nwin = clips * sharding.chunk_windows(LONG_FRAMES, T_FRAMES)
+
+            def f():
+                return streaming.separate_long_many(m, ls, ld, window=T_FRAMES, max_batch=256)
+            lel, _, _ = timed(f, steps, 1, False)
+            del ls
+        finally:
+            ops.set_conv_math(prev)
+            m.train()
+        return {"metric": "windows/sec = utterances/sec (30 s clips cut into independent 301-frame windows, 256 windows per forward batch, eval "
+                          "BatchNorm: BASELINE configs[4]), " + MATH_LABEL[math],
+                "value": round(world * nwin * steps / lel, 2), "unit": "utterances/s", "clips_per_s": round(world * clips * steps / lel, 2),
+                "clips_per_gpu_and_step": clips, "windows_per_step": nwin, "steps": steps, "warmup": 1, "ms_per_step": round(1e3 * lel / steps, 3)}
+
     # ---- the same training step in another arithmetic (own model, own trainer, same inputs) ----------------
     def train_leg(math, steps, warmup):
         prev = ops.get_conv_math()
@@ -479,11 +525,14 @@ def main():
         finally:
             ops.set_conv_math(prev)
 
-    fwd = fwd16 = other = strict = None
+    fwd = fwd16 = other = strict = lform = None
     if train and not args.no_extras:
         fwd = forward_leg(model, "f16x3" if conv_math == "bf16" else conv_math)      # configs[1]: fp32-class forward
         if conv_math == "bf16":
             fwd16 = forward_leg(model, "bf16")
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
+        lform = {m_: longform_leg(model, m_) for m_ in (("bf16", "f16x3") if conv_math == "bf16" else (conv_math,))}
         if conv_math in ("bf16", "f16x3"):
             ops.release_workspaces()
             torch.cuda.empty_cache()
@@ -539,6 +588,8 @@ def main():
             line["forward"] = fwd
         if fwd16 is not None:
             line["forward_bf16"] = fwd16
+        if lform is not None:
+            line["longform"] = lform
         if other is not None:
             line["fp32_class" if conv_math == "bf16" else "bf16"] = other
         if strict is not None:

@@ -44,7 +44,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these are its only exports */
 #endif
 
-#define VS_ABI_VERSION 6
+#define VS_ABI_VERSION 7
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -224,11 +224,27 @@ int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const f
 int vs_cvt_rows_bf16(const float* src, long long rows, int K, int ld, void* dst, int Kp, void* stream);
 int vs_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                  const float* rowbias, int ldrb, int group, int accumulate, void* stream);
+/* The same contraction with its result rows stored into TWO matrices stacked along M: rows m < split_m go to C + m * ldc,
+ * rows m >= split_m to C2 + (m - split_m) * ldc.  This is how vs_backward writes dW_ih of both LSTM directions from ONE
+ * col x col contraction over K = B*T (dxg^T @ feat, M = 8H: rows < 4H -> lstm.weight_ih_l0.grad, the rest -> _reverse). */
+int vs_gemm_bf16_split(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, float* C2, int ldc, int split_m,
+                       int M, int N, int K, int accumulate, void* stream);
 /* the memory-bound kernels around them.  cnn1: x [B][T][F] fp32 -> [B][T][F][64] bf16 (bn_stats as above);
  * BatchNorm + activation apply a = act(z * scale[c] + shift[c]) over npix pixels (a may alias z); cnn8 + transpose/view:
  * [B][T][F][64] bf16 -> [B][T][8][F] fp32. */
 int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
                        int B, int T, int F, int act, double* bn_stats, void* stream);
+/* Train-mode nn.BatchNorm2d between a conv that accumulated statistics and the apply pass (models/voicesplit/model.py:19 under
+ * model.train(), train.py:84): stats = [slots][C][2] doubles {sum, sum of squares} over `count` values per channel -- what
+ * vs_nhwc_conv / vs_nhwc_conv_first / vs_nhwc_conv_last_pre leave in bn_stats (slots = 64, C = 64 resp. 8, count = B*T*F);
+ * the slots are folded into slot 0 (stats is modified).  Out: scale[c] = gamma / sqrt(var + eps), shift[c] = beta - mean * scale
+ * (biased variance: the operands of vs_nhwc_bn_apply, a = act(z * scale + shift)), mean_out / invstd_out (may be NULL: what the
+ * backward kernels take as bn_mean / bn_invstd), and running_mean / running_var updated in place exactly as nn.BatchNorm2d
+ * does: r = (1 - momentum) r + momentum * {mean, unbiased variance}; pass both as NULL for no update.  The reference uses
+ * eps = 1e-5, momentum = 0.1 (nn.BatchNorm2d defaults).  num_batches_tracked is the caller's (host-side counter). */
+int vs_bn_finalize(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float eps, float momentum,
+                   float* scale, float* shift, float* mean_out, float* invstd_out, void* stream);
 int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, void* stream);
 int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const float* shift, float* out,
                       int B, int T, int F, int act, void* stream);

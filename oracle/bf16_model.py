@@ -53,11 +53,14 @@ def _rnd(x, fwd: bool, bwd: bool = False):
 
 
 def gradients(sd: Dict[str, torch.Tensor], x: torch.Tensor, dvec: torch.Tensor, w: torch.Tensor, act: str = "mish",
-              bf16: bool = True) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+              bf16: bool = True, dtype=torch.float64) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
     """d(sum(mask * w))/d(parameter) in fp64, training-mode BatchNorm; bf16=True injects the storage roundings of the
-    bf16 configuration, bf16=False is the exact reference.  Returns (gradients by state_dict key, mask)."""
-    P = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    x, dvec, w = x.double(), dvec.double(), w.double()
+    bf16 configuration, bf16=False is the exact reference.  Returns (gradients by state_dict key, mask).
+    dtype: the carrier arithmetic -- float64 everywhere except the full-size B = 8 fixture of oracle/make_golden.py
+    --bf16-envelope, whose autograd graph does not fit this container's memory in fp64 and runs in float32 (its 6e-8
+    rounding is four orders below the bf16 roundings under study)."""
+    P = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    x, dvec, w = x.to(dtype), dvec.to(dtype), w.to(dtype)
     B, T, _ = x.shape
     h = x.unsqueeze(1)
     for i, spec in enumerate(R.CONV_TABLE):

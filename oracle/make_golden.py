@@ -197,6 +197,44 @@ def main_grads():
         print(f"{name}: {len(list(model.parameters()))} gradients -> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def main_bf16_envelope():
+    """The IDEAL-bf16 gradients of the metric configuration's fixture (vs_full_b8_train_grads: full size, 8 utterances,
+    batch-statistics BatchNorm): oracle/bf16_model.py -- the reference graph with bf16 rounding injected at the storage
+    points of VS_MATH_BF16 and nothing else -- on the same seeded inputs, thinned exactly like the upstream gradients of
+    that fixture.  tests/test_gpu_bf16.py holds the HIP path to the envelope these define against the UPSTREAM gradients
+    (how far a perfect implementation of bf16 storage is from the exact result ON THIS FIXTURE).  Needs no reference
+    import; the carrier arithmetic is float32 (see bf16_model.gradients) and the run takes ~25 GB and several minutes."""
+    from oracle import bf16_model
+    from oracle import reference_backward as RB
+    name, model_name, dims, B, T, seed, training, gain = [c for c in GRAD_CASES if c[0] == "vs_full_b8_train_grads"][0]
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd = R.spread_logits(R.build_state_dict(dims, seed), gain)
+    up = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    assert str(up["sd_sha256"]) == state_dict_digest(sd), "RNG drift: the upstream fixture was made from other weights"
+    x, dvec = R.synthetic_inputs(B, T, dims, seed)
+    w = RB.loss_weights(B, T, dims["fc2_dim"], seed)
+    ideal, mask = bf16_model.gradients(sd, x, dvec, w, act="mish", bf16=True, dtype=torch.float32)
+    out = {"of": np.array(name), "sd_sha256": np.array(state_dict_digest(sd)), "torch_version": np.array(torch.__version__),
+           "carrier": np.array("float32"), "fwd/mask": mask.numpy()[:, ::8].astype(np.float32)}
+    worst_err, worst_cos = 0.0, 1.0
+    for k, gk in ideal.items():
+        t = RB.thin_grad(gk.detach()).double().numpy()
+        out["grad/" + k] = t.astype(np.float32)
+        ref = up["grad/" + k].astype(np.float64)
+        if k in {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}:
+            continue                               # conv bias in front of a batch-statistics BatchNorm: the true gradient is
+                                                   # exactly zero (the upstream fp32 value is rounding noise of order 1e-9)
+        err = float(np.abs(t - ref).max() / float(up["gabs/" + k]))
+        cos = float((t @ ref) / max(np.linalg.norm(t) * np.linalg.norm(ref), 1e-300))
+        worst_err, worst_cos = max(worst_err, err), min(worst_cos, cos)
+        print(f"  {k:32s} ideal err {err:.3f} cos {cos:.4f}")
+    mse = float(((out["fwd/mask"].astype(np.float64) - up["fwd/mask"]) ** 2).mean())
+    path = os.path.join(GOLDEN_DIR, name.replace("_grads", "_bf16_ideal") + ".npz")
+    np.savez(path, **out)
+    print(f"{os.path.basename(path)}: worst ideal err {worst_err:.3f}, worst cosine {worst_cos:.4f}, mask MSE {mse:.2e} "
+          f"-> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def main_loss():
     """Pins oracle/reference_loss.sisnr_with_pit to the upstream SiSNR_With_Pit
     (utils/generic_utils.py:416-474): seeded waveforms in, loss and d(loss)/d(estimate) out."""
@@ -284,7 +322,9 @@ def main_real():
 
 
 if __name__ == "__main__":
-    if "--real" in sys.argv:
+    if "--bf16-envelope" in sys.argv:
+        main_bf16_envelope()
+    elif "--real" in sys.argv:
         main_real()
     elif "--powerlaw" in sys.argv:
         main_powerlaw()

@@ -75,6 +75,12 @@ def test_workspace_layout_and_argument_errors():
     assert lib.vs_bilstm_recurrent_math(None, None, None, None, None, None, 1, 1, 8, 1, None) != 0 and b"NULL" in lib.vs_last_error()
     assert lib.vs_bilstm_recurrent_bwd_math(None, None, None, None, None, 1, 1, 8, 9, None) != 0 and b"unknown math" in lib.vs_last_error()
     assert lib.vs_nhwc_conv_last_pre(None, None, None, 2, None, None, None, None, None, 1, 1, 8, None) != 0 and b"NULL" in lib.vs_last_error()
+    # the exported BatchNorm finalize refuses NULL statistics / constants and half a pair of running buffers before any launch
+    assert lib.vs_bn_finalize(None, 64, 1000.0, 64, None, None, None, None, 1e-5, 0.1, None, None, None, None, None) != 0
+    assert b"bn_finalize" in lib.vs_last_error()
+    one = ctypes.c_void_p(256)
+    assert lib.vs_bn_finalize(one, 64, 1000.0, 64, one, one, one, None, 1e-5, 0.1, one, one, None, None, None) != 0 and b"both running" in lib.vs_last_error()
+    assert lib.vs_bn_finalize(one, 64, 1000.0, 64, one, one, None, None, 1e-5, 1.5, one, one, None, None, None) != 0 and b"momentum" in lib.vs_last_error()
     assert lib.vs_set_lstm_kernel(3) == 0 and lib.vs_set_lstm_kernel(4) != 0 and lib.vs_set_lstm_kernel(0) == 0
     # h ping / pong / flags regions are sized for the 16-wide K chunks of the f16 form (H = 24 -> 32)
     assert lib.vs_lstm_state_floats(3, 24) == 3 * 2 * 32 * 32 + 64 and lib.vs_lstm_state_floats(64, 400) == 3 * 2 * 400 * 64 + 64
@@ -127,3 +133,34 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle/" not in text and "reference_forward" not in text, f
+
+
+def test_tensor_index_follows_the_module_tree_and_transients_stay_out_of_copies():
+    """The cached (key, owning dict, name) index behind every C-ABI call is rebuilt when the module tree changes below
+    the top level too, and caches / foreign views do not travel with deepcopy or pickling."""
+    import copy
+    import pickle
+    import voicesplit_amd as V
+    m = V.VoiceSplit(V.default_config(37, 16, 24, 40, 37))
+    t0 = m._tensors()
+    assert list(t0) == list(m.state_dict())
+    old_w = m.conv[5].weight
+    m.conv[5] = torch.nn.Conv2d(64, 64, kernel_size=(7, 1))           # a child of a child replaced: Sequential.__setitem__
+    assert m._tensors()["conv.5.weight"] is m.conv[5].weight and m._tensors()["conv.5.weight"] is not old_w
+    m.fc1.register_buffer("extra_stat", torch.zeros(3))               # a buffer registered on a child
+    assert "fc1.extra_stat" in m._tensors()
+    m.fc1.register_buffer("scratch", torch.zeros(3), persistent=False)
+    assert "fc1.scratch" not in m._tensors()                          # state_dict() semantics: persistent buffers only
+    m.lstm.weight_hh_l0 = torch.nn.Parameter(torch.zeros_like(m.lstm.weight_hh_l0))   # a replaced tensor is read through the dict
+    assert m._tensors()["lstm.weight_hh_l0"] is m.lstm.weight_hh_l0
+    assert [k for k, _ in m._named_params()] == [k for k, _ in m.named_parameters()]
+    # transients
+    m.__dict__["_last_tape"] = ("tape", "dims")
+    m.set_gradient_sink({"fc1.weight": torch.zeros_like(m.fc1.weight)})
+    m.__dict__["_prepared"] = object()
+    for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert not any(k in c.__dict__ for k in m._TRANSIENT)
+        assert list(c._tensors()) == list(m._tensors()) and c._tensors()["fc2.weight"] is c.fc2.weight
+    assert "_grad_sink" in m.__dict__
+    m.set_gradient_sink(None)
+    assert "_grad_sink" not in m.__dict__

@@ -37,6 +37,8 @@ LSTM_TOL = 0.12
 MASK_ABS_TOL = 0.1
 GRAD_TOL = 0.6
 COS_MIN = 0.90
+FULL_GRAD_TOL = 0.45       # the full-size metric-configuration fixture (vs_full_b8_train_grads)
+FULL_COS_MIN = 0.95
 
 
 def _rel(got, ref):
@@ -111,11 +113,15 @@ def test_bf16_module_forward_and_backward_vs_fp64_oracle(cls_name, act, training
     assert not bad, bad            # `not <`: a NaN gradient is a failure, not a pass
 
 
-def test_bf16_metric_configuration_vs_upstream_golden():
-    """Full size, 8 utterances, batch-statistics BatchNorm (the pinned metric configuration) in bf16 arithmetic
-    against the UPSTREAM module's forward tensors and gradients."""
+_FULL_B8 = {}
+
+
+def _full_b8_run():
+    """One bf16 training-mode forward + backward of the pinned metric configuration (full size, 8 utterances), shared by
+    the two tests below: (table of errors vs the UPSTREAM fixture, thinned HIP gradients)."""
+    if _FULL_B8:
+        return _FULL_B8["table"], _FULL_B8["grads"], _FULL_B8["g"]
     import voicesplit_amd as V
-    from voicesplit_amd import ops
     g = load_golden_grads("vs_full_b8_train_grads")
     d = g["dims"]
     sd = R.spread_logits(R.build_state_dict(d, g["seed"]), g["gain"])
@@ -130,17 +136,67 @@ def test_bf16_metric_configuration_vs_upstream_golden():
     table = {"fwd/mask_abs": float(np.abs(mask.detach().cpu().numpy()[:, ::8] - g["fwd/mask"]).max()),
              "fwd/mask_mse": float(((mask.detach().cpu().numpy()[:, ::8] - g["fwd/mask"]) ** 2).mean())}
     zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}
+    grads = {}
     for k, p in m.named_parameters():
         if k in zero:
             continue
         got = RB.thin_grad(p.grad.detach().cpu()).double().numpy()
         ref = g["grads"][k].astype(np.float64)
+        grads[k] = got
         table["grad/" + k] = float(np.abs(got - ref).max() / max(g["gabs"][k], 1e-30))
         table["cos/" + k] = float((got @ ref) / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-300))
     _dump("vs_full_b8_train", table)
+    _FULL_B8.update(table=table, grads=grads, g=g)
+    del m, mask
+    from voicesplit_amd import ops
+    ops.release_workspaces()
+    torch.cuda.empty_cache()
+    return table, grads, g
+
+
+def test_bf16_metric_configuration_vs_upstream_golden():
+    """Full size, 8 utterances, batch-statistics BatchNorm (the pinned metric configuration) in bf16 arithmetic
+    against the UPSTREAM module's forward tensors and gradients."""
+    table, _, _ = _full_b8_run()
     assert table["fwd/mask_abs"] < MASK_ABS_TOL and table["fwd/mask_mse"] < 1e-4, table
-    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < GRAD_TOL) or (k.startswith("cos/") and not v >= COS_MIN)}
+    # this fixture (default-scale activations at full size) is milder than the small stress fixtures above: its own, tighter
+    # bounds -- measured 0.33 of a tensor's maximum / cosine 0.963 at worst (ideal bf16 storage: 0.30 / 0.955)
+    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < FULL_GRAD_TOL) or (k.startswith("cos/") and not v >= FULL_COS_MIN)}
     assert not bad, bad            # `not <`: a NaN gradient is a failure, not a pass
+
+
+def test_bf16_metric_configuration_inside_the_ideal_envelope_at_full_size():
+    """The envelope argument ON the fixture it is used to excuse (VERDICT round 3, next #1a): tests/golden/
+    vs_full_b8_train_bf16_ideal.npz holds the gradients of oracle/bf16_model.py -- the reference graph with bf16 rounding
+    injected at this path's storage points and nothing else -- on the metric configuration's fixture (made by
+    `python -m oracle.make_golden --bf16-envelope`).  Against the UPSTREAM gradients of that fixture the HIP path may be
+    worse than that ideal by a rounding-order margin only: worst tensor error <= 1.5 x ideal + 0.05, worst cosine >=
+    ideal - 0.03, and the same per tensor with the margins of one more rounding (2 x + 0.05, - 0.05)."""
+    table, grads, g = _full_b8_run()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs_full_b8_train_bf16_ideal.npz"))
+    assert str(z["sd_sha256"]) == g["sd_sha256"]
+    env = {}
+    for k, got in grads.items():
+        ref = g["grads"][k].astype(np.float64)
+        ideal = z["grad/" + k].astype(np.float64)
+        env["ideal_err/" + k] = float(np.abs(ideal - ref).max() / max(g["gabs"][k], 1e-30))
+        env["ideal_cos/" + k] = float((ideal @ ref) / max(np.linalg.norm(ideal) * np.linalg.norm(ref), 1e-300))
+        env["hip_err/" + k], env["hip_cos/" + k] = table["grad/" + k], table["cos/" + k]
+        env["hip_vs_ideal_cos/" + k] = float((got @ ideal) / max(np.linalg.norm(got) * np.linalg.norm(ideal), 1e-300))
+    env["ideal_mask_mse"] = float(((z["fwd/mask"].astype(np.float64) - g["fwd/mask"]) ** 2).mean())
+    env["hip_mask_mse"] = table["fwd/mask_mse"]
+    _dump("vs_full_b8_envelope", env)
+    hip_err = max(v for k, v in env.items() if k.startswith("hip_err/"))
+    ideal_err = max(v for k, v in env.items() if k.startswith("ideal_err/"))
+    hip_cos = min(v for k, v in env.items() if k.startswith("hip_cos/"))
+    ideal_cos = min(v for k, v in env.items() if k.startswith("ideal_cos/"))
+    assert hip_err == hip_err and hip_cos == hip_cos
+    assert hip_err <= 1.5 * ideal_err + 0.05, (hip_err, ideal_err)
+    assert hip_cos >= ideal_cos - 0.03, (hip_cos, ideal_cos)
+    bad = {k: (env["hip_err/" + k], env["ideal_err/" + k], env["hip_cos/" + k], env["ideal_cos/" + k]) for k in grads
+           if not (env["hip_err/" + k] <= 2.0 * env["ideal_err/" + k] + 0.05 and env["hip_cos/" + k] >= env["ideal_cos/" + k] - 0.05)}
+    assert not bad, bad
+    assert env["hip_mask_mse"] <= 2.0 * env["ideal_mask_mse"] + 2e-5, (env["hip_mask_mse"], env["ideal_mask_mse"])
 
 
 def test_bf16_gradients_sit_inside_the_ideal_bf16_envelope():

@@ -122,6 +122,134 @@ def test_dataset_collate_on_gpu_and_cli_dry_run(tmp_path):
                   "--checkpoint_path", str(tmp_path / "logs" / "checkpoint_3.pt")])
 
 
+# ---- the combination bench.py times: Trainer + gradient sink + SI-SNR loss head, in both arithmetics, against the oracle ----
+class _math:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from voicesplit_amd import ops
+        self.prev = ops.get_conv_math()
+        ops.set_conv_math(self.name)
+
+    def __exit__(self, *exc):
+        from voicesplit_amd import ops
+        ops.set_conv_math(self.prev)
+
+
+def _small_cfg(dims, lr=1e-3):
+    """A model small enough for the fp64 oracle with an STFT geometry that fits it (n_fft = 2 (F - 1), hop 16, window 40)."""
+    import voicesplit_amd as V
+    c = V.default_config(**dims)
+    c.audio["voicefilter"].update({"hop_length": 16, "win_length": 40})
+    c.train_config["learning_rate"] = lr
+    return c
+
+
+def _loss_batch(B, T, F, E, hop, seed, ragged=False):
+    from voicesplit_amd.trainer import synthetic_batches
+    emb, target, mixed, seq_len, _tw, phase = next(iter(synthetic_batches(1, B, T, F, E, hop, torch.device("cuda"), seed)))
+    if ragged:
+        seq_len = (seq_len - torch.arange(B, device=seq_len.device, dtype=seq_len.dtype) * (hop * 3)).contiguous()
+    return emb, target, mixed, seq_len, None, phase
+
+
+#            arithmetic  |loss - oracle|  worst gradient error / tensor max   worst cosine
+_STEP_BOUNDS = {"f16x3": (2e-4, 2e-3, 0.99999),      # fp32-class; 2e-3: a head ReLU may sit on the other side of a kink
+                "bf16": (5e-2, 0.6, 0.90)}           # the bounds of tests/test_gpu_bf16.py
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16"])
+@pytest.mark.parametrize("case", ["small", "full_dims"])
+def test_trainer_step_with_gradient_sink_and_sisnr_vs_oracle(math, case):
+    """Exactly what bench.py's default line times -- Trainer.train_step with the library writing its gradients into the
+    all-reduce bucket (set_gradient_sink) and vs_sisnr_loss as criterion -- against the CPU oracle of the same step
+    (oracle/reference_backward.forward_with_graph -> oracle/reference_loss.training_loss -> autograd, fp64):
+    loss value and every parameter gradient as they sit in the bucket after the (one-rank) all-reduce."""
+    import voicesplit_amd as V
+    from oracle import reference_backward as RB
+    from oracle import reference_loss as RL
+    from voicesplit_amd.trainer import Trainer
+    if case == "small":
+        dims, B, T, ragged = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53), 3, 45, True
+        c = _small_cfg(dims)
+    else:
+        dims, B, T, ragged = dict(num_freq=601, emb_dim=256, lstm_dim=400, fc1_dim=600, fc2_dim=601), 2, 21, False
+        c = V.default_config(**dims)
+        c.train_config["learning_rate"] = 1e-3
+    acfg = c.audio["voicefilter"]
+    torch.manual_seed(5)
+    model = V.VoiceSplit(c)
+    with torch.no_grad():                                 # a BatchNorm affine that is not the identity
+        for m in model.conv:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = _loss_batch(B, T, dims["num_freq"], dims["emb_dim"], acfg["hop_length"], 6, ragged)
+    emb, target, mixed, seq_len, _, phase = batch
+    with _math(math):
+        tr = Trainer(model.cuda(), c)
+        assert tr._sink, "the HIP modules must take the gradient-sink path"
+        loss = tr.train_step(batch)
+        got = {n: p.grad.detach().clone() for n, p in tr.model.named_parameters()}
+        assert all(g.data_ptr() == v.data_ptr() for g, v in zip((p.grad for p in tr.bucket.params), tr.bucket.views))
+    # the oracle's step
+    P = {k: (v.double().clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else
+             (v.double().clone() if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    out = RB.forward_with_graph(P, mixed.cpu().double(), emb.cpu().double(), "mish", True)
+    ref_loss, _ = RL.training_loss(out["mask"], mixed.cpu().double(), target.cpu().double(), phase.cpu().double(), seq_len.cpu().long(),
+                                   n_fft=acfg["n_fft"], hop_length=acfg["hop_length"], win_length=acfg["win_length"])
+    ref_loss.backward()
+    ltol, gtol, cmin = _STEP_BOUNDS[math]
+    table = {"loss": loss, "ref_loss": float(ref_loss)}
+    zero = {f"conv.{i}.bias" for i in (1, 5, 9, 13, 17, 21, 25, 28)}        # in front of a batch-statistics BatchNorm: exactly 0
+    for k, g in got.items():
+        r = P[k].grad
+        if k in zero:
+            assert g.abs().max().item() == 0.0 and r.abs().max().item() < 1e-9, k
+            continue
+        gd = g.double().cpu()
+        table["grad/" + k] = float((gd - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        table["cos/" + k] = float((gd.reshape(-1) @ r.reshape(-1)) / (gd.norm() * r.norm()).clamp_min(1e-300))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"errors_trainer_{math}_{case}.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    assert abs(loss - float(ref_loss)) <= ltol * max(1.0, abs(float(ref_loss))), (loss, float(ref_loss))
+    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < gtol) or (k.startswith("cos/") and not v >= cmin)}
+    assert not bad, bad
+
+
+def test_bf16_training_trajectory_follows_the_fp32_class_one():
+    """Does the bf16 step TRAIN?  40 Adam steps (lr 1e-3) over four fixed synthetic batches from one seed, once in
+    VS_MATH_BF16 and once in VS_MATH_F16X3 (fp32-class, the arithmetic that carries the 1e-4 contract): both losses must
+    fall, and the bf16 trajectory must stay with the fp32-class one (the mean of the last 8 steps within 3 % of the
+    total descent + 0.02, every step within 10 % + 0.05)."""
+    import voicesplit_amd as V
+    from voicesplit_amd.trainer import Trainer
+    dims = dict(num_freq=101, emb_dim=32, lstm_dim=48, fc1_dim=64, fc2_dim=101)
+    B, T, steps = 4, 60, 40
+    c = _small_cfg(dims, lr=1e-3)
+    batches = [_loss_batch(B, T, 101, 32, 16, 20 + i) for i in range(4)]
+    traj = {}
+    for math in ("f16x3", "bf16"):
+        torch.manual_seed(11)
+        with _math(math):
+            tr = Trainer(V.VoiceSplit(c).cuda(), c)
+            traj[math] = [tr.train_step(batches[s % 4]) for s in range(steps)]
+            assert tr.model.lstm_status() == 0
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "trajectory_bf16_vs_f16x3.json"), "w") as f:
+        json.dump(traj, f, indent=1)
+    f32, b16 = np.array(traj["f16x3"]), np.array(traj["bf16"])
+    assert np.isfinite(f32).all() and np.isfinite(b16).all()
+    descent = f32[:4].mean() - f32[-8:].mean()
+    assert descent > 0.3, f"the fp32-class run did not train: {f32[:4].mean():.3f} -> {f32[-8:].mean():.3f}"
+    assert b16[:4].mean() - b16[-8:].mean() > 0.8 * descent, (b16[:4].mean(), b16[-8:].mean(), descent)
+    assert abs(b16[-8:].mean() - f32[-8:].mean()) <= 0.03 * descent + 0.02, (b16[-8:].mean(), f32[-8:].mean(), descent)
+    assert (np.abs(b16 - f32) <= 0.10 * descent + 0.05).all(), float(np.abs(b16 - f32).max())
+
+
 def test_rccl_world1_bucket_all_reduce_on_device():
     """The RCCL leg of the training step on the hardware that IS available (one GPU): init_process_group("nccl")
     at world 1, the flat gradient bucket all-reduced on the device through RCCL, group destroyed.  (The N > 1

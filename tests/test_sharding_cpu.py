@@ -158,3 +158,21 @@ def test_single_rank_group_under_the_launcher_and_alone(tmp_path):
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                                "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=180)
     assert launched.returncode == 0 and "HOW env" in launched.stdout, launched.stdout + launched.stderr
+
+
+def test_bucket_reattaches_a_grad_the_sink_wrote_and_zeroes_one_nobody_wrote():
+    """all_reduce(written=True) (the trainer's gradient sink wrote the views itself): a .grad set to None in between is
+    re-attached with its contents intact; without `written` the old rule holds -- no gradient arrived, the slot is zeroed
+    and .grad stays None so that the optimizer skips the parameter."""
+    from voicesplit_amd.sharding import GradientBucket
+    lin = torch.nn.Linear(5, 3)
+    b = GradientBucket(lin.parameters()).attach()
+    b.views[0].fill_(2.0)
+    b.views[1].fill_(3.0)
+    lin.weight.grad = None                      # zero_grad(set_to_none=True) by some outer loop
+    b.all_reduce(1, written=True)
+    assert lin.weight.grad is not None and lin.weight.grad.data_ptr() == b.views[0].data_ptr()
+    assert float(b.views[0].sum()) == 2.0 * 15 and float(b.views[1].sum()) == 9.0
+    lin.weight.grad = None
+    b.all_reduce(1)
+    assert lin.weight.grad is None and float(b.views[0].abs().sum()) == 0.0 and float(b.views[1].sum()) == 9.0

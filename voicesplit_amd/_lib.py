@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class VsDims(Structure):
@@ -107,7 +107,9 @@ SIGNATURES = {
     "vs_nhwc_conv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_cvt_rows_bf16": (c_int, [_P, c_longlong, c_int, c_int, _P, c_int, _P]),
     "vs_gemm_bf16": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "vs_gemm_bf16_split": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_first": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vs_bn_finalize": (c_int, [_P, c_int, ctypes.c_double, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "vs_nhwc_bn_apply": (c_int, [_P, _P, c_longlong, c_int, _P, _P, _P]),
     "vs_nhwc_conv_last": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_last_pre": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -198,10 +198,13 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
                             hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl,
                             bool feat_bf16_ready) {
+  // the bf16 configuration's own GEMM (gemm_bf16.hip): feat and W_ih as bf16 arrays that the backward pass reuses.  It needs
+  // room for the bf16 copy of feat, and for the bf16 W_ih unless that arrives prepared (vs_prepare_weights keeps it in the
+  // prepared blob): a B = 1 clip of a second has room for the first but not for the 31 MB of the second.
+  const VsLstmBf16Layout Lb16 = vs_lstm_bf16_layout(M, K, H);
   if (math == VS_MATH_BF16 && scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0 &&
-      scratch_bytes >= vs_lstm_bf16_layout(M, K, H).total) {
-    // the bf16 configuration's own GEMM (gemm_bf16.hip): feat and W_ih as bf16 arrays that the backward pass reuses
-    const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K, H);
+      scratch_bytes >= (prep_wh ? Lb16.wih : Lb16.dxg)) {
+    const VsLstmBf16Layout& Lb = Lb16;
     char* base = static_cast<char*>(scratch);
     if (!feat_bf16_ready) {      // (the training forward's BatchNorm apply of cnn8 writes it itself)
       if (int rc = vs_cvt_rows_bf16_impl(feat, M, K, K, base + Lb.feat, Lb.Kp, stream)) return rc;
@@ -213,6 +216,12 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
     const void* wih = prep_wh ? static_cast<const void*>(prep_wh) : static_cast<const void*>(static_cast<char*>(scratch) + Lb.wih);
     return vs_gemm_bf16_impl(0, 0, static_cast<char*>(scratch) + Lb.feat, Lb.Kp, wih, Lb.Kp, xg, 8 * H, nullptr, 0, M, 8 * H, K,
                              rowbias, 8 * H, T, 0, stream);
+  }
+  if (math == VS_MATH_BF16) {
+    // no room for the bf16 operand copies: the split-operand GEMM below re-derives its operands from the fp32 tensors.  A
+    // prepared blob of this arithmetic holds W_ih as bf16 bits (no f16 halves, no scale) -- never to be read as the split form.
+    prep_wscale2 = nullptr;
+    prep_wh = prep_wl = nullptr;
   }
   if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
@@ -366,6 +375,12 @@ int vs_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, int lda, const void*
   return vs_gemm_bf16_impl(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, nullptr, 0, M, N, K, rowbias, ldrb, group, accumulate, (hipStream_t)stream);
 }
 
+int vs_gemm_bf16_split(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, float* C2, int ldc, int split_m,
+                       int M, int N, int K, int accumulate, void* stream) {
+  VS_REQUIRE(C2 && split_m > 0 && split_m < M, "gemm_bf16_split: needs C2 and 0 < split_m < M (split_m %d, M %d)", split_m, M);
+  return vs_gemm_bf16_impl(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, C2, split_m, M, N, K, nullptr, 0, 1, accumulate, (hipStream_t)stream);
+}
+
 int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
                        int B, int T, int F, int act, double* bn_stats, void* stream) {
   return vs_nhwc_conv_first_impl(x, w, scale, shift, out, B, T, F, act, bn_stats, (hipStream_t)stream);
@@ -373,6 +388,17 @@ int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const
 
 int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, void* stream) {
   return vs_nhwc_bn_apply_impl(z, a, npix, act, scale, shift, (hipStream_t)stream);
+}
+
+// train-mode BatchNorm2d between a conv that accumulated statistics and the apply pass (the piecewise form of what
+// vs_forward_train does per layer)
+int vs_bn_finalize(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float eps, float momentum,
+                   float* scale, float* shift, float* mean_out, float* invstd_out, void* stream) {
+  VS_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f, "bn_finalize: eps %g / momentum %g out of range", (double)eps, (double)momentum);
+  VS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: give both running buffers or neither");
+  return vs_bn_finalize_impl(stats, slots, count, C, gamma, beta, running_mean, running_var, eps, momentum, scale, shift, mean_out, invstd_out,
+                             (hipStream_t)stream);
 }
 
 int vs_nhwc_conv_last(const void* in, const float* w, const float* scale, const float* shift, float* out,

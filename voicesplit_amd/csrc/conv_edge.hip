@@ -169,8 +169,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   if (mean_out) mean_out[c] = (float)mean;          // saved for the backward pass
   if (invstd_out) invstd_out[c] = is;
   const double unb = count > 1 ? var * (count / (count - 1)) : var;
-  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
 }
 
 // y = act(x*scale[c] + shift[c]) over rows [R][L], channel = r % C; y may alias x (in place).
@@ -371,7 +371,8 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
 int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float eps, float momentum,
                         float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t stream) {
-  VS_REQUIRE(stats && C > 0 && count > 0, "bn_finalize: bad argument");
+  VS_REQUIRE(stats && C > 0 && count > 0 && slots >= 1, "bn_finalize: bad argument (stats %p, slots %d, C %d, count %g)", (void*)stats, slots, C, count);
+  VS_REQUIRE(gamma && beta && scale && shift, "bn_finalize: NULL gamma / beta / scale / shift");
   if (slots > 1) hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, slots);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, gamma, beta,
                      eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);

@@ -16,6 +16,8 @@ initialisation (same RNG consumption order as the upstream constructor) and key 
 ``forward`` is never called: ``forward`` hands raw device pointers to ``vs_forward`` in
 ``libvoicesplit_hip.so``.  Inputs on a CPU device raise; there is no fallback.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -51,7 +53,9 @@ class _MaskForward(torch.autograd.Function):
         mask = ops.forward_train(sd, x, dvec_c, dims, module.conv_act, module.training, tape)
         module._bump_bn_counters()
         ctx.module, ctx.dims, ctx.tape = module, dims, tape
-        module.__dict__["_last_tape"] = (tape, dims)
+        # for lstm_status(): a WEAK reference -- a strong one would keep a 25-49 GB tape alive past its recycling (and past
+        # the pool cap), beside the next, larger one when B or T grows, and inside every deepcopy / pickle of the module
+        module.__dict__["_last_tape"] = (weakref.ref(tape), dims)
         ctx.training = module.training
         ctx.names = [n for n, _ in module._named_params()]
         ctx.save_for_backward(x, dvec_c, mask)
@@ -101,21 +105,45 @@ class _MaskNet(nn.Module):
         m = self.config.model
         return ops.make_dims(B, T, self.audio["num_freq"], m["emb_dim"], m["lstm_dim"], m["fc1_dim"], m["fc2_dim"])
 
+    _TRANSIENT = ("_last_tape", "_grad_sink", "_tensor_index", "_tree_check", "_prepared")
+
+    def __getstate__(self):
+        # copy.deepcopy / torch.save(model): caches and views into other objects' memory (the last tape, a trainer's
+        # gradient bucket, prepared eval weights) are not part of the module
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
     def __setattr__(self, name, value):
         # a replaced sub-module / parameter invalidates the cached tensor index (see _tensors)
         if isinstance(value, (nn.Module, nn.Parameter)):
             self.__dict__.pop("_tensor_index", None)
         super().__setattr__(name, value)
 
+    def _index_is_current(self) -> bool:
+        """Is the module tree still the one the index was built from?  Identity of every child in its parent's
+        ``_modules`` and identity + length of every module's ``_parameters`` / ``_buffers`` dict: ~35 modules, a few
+        microseconds -- ``model.conv[i] = layer``, ``register_buffer`` / ``register_parameter`` on a child or a replaced
+        ``_parameters`` dict all show up here (a replaced TENSOR needs no check: tensors are read through the dicts)."""
+        links, dicts = self.__dict__["_tree_check"]
+        for parent_modules, name, child in links:
+            if parent_modules.get(name) is not child:
+                return False
+        for mod, pd, pl, bd, bl in dicts:
+            if mod._parameters is not pd or len(pd) != pl or mod._buffers is not bd or len(bd) != bl:
+                return False
+        return True
+
     def _tensors(self):
-        """{state_dict key: tensor} of every parameter and buffer.  The module tree is fixed after construction, so the walk
-        of named_parameters() / named_buffers() (~0.1 ms of host time in front of every step's first kernel) is done once:
-        what is kept is (key, owning dict, name), and the tensors are read from the owning modules' dicts on every call
-        -- load_state_dict, .to(), optimizer steps and parameter re-assignment are all seen; assigning a new sub-module to
-        this module drops the index (``__setattr__``)."""
+        """{state_dict key: tensor} of every parameter and persistent buffer.  The walk of named_parameters() /
+        named_buffers() (~0.1 ms of host time in front of every step's first kernel) is done once: what is kept is (key,
+        owning dict, name), and the tensors are read from the owning modules' dicts on every call -- load_state_dict,
+        .to(), optimizer steps and parameter re-assignment are all seen; a change of the module TREE (new / replaced /
+        removed sub-module, parameter or buffer anywhere below) is detected by ``_index_is_current`` and rebuilds it."""
         index = self.__dict__.get("_tensor_index")
-        if index is None:
-            index = []
+        if index is None or not self._index_is_current():
+            index, links, dicts = [], [], []
             for mod_name, mod in self.named_modules():
                 prefix = mod_name + "." if mod_name else ""
                 for n in mod._parameters:
@@ -124,7 +152,11 @@ class _MaskNet(nn.Module):
                 for n in mod._buffers:
                     if mod._buffers[n] is not None and n not in mod._non_persistent_buffers_set:
                         index.append((prefix + n, mod._buffers, n))
+                dicts.append((mod, mod._parameters, len(mod._parameters), mod._buffers, len(mod._buffers)))
+                for cn, child in mod._modules.items():
+                    links.append((mod._modules, cn, child))
             self.__dict__["_tensor_index"] = index
+            self.__dict__["_tree_check"] = (links, dicts)
         return {k: d[n] for k, d, n in index}
 
     def set_gradient_sink(self, sink):
@@ -132,7 +164,9 @@ class _MaskNet(nn.Module):
         parameter gradients (vs_backward writes, it never accumulates) and hands autograd nothing for those parameters:
         when they are the ``.grad`` tensors themselves (views into the trainer's all-reduce bucket,
         sharding.GradientBucket) the 47 ``grad += new`` launches and the zeroing of a step disappear.  The caller owns
-        the zero_grad semantics: every backward replaces the contents (no accumulation over several backward calls)."""
+        the zero_grad semantics: every backward replaces the contents (no accumulation over several backward calls).
+        The sink is hidden state: whoever installs it removes it (``Trainer.train_step`` installs it around its own
+        ``loss.backward()`` only), otherwise a plain loop over the same model would see no ``.grad`` for these keys."""
         if sink is None:
             self.__dict__.pop("_grad_sink", None)
         else:
@@ -140,7 +174,8 @@ class _MaskNet(nn.Module):
 
     def _named_params(self):
         """[(key, parameter)] in named_parameters() order, from the same index (no module-tree walk)."""
-        self._tensors() if "_tensor_index" not in self.__dict__ else None
+        if "_tensor_index" not in self.__dict__ or not self._index_is_current():
+            self._tensors()
         return [(k, d[n]) for k, d, n in self.__dict__["_tensor_index"] if isinstance(d[n], nn.Parameter)]
 
     def train(self, mode: bool = True):
@@ -183,7 +218,10 @@ class _MaskNet(nn.Module):
         last = self.__dict__.get("_last_tape")
         if last is None:
             return 0
-        tape, dims = last
+        ref, dims = last
+        tape = ref()
+        if tape is None:                 # released since: nothing to ask (the pool keeps a recycled tape alive, so the usual
+            return 0                     # call -- right after a step -- finds it; it then reports the LAST launch on that buffer)
         return ops.lstm_status(dims, tape=tape)
 
     def long_form_stages(self):

@@ -657,10 +657,11 @@ def colsum(x, groups: int, rows: int):
 # ---------------------------------------------------------------------------------------------
 # channels-last bf16 kernels of the VS_MATH_BF16 path (csrc/conv_nhwc.hip); unit-test surface
 # ---------------------------------------------------------------------------------------------
-def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = False, stats: bool = False):
+def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = False, stats=False):
     """x [B,T,F,64] bf16 (channels last), w [64,64,KT,KF] fp32 -> act(conv(x) * scale + shift) as [B,T,F,64] bf16,
     'same' zero padding, time dilation `dil`.  stats: also return the per-channel {sum, sum of squares} of the
-    outputs, [64, 2] float64 (train-mode BatchNorm statistics; act must be "none")."""
+    outputs, [64, 2] float64 (train-mode BatchNorm statistics; act must be "none"); stats="raw": the 64 partial slots
+    [64 slots, 64, 2] as the kernel left them (what vs_bn_finalize takes)."""
     lib = _lib.load()
     _dev_check(x, "x", torch.bfloat16)
     for n, t in (("w", w), ("scale", scale), ("shift", shift)):
@@ -675,6 +676,8 @@ def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = Fal
     st = torch.zeros(64, 64, 2, dtype=torch.float64, device=x.device) if stats else None
     check(lib.vs_nhwc_conv(_p(x), _p(packed), _p(scale), _p(shift), _p(out), B, T, F, KT, KF, dil, ACT_CODES[act],
                            _p(st), _stream()), "vs_nhwc_conv")
+    if stats == "raw":
+        return out, st
     return (out, st.sum(0)) if stats else out
 
 
@@ -699,6 +702,20 @@ def nhwc_conv_first(x, w, scale, shift, act: str, stats: bool = False):
     check(lib.vs_nhwc_conv_first(_p(x), _p(w), _p(scale), _p(shift), _p(out), B, T, F, ACT_CODES[act], _p(st), _stream()),
           "vs_nhwc_conv_first")
     return (out, st.sum(0)) if stats else out
+
+
+def bn_finalize(stats, count: float, gamma, beta, running_mean=None, running_var=None, eps: float = 1e-5, momentum: float = 0.1):
+    """Train-mode BatchNorm2d constants from epilogue statistics (vs_bn_finalize): stats [slots, C, 2] float64 {sum, sum of
+    squares} (folded in place) -> (scale, shift, mean, invstd); running_mean / running_var are updated in place when given."""
+    lib = _lib.load()
+    _dev_check(stats, "stats", torch.float64)
+    for n, t in (("gamma", gamma), ("beta", beta)):
+        _dev_check(t, n)
+    slots, C = stats.shape[0], stats.shape[1]
+    scale, shift, mean, invstd = (torch.empty(C, dtype=torch.float32, device=stats.device) for _ in range(4))
+    check(lib.vs_bn_finalize(_p(stats), slots, float(count), C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, momentum,
+                             _p(scale), _p(shift), _p(mean), _p(invstd), _stream()), "vs_bn_finalize")
+    return scale, shift, mean, invstd
 
 
 def nhwc_bn_apply(z, scale, shift, act: str):
@@ -860,6 +877,21 @@ def gemm_bf16(A, B, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bo
     check(lib.vs_gemm_bf16(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), C.shape[1], M, N, K,
                            _p(rowbias), rowbias.shape[1] if rowbias is not None else 0, group, int(accumulate), _stream()), "vs_gemm_bf16")
     return C
+
+
+def gemm_bf16_split(A, B, M: int, N: int, K: int, split_m: int, a_kmajor: bool = False, b_kmajor: bool = False, ldc: Optional[int] = None):
+    """The same contraction stored into two matrices stacked along M (vs_gemm_bf16_split: the dW_ih store of vs_backward):
+    returns (C [split_m, ldc], C2 [M - split_m, ldc]); columns >= N are left untouched (NaN-filled here so a test sees a
+    stray store)."""
+    lib = _lib.load()
+    _dev_check(A, "A", torch.bfloat16)
+    _dev_check(B, "B", torch.bfloat16)
+    ldc = N if ldc is None else ldc
+    C = torch.full((split_m, ldc), float("nan"), dtype=torch.float32, device=A.device)
+    C2 = torch.full((M - split_m, ldc), float("nan"), dtype=torch.float32, device=A.device)
+    check(lib.vs_gemm_bf16_split(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), _p(C2), ldc, split_m,
+                                 M, N, K, 0, _stream()), "vs_gemm_bf16_split")
+    return C, C2
 
 
 def cvt_rows_bf16(x, K: int, Kp: int):

@@ -105,14 +105,20 @@ class GradientBucket:
             p.grad = v
         return self
 
-    def all_reduce(self, world: int, force: bool = False):
+    def all_reduce(self, world: int, force: bool = False, written: bool = False):
         """Sum over ranks, then divide by `world` (call after backward has finished: the
         collective must not be co-scheduled with the persistent LSTM kernels).  force: issue the
-        collective even at world 1 (a one-rank RCCL all-reduce: used to exercise the device path)."""
+        collective even at world 1 (a one-rank RCCL all-reduce: used to exercise the device path).
+        written: the views were just written by the producer of the gradients itself (the library's
+        gradient sink, trainer.py) -- a ``.grad`` that someone set to None in between
+        (``zero_grad(set_to_none=True)``) is re-attached, not zeroed."""
         import torch.distributed as dist
         for p, v in zip(self.params, self.views):
             if p.grad is None:
-                v.zero_()
+                if written:
+                    p.grad = v
+                else:
+                    v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():        # someone re-created .grad: copy in
                 v.copy_(p.grad)
                 p.grad = v

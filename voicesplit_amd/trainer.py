@@ -118,10 +118,14 @@ class Trainer:
         self.bucket = GradientBucket(model.parameters(), group, extra=1).attach()
         # the HIP modules write their gradients straight into the bucket's .grad views (no `grad += new` per parameter,
         # no zeroing per step); any other module goes through autograd's accumulation into the zeroed bucket
+        # (the sink is installed around train_step's own backward only: a plain zero_grad / backward / step loop over the
+        # same model, before or after this trainer existed, gets its gradients through autograd as usual; parameters whose
+        # requires_grad is switched on after construction are in neither the bucket nor the sink -- build a new Trainer)
         self._sink = hasattr(model, "set_gradient_sink") and self.bucket.flat.is_cuda
+        self._sink_map = None
         if self._sink:
             names = {id(p): n for n, p in model.named_parameters()}
-            model.set_gradient_sink({names[id(p)]: v for p, v in zip(self.bucket.params, self.bucket.views)})
+            self._sink_map = {names[id(p)]: v for p, v in zip(self.bucket.params, self.bucket.views)}
         self.device = self.bucket.flat.device
         self.step = 0
         if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
@@ -191,9 +195,15 @@ class Trainer:
         loss = self.criterion(mask, mixed, target, seq_len, phase)          # :95-108
         if not self._sink:
             self.bucket.zero()                                              # optimizer.zero_grad()
-        loss.backward()                                                     # :110
+            loss.backward()                                                 # :110
+        else:
+            self.model.set_gradient_sink(self._sink_map)
+            try:
+                loss.backward()                                             # :110, written straight into the bucket views
+            finally:
+                self.model.set_gradient_sink(None)
         self.bucket.extra[0] = loss.detach()
-        self.bucket.all_reduce(self.world)                                  # the one exchange step
+        self.bucket.all_reduce(self.world, written=self._sink)              # the one exchange step
         self.optimizer.step()                                               # :111
         self.step += 1                                                      # :112
         value = float(self.bucket.extra[0].item())                          # :114 (the reference syncs here too)
