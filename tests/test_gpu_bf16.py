@@ -1,25 +1,42 @@
-"""GPU: VS_MATH_BF16 (BASELINE configs[2]: bf16 forward + backward) -- the opt-in arithmetic in which the
-dense contractions of the path (64->64 convs forward / data / weight gradient, the LSTM input GEMM and its
-two backward contractions) round their operands to bf16 and issue ONE v_mfma_f32_32x32x16_bf16 product with
-fp32 accumulation; the tape, BatchNorm statistics, the recurrence, the head and the master weights stay fp32.
+"""GPU: VS_MATH_BF16 (BASELINE configs[2]: bf16 forward + backward, the configuration bench.py's headline is quoted on).
 
-bf16 keeps 8 significant bits (2^-9 = 2e-3 relative rounding per operand), so this mode does NOT meet the
-path's fp32 contract (1e-4) and never runs unless asked for.  It is held to the bounds below against the
-same oracles as the default arithmetic, on the same stress fixtures (randomised BatchNorm statistics,
-recurrent / head weights scaled up so that logits spread -- chosen to make errors visible).
-Measured on MI355X (round 2; every value is dumped to gpurun_out/errors_bf16_*.json):
+What this arithmetic is (round 3 onwards): conv activations and the training tape are STORED as
+channels-last bf16 [B][T][F][64] (z = conv + bias and a = act(BN(z)) of cnn1..cnn7, the gradients between layers), every
+dense contraction -- the 64->64 convs forward / data gradient / weight gradient, the three LSTM GEMMs, fc1 / fc2 and their
+backward contractions, dW_hh -- issues ONE bf16 MFMA product per product on bf16-rounded operands with fp32 accumulation;
+the recurrent product h @ W_hh^T runs on f16 operands forward and on bf16 operands in the BPTT.  fp32 stay: accumulators,
+BatchNorm statistics (fp64 across workgroups), gate arithmetic and cell state, the loss head, master weights / state_dict.
 
-                                   frozen BatchNorm      batch-statistics BatchNorm     bound asserted
-  conv stack output (rel. range)   4e-4 .. 6e-4          8e-3 .. 1.1e-2                 3e-2
-  LSTM output                      3e-3 .. 5e-3          3.6e-2 .. 4.5e-2               8e-2
-  mask, max abs                    2e-3 .. 4e-3          1.9e-2 .. 3.7e-2               6e-2
-  mask MSE (BASELINE: <= 1e-4)     1e-7 .. 3e-7          1.3e-5 .. 2.8e-5               1e-4
-  gradients, max / tensor max      6.5e-2                0.23 .. 0.41 (W_ih)            0.6
-  gradients, cosine vs fp64        >= 0.9986             >= 0.948                       0.93
+bf16 keeps 8 significant bits (2^-9 = 2e-3 relative rounding per stored value), so this mode does NOT meet the path's fp32
+contract (1e-4) and never runs unless asked for.  It is held to the bounds below against the same oracles as the default
+arithmetic, on stress fixtures (randomised BatchNorm statistics, recurrent / head weights scaled up so that logits spread --
+chosen to make errors visible) and on the pinned metric-configuration fixture of the UPSTREAM module.
+Measured on MI355X this round (round 4; every value is dumped to gpurun_out/errors_bf16_*.json, errors_trainer_*.json):
 
-(batch statistics subtract each channel's mean, so a rounding error that is 2e-3 of |z| becomes a larger
-fraction of the normalised value whenever the mean dominates the spread; the recurrence with scaled-up
-W_hh amplifies what reaches it.)  The BASELINE bound on the mask (MSE <= 1e-4) holds in every case."""
+  small stress fixtures            frozen BatchNorm       batch-statistics BatchNorm          bound asserted
+                                   VoiceSplit/VoiceFilter VoiceSplit (Mish) VoiceFilter (ReLU) Mish    ReLU
+  conv stack output (rel. range)   1.1e-3 / 1.4e-3        1.6e-2            2.2e-2             3e-2    3e-2
+  LSTM output                      3.2e-3 / 4.8e-3        4.9e-2            8.7e-2             8e-2    0.12
+  mask, max abs                    3.4e-3 / 5.6e-3        4.0e-2            8.3e-2             6e-2    0.1
+  mask MSE (BASELINE: <= 1e-4)     1e-6                   3.3e-5            6.6e-5             1e-4    1e-4
+  gradients, max / tensor max      6.2e-2 / 6.4e-2        0.52              0.41               0.6     0.6
+  gradients, cosine vs fp64        0.9989 / 0.9988        0.971             0.927              0.93    0.90
+
+  metric configuration, full size, B = 8, upstream fixture:  mask max abs 0.058, mask MSE 6.3e-5 (ideal bf16 storage: 6.2e-5),
+  worst gradient 0.33 of its tensor's maximum / cosine 0.963 (ideal bf16 storage: 0.30 / 0.955); bounds 0.45 / 0.95 and the
+  envelope test.  Trainer + gradient sink + SI-SNR head (tests/test_gpu_trainer.py): loss 27.424 vs 27.426, worst gradient
+  0.56 / cosine 0.975 (full dims, B = 2, T = 21), 0.29 / 0.987 (small); 40-step trajectory 27.5 -> 15.56 vs 27.5 -> 15.87 fp32-class.
+
+Bounds and why.  The VoiceSplit (Mish) column -- the default model and the headline -- is held to the bounds of round 2
+(3e-2 / 8e-2 / 6e-2 / 0.93).  The VoiceFilter (ReLU) column under batch statistics keeps the wider bounds of round 3 (0.12 /
+0.1 / 0.90): with the tape and the inter-layer gradients stored in bf16 (round 2 stored them in fp32 and rounded operands only),
+a value that rounds across a ReLU kink flips a whole branch in seven consecutive layers, and batch statistics then renormalise
+the result -- an error a smooth activation does not have; the mask MSE bound (BASELINE's 1e-4) is the same for both and holds
+with 1.5x margin at worst.  (Batch statistics subtract each channel's mean, so a rounding error that is 2e-3 of |z| becomes a
+larger fraction of the normalised value whenever the mean dominates the spread; the recurrence with scaled-up W_hh amplifies
+what reaches it.)  How much of the gradient error is the arithmetic's own is measured, not argued: oracle/bf16_model.py (fp64
+with bf16 rounding injected at this path's storage points and nothing else) gives the error of a PERFECT implementation of
+bf16 storage; the envelope tests hold the kernels to it on the small fixture AND on the full-size metric fixture."""
 import json
 import os
 
@@ -32,11 +49,11 @@ from oracle import reference_backward as RB
 from oracle import reference_forward as R
 
 pytestmark = pytest.mark.gpu
-FEAT_TOL = 4e-2
-LSTM_TOL = 0.12
-MASK_ABS_TOL = 0.1
+FEAT_TOL = 3e-2
+LSTM_TOL = {"mish": 8e-2, "relu": 0.12}
+MASK_ABS_TOL = {"mish": 6e-2, "relu": 0.1}
 GRAD_TOL = 0.6
-COS_MIN = 0.90
+COS_MIN = {"mish": 0.93, "relu": 0.90}
 FULL_GRAD_TOL = 0.45       # the full-size metric-configuration fixture (vs_full_b8_train_grads)
 FULL_COS_MIN = 0.95
 
@@ -107,9 +124,9 @@ def test_bf16_module_forward_and_backward_vs_fp64_oracle(cls_name, act, training
         table["grad/" + k] = _rel(p.grad, ref[k])
         table["cos/" + k] = _cos(p.grad, ref[k])
     _dump(f"{cls_name}_{training}", table)
-    assert table["fwd/feat"] < FEAT_TOL and table["fwd/lstm_out"] < LSTM_TOL, table
-    assert table["fwd/mask_abs"] < MASK_ABS_TOL and table["fwd/mask_mse"] < 1e-4, table
-    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < GRAD_TOL) or (k.startswith("cos/") and not v >= COS_MIN)}
+    assert table["fwd/feat"] < FEAT_TOL and table["fwd/lstm_out"] < LSTM_TOL[act], table
+    assert table["fwd/mask_abs"] < MASK_ABS_TOL[act] and table["fwd/mask_mse"] < 1e-4, table
+    bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < GRAD_TOL) or (k.startswith("cos/") and not v >= COS_MIN[act])}
     assert not bad, bad            # `not <`: a NaN gradient is a failure, not a pass
 
 
@@ -158,7 +175,7 @@ def test_bf16_metric_configuration_vs_upstream_golden():
     """Full size, 8 utterances, batch-statistics BatchNorm (the pinned metric configuration) in bf16 arithmetic
     against the UPSTREAM module's forward tensors and gradients."""
     table, _, _ = _full_b8_run()
-    assert table["fwd/mask_abs"] < MASK_ABS_TOL and table["fwd/mask_mse"] < 1e-4, table
+    assert table["fwd/mask_abs"] < MASK_ABS_TOL["mish"] + 2e-2 and table["fwd/mask_mse"] < 1e-4, table      # 0.058 measured: 301 x 601 x 8 values
     # this fixture (default-scale activations at full size) is milder than the small stress fixtures above: its own, tighter
     # bounds -- measured 0.33 of a tensor's maximum / cosine 0.963 at worst (ideal bf16 storage: 0.30 / 0.955)
     bad = {k: v for k, v in table.items() if (k.startswith("grad/") and not v < FULL_GRAD_TOL) or (k.startswith("cos/") and not v >= FULL_COS_MIN)}
