@@ -7,7 +7,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from voicesplit_amd import ops  # noqa: E402
+from voicesplit_amd import _lib, ops  # noqa: E402
+
+if os.environ.get("VS_MICRO_LIB"):          # e.g. an ablation build (voicesplit_amd/libvoicesplit_hip_abl.so)
+    _lib.load(os.path.join(ROOT, os.environ["VS_MICRO_LIB"]))
 
 
 def main():

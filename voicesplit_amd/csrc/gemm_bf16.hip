@@ -20,6 +20,8 @@
 // (+ optional per-row-group bias, or accumulate into C).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vs_internal.h"
 
 namespace {
@@ -48,6 +50,7 @@ struct GemmBf16Args {
   const float* rowbias; int ldrb, group;
   int accumulate;
   int tiles_m, tiles_n, band;
+  int vec_ok;                         // C (C2, rowbias) 16-byte aligned with leading dimensions that are multiples of 4: 16-byte epilogue accesses
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
@@ -309,6 +312,260 @@ void gemm_bf16_kernel(GemmBf16Args g) {
   }
 }
 
+// ---- round 4: the same kernel with the side work INSIDE the MFMA rows ---------------------------------------------
+// What bounded gemm_bf16_kernel above was found in its ISA (tools/isa_loop_stats.py): a K step is 16 rows of 8 back-to-back
+// MFMAs with ALL the side work of a row -- two fragment reads, two DMA chunks of 6 instructions each -- issued between two
+// rows.  A wave issues in order, one instruction per ~4 cycles: while those ~16 instructions issue the
+// matrix pipe finishes the row's last MFMA after 16 cycles and then idles ~50; 128 of 180 cycles per row = the measured
+// 0.42-0.46 busy fraction.  Between two MFMAs of a row, on the other hand, the pipe is busy 16 cycles and the wave needs 4
+// to issue the next one: up to two more instructions fit there for free.  So:
+//  * every MFMA is followed by ONE slot of side work (sched_barrier after each): fragment read, "M0 <- chunk's LDS address",
+//    the chunk's buffer_load ... lds, a scalar offset update -- a DMA chunk is 3 instructions in 3 slots (was 7-8 in one
+//    place): M0 is set by s_add_i32 straight from the stage base (never saved / restored: nothing else in the kernel uses
+//    it), the scalar offset runs (one s_add per chunk), the two tile descriptors advance by a constant per K step (3 scalar
+//    instructions each, in slots of the second k-half) and are rebuilt only when the prefetch cursor moves to a new tile;
+//  * the per-step bubble is gone: the step's barrier sits in front of the LAST row -- by then every fragment of the stage
+//    has been read into registers and the next stage's DMA was issued more than a thousand cycles ago -- and the first nine
+//    fragment reads of the next step (8 B + 1 A, into the registers of the finished k-half) ride on the last row's MFMAs.
+// DR: the 16 DMA chunks of a step are issued in the first DR rows (8: chunk a of both operands in row a; 4: chunks 2a, 2a+1 in row a
+// -- 4 more rows for the lines to arrive before the step's barrier)
+// ABL (timing ablations, built with -DVS_ABLATION only; results are meaningless): 1 = no fragment reads inside the K loop (the MFMAs
+// run on whatever the registers hold), 2 = no per-step wait + barrier, 3 = both
+template <bool AK, bool BK_, int DR, int ABL = 0>
+__global__ __launch_bounds__(256, 1)
+void gemm_bf16_il_kernel(GemmBf16Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE_BYTES];
+  using OA = Operand<AK, TM>;
+  using OB = Operand<BK_, TN>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(const lds_byte*)smem;
+  const int nk = (g.K + BK - 1) / BK;
+
+  const int per = (int)(gridDim.x >> 3);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int tpx = (ntiles + 7) / 8;
+  const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+  auto tile_id = [&](int j) { return xcd * tpx + slot + j * per; };
+  auto tile_ok = [&](int j) { const int t = tile_id(j); return slot + j * per < tpx && t < ntiles; };
+
+  int pj = 0, pk = 0, ptm = 0, ptn = 0;
+  bool plive = tile_ok(0) && tile_of(g, tile_id(0), ptm, ptn);
+  int pstage = 0;
+  // fragment base of this lane INCLUDING the wave's tile origin (rows 128 wm / columns 128 wn of the workgroup tile): what is
+  // left per fragment is an immediate offset (row form: + 2048 a) or an XOR with an inline constant (col form: ^ (a << 5))
+  const unsigned fbA = AK ? (OA::frag_base(lane) ^ (unsigned)((wm * 8) << 5)) : (OA::frag_base(lane) + (unsigned)(wm * 128 * 128));
+  const unsigned fbB = BK_ ? (OB::frag_base(lane) ^ (unsigned)((wn * 8) << 5)) : (OB::frag_base(lane) + (unsigned)(wn * 128 * 128));
+  const typename OA::LaneDma la = OA::lane_dma(g.lda, wave, lane);
+  const typename OB::LaneDma lb = OB::lane_dma(g.ldb, wave, lane);
+  const unsigned pitchA = OA::chunk_pitch(g.lda), pitchB = OB::chunk_pitch(g.ldb);
+  // per K step the tile origin moves by BK elements along k: BK * 2 bytes (row form) or BK lines (col form)
+  const unsigned kstepA = AK ? (unsigned)BK * (unsigned)g.lda * 2u : (unsigned)BK * 2u;
+  const unsigned kstepB = BK_ ? (unsigned)BK * (unsigned)g.ldb * 2u : (unsigned)BK * 2u;
+  // g.accumulate < 0 (VOICESPLIT_GEMM_ABL=nodma, timing ablation only): every descriptor is empty -- the DMA instructions issue and
+  // zero-fill the stage without touching memory: what is left is the kernel's time without the memory side
+  const bool feed = g.accumulate >= 0;
+  u4v dA = OA::tile_desc(g.A, g.lda, g.M, g.K, ptm * TM, 0, plive && feed), dB = OB::tile_desc(g.B, g.ldb, g.N, g.K, ptn * TN, 0, plive && feed);
+  unsigned soffA = 0, soffB = 0;                                     // running scalar offset of the next chunk (wave-uniform)
+  unsigned dstA = lds0 + (unsigned)(wave * 1024);                    // LDS address of this wave's chunk 0 in the prefetch stage
+  auto dma_load = [&](unsigned voff, const u4v& desc, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(desc), "s"(soff) : "memory");
+  };
+  auto adv = [&](u4v& d, unsigned step) {                            // 48-bit base += step (add + add-with-carry), num_records -= step
+    const unsigned long long b = (((unsigned long long)d[1] << 32) | d[0]) + step;
+    d[0] = (unsigned)b;
+    d[1] = (unsigned)(b >> 32);
+    d[2] -= step;
+  };
+  // the step's last piece of cursor bookkeeping (outside the MFMA rows: a handful of scalar instructions; the descriptor
+  // rebuild only when the cursor moves to another tile, once per nk steps)
+  auto pf_done = [&]() {
+    pstage ^= 1;
+    dstA = lds0 + (unsigned)(pstage * STAGE_BYTES) + (unsigned)(wave * 1024);
+    if (++pk == nk) {
+      pk = 0;
+      ++pj;
+      plive = tile_ok(pj) && tile_of(g, tile_id(pj), ptm, ptn);
+      dA = OA::tile_desc(g.A, g.lda, g.M, g.K, ptm * TM, 0, plive && feed);
+      dB = OB::tile_desc(g.B, g.ldb, g.N, g.K, ptn * TN, 0, plive && feed);
+    }
+  };
+  if (plive) {                                                       // cold start: the first stage in one go
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dstA + (unsigned)(c * 4096)) : "memory");
+      dma_load(AK ? la.off[c & 1] : la.off[0], dA, soffA);
+      soffA += pitchA;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dstA + (unsigned)(A_BYTES + c * 4096)) : "memory");
+      dma_load(BK_ ? lb.off[c & 1] : lb.off[0], dB, soffB);
+      soffB += pitchB;
+    }
+    soffA = soffB = 0;
+    adv(dA, kstepA);
+    adv(dB, kstepB);
+    pf_done();
+  }
+
+  int cstage = 0;
+  vs_bf16x8 bf[2][WB], afc, afn;
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned fa = lds0 + fbA, fb = lds0 + (unsigned)A_BYTES + fbB;
+    asm volatile("" : "+v"(fa), "+v"(fb));
+#pragma unroll
+    for (int b = 0; b < WB; ++b) bf[0][b] = OB::frag(fb, b * 16, 0);
+    afc = OA::frag(fa, 0, 0);
+    afn = afc;
+  }
+  for (int j = 0; tile_ok(j); ++j) {
+    int tm, tn;
+    if (!tile_of(g, tile_id(j), tm, tn)) break;
+    f32x4 acc[WA][WB];
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+      for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < nk; ++ks) {
+      // !plive (end of the job): empty descriptors stay empty.  (plive is wave-uniform but lives in a vector register: made
+      // scalar explicitly, or the descriptors it touches would leave the scalar registers the DMA instruction needs them in)
+      const unsigned lv = (unsigned)__builtin_amdgcn_readfirstlane(plive ? 1 : 0);
+      const unsigned stepA = (feed ? lv : 0u) * kstepA, stepB = (feed ? lv : 0u) * kstepB;
+      unsigned fa = lds0 + (unsigned)(cstage * STAGE_BYTES) + fbA, fb = lds0 + (unsigned)(cstage * STAGE_BYTES + A_BYTES) + fbB;
+      unsigned fan = lds0 + (unsigned)((cstage ^ 1) * STAGE_BYTES) + fbA, fbn = lds0 + (unsigned)((cstage ^ 1) * STAGE_BYTES + A_BYTES) + fbB;
+      asm volatile("" : "+v"(fa), "+v"(fb), "+v"(fan), "+v"(fbn));   // opaque: no hoisting of the derived addresses out of the loop
+      const unsigned dstB = dstA + (unsigned)A_BYTES;
+      __builtin_amdgcn_sched_barrier(0);
+      auto row = [&](auto RC) {
+        constexpr int R = decltype(RC)::value;
+        constexpr int kh = R >> 3, a = R & 7;
+        if (R == 15) {
+          // every fragment of this stage is in registers (the A fragment of this row was read one row ago), this wave's pieces
+          // of the next stage were issued in rows 0..7: after the barrier the next stage is complete and this one is free
+          if (!(ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+          // (inline assembly with the accumulator tied to an AGPR: given the builtin, the register allocator spread the 64
+          // accumulator tiles over both register files and moved 280 registers between them every K step)
+          // operand roles swapped (the B fragment goes in as the instruction's A): the lane then holds C[m = 16a + (lane & 15)]
+          // [n = 16b + 4 (lane >> 4) + 0..3] -- four CONSECUTIVE columns of one row, one 16-byte store per tile in the epilogue
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0" : "+a"(acc[a][b]) : "v"(afc), "v"(bf[kh][b]));
+          // ---- the slot behind MFMA b of row R ----
+          if (ABL & 1) {
+          } else if (R < 15) {
+            if (b == 0) afn = (a + 1 < WA) ? OA::frag(fa, (a + 1) * 16, kh) : OA::frag(fa, 0, 1);
+            if (kh == 0 && b == 1) bf[1][a] = OB::frag(fb, a * 16, 1);
+          } else {
+            bf[0][b] = OB::frag(fbn, b * 16, 0);          // the next step's first fragments, from the other stage
+            if (b == WB - 1) afn = OA::frag(fan, 0, 0);
+          }
+          if (kh == 0 && DR == 8) {                                  // DMA chunks a of both operands: 3 + 3 instructions in 5 slots
+            if (b == 2) asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstA), "n"(a * 4096) : "scc", "memory");
+            if (b == 3) dma_load(AK ? la.off[a & 1] : la.off[0], dA, soffA);
+            if (b == 4) { soffA += pitchA; asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstB), "n"(a * 4096) : "scc", "memory"); }
+            if (b == 5) dma_load(BK_ ? lb.off[a & 1] : lb.off[0], dB, soffB);
+            if (b == 6) soffB += pitchB;
+          } else if (kh == 0 && DR == 4) {                           // rows 0..3: chunks 2a and 2a+1 of both operands, one instruction per slot
+            if (a < 4) {
+              constexpr int c0 = (2 * a) & 7, c1 = (2 * a + 1) & 7;
+              if (b == 0) asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstA), "n"(c0 * 4096) : "scc", "memory");
+              if (b == 1) { dma_load(AK ? la.off[c0 & 1] : la.off[0], dA, soffA); soffA += pitchA; }
+              if (b == 2) asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstB), "n"(c0 * 4096) : "scc", "memory");
+              if (b == 3) { dma_load(BK_ ? lb.off[c0 & 1] : lb.off[0], dB, soffB); soffB += pitchB; }
+              if (b == 4) asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstA), "n"(c1 * 4096) : "scc", "memory");
+              if (b == 5) { dma_load(AK ? la.off[c1 & 1] : la.off[0], dA, soffA); soffA += pitchA; }
+              if (b == 6) asm volatile("s_add_i32 m0, %0, %1" :: "s"(dstB), "n"(c1 * 4096) : "scc", "memory");
+              if (b == 7) { dma_load(BK_ ? lb.off[c1 & 1] : lb.off[0], dB, soffB); soffB += pitchB; }
+            }
+          } else {
+            if (a == 0 && b == 2) adv(dA, stepA);
+            if (a == 1 && b == 2) adv(dB, stepB);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        afc = afn;
+      };
+      row(std::integral_constant<int, 0>{});  row(std::integral_constant<int, 1>{});  row(std::integral_constant<int, 2>{});
+      row(std::integral_constant<int, 3>{});  row(std::integral_constant<int, 4>{});  row(std::integral_constant<int, 5>{});
+      row(std::integral_constant<int, 6>{});  row(std::integral_constant<int, 7>{});  row(std::integral_constant<int, 8>{});
+      row(std::integral_constant<int, 9>{});  row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
+      row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{});
+      row(std::integral_constant<int, 15>{});
+      soffA = soffB = 0;
+      if (lv) pf_done();
+      cstage ^= 1;
+    }
+    // the MFMAs above are opaque to the compiler's hazard recognizer: let the last one drain before its result is read
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // Epilogue.  Round 3's (one dword store per accumulator register, per-element bound checks, 64-bit address arithmetic per
+    // store, the row-bias loads chained load -> add -> store) cost 40 us per tile -- a quarter of the xg contraction, more
+    // with the row bias (tools/gemm_epilogue_probe.py: T(2K) - T(K) against 2 T(K) - T(2K)).  Now: one row pointer per
+    // accumulator row block, eight 16-byte stores at immediate offsets, the bias as one 16-byte load per tile; tiles that
+    // stick out of the matrix (and unaligned outputs) take the element-wise path.
+    const int i = lane & 15, gq = lane >> 4;
+    const bool whole = g.vec_ok && tm * TM + TM <= g.M && tn * TN + TN <= g.N;
+    const int n0 = tn * TN + wn * 128 + 4 * gq;
+    auto bias_ptr = [&](int a) -> const float* {
+      int m = tm * TM + wm * 128 + a * 16 + i;
+      m = m < g.M ? m : g.M - 1;
+      return g.rowbias + (size_t)(m / g.group) * g.ldrb + n0;
+    };
+    // the row bias of block a + 1 is loaded while block a is stored: one exposed load latency per tile instead of eight
+    f32x4 bias_nx[WB];
+    if (whole && g.rowbias) {
+      const float* rb0 = bias_ptr(0);
+#pragma unroll
+      for (int b = 0; b < WB; ++b) bias_nx[b] = *reinterpret_cast<const f32x4*>(rb0 + 16 * b);
+    }
+#pragma unroll
+    for (int a = 0; a < WA; ++a) {
+      const int m = tm * TM + wm * 128 + a * 16 + i;
+      const int mc = m < g.M ? m : g.M - 1;                                    // (rows beyond the matrix: pointers stay valid, nothing is stored)
+      float* crow = ((g.C2 && mc >= g.split_m) ? g.C2 + (size_t)(mc - g.split_m) * g.ldc : g.C + (size_t)mc * g.ldc) + n0;
+      const float* rb = g.rowbias ? g.rowbias + (size_t)(mc / g.group) * g.ldrb + n0 : nullptr;
+      if (whole) {
+        f32x4 v[WB];
+#pragma unroll
+        for (int b = 0; b < WB; ++b) v[b] = acc[a][b];
+        if (rb) {
+#pragma unroll
+          for (int b = 0; b < WB; ++b) v[b] += bias_nx[b];
+          if (a + 1 < WA) {
+            const float* rbn = bias_ptr(a + 1);
+#pragma unroll
+            for (int b = 0; b < WB; ++b) bias_nx[b] = *reinterpret_cast<const f32x4*>(rbn + 16 * b);
+          }
+        }
+        if (g.accumulate > 0) {
+#pragma unroll
+          for (int b = 0; b < WB; ++b) v[b] += *reinterpret_cast<const f32x4*>(crow + 16 * b);
+        }
+#pragma unroll
+        for (int b = 0; b < WB; ++b) *reinterpret_cast<f32x4*>(crow + 16 * b) = v[b];
+      } else if (m < g.M) {
+#pragma unroll
+        for (int b = 0; b < WB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 16 * b + e;
+            if (n < g.N) {
+              float v = acc[a][b][e];
+              if (rb) v += rb[16 * b + e];
+              if (g.accumulate > 0) v += crow[16 * b + e];
+              crow[16 * b + e] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
 // fp32 [rows][ld] (K valid columns) -> bf16 [rows][Kp], zero padded
 __global__ __launch_bounds__(256)
 void cvt_rows_bf16_kernel(const float* __restrict__ src, long long rows, int K, int ld, unsigned short* __restrict__ dst, int Kp) {
@@ -357,32 +614,51 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   VS_REQUIRE(a_kmajor || lda >= (K + BK - 1) / BK * BK, "gemm_bf16: row-form A must be padded to a multiple of %d in k", BK);
   VS_REQUIRE(b_kmajor || ldb >= (K + BK - 1) / BK * BK, "gemm_bf16: row-form B must be padded to a multiple of %d in k", BK);
   GemmBf16Args g{reinterpret_cast<const unsigned short*>(A), lda, reinterpret_cast<const unsigned short*>(B), ldb, C, ldc, C2, split_m,
-                 M, N, K, rowbias, ldrb, group > 0 ? group : 1, accumulate, (M + TM - 1) / TM, (N + TN - 1) / TN, 8};
+                 M, N, K, rowbias, ldrb, group > 0 ? group : 1, accumulate, (M + TM - 1) / TM, (N + TN - 1) / TN, 8, 0};
+  g.vec_ok = ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
+             (!rowbias || (ldrb % 4 == 0 && (reinterpret_cast<uintptr_t>(rowbias) & 15) == 0));
   static int cus = gemm_cus();
   const long long ntiles = (long long)g.tiles_m * g.tiles_n;
   long long nwg = cus / 8 * 8;
   if (nwg > (ntiles + 7) / 8 * 8) nwg = (ntiles + 7) / 8 * 8;
   if (nwg < 8) nwg = 8;
   const dim3 grid((unsigned)nwg), block(256);
-  // placement of the DMA instructions inside a step, per operand-form pair (measured, tools/gemm_micro.py; the
-  // VOICESPLIT_GEMM_DMA environment variable -- three digits: row x row, row x col, col x col -- overrides it for A/B timing)
-  static const int dm_cfg = [] {
-    const char* e = getenv("VOICESPLIT_GEMM_DMA");
-    int v = 122;                                         // measured with the descriptor form of the chunks (profiles/r03_gemm_l2_prefetch.md)
-    if (e && e[0] && e[1] && e[2]) v = (e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0');
-    return v;
-  }();
   const int form = (!a_kmajor && !b_kmajor) ? 0 : (!a_kmajor && b_kmajor) ? 1 : (a_kmajor && b_kmajor) ? 2 : 3;
   VS_REQUIRE(form != 3, "gemm_bf16: the col x row form is not used by the path");
-  const int dm = form == 0 ? dm_cfg / 100 : form == 1 ? (dm_cfg / 10) % 10 : dm_cfg % 10;
-  VS_REQUIRE(dm >= 0 && dm <= 2, "gemm_bf16: VOICESPLIT_GEMM_DMA digit %d", dm);
-#define VS_GEMM_LAUNCH(AK_, BK2_, DM_) hipLaunchKernelGGL((gemm_bf16_kernel<AK_, BK2_, DM_>), grid, block, 0, stream, g)
-#define VS_GEMM_FORM(AK_, BK2_) do { if (dm == 0) VS_GEMM_LAUNCH(AK_, BK2_, 0); else if (dm == 1) VS_GEMM_LAUNCH(AK_, BK2_, 1); else VS_GEMM_LAUNCH(AK_, BK2_, 2); } while (0)
-  if (form == 0) VS_GEMM_FORM(false, false);
-  else if (form == 1) VS_GEMM_FORM(false, true);
-  else VS_GEMM_FORM(true, true);
-#undef VS_GEMM_FORM
-#undef VS_GEMM_LAUNCH
+  // round 4: the interleaved kernel (side work in the slots behind the MFMAs); VOICESPLIT_GEMM_KERNEL=old selects the round-3
+  // kernel for A/B timing (same arithmetic, same summation order: bit-identical results)
+  static const bool use_old = [] { const char* e = getenv("VOICESPLIT_GEMM_KERNEL"); return e && e[0] == 'o'; }();
+  if (!use_old) {
+    // VOICESPLIT_GEMM_DR: three digits (row x row, row x col, col x col), each 4 or 8 = rows the DMA chunks are issued in (A/B timing)
+    static const int dr_cfg = [] { const char* e = getenv("VOICESPLIT_GEMM_DR"); return (e && e[0] && e[1] && e[2]) ? (e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0') : 888; }();
+    static const bool nodma = [] { const char* e = getenv("VOICESPLIT_GEMM_ABL"); return e && e[0] == 'n'; }();
+    if (nodma) g.accumulate = -1;                          // timing ablation: results are meaningless
+    const int dr = form == 0 ? dr_cfg / 100 : form == 1 ? (dr_cfg / 10) % 10 : dr_cfg % 10;
+    VS_REQUIRE(dr == 4 || dr == 8, "gemm_bf16: VOICESPLIT_GEMM_DR digit %d", dr);
+#ifdef VS_ABLATION
+    static const int abl = [] { const char* e = getenv("VOICESPLIT_GEMM_ABL"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }();
+    if (abl && form == 0) {
+      if (abl == 1) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 1>), grid, block, 0, stream, g);
+      else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 2>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 3>), grid, block, 0, stream, g);
+      VS_LAUNCH_CHECK();
+      return 0;
+    }
+#endif
+#define VS_GEMM_IL(AK_, BK2_) do { if (dr == 4) hipLaunchKernelGGL((gemm_bf16_il_kernel<AK_, BK2_, 4>), grid, block, 0, stream, g); \
+                                   else hipLaunchKernelGGL((gemm_bf16_il_kernel<AK_, BK2_, 8>), grid, block, 0, stream, g); } while (0)
+    if (form == 0) VS_GEMM_IL(false, false);
+    else if (form == 1) VS_GEMM_IL(false, true);
+    else VS_GEMM_IL(true, true);
+#undef VS_GEMM_IL
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
+  // the round-3 kernel with the DMA placement that was measured fastest per operand-form pair -- row x row: two chunks in front
+  // of each of the first 8 MFMA rows, the two col forms: one in front of each of the 16 rows (profiles/r03_gemm_l2_prefetch.md)
+  if (form == 0) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 1>), grid, block, 0, stream, g);
+  else if (form == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 2>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 2>), grid, block, 0, stream, g);
   VS_LAUNCH_CHECK();
   return 0;
 }
