@@ -234,6 +234,23 @@ int vs_gemm_bf16_split(int a_kmajor, int b_kmajor, const void* A, int lda, const
  * [B][T][F][64] bf16 -> [B][T][8][F] fp32. */
 int vs_nhwc_conv_first(const float* x, const float* w, const float* scale, const float* shift, void* out,
                        int B, int T, int F, int act, double* bn_stats, void* stream);
+/* cnn1 by recomputation (what vs_forward_train / vs_backward run in VS_MATH_BF16): cnn1 (models/voicesplit/model.py:17-19) is 7
+ * multiply-adds per output and its input is 1/64 of its output, so neither its conv output z1 nor a separate BatchNorm apply
+ * pass is needed.  vs_nhwc_first_moments: x [B][T][F] -> the 35 moments of its seven zero-padded shifts x_k = x[..][f + k - 3]
+ * (doubles: S[k] = sum x_k, k = 0..6, then R[k][k'] = sum x_k x_k' for k <= k', row by row).  vs_nhwc_first_stats: the
+ * per-channel {sum, sum of squares} of z1 = conv(x) + bias over count = B*T*F pixels that follow from them (stats [64][2],
+ * one slot: feed vs_bn_finalize with slots = 1).  The forward is then ONE pass, vs_nhwc_conv_first with the BatchNorm folded
+ * into its arguments: scale = bn scale, shift = bn shift + bias * bn scale.  vs_nhwc_first_bwd: the whole backward of cnn1 +
+ * BatchNorm + activation in ONE pass over da1 [B][T][F][64] bf16 (z1 recomputed from x beside the derivative; the BatchNorm
+ * backward is linear in dy and z, so the weight gradient follows from sum dy x_k and the moments): dgamma, dbeta, dbias [64],
+ * dw [64][7] (all overwritten); scale / shift / mean / invstd = vs_bn_finalize's outputs (shift WITHOUT the bias fold);
+ * scratch = vs_nhwc_first_bwd_scratch_doubles() doubles. */
+int vs_nhwc_first_moments(const float* x, int B, int T, int F, double* moments /* [35] */, void* stream);
+int vs_nhwc_first_stats(const double* moments, const float* w, const float* bias, double count, double* stats /* [64][2] */, void* stream);
+int vs_nhwc_first_bwd_scratch_doubles(void);
+int vs_nhwc_first_bwd(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int bn_mode,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, void* stream);
 /* Train-mode nn.BatchNorm2d between a conv that accumulated statistics and the apply pass (models/voicesplit/model.py:19 under
  * model.train(), train.py:84): stats = [slots][C][2] doubles {sum, sum of squares} over `count` values per channel -- what
  * vs_nhwc_conv / vs_nhwc_conv_first / vs_nhwc_conv_last_pre leave in bn_stats (slots = 64, C = 64 resp. 8, count = B*T*F);
@@ -347,7 +364,8 @@ typedef struct vs_grads {
 typedef struct vs_tape_layout {
   size_t total_bytes;
   /* saved by the forward */
-  size_t z[7];                /* conv+bias outputs of cnn1..cnn7 before BatchNorm [B][64][T][F] */
+  size_t z[7];                /* conv+bias outputs of cnn1..cnn7 before BatchNorm [B][64][T][F] (VS_MATH_BF16: z[0] is not
+                                 kept -- cnn1 is recomputed from x -- and a[6] only under VS_BN_EVAL) */
   size_t a[7];                /* act(BN(z)) = input of the next layer                           */
   size_t z8;                  /* cnn8 conv+bias [B][T][8][F]                                    */
   size_t feat;                /* act(BN(z8)) = LSTM features [B][T][8F]                         */

@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE (oracle/): what bf16 STORAGE costs the parameter gradients of the path, independent of any
 kernel.  The reference forward (models/voicesplit/model.py:66-89: conv stack with batch-statistics BatchNorm, d-vector
 concat, BiLSTM, head) in fp64 autograd with bf16 rounding injected exactly where the VS_MATH_BF16 configuration rounds:
-the 64->64 conv weights, z = conv + bias, a = act(BN(z)), the gradients flowing back through those two, and the operands
+the 64->64 conv weights, z = conv + bias of cnn2..cnn7 (cnn1's is recomputed from x, never stored), a = act(BN(z)) of
+cnn1..cnn7, the gradients flowing back through those, and the operands
 of the LSTM input GEMM, of fc1 / fc2 and of their backward contractions.  The recurrent product is rounded as the kernels round it (h, W_hh to f16
 forward; gate gradients, W_hh^T to bf16 in the BPTT).  Accumulation, statistics and the gate arithmetic are exact.
 The difference between these gradients and the unrounded ones is the envelope a correct bf16 implementation lives in;
@@ -68,7 +69,7 @@ def gradients(sd: Dict[str, torch.Tensor], x: torch.Tensor, dvec: torch.Tensor, 
         if bf16 and 1 <= i <= 6:
             wt = _rnd(wt, True)
         z = F.conv2d(h, wt, P[f"conv.{spec.conv_idx}.bias"], padding=((spec.kt // 2) * spec.dil_t, spec.kf // 2), dilation=(spec.dil_t, 1))
-        if i < 7:
+        if 1 <= i < 7:          # (cnn1's z is never stored: the path recomputes it from x in fp32, forward and backward -- round 4)
             z = _rnd(z, bf16, bf16)
         m = z.mean((0, 2, 3), keepdim=True)
         v = ((z - m) ** 2).mean((0, 2, 3), keepdim=True)

@@ -446,3 +446,84 @@ def test_cnn8_applies_the_batchnorm_of_cnn7_itself(act):
     dy0, dw0, st0 = ops.nhwc_conv_last_bwd_dy(dz8, w8, a7, z7, act, psc, psh, mean, invstd)
     dy1, dw1, st1 = ops.nhwc_conv_last_bwd_dy(dz8, w8, None, z7, act, psc, psh, mean, invstd)
     assert torch.equal(dy0, dy1) and torch.equal(dw0, dw1) and torch.equal(st0.sum(0), st1.sum(0))
+
+
+# ---- cnn1 by recomputation (round 4): statistics from the input's moments, one-pass forward, one-pass backward -----------------
+def _shifts(x):
+    """x [B,T,F] -> [B,T,F,7]: x[..., f + k - 3], zero outside the row (ZeroPad2d((3, 3, 0, 0)))."""
+    xp = F.pad(x, (3, 3))
+    return torch.stack([xp[..., k:k + x.shape[-1]] for k in range(7)], -1)
+
+
+@pytest.mark.parametrize("B,T,Fq", [(2, 13, 75), (1, 5, 4), (3, 40, 601)])
+def test_cnn1_statistics_from_input_moments(B, T, Fq):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(B + T + Fq)
+    x = torch.rand(B, T, Fq, generator=g)
+    w = torch.randn(64, 1, 1, 7, generator=g) * 0.4
+    bias = torch.randn(64, generator=g) * 0.3
+    mom = ops.nhwc_first_moments(x.cuda())
+    xs = _shifts(x.double())                                                    # [B,T,F,7]
+    S = xs.sum((0, 1, 2))
+    R = torch.einsum("btfk,btfl->kl", xs, xs)
+    ref = torch.cat([S] + [R[k, k:] for k in range(7)])
+    assert mom.shape == (35,)
+    assert torch.allclose(mom.cpu(), ref, rtol=2e-6, atol=1e-9 * ref.abs().max().item())
+    st = ops.nhwc_first_stats(mom, w.cuda(), bias.cuda(), B * T * Fq).cpu()
+    z = F.conv2d(x.double()[:, None], w.double(), bias.double(), padding=(0, 3))
+    assert torch.allclose(st[0, :, 0], z.sum((0, 2, 3)), rtol=1e-5, atol=1e-6 * z.abs().sum((0, 2, 3)).max().item())
+    assert torch.allclose(st[0, :, 1], (z * z).sum((0, 2, 3)), rtol=1e-5)
+    # ... and through vs_bn_finalize (one slot) they give the BatchNorm constants of train mode
+    n = B * T * Fq
+    gamma, beta = (torch.rand(64, generator=g) + 0.5), torch.randn(64, generator=g) * 0.2
+    scale, shift, mean, invstd = ops.bn_finalize(st.cuda(), n, gamma.cuda(), beta.cuda())
+    m, v = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    assert torch.allclose(mean.double().cpu(), m, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(invstd.double().cpu(), 1 / torch.sqrt(v + 1e-5), rtol=2e-5)
+    # the one-pass forward: a1 = act(BN(z1)) with the BatchNorm folded into the kernel's arguments
+    for act in ("mish", "relu"):
+        a1 = ops.nhwc_conv_first(x.cuda(), w.cuda(), scale, shift + bias.cuda() * scale, act).double().cpu()
+        ref_a = _act((z - m.view(1, -1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1) + 1e-5) * gamma.double().view(1, -1, 1, 1)
+                     + beta.double().view(1, -1, 1, 1), act).permute(0, 2, 3, 1)
+        err = (a1 - ref_a).abs()
+        assert (err <= 2.0 ** -8 * ref_a.abs() + 1e-4).all(), (act, err.max().item())
+
+
+@pytest.mark.parametrize("act", ["mish", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B,T,Fq", [(2, 13, 75), (3, 40, 301)])
+def test_cnn1_one_pass_backward(act, training, B, T, Fq):
+    """vs_nhwc_first_bwd: d/d{conv.1.weight, conv.1.bias, conv.2.weight, conv.2.bias} of sum(da * act(BN(conv(x) + bias))) for a
+    bf16 upstream gradient da -- against fp64 autograd through exactly that graph (batch statistics or frozen ones)."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(17 + T)
+    x = torch.rand(B, T, Fq, generator=g)
+    w = (torch.randn(64, 1, 1, 7, generator=g) * 0.4)
+    bias = torch.randn(64, generator=g) * 0.3
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    rmean, rvar = torch.randn(64, generator=g) * 0.2 + 0.8, torch.rand(64, generator=g) * 0.2 + 0.1
+    da = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16)
+    wd, bd, gd, btd = (t.double().clone().requires_grad_(True) for t in (w, bias, gamma, beta))
+    z = F.conv2d(x.double()[:, None], wd, bd, padding=(0, 3))
+    if training:
+        m, v = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        m, v = rmean.double().view(1, -1, 1, 1), rvar.double().view(1, -1, 1, 1)
+    y = (z - m) / torch.sqrt(v + 1e-5) * gd.view(1, -1, 1, 1) + btd.view(1, -1, 1, 1)
+    if act == "relu":                                   # keep clear of the kink (the kernel recomputes y in fp32)
+        da = (da.float() * (y.detach().abs() > 1e-4).permute(0, 2, 3, 1).float()).to(torch.bfloat16)
+    (_act(y, act) * da.double().permute(0, 3, 1, 2)).sum().backward()
+    mean = m.detach().reshape(-1).float()
+    invstd = (1 / torch.sqrt(v.detach() + 1e-5)).reshape(-1).float()
+    scale = (gamma.double() * invstd.double()).float()
+    shift = (beta.double() - mean.double() * scale.double()).float()
+    dw, dg, db, dbias = ops.nhwc_first_bwd(da.cuda(), x.cuda(), w.cuda(), bias.cuda(), act, training, scale.cuda(), shift.cuda(),
+                                           mean.cuda(), invstd.cuda())
+    for got, ref, nm in ((dw, wd.grad.reshape(64, 7), "dw"), (dg, gd.grad, "dgamma"), (db, btd.grad, "dbeta")):
+        e = ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        assert e < 2e-4, (nm, e)
+    if training:
+        assert dbias.abs().max().item() == 0.0 and bd.grad.abs().max().item() < 1e-6 * db.abs().max().item() + 1e-9
+    else:
+        e = ((dbias.double().cpu() - bd.grad).abs().max() / bd.grad.abs().max()).item()
+        assert e < 2e-4, ("dbias", e)

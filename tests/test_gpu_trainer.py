@@ -174,7 +174,7 @@ def test_trainer_step_with_gradient_sink_and_sisnr_vs_oracle(math, case):
         dims, B, T, ragged = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53), 3, 45, True
         c = _small_cfg(dims)
     else:
-        dims, B, T, ragged = dict(num_freq=601, emb_dim=256, lstm_dim=400, fc1_dim=600, fc2_dim=601), 2, 21, False
+        dims, B, T, ragged = dict(num_freq=601, emb_dim=256, lstm_dim=400, fc1_dim=600, fc2_dim=601), 4, 31, False
         c = V.default_config(**dims)
         c.train_config["learning_rate"] = 1e-3
     acfg = c.audio["voicefilter"]

@@ -109,6 +109,10 @@ SIGNATURES = {
     "vs_gemm_bf16": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "vs_gemm_bf16_split": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_first": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vs_nhwc_first_moments": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "vs_nhwc_first_stats": (c_int, [_P, _P, _P, ctypes.c_double, _P, _P]),
+    "vs_nhwc_first_bwd_scratch_doubles": (c_int, []),
+    "vs_nhwc_first_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vs_bn_finalize": (c_int, [_P, c_int, ctypes.c_double, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "vs_nhwc_bn_apply": (c_int, [_P, _P, c_longlong, c_int, _P, _P, _P]),
     "vs_nhwc_conv_last": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -390,6 +390,22 @@ int vs_nhwc_bn_apply(const void* z, void* a, long long npix, int act, const floa
   return vs_nhwc_bn_apply_impl(z, a, npix, act, scale, shift, (hipStream_t)stream);
 }
 
+// cnn1 by recomputation (nhwc_edge.hip)
+int vs_nhwc_first_moments(const float* x, int B, int T, int F, double* moments, void* stream) {
+  return vs_nhwc_first_moments_impl(x, B, T, F, moments, (hipStream_t)stream);
+}
+int vs_nhwc_first_stats(const double* moments, const float* w, const float* bias, double count, double* stats, void* stream) {
+  return vs_nhwc_first_stats_impl(moments, w, bias, count, stats, (hipStream_t)stream);
+}
+int vs_nhwc_first_bwd_scratch_doubles(void) { return VS_FIRST_BWD_SCRATCH_DOUBLES; }
+int vs_nhwc_first_bwd(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int bn_mode,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, void* stream) {
+  VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "nhwc_first_bwd: unknown bn_mode %d", bn_mode);
+  return vs_nhwc_first_bwd_impl(da, x, w, bias, B, T, F, act, bn_mode == VS_BN_TRAIN, scale, shift, mean, invstd, dgamma, dbeta, dbias, dw,
+                                scratch, (hipStream_t)stream);
+}
+
 // train-mode BatchNorm2d between a conv that accumulated statistics and the apply pass (the piecewise form of what
 // vs_forward_train does per layer)
 int vs_bn_finalize(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
@@ -589,9 +605,16 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
     };
     {
       ProfScope ps(VS_PROF_CNN1, stream);
-      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
-      if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, scale, shift, abuf[c], B, T, F, layer_act, train ? stats : nullptr, stream)) return rc;
-      if (train) { if (int rc = bn_train(0, abuf[c])) return rc; }
+      if (train) {
+        // cnn1 by recomputation (nhwc_edge.hip): statistics of z1 from the input's moments, then one pass that writes act(BN(z1))
+        const vs_conv_layer& cl = p->conv[0];
+        double* mom = stats + 128;                          // behind slot 0 of the statistics scratch
+        if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
+        if (int rc = vs_nhwc_first_stats_impl(mom, cl.weight, cl.bias, (double)npix, stats, stream)) return rc;
+        if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, cl.bn_weight, cl.bn_bias, cl.bn_running_mean, cl.bn_running_var, kBnEps,
+                                         kBnMomentum, scale, shift, nullptr, nullptr, stream)) return rc;
+        if (int rc = vs_nhwc_conv_first_impl(x, cl.weight, scale, shift, abuf[c], B, T, F, conv_act, nullptr, stream, cl.bias)) return rc;
+      } else if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, scale, shift, abuf[c], B, T, F, layer_act, nullptr, stream)) return rc;
     }
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;

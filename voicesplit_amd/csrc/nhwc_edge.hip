@@ -43,12 +43,17 @@ __device__ __forceinline__ void fold_channel_sums(float (&v)[NV][8], double* __r
 // The 7 input samples x[f-3 .. f+3] of a pixel for all 8 lanes that share it (one lane per 8 channels): lane `piece`
 // loads sample `piece` (one load instruction per wave instead of seven mostly redundant ones) and the group exchanges
 // them by lane permutes.
-__device__ __forceinline__ void gather_x7(const float* xr, int f, int F, int piece, float (&xv)[7]) {
+__device__ __forceinline__ float load_x7(const float* xr, int f, int F, int piece) {
   const int ff = f + piece - 3;
-  const float mine = (piece < 7 && ff >= 0 && ff < F) ? xr[ff] : 0.f;
+  return (piece < 7 && ff >= 0 && ff < F) ? xr[ff] : 0.f;
+}
+__device__ __forceinline__ void exchange_x7(float mine, float (&xv)[7]) {
   const int base = (int)(threadIdx.x & 56u);               // first lane of the pixel's group inside the wave
 #pragma unroll
   for (int k = 0; k < 7; ++k) xv[k] = __shfl(mine, base + k, 64);
+}
+__device__ __forceinline__ void gather_x7(const float* xr, int f, int F, int piece, float (&xv)[7]) {
+  exchange_x7(load_x7(xr, f, F, piece), xv);
 }
 
 // ---- cnn1 ---------------------------------------------------------------------------------------------------
@@ -57,16 +62,20 @@ template <int ACT, bool STATS>
 __global__ __launch_bounds__(256)
 void nhwc_conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                             const float* __restrict__ shift, unsigned short* __restrict__ out, long long npix, int F,
-                            double* __restrict__ stats) {
+                            double* __restrict__ stats, const float* __restrict__ bias) {
   __shared__ float red[4 * 2 * 64];
   const int piece = threadIdx.x & 7;                      // channels 8*piece .. 8*piece+7
-  float wr[8][7], sc[8], sh[8];
+  // the lane's 8 channels as 4 pairs: v_pk_fma_f32 does two channels per issue slot (with 64 channels x 7 taps + Mish per
+  // pixel this kernel is VALU-, not HBM-bound once the BatchNorm + activation ride in it)
+  vs_f32x2 wr[4][7], sc[4], sh[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = scale[piece * 8 + j];
-    sh[j] = shift[piece * 8 + j];
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = piece * 8 + 2 * q;
+    sc[q] = vs_f32x2{scale[c0], scale[c0 + 1]};
+    // bias != NULL: scale / shift are a BatchNorm's constants for z = conv + bias: act(scale (conv + bias) + shift)
+    sh[q] = bias ? vs_f32x2{fmaf(bias[c0], sc[q].x, shift[c0]), fmaf(bias[c0 + 1], sc[q].y, shift[c0 + 1])} : vs_f32x2{shift[c0], shift[c0 + 1]};
 #pragma unroll
-    for (int k = 0; k < 7; ++k) wr[j][k] = w[(piece * 8 + j) * 7 + k];
+    for (int k = 0; k < 7; ++k) wr[q][k] = vs_f32x2{w[c0 * 7 + k], w[(c0 + 1) * 7 + k]};
   }
   float acc[2][8];
 #pragma unroll
@@ -75,21 +84,32 @@ void nhwc_conv_first_kernel(const float* __restrict__ x, const float* __restrict
   const int sr = (int)(stride % F);                       // the column is carried along: one 64-bit division per launch, not per pixel
   long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   int f = (int)(p % F);
-  for (; p < npix; p += stride, f += sr) {
-    if (f >= F) f -= F;
+  // the next pixel's input sample is loaded before this one is computed: the loop is otherwise load -> ~150 VALU -> store with
+  // nothing in flight (4 waves per SIMD do not cover a 2 us miss)
+  float mine = p < npix ? load_x7(x + (p - f), f, F, piece) : 0.f;
+  for (; p < npix; p += stride) {
+    int fn = f + sr;
+    if (fn >= F) fn -= F;
+    const long long pn = p + stride;
+    const float mine_next = pn < npix ? load_x7(x + (pn - fn), fn, F, piece) : 0.f;
     float xv[7];
-    gather_x7(x + (p - f), f, F, piece, xv);
-    float y[8];
+    exchange_x7(mine, xv);
+    mine = mine_next;
+    f = fn;
+    u4v pk;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float s = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      vs_f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 7; ++k) s = fmaf(wr[j][k], xv[k], s);
-      y[j] = vs_act_fast<ACT>(fmaf(s, sc[j], sh[j]));
-      if (STATS) { acc[0][j] += y[j]; acc[1][j] = fmaf(y[j], y[j], acc[1][j]); }
+      for (int k = 0; k < 7; ++k) s2 = __builtin_elementwise_fma(wr[q][k], vs_f32x2{xv[k], xv[k]}, s2);
+      const vs_f32x2 y = vs_act_fast2<ACT>(__builtin_elementwise_fma(s2, sc[q], sh[q]));
+      if (STATS) {
+        acc[0][2 * q] += y.x; acc[0][2 * q + 1] += y.y;
+        acc[1][2 * q] = fmaf(y.x, y.x, acc[1][2 * q]); acc[1][2 * q + 1] = fmaf(y.y, y.y, acc[1][2 * q + 1]);
+      }
+      pk[q] = vs_pack_bf16(y.x, y.y);
     }
-    const u4v pk = {vs_pack_bf16(y[0], y[1]), vs_pack_bf16(y[2], y[3]), vs_pack_bf16(y[4], y[5]), vs_pack_bf16(y[6], y[7])};
-    *reinterpret_cast<u4v*>(out + p * 64 + piece * 8) = pk;
+    __builtin_nontemporal_store(pk, reinterpret_cast<u4v*>(out + p * 64 + piece * 8));
   }
   if (STATS) fold_channel_sums<2>(acc, stats, red);
 }
@@ -398,24 +418,54 @@ __device__ __forceinline__ void nhwc_act_both(float y, float& a, float& d) {
 
 // RECOMP: a7 is not read but recomputed from z7 (a7 = bf16(act(z7 * scale + shift)), the forward's own values: see
 // nhwc_conv_last_kernel's PRE form) -- one 1.48 GB operand stream less
+// activation and derivative for a pair of channels (the packed form of nhwc_act_both: the activation is bitwise vs_mish_fast2's,
+// i.e. what nhwc_bn_apply_kernel and the PRE form of nhwc_conv_last_kernel store; no selects: at the y = 20 clamp n r = 1 and the
+// derivative's second term vanishes in fp32)
+template <int ACT>
+__device__ __forceinline__ void nhwc_act_both2(vs_f32x2 y, vs_f32x2& a, vs_f32x2& d) {
+  if (ACT == VS_ACT_MISH) {
+    const vs_f32x2 yc = {fminf(y.x, 20.0f), fminf(y.y, 20.0f)};
+    const vs_f32x2 e = yc * 1.44269504088896340736f;
+    const vs_f32x2 u = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const vs_f32x2 n = u * (u + 2.0f);
+    const vs_f32x2 dn = n + 2.0f;
+    const vs_f32x2 r = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+    a = y * (n * r);
+    d = r * __builtin_elementwise_fma((yc * 4.0f) * r, __builtin_elementwise_fma(u, u, u), n);
+  } else if (ACT == VS_ACT_RELU) {
+    a = vs_f32x2{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};
+    d = vs_f32x2{y.x > 0.0f ? 1.0f : 0.0f, y.y > 0.0f ? 1.0f : 0.0f};
+  } else {
+    a = y;
+    d = vs_f32x2{1.0f, 1.0f};
+  }
+}
+
+// Round 4: channel PAIRS throughout (v_pk_fma_f32: the 64 + 64 FMAs of the data and weight gradient and the activation /
+// derivative were ~310 VALU instructions per pixel piece -- the kernel ran at 3 TB/s, VALU-bound), and the next pixel's
+// operands are in flight while this one is computed (2 waves per SIMD do not hide a load issued at the top of its own iteration).
 template <int DYACT, bool RECOMP = false>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __restrict__ w, const u4v* __restrict__ a7,
                                u4v* __restrict__ din, float* __restrict__ part, long long npix, int F, LastBwdBn bn) {
   __shared__ float red[4 * 8 * 64];
   const int piece = threadIdx.x & 7;
-  float wr[8][8], acc[8][8];            // [co][j], ci = 8 piece + j
-  float sc[8], sh[8], mu[8], is[8], bacc[2][8];
+  vs_f32x2 wr[8][4], acc[8][4];            // [co][pair], ci = 8 piece + 2 pair + {0, 1}
+  vs_f32x2 sc[4], sh[4], mu[4], is[4], bacc[2][4];
 #pragma unroll
   for (int co = 0; co < 8; ++co)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { wr[co][j] = w[co * 64 + piece * 8 + j]; acc[co][j] = 0.f; }
+    for (int q = 0; q < 4; ++q) {
+      wr[co][q] = vs_f32x2{w[co * 64 + piece * 8 + 2 * q], w[co * 64 + piece * 8 + 2 * q + 1]};
+      acc[co][q] = vs_f32x2{0.f, 0.f};
+    }
   if (DYACT >= 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = piece * 8 + j;
-      sc[j] = bn.scale[c]; sh[j] = bn.shift[c]; mu[j] = bn.mean[c]; is[j] = bn.invstd[c];
-      bacc[0][j] = 0.f; bacc[1][j] = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int c = piece * 8 + 2 * q;
+      sc[q] = vs_f32x2{bn.scale[c], bn.scale[c + 1]}; sh[q] = vs_f32x2{bn.shift[c], bn.shift[c + 1]};
+      mu[q] = vs_f32x2{bn.mean[c], bn.mean[c + 1]}; is[q] = vs_f32x2{bn.invstd[c], bn.invstd[c + 1]};
+      bacc[0][q] = vs_f32x2{0.f, 0.f}; bacc[1][q] = vs_f32x2{0.f, 0.f};
     }
   }
   const long long stride = (long long)gridDim.x * 32;
@@ -424,53 +474,69 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
   long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   long long row = p / F;
   int f = (int)(p - row * F);
-  for (; p < npix; p += stride, f += sr, row += sq) {
-    if (f >= F) { f -= F; ++row; }
-    const float* dzr = dz8 + row * 8 * F + f;
-    float d[8];
+  // operands of a pixel piece, fetched one iteration ahead
+  struct In { float d[8]; u4v zv, av; };
+  auto fetch = [&](long long pq, long long rq, int fq, In& in) {
+    const float* dzr = dz8 + rq * 8 * F + fq;
 #pragma unroll
-    for (int co = 0; co < 8; ++co) d[co] = dzr[(size_t)co * F];
-    u4v av, zv = {0u, 0u, 0u, 0u};
-    float zf[8], dact[8];
+    for (int co = 0; co < 8; ++co) in.d[co] = dzr[(size_t)co * F];
+    if (DYACT >= 0) in.zv = __builtin_nontemporal_load(bn.z + pq * 8 + piece);
+    if (!RECOMP) in.av = __builtin_nontemporal_load(a7 + pq * 8 + piece);
+  };
+  In cur, nxt;
+  cur.zv = cur.av = nxt.zv = nxt.av = u4v{0u, 0u, 0u, 0u};
+  if (p < npix) fetch(p, row, f, cur);
+  for (; p < npix; p += stride) {
+    int fn = f + sr;
+    long long rown = row + sq;
+    if (fn >= F) { fn -= F; ++rown; }
+    const long long pn = p + stride;
+    if (pn < npix) fetch(pn, rown, fn, nxt);
+    vs_f32x2 zf[4], dact[4];
+    u4v av = cur.av;
     if (DYACT >= 0) {
-      zv = __builtin_nontemporal_load(bn.z + p * 8 + piece);
-      float aj[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        zf[j] = (j & 1) ? bf_hi(zv[j >> 1]) : bf_lo(zv[j >> 1]);
-        nhwc_act_both<(DYACT >= 0 ? DYACT : VS_ACT_NONE)>(fmaf(zf[j], sc[j], sh[j]), aj[j], dact[j]);
-      }
-      if (RECOMP) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = vs_pack_bf16(aj[2 * q], aj[2 * q + 1]);
-      }
-    }
-    if (!RECOMP) av = __builtin_nontemporal_load(a7 + p * 8 + piece);
-    float g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
-#pragma unroll
-    for (int co = 0; co < 8; ++co)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        g[2 * q] = fmaf(wr[co][2 * q], d[co], g[2 * q]);
-        g[2 * q + 1] = fmaf(wr[co][2 * q + 1], d[co], g[2 * q + 1]);
-        acc[co][2 * q] = fmaf(d[co], bf_lo(av[q]), acc[co][2 * q]);
-        acc[co][2 * q + 1] = fmaf(d[co], bf_hi(av[q]), acc[co][2 * q + 1]);
-      }
-    if (DYACT >= 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float zj = zf[j];
-        g[j] *= dact[j];
-        bacc[0][j] += g[j];
-        bacc[1][j] = fmaf(g[j], (zj - mu[j]) * is[j], bacc[1][j]);
+        zf[q] = vs_f32x2{bf_lo(cur.zv[q]), bf_hi(cur.zv[q])};
+        vs_f32x2 aq;
+        nhwc_act_both2<(DYACT >= 0 ? DYACT : VS_ACT_NONE)>(__builtin_elementwise_fma(zf[q], sc[q], sh[q]), aq, dact[q]);
+        if (RECOMP) av[q] = vs_pack_bf16(aq.x, aq.y);
       }
     }
-    din[p * 8 + piece] = u4v{vs_pack_bf16(g[0], g[1]), vs_pack_bf16(g[2], g[3]), vs_pack_bf16(g[4], g[5]), vs_pack_bf16(g[6], g[7])};
+    vs_f32x2 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = vs_f32x2{0.f, 0.f};
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      const vs_f32x2 dd = {cur.d[co], cur.d[co]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g[q] = __builtin_elementwise_fma(wr[co][q], dd, g[q]);
+        acc[co][q] = __builtin_elementwise_fma(dd, vs_f32x2{bf_lo(av[q]), bf_hi(av[q])}, acc[co][q]);
+      }
+    }
+    if (DYACT >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g[q] *= dact[q];
+        bacc[0][q] += g[q];
+        bacc[1][q] = __builtin_elementwise_fma(g[q], (zf[q] - mu[q]) * is[q], bacc[1][q]);
+      }
+    }
+    __builtin_nontemporal_store(u4v{vs_pack_bf16(g[0].x, g[0].y), vs_pack_bf16(g[1].x, g[1].y), vs_pack_bf16(g[2].x, g[2].y), vs_pack_bf16(g[3].x, g[3].y)},
+                                din + p * 8 + piece);
+    cur = nxt;
+    f = fn;
+    row = rown;
   }
   if (DYACT >= 0) {
-    fold_channel_sums<2>(bacc, bn.stats, red);
+    float b8[2][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      b8[0][2 * q] = bacc[0][q].x; b8[0][2 * q + 1] = bacc[0][q].y;
+      b8[1][2 * q] = bacc[1][q].x; b8[1][2 * q + 1] = bacc[1][q].y;
+    }
+    fold_channel_sums<2>(b8, bn.stats, red);
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -478,7 +544,7 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
   for (int co = 0; co < 8; ++co)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float s = acc[co][j];
+      float s = (j & 1) ? acc[co][j >> 1].y : acc[co][j >> 1].x;
       s += __shfl_xor(s, 8, 64);
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
@@ -487,6 +553,201 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
   __syncthreads();
   for (int i = threadIdx.x; i < 512; i += 256)
     part[(size_t)blockIdx.x * 512 + i] = red[i] + red[512 + i] + red[1024 + i] + red[1536 + i];
+}
+
+// ---- cnn1 by recomputation (round 4) ---------------------------------------------------------------------------------
+// cnn1 is 7 MACs per output and its input is 1/64 of its output: nothing of it needs to be WRITTEN to be available again.
+// Train-mode BatchNorm needs the batch statistics of z1 = conv(x) + bias before the activation can be applied -- but z1 is
+// linear in seven shifted copies of x, so its per-channel sum and sum of squares follow from the 7 sums S[k] and the 28
+// products R[k][k'] of the shifted inputs (ONE pass over the 46 MB input, independent of the 64 channels):
+//   sum z_c   = sum_k w[c][k] S[k] + N b_c          sum z_c^2 = sum_kk' w[c][k] w[c][k'] R[k][k'] + 2 b_c sum_k w[c][k] S[k] + N b_c^2
+// The forward then writes a1 = act(BN(z1)) in one pass (no z1 tensor, no apply pass); the backward recomputes z1 from x
+// beside the derivative and needs ONE pass over da1: the BatchNorm backward dz = cA dy + cB z + cC is linear in dy and z,
+// so dw[c][k] = sum dz x_k = cA sum(dy x_k) + cB sum(z x_k) + cC S[k], with sum(z x_k) = sum_k' w[c][k'] R[k'][k] + b_c S[k].
+// x_k = x[b][t][f + k - 3], zero outside the row (ZeroPad2d((3, 3, 0, 0)), models/voicesplit/model.py:17).
+constexpr int kMomN = 7 + 28;                            // S[0..6], then R[k][k'] for k <= k' row by row
+
+__global__ __launch_bounds__(256)
+void nhwc_first_moments_kernel(const float* __restrict__ x, long long npix, int F, double* __restrict__ mom) {
+  __shared__ float red[4][kMomN];
+  float acc[kMomN];
+#pragma unroll
+  for (int i = 0; i < kMomN; ++i) acc[i] = 0.f;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride) {
+    const int f = (int)(p % F);
+    const float* xr = x + (p - f);
+    float xv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int ff = f + k - 3;
+      xv[k] = (ff >= 0 && ff < F) ? xr[ff] : 0.f;
+    }
+    int i = 7;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      acc[k] += xv[k];
+#pragma unroll
+      for (int k2 = k; k2 < 7; ++k2) { acc[i] = fmaf(xv[k], xv[k2], acc[i]); ++i; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kMomN; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMomN) atomicAdd(mom + threadIdx.x, (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
+}
+
+__device__ __forceinline__ double mom_R(const double* mom, int k, int k2) {          // R[k][k2], symmetric
+  if (k > k2) { const int t = k; k = k2; k2 = t; }
+  return mom[7 + k * 7 - k * (k - 1) / 2 + (k2 - k)];
+}
+
+// stats[c] = {sum z_c, sum z_c^2} over the `count` pixels, from the moments (one thread per channel, fp64)
+__global__ void nhwc_first_stats_kernel(const double* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ bias,
+                                        double count, double* __restrict__ stats) {
+  const int c = threadIdx.x;
+  if (c >= 64) return;
+  const double b = bias[c];
+  double ws = 0.0, q = 0.0;
+  for (int k = 0; k < 7; ++k) {
+    ws += (double)w[c * 7 + k] * mom[k];
+    for (int k2 = 0; k2 < 7; ++k2) q += (double)w[c * 7 + k] * (double)w[c * 7 + k2] * mom_R(mom, k, k2);
+  }
+  stats[2 * c] = ws + count * b;
+  stats[2 * c + 1] = q + 2.0 * b * ws + count * b * b;
+}
+
+// one pass over da1: per channel sum dy, sum dy xhat, sum dy x_k (k = 0..6) with z1 recomputed from x
+// act'(y) for a pair of channels; Mish' = r (n + 4 y u (u + 1) r), u = e^y, n = u (u + 2), r = 1 / (n + 2) (the identity derived at
+// conv_nhwc.hip's dy epilogue): one exp2 and one rcp per channel, the rest packed; y clamped at 20, where the expression is 1 to fp32
+template <int ACT>
+__device__ __forceinline__ vs_f32x2 nhwc_act_grad2(vs_f32x2 y) {
+  if (ACT == VS_ACT_RELU) return vs_f32x2{y.x > 0.f ? 1.f : 0.f, y.y > 0.f ? 1.f : 0.f};
+  if (ACT == VS_ACT_MISH) {
+    const vs_f32x2 yc = {fminf(y.x, 20.0f), fminf(y.y, 20.0f)};
+    const vs_f32x2 e = yc * 1.44269504088896340736f;
+    const vs_f32x2 u = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const vs_f32x2 n = u * (u + 2.0f);
+    const vs_f32x2 d = n + 2.0f;
+    const vs_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const vs_f32x2 t = __builtin_elementwise_fma(u, u, u);
+    return r * __builtin_elementwise_fma((yc * 4.0f) * r, t, n);
+  }
+  return vs_f32x2{1.f, 1.f};
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_first_bwd_kernel(const u4v* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                           long long npix, int F, const float* __restrict__ scale, const float* __restrict__ shift,
+                           const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ acc_out /* [64][9] */) {
+  __shared__ float red[4 * 9 * 64];
+  const int piece = threadIdx.x & 7;
+  // channel pairs throughout (v_pk_*_f32): per pixel and pair 7 FMAs for z, the derivative, 9 FMAs into the sums
+  vs_f32x2 wr[4][7], bs[4], sc[4], sh[4], mu[4], is[4], acc[9][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = piece * 8 + 2 * q;
+    bs[q] = vs_f32x2{bias[c0], bias[c0 + 1]};
+    sc[q] = vs_f32x2{scale[c0], scale[c0 + 1]};
+    sh[q] = vs_f32x2{shift[c0], shift[c0 + 1]};
+    mu[q] = vs_f32x2{mean[c0], mean[c0 + 1]};
+    is[q] = vs_f32x2{invstd[c0], invstd[c0 + 1]};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wr[q][k] = vs_f32x2{w[c0 * 7 + k], w[(c0 + 1) * 7 + k]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k][q] = vs_f32x2{0.f, 0.f};
+  }
+  const long long stride = (long long)gridDim.x * 32;
+  const int sr = (int)(stride % F);
+  long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  int f = (int)(p % F);
+  // The next pixel's gradient piece and input sample are loaded before this one is computed.  (Measured, tools/edge_micro.py at
+  // B = 64: 1.07 ms = 1.4 TB/s with or without this, with a ring three deep, and with branch-free loads -- the loop is bound by its
+  // ~160 packed VALU instructions + 16 transcendentals per 8-channel piece at 2 waves per SIMD, not by the loads.)
+  auto process = [&](float mine, const u4v& g) {
+    float xv[7];
+    exchange_x7(mine, xv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vs_f32x2 zv = bs[q];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) zv = __builtin_elementwise_fma(wr[q][k], vs_f32x2{xv[k], xv[k]}, zv);
+      const vs_f32x2 dy = vs_f32x2{bf_lo(g[q]), bf_hi(g[q])} * nhwc_act_grad2<ACT>(__builtin_elementwise_fma(zv, sc[q], sh[q]));
+      acc[0][q] += dy;
+      acc[1][q] = __builtin_elementwise_fma(dy, (zv - mu[q]) * is[q], acc[1][q]);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc[2 + k][q] = __builtin_elementwise_fma(dy, vs_f32x2{xv[k], xv[k]}, acc[2 + k][q]);
+    }
+  };
+  float mine = 0.f;
+  u4v g = {0u, 0u, 0u, 0u};
+  if (p < npix) {
+    mine = load_x7(x + (p - f), f, F, piece);
+    g = __builtin_nontemporal_load(da + p * 8 + piece);
+  }
+  for (; p < npix; p += stride) {
+    int fn = f + sr;
+    if (fn >= F) fn -= F;
+    const long long pn = p + stride;
+    float mine_next = 0.f;
+    u4v g_next = {0u, 0u, 0u, 0u};
+    if (pn < npix) {
+      mine_next = load_x7(x + (pn - fn), fn, F, piece);
+      g_next = __builtin_nontemporal_load(da + pn * 8 + piece);
+    }
+    process(mine, g);
+    mine = mine_next;
+    g = g_next;
+    f = fn;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = (j & 1) ? acc[k][j >> 1].y : acc[k][j >> 1].x;
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 8) red[(wave * 9 + k) * 64 + lane * 8 + j] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+    const int k = i / 64, c = i - k * 64;
+    atomicAdd(acc_out + c * 9 + k, (double)(red[(0 * 9 + k) * 64 + c] + red[(1 * 9 + k) * 64 + c] + red[(2 * 9 + k) * 64 + c] + red[(3 * 9 + k) * 64 + c]));
+  }
+}
+
+// parameter gradients of cnn1 + its BatchNorm from the sums above and the input moments (one thread per channel, fp64)
+__global__ void nhwc_first_bwd_finalize_kernel(const double* __restrict__ acc /* [64][9] */, const double* __restrict__ mom,
+                                               const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                                               const float* __restrict__ mean, const float* __restrict__ invstd, double count, int train,
+                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ dw) {
+  const int c = threadIdx.x;
+  if (c >= 64) return;
+  const double sdy = acc[c * 9], sdyx = acc[c * 9 + 1];
+  dgamma[c] = (float)sdyx;
+  dbeta[c] = (float)sdy;
+  const double cA = scale[c];                              // gamma * invstd
+  double cB = 0.0, cC = 0.0;
+  if (train) {
+    cB = -cA * (double)invstd[c] * sdyx / count;
+    cC = -cA * sdy / count - cB * (double)mean[c];
+  }
+  dbias[c] = train ? 0.f : (float)(cA * sdy);              // batch statistics: the gradient of a bias in front of them is exactly zero
+  const double b = bias[c];
+  for (int k = 0; k < 7; ++k) {
+    double zx = b * mom[k];                                // sum z x_k
+    for (int k2 = 0; k2 < 7; ++k2) zx += (double)w[c * 7 + k2] * mom_R(mom, k2, k);
+    dw[c * 7 + k] = (float)(cA * acc[c * 9 + 2 + k] + cB * zx + cC * mom[k]);
+  }
 }
 
 int stream_blocks(long long items_per_block_sweep, long long total) {
@@ -498,7 +759,7 @@ int stream_blocks(long long items_per_block_sweep, long long total) {
 }  // namespace
 
 int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, const float* shift, void* out,
-                            int B, int T, int F, int act, double* bn_stats, hipStream_t stream) {
+                            int B, int T, int F, int act, double* bn_stats, hipStream_t stream, const float* bias) {
   VS_REQUIRE(x && w && scale && shift && out, "nhwc conv_first: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_first: bad shape");
   const long long npix = (long long)B * T * F;
@@ -506,11 +767,52 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
   unsigned short* o = reinterpret_cast<unsigned short*>(out);
   if (bn_stats) {
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_first: fused statistics go with no activation");
-    hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, bn_stats);
-  } else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_NONE, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr);
-  else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_MISH, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_RELU, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr);
+    hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, bn_stats, bias);
+  } else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_NONE, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr, bias);
+  else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_MISH, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr, bias);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_first_kernel<VS_ACT_RELU, false>), grid, block, 0, stream, x, w, scale, shift, o, npix, F, nullptr, bias);
   else VS_REQUIRE(false, "nhwc conv_first: unsupported activation %d", act);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn1 by recomputation: the input moments (35 doubles: S[7], R[k <= k'] row by row), the batch statistics of z1 they imply
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t stream) {
+  VS_REQUIRE(x && mom && B > 0 && T > 0 && F > 0, "nhwc first_moments: bad argument");
+  const long long npix = (long long)B * T * F;
+  VS_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * kMomN, stream));
+  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3(stream_blocks(256 * 16, npix)), dim3(256), 0, stream, x, npix, F, mom);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bias, double count, double* stats, hipStream_t stream) {
+  VS_REQUIRE(mom && w && bias && stats && count > 0, "nhwc first_stats: bad argument");
+  hipLaunchKernelGGL(nhwc_first_stats_kernel, dim3(1), dim3(64), 0, stream, mom, w, bias, count, stats);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// cnn1 + its BatchNorm + activation backward in ONE pass over da1 (z1 recomputed from x): dgamma, dbeta, dbias, dw [64][7].
+// scratch: 64 * 9 + 35 doubles
+int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t stream) {
+  VS_REQUIRE(da && x && w && bias && scale && shift && mean && invstd && dgamma && dbeta && dbias && dw && scratch, "nhwc first_bwd: NULL argument");
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc first_bwd: bad shape");
+  const long long npix = (long long)B * T * F;
+  double* acc = scratch;
+  double* mom = scratch + 64 * 9;
+  VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 64 * 9, stream));
+  if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
+  const dim3 grid(stream_blocks(32, npix)), block(256);
+  const u4v* g = reinterpret_cast<const u4v*>(da);
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
+  else VS_REQUIRE(false, "nhwc first_bwd: unsupported activation %d", act);
+  hipLaunchKernelGGL(nhwc_first_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, acc, mom, w, bias, scale, mean, invstd, (double)npix, train,
+                     dgamma, dbeta, dbias, dw);
   VS_LAUNCH_CHECK();
   return 0;
 }

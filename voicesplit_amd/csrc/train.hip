@@ -5,6 +5,7 @@
 // Reference graph being differentiated: models/voicesplit/model.py:66-89 (forward) as driven by
 // train.py:94-110 (mask -> loss -> loss.backward()).
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/voicesplit_hip.h"
@@ -33,7 +34,8 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   // conv activations: fp32 [B][64][T][F], or channels-last bf16 [B][T][F][64] in the bf16 configuration (half the bytes)
   const size_t act = B * 64 * T * F * (d->math == VS_MATH_BF16 ? 2 : 4);
-  for (int l = 0; l < 7; ++l) { L->z[l] = take(act); L->a[l] = take(act); }
+  // (bf16 configuration: cnn1 is recomputed from x in the backward pass -- no z[0] tensor, round 4)
+  for (int l = 0; l < 7; ++l) { L->z[l] = take(d->math == VS_MATH_BF16 && l == 0 ? 256 : act); L->a[l] = take(act); }
   L->z8 = take(M * 8 * F * 4);
   L->feat = take(M * 8 * F * 4);
   L->bn_scale = take(8 * 64 * 4);
@@ -61,7 +63,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   L->consts = take(128 * 4);
   L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);
   L->bn_coef = take(3 * 64 * 4);
-  L->first_acc = take(448 * 8);
+  L->first_acc = take((VS_FIRST_BWD_SCRATCH_DOUBLES > 448 ? VS_FIRST_BWD_SCRATCH_DOUBLES : 448) * 8);
   L->colsum_tmp = take(B * max3(8 * H, d->FC1, d->FC2) * 4);
   // one scratch region, reused by the stream-ordered consumers: conv wgrad partial sums,
   // cnn8 wgrad partials, split-K partials of the fc / W_hh weight gradients
@@ -177,10 +179,20 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       return vs_nhwc_bn_apply_impl(at<void>(tape, L.z[l]), at<void>(tape, L.a[l]), npix, conv_act, sc, sh, stream);
     };
     {
+      // cnn1 by recomputation: the batch statistics of z1 = conv(x) + bias from the 35 moments of the input's seven shifts (one
+      // pass over the 46 MB input), then ONE pass that writes a1 = act(BN(z1)): no z1 tensor, no apply pass (nhwc_edge.hip)
       VsProfScope ps(VS_PROF_CNN1, stream);
-      if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
-      if (int rc = vs_nhwc_conv_first_impl(x, p->conv[0].weight, ones, p->conv[0].bias, at<void>(tape, L.z[0]), B, T, F, VS_ACT_NONE,
-                                           train ? stats : nullptr, stream)) return rc;
+      const vs_conv_layer& c = p->conv[0];
+      if (train) {
+        double* mom = at<double>(tape, L.first_acc);
+        if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
+        if (int rc = vs_nhwc_first_stats_impl(mom, c.weight, c.bias, (double)npix, stats, stream)) return rc;
+        if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
+                                         kBnMomentum, scale, shift, mean, invstd, stream)) return rc;
+      } else {
+        if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, 64, scale, shift, mean, invstd, stream)) return rc;
+      }
+      if (int rc = vs_nhwc_conv_first_impl(x, c.weight, scale, shift, at<void>(tape, L.a[0]), B, T, F, conv_act, nullptr, stream, c.bias)) return rc;
     }
     // cnn7's BatchNorm + activation is applied by its consumer: cnn8 is an HBM-bound kernel with idle VALU (forward: on the
     // way into its matrix pipe; backward: recomputed beside the derivative), so train mode has no apply pass over z7
@@ -191,7 +203,6 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       return vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
                                  kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, mean + 64 * l, invstd + 64 * l, stream);
     };
-    if (int rc = bn16(0)) return rc;
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;
       void* packed = at<void>(tape, L.conv_packed[i]);
@@ -543,13 +554,23 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
+    // A/B switch (VOICESPLIT_BWD_DY=0): the data gradients of cnn3..cnn7 as plain convs, the activation derivative and the
+    // BatchNorm-backward sums taken by the two-pass BatchNorm backward beside the weight gradient instead (round 2's form)
+    static const bool dy_form = [] { const char* e = getenv("VOICESPLIT_BWD_DY"); return !(e && e[0] == '0'); }();
+    bool have_dy = true;               // gb[c] holds dy (activation derivative applied, sums in `stats`) -- cnn8's backward above produced it
     for (int i = 5; i >= 0; --i) {
       const int l = i + 1;
       {
         VsProfScope ps(VS_PROF_BWD_BN, stream);
-        if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
-                                                 invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                                 stats, coef, stream)) return rc;
+        if (have_dy) {
+          if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
+                                                   invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
+                                                   stats, coef, stream)) return rc;
+        } else {
+          if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
+                                               mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
+                                               stats, coef, stream)) return rc;
+        }
       }
       if (pending) {                 // the previous layer's weight gradient still reads the buffer this data gradient writes
         VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
@@ -558,10 +579,19 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       {
         VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
         if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, pack_t, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
-        if (int rc = zero_stats()) return rc;
-        if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
-                                          shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
-                                          B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+        if (l == 1 || !dy_form) {
+          // cnn2's data gradient is the plain conv: the activation derivative of cnn1 needs z1, which is recomputed from x by
+          // cnn1's one-pass backward below (no dy epilogue here, no z1 tensor)
+          if (int rc = vs_nhwc_conv_impl(gb[c], pack_t, ones, zeros, gb[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE,
+                                         nullptr, stream)) return rc;
+          have_dy = false;
+        } else {
+          have_dy = true;
+          if (int rc = zero_stats()) return rc;
+          if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
+                                            shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
+                                            B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+        }
       }
       hipStream_t ws = stream;
       if (side) {
@@ -585,10 +615,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
       side_join.forked = false;
     }
-    VsProfScope ps(VS_PROF_BWD_BN, stream);
-    return vs_nhwc_bn_bwd_first_from_dy_impl(gb[c], at<void>(tape, L.z[0]), x, B, T, F, train, scale, mean, invstd,
-                                             g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight, stats, coef,
-                                             at<double>(tape, L.first_acc), stream);
+    VsProfScope ps(VS_PROF_BWD_EDGE, stream);
+    return vs_nhwc_first_bwd_impl(gb[c], x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
+                                  g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
+                                  at<double>(tape, L.first_acc), stream);
   }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;

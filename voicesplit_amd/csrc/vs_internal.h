@@ -77,7 +77,16 @@ size_t vs_nhwc_wgrad_partial_floats(int KT, int KF);
 int vs_nhwc_wgrad_impl(const void* dz, const void* a_in, float* part, float* dw, int B, int T, int F, int KT, int KF, int dil, hipStream_t);
 // nhwc_edge.hip: the HBM-bound kernels around them (cnn1, BatchNorm apply, cnn8)
 int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, const float* shift, void* out,
-                            int B, int T, int F, int act, double* bn_stats, hipStream_t);
+                            int B, int T, int F, int act, double* bn_stats, hipStream_t,
+                            const float* bias = nullptr /* scale / shift are BatchNorm constants of conv + bias */);
+// cnn1 by recomputation (nhwc_edge.hip): input moments -> batch statistics of z1; one-pass backward
+#define VS_FIRST_MOMENTS 35
+#define VS_FIRST_BWD_SCRATCH_DOUBLES (64 * 9 + VS_FIRST_MOMENTS)
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t);
+int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bias, double count, double* stats, hipStream_t);
+int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t);
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr,

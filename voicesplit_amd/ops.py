@@ -718,6 +718,40 @@ def bn_finalize(stats, count: float, gamma, beta, running_mean=None, running_var
     return scale, shift, mean, invstd
 
 
+def nhwc_first_moments(x):
+    """x [B,T,F] fp32 -> the 35 float64 moments of its seven zero-padded shifts (vs_nhwc_first_moments)."""
+    lib = _lib.load()
+    _dev_check(x, "x")
+    B, T, F = x.shape
+    mom = torch.empty(35, dtype=torch.float64, device=x.device)
+    check(lib.vs_nhwc_first_moments(_p(x), B, T, F, _p(mom), _stream()), "vs_nhwc_first_moments")
+    return mom
+
+
+def nhwc_first_stats(mom, w, bias, count: float):
+    """moments -> [1, 64, 2] float64 {sum, sum of squares} of z1 = conv(x) + bias (one slot of vs_bn_finalize)."""
+    lib = _lib.load()
+    _dev_check(mom, "moments", torch.float64)
+    stats = torch.empty(1, 64, 2, dtype=torch.float64, device=mom.device)
+    check(lib.vs_nhwc_first_stats(_p(mom), _p(w), _p(bias), float(count), _p(stats), _stream()), "vs_nhwc_first_stats")
+    return stats
+
+
+def nhwc_first_bwd(da, x, w, bias, act: str, training: bool, scale, shift, mean, invstd):
+    """cnn1 + BatchNorm + activation backward in one pass over da [B,T,F,64] bf16 -> (dw [64,7], dgamma, dbeta, dbias)."""
+    lib = _lib.load()
+    _dev_check(da, "da", torch.bfloat16)
+    _dev_check(x, "x")
+    B, T, F = x.shape
+    dev = x.device
+    dg, db, dbias = (torch.empty(64, dtype=torch.float32, device=dev) for _ in range(3))
+    dw = torch.empty(64, 7, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.vs_nhwc_first_bwd_scratch_doubles(), dtype=torch.float64, device=dev)
+    check(lib.vs_nhwc_first_bwd(_p(da), _p(x), _p(w), _p(bias), B, T, F, ACT_CODES[act], BN_TRAIN if training else BN_EVAL, _p(scale), _p(shift),
+                                _p(mean), _p(invstd), _p(dg), _p(db), _p(dbias), _p(dw), _p(scratch), _stream()), "vs_nhwc_first_bwd")
+    return dw, dg, db, dbias
+
+
 def nhwc_bn_apply(z, scale, shift, act: str):
     lib = _lib.load()
     _dev_check(z, "z", torch.bfloat16)
