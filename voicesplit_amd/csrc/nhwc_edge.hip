@@ -781,7 +781,11 @@ int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom,
   VS_REQUIRE(x && mom && B > 0 && T > 0 && F > 0, "nhwc first_moments: bad argument");
   const long long npix = (long long)B * T * F;
   VS_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * kMomN, stream));
-  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3(stream_blocks(256 * 16, npix)), dim3(256), 0, stream, x, npix, F, mom);
+  // at most two workgroups per CU: every workgroup ends in 35 fp64 atomics on the SAME 35 addresses, which the L2 serialises (2048
+  // workgroups: 90 us for a pass over 46 MB)
+  long long nb = (npix + 256 * 16 - 1) / (256 * 16);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, stream, x, npix, F, mom);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -797,14 +801,17 @@ int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bia
 // scratch: 64 * 9 + 35 doubles
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t stream) {
+                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t stream, const double* moments) {
   VS_REQUIRE(da && x && w && bias && scale && shift && mean && invstd && dgamma && dbeta && dbias && dw && scratch, "nhwc first_bwd: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc first_bwd: bad shape");
   const long long npix = (long long)B * T * F;
   double* acc = scratch;
-  double* mom = scratch + 64 * 9;
   VS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 64 * 9, stream));
-  if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
+  const double* mom = moments;                             // the forward's (vs_forward_train keeps them in the tape), or recomputed here
+  if (!mom) {
+    if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, scratch + 64 * 9, stream)) return rc;
+    mom = scratch + 64 * 9;
+  }
   const dim3 grid(stream_blocks(32, npix)), block(256);
   const u4v* g = reinterpret_cast<const u4v*>(da);
   if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);

@@ -63,7 +63,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   L->consts = take(128 * 4);
   L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);
   L->bn_coef = take(3 * 64 * 4);
-  L->first_acc = take((VS_FIRST_BWD_SCRATCH_DOUBLES > 448 ? VS_FIRST_BWD_SCRATCH_DOUBLES : 448) * 8);
+  L->first_acc = take((64 + VS_FIRST_BWD_SCRATCH_DOUBLES) * 8);      // [cnn1's input moments (forward -> backward)][backward scratch]
   L->colsum_tmp = take(B * max3(8 * H, d->FC1, d->FC2) * 4);
   // one scratch region, reused by the stream-ordered consumers: conv wgrad partial sums,
   // cnn8 wgrad partials, split-K partials of the fc / W_hh weight gradients
@@ -183,9 +183,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       // pass over the 46 MB input), then ONE pass that writes a1 = act(BN(z1)): no z1 tensor, no apply pass (nhwc_edge.hip)
       VsProfScope ps(VS_PROF_CNN1, stream);
       const vs_conv_layer& c = p->conv[0];
+      // (the moments stay in the tape for the backward pass: first_acc = [35 moments, padded to 64][backward scratch])
+      double* mom = at<double>(tape, L.first_acc);
+      if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
       if (train) {
-        double* mom = at<double>(tape, L.first_acc);
-        if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
         if (int rc = vs_nhwc_first_stats_impl(mom, c.weight, c.bias, (double)npix, stats, stream)) return rc;
         if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
                                          kBnMomentum, scale, shift, mean, invstd, stream)) return rc;
@@ -618,7 +619,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     VsProfScope ps(VS_PROF_BWD_EDGE, stream);
     return vs_nhwc_first_bwd_impl(gb[c], x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
                                   g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
-                                  at<double>(tape, L.first_acc), stream);
+                                  at<double>(tape, L.first_acc) + 64, stream, at<double>(tape, L.first_acc));
   }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;

@@ -86,7 +86,8 @@ int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom,
 int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bias, double count, double* stats, hipStream_t);
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t);
+                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t,
+                           const double* moments = nullptr /* of x, when the caller still has them */);
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr,
