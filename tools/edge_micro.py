@@ -9,7 +9,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from voicesplit_amd import ops  # noqa: E402
+from voicesplit_amd import _lib, ops  # noqa: E402
+
+if os.environ.get("VS_MICRO_LIB"):          # a variant build of the library for A/B timing
+    _lib.load(os.path.join(ROOT, os.environ["VS_MICRO_LIB"]))
 
 
 def timed(fn, reps=5):

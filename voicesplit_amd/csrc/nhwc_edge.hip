@@ -137,7 +137,7 @@ void nhwc_bn_apply_kernel(const u4v* __restrict__ z, u4v* __restrict__ a, const 
     }
     return o;
   };
-  for (; i + stride < npieces; i += 2 * stride) {         // two pieces in flight per lane
+  for (; i + stride < npieces; i += 2 * stride) {         // two pieces in flight per lane (four: 0.628 vs 0.625 ms at B = 64, round 4)
     const u4v v0 = __builtin_nontemporal_load(z + i), v1 = __builtin_nontemporal_load(z + i + stride);
     __builtin_nontemporal_store(apply(v0), a + i);
     __builtin_nontemporal_store(apply(v1), a + i + stride);
@@ -669,8 +669,11 @@ void nhwc_first_bwd_kernel(const u4v* __restrict__ da, const float* __restrict__
   long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   int f = (int)(p % F);
   // The next pixel's gradient piece and input sample are loaded before this one is computed.  (Measured, tools/edge_micro.py at
-  // B = 64: 1.07 ms = 1.4 TB/s with or without this, with a ring three deep, and with branch-free loads -- the loop is bound by its
-  // ~160 packed VALU instructions + 16 transcendentals per 8-channel piece at 2 waves per SIMD, not by the loads.)
+  // B = 64: 1.07-1.10 ms = 1.4 TB/s with or without this, with a ring three deep, with branch-free loads, and with a two-deep ring
+  // of untracked inline-assembly loads + explicit vmcnt at one wave per SIMD -- and the scalar form of the arithmetic ran the
+  // same 1.1-1.2 ms as this packed one.  The loop is bound by its VALU work: ~160 instructions + 16 transcendentals per 8-channel
+  // piece, and v_pk_fma_f32 buys nothing over two v_fma_f32 here.  Halving it means the matrix pipe: z as a K = 7 contraction and
+  // the sums of dy x_k as a contraction over pixels -- not built.)
   auto process = [&](float mine, const u4v& g) {
     float xv[7];
     exchange_x7(mine, xv);
