@@ -235,6 +235,39 @@ def main_bf16_envelope():
           f"-> {os.path.getsize(path) / 1e3:.0f} kB")
 
 
+def main_audio():
+    """The audio legs either side of the model, through the UPSTREAM class openVoiceFilterAudioProcessor
+    (utils/audio_processor.py:440-567) executed by oracle/_refimport.import_reference_audio -- i.e. the reference's own lines for
+    wav2spec (:469-476), spec2wav with the mixture's phase (:483-491) and torch_spec2wav (:498-509: denormalisation, the
+    exp(cos) / exp(sin) spectrum, the non-periodic Hann window, the iSTFT arguments), with librosa.stft / librosa.istft /
+    torchaudio.functional.istft (absent from this image; the last one removed from torchaudio itself) stood in by torch.stft /
+    torch.istft.  Input: 0.5 s of one of the reference's demo mixtures and a seeded mask (not stored: torch.rand from the recorded seed)."""
+    from scipy.io import wavfile
+    from oracle._refimport import REFERENCE_ROOT, import_reference_audio
+    AP = import_reference_audio()
+    cfg = dict(sample_rate=16000, n_fft=1200, num_freq=601, hop_length=160, win_length=400, preemphasis=0.97, power=1.5,
+               min_level_db=-100.0, ref_level_db=20.0, num_mels=40, griffin_lim_iters=60)          # config.json:83-95
+    ap = AP(**cfg)
+    path = os.path.join(REFERENCE_ROOT, "datasets", "LibriSpeech", "audios_demo", "2_speakers", "noisy",
+                        "1701-141760-0023.251-136532-0023.wav")
+    sr, wav = wavfile.read(path)
+    assert sr == 16000 and wav.dtype == np.float32
+    wav = np.ascontiguousarray(wav[24000:24000 + 8000])                  # 0.5 s
+    spec, phase = ap.wav2spec(wav.astype(np.float64))                   # [51, 601] each
+    g = torch.Generator().manual_seed(123)
+    mask = torch.rand(spec.shape, generator=g, dtype=torch.float64).numpy()
+    wav_np = ap.spec2wav(spec * mask, phase)                            # numpy iSTFT with the mixture's phase (test.py's path)
+    wav_t = ap.torch_spec2wav(torch.from_numpy(spec * mask)[None], torch.from_numpy(phase)[None])[0].numpy()   # train.py:99
+    out = {"wav": wav, "mask_seed": np.array(123), "mask_sum": np.array(mask.sum()), "spec": spec, "phase": phase, "spec2wav": wav_np,
+           "torch_spec2wav": wav_t,
+           "torch_version": np.array(torch.__version__),
+           "source": np.array("datasets/LibriSpeech/audios_demo/2_speakers/noisy/1701-141760-0023.251-136532-0023.wav[24000:32000]")}
+    p = os.path.join(GOLDEN_DIR, "audio_upstream.npz")
+    np.savez_compressed(p, **out)
+    print(f"audio_upstream: spec [{spec.min():.3f}, {spec.max():.3f}], |spec2wav| <= {np.abs(wav_np).max():.3f}, "
+          f"|torch_spec2wav| <= {np.abs(wav_t).max():.3f} -> {os.path.getsize(p) / 1e3:.0f} kB")
+
+
 def main_loss():
     """Pins oracle/reference_loss.sisnr_with_pit to the upstream SiSNR_With_Pit
     (utils/generic_utils.py:416-474): seeded waveforms in, loss and d(loss)/d(estimate) out."""
@@ -324,6 +357,8 @@ def main_real():
 if __name__ == "__main__":
     if "--bf16-envelope" in sys.argv:
         main_bf16_envelope()
+    elif "--audio" in sys.argv:
+        main_audio()
     elif "--real" in sys.argv:
         main_real()
     elif "--powerlaw" in sys.argv:

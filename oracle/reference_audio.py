@@ -4,10 +4,12 @@ Restates, in numpy, ``openVoiceFilterAudioProcessor`` of utils/audio_processor.p
   * ``wav2spec``          :469-476  (stft :511-514, amp_to_db :537-538, normalize :543-544)
   * ``spec2wav`` w/ phase :483-491  (denormalize :546-547, db_to_amp :540-541, istft_phase :478-481)
 
-**Parity unpinned against upstream** (pinned instead to an independent implementation of the same
-algorithm, torch.stft / torch.istft, in tests/test_oracle.py): both call librosa (0.6-era ``librosa.stft`` / ``librosa.istft``),
-which is a third-party dependency that is not installed in this image, so the reference functions
-cannot be executed here.  Their published algorithm is restated instead:
+**Pinned to the upstream call sites, with the third-party transforms stood in** (round 4): librosa (0.6-era ``librosa.stft`` /
+``librosa.istft``) is not installed in this image, so ``oracle/_refimport.import_reference_audio`` executes the UPSTREAM class
+with ``torch.stft`` / ``torch.istft`` answering those two calls; ``oracle/make_golden.py --audio`` commits what the upstream lines
+return on a real clip (tests/golden/audio_upstream.npz) and tests/test_oracle.py holds this restatement to it (1e-9 on the
+spectrogram, 1e-12 on the waveform).  What stays outside the pin is librosa's own implementation of the two transforms; their
+published algorithm is restated here and cross-checked against torch's independent implementation to 1e-12:
 ``stft``: reflect-pad n_fft//2, frames of n_fft at stride hop, times the periodic Hann window of
 win_length zero-padded (centred) to n_fft, rfft;  ``istft``: irfft per frame, times the same padded
 window, overlap-add, divide by the overlap-added squared window where it exceeds ``tiny``, trim

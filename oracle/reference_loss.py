@@ -9,13 +9,15 @@ as composed by train.py:95-108.
 Pinning: ``SiSNR_With_Pit`` is pinned against the upstream class (``oracle/make_golden.py --loss``
 imports it from /root/reference and commits inputs/outputs to tests/golden/sisnr_loss.npz).
 ``power_law_compressed_loss`` is pinned the same way (tests/golden/powerlaw_loss.npz).
-``torch_spec2wav`` itself is **parity unpinned against upstream**: it calls
-``torchaudio.functional.istft``, which no longer exists in torchaudio (and torchaudio is not in
-this image), so the reference function cannot be executed.  The restatement uses ``torch.istft``,
-which is that function's successor with the same algorithm (irfft per frame, multiply by the
-zero-padded window, overlap-add, divide by the overlap-added squared window, trim n_fft/2 on both
-sides); everything else (denormalisation, the exp(cos)/exp(sin) spectrum, the non-periodic Hann
-window from ``hamming_window(win, periodic=False, alpha=.5, beta=.5)``) follows the cited lines.
+``torch_spec2wav`` is pinned to the upstream lines with ONE substitution (round 4): it calls
+``torchaudio.functional.istft``, which no longer exists in torchaudio (and torchaudio is not in this image);
+``oracle/_refimport.import_reference_audio`` executes the UPSTREAM function with that one call answered by ``torch.istft`` --
+the same routine after its move into torch (irfft per frame, multiply by the zero-padded window, overlap-add, divide by the
+overlap-added squared window, trim n_fft/2 on both sides) -- and ``oracle/make_golden.py --audio`` commits its output on a real
+clip (tests/golden/audio_upstream.npz; tests/test_oracle.py: this restatement reproduces it to 1e-6 of the waveform's maximum,
+the fp32 window of the upstream call being the difference).  Everything upstream's own -- the denormalisation, the
+exp(cos) / exp(sin) spectrum, the non-periodic Hann window from ``hamming_window(win, periodic=False, alpha=.5, beta=.5)``, the
+iSTFT arguments -- is therefore pinned; torchaudio's removed implementation itself is not.
 """
 from itertools import permutations
 

@@ -100,3 +100,36 @@ def test_real_clip_waveform_to_mask_matches_upstream():
         mask_c = m(spec_gpu, dvec).cpu().numpy()
     assert ((mask_c - ref) ** 2).mean() < 1e-4                                  # BASELINE: mask MSE <= 1e-4
     assert np.quantile(np.abs(mask_c - ref), 0.999) < 1e-2
+
+
+def test_gpu_audio_legs_against_the_upstream_audio_processor():
+    """The HIP front / back end and the training-side iSTFT against what the UPSTREAM openVoiceFilterAudioProcessor returned on
+    0.5 s of a reference demo mixture (tests/golden/audio_upstream.npz, made by `oracle/make_golden.py --audio` from
+    utils/audio_processor.py:469-509 with torch.stft / torch.istft standing in for librosa's and torchaudio's removed transform):
+    vs_wav_to_spec vs wav2spec, vs_spec_to_wav vs spec2wav with the mixture's phase, vs_sisnr_loss's estimated waveform vs
+    torch_spec2wav (the exp(cos) / exp(sin) spectrum and the non-periodic Hann window of :498-509)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from voicesplit_amd import audio, losses
+    z = np.load(os.path.join(GOLDEN_DIR, "audio_upstream.npz"))
+    g = torch.Generator().manual_seed(int(z["mask_seed"]))
+    mask = torch.rand(z["spec"].shape, generator=g, dtype=torch.float64)
+    assert abs(float(mask.sum()) - float(z["mask_sum"])) < 1e-9
+    wav = torch.from_numpy(z["wav"])[None].cuda()
+    spec, phase = audio.wav_to_spec(wav, AUDIO)
+    lin = lambda s_: np.power(10.0, ((s_ - 1.0) * 100.0 + 20.0) / 20.0)
+    got, ref = lin(spec[0].cpu().double().numpy()), lin(z["spec"])
+    assert (np.abs(got - ref) <= 2e-5 * ref + 3e-6 * ref.max(axis=1, keepdims=True)).all()
+    assert np.median(np.abs(spec[0].cpu().double().numpy() - z["spec"])) < 1e-6
+    strong = ref > 1e-2 * ref.max()
+    d = np.angle(np.exp(1j * (phase[0].cpu().double().numpy() - z["phase"])))
+    assert np.abs(d[strong]).max() < 1e-3
+    # back end on the UPSTREAM spectrogram / phase / mask
+    s32, p32, m32 = (torch.from_numpy(a.astype(np.float32))[None].cuda() for a in (z["spec"], z["phase"], mask.numpy()))
+    out = audio.spec_to_wav(s32, p32, AUDIO, mask=m32)[0].cpu().double().numpy()
+    assert np.abs(out - z["spec2wav"]).max() <= 3e-5 * np.abs(z["spec2wav"]).max()
+    # the loss head's waveform: mixed * mask -> torch_spec2wav (train.py:95-99)
+    tgt = torch.rand(1, *z["spec"].shape, generator=torch.Generator().manual_seed(1)).cuda()
+    _loss, est = losses.sisnr_loss(m32, s32, tgt, p32, None, AUDIO, return_wav=True)
+    est = est[0].cpu().double().numpy()
+    assert np.abs(est - z["torch_spec2wav"]).max() <= 3e-5 * np.abs(z["torch_spec2wav"]).max()

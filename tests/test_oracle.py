@@ -6,6 +6,7 @@
 3. the explicit LSTM recurrence / Mish restatements against torch's own ops.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -313,3 +314,48 @@ def test_bf16_storage_model_is_the_pinned_oracle_plus_roundings():
     worst = max(((ideal[k] - exact[k]).abs().max() / exact[k].abs().max()).item() for k in exact if k not in zero)
     assert 0.02 < worst < 1.5, worst                     # far above 2^-9, far below "wrong"
     assert float(((mask16 - mask) ** 2).mean()) < 1e-5   # while the mask itself barely moves
+
+
+# ---- the audio legs against the UPSTREAM audio processor (round 4) ------------------------------------------------------------
+def _audio_fixture():
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "audio_upstream.npz"))
+    g = torch.Generator().manual_seed(int(z["mask_seed"]))
+    mask = torch.rand(z["spec"].shape, generator=g, dtype=torch.float64).numpy()
+    assert abs(mask.sum() - float(z["mask_sum"])) < 1e-9, "torch.rand drifted: the fixture's mask cannot be rebuilt"
+    return z, mask
+
+
+def test_audio_oracles_reproduce_the_upstream_audio_processor():
+    """tests/golden/audio_upstream.npz = the reference's own openVoiceFilterAudioProcessor (utils/audio_processor.py:440-567) run
+    by `oracle/make_golden.py --audio`: wav2spec, spec2wav with the mixture's phase, torch_spec2wav on 0.5 s of a demo mixture.
+    (librosa / torchaudio.functional.istft are not obtainable: the upstream lines ran with torch.stft / torch.istft standing in for
+    those two transforms -- oracle/_refimport.py.)  The numpy restatement (oracle/reference_audio.py) and the torch one
+    (oracle/reference_loss.torch_spec2wav) must reproduce what the UPSTREAM code returned."""
+    from oracle import reference_audio as RA
+    from oracle import reference_loss as RL
+    z, mask = _audio_fixture()
+    spec, phase = RA.wav2spec(z["wav"].astype(np.float64))
+    assert spec.shape == z["spec"].shape == (51, 601)
+    assert np.abs(spec - z["spec"]).max() < 1e-9
+    strong = z["spec"] > 0.2                                       # the phase of an empty bin is noise in both
+    assert np.abs(np.angle(np.exp(1j * (phase - z["phase"]))))[strong].max() < 1e-6
+    back = RA.spec2wav(z["spec"] * mask, z["phase"])
+    assert np.abs(back - z["spec2wav"]).max() < 1e-12
+    tw = RL.torch_spec2wav(torch.from_numpy(z["spec"] * mask)[None], torch.from_numpy(z["phase"])[None])[0].numpy()
+    assert np.abs(tw - z["torch_spec2wav"]).max() <= 1e-6 * np.abs(z["torch_spec2wav"]).max()
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted")
+def test_audio_fixture_is_what_the_live_upstream_class_returns():
+    from oracle._refimport import import_reference_audio
+    z, mask = _audio_fixture()
+    ap = import_reference_audio()(sample_rate=16000, n_fft=1200, num_freq=601, hop_length=160, win_length=400, preemphasis=0.97, power=1.5,
+                                  min_level_db=-100.0, ref_level_db=20.0, num_mels=40, griffin_lim_iters=60)
+    spec, phase = ap.wav2spec(z["wav"].astype(np.float64))
+    assert np.array_equal(spec, z["spec"]) and np.array_equal(phase, z["phase"])
+    assert np.abs(ap.spec2wav(z["spec"] * mask, z["phase"]) - z["spec2wav"]).max() < 1e-15
+    tw = ap.torch_spec2wav(torch.from_numpy(z["spec"] * mask)[None], torch.from_numpy(z["phase"])[None])[0].numpy()
+    assert np.abs(tw - z["torch_spec2wav"]).max() < 1e-12
+    import sys
+    assert "librosa" not in sys.modules and "torchaudio" not in sys.modules       # the stand-ins do not leak

@@ -9,7 +9,9 @@
 as ONE call into libvoicesplit_hip.so (``vs_sisnr_loss``): the iSTFT as a GEMM against the windowed
 inverse-DFT basis, gather overlap-add, SI-SNR moments, and the gradient w.r.t. the mask.  The
 reference's ``torch_inv_spectrogram`` cannot run any more (``torchaudio.functional.istft`` was
-removed from torchaudio); this is its replacement on the device, quirks included.
+removed from torchaudio); this is its replacement on the device, quirks included -- checked on the GPU
+against the upstream lines themselves, executed with ``torch.istft`` in the removed call's place
+(tests/golden/audio_upstream.npz, tests/test_gpu_audio.py).
 """
 import ctypes
 
