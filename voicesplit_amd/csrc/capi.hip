@@ -102,7 +102,7 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
 // the parameters alone -- BatchNorm folded into per-channel scale/shift, conv weights in MFMA fragment order with
 // their power-of-two scale, W_ih split into f16 halves with its scale, W_hh in fragment order.  Independent of B, T.
 struct PrepLayout {
-  size_t bn_scale, bn_shift, conv_packed[6], conv_wscale, gemm_wscale, wih_hi, wih_lo, lstm_packed, total_bytes;
+  size_t bn_scale, bn_shift, conv_packed[6], conv_wscale, gemm_wscale, wih_hi, wih_lo, lstm_packed, head_packed, total_bytes;
 };
 struct Prep {
   float *bn_scale, *bn_shift;
@@ -111,6 +111,7 @@ struct Prep {
   float* gemm_wscale;     // [8]: scale2 of W_ih at [0..1], |max| scratch at [4]
   _Float16 *wih_hi, *wih_lo;
   float* lstm_packed;
+  void* head_packed;      // VS_MATH_BF16: fc1 / fc2 in the fused head's fragment order (head_fused.hip), else NULL
 };
 
 int prep_layout(const vs_dims* d, PrepLayout* L) {
@@ -126,6 +127,7 @@ int prep_layout(const vs_dims* d, PrepLayout* L) {
   L->wih_hi = take((size_t)8 * d->H * Kp * 2);
   L->wih_lo = take((size_t)8 * d->H * Kp * 2);
   L->lstm_packed = take(vs_lstm_packed_floats(d->H) * 4);
+  L->head_packed = take(d->math == VS_MATH_BF16 && vs_head_fused_supported(2 * d->H, d->FC1, d->FC2) ? vs_head_fused_packed_bytes(2 * d->H, d->FC1, d->FC2) : 0);
   L->total_bytes = off;
   return 0;
 }
@@ -145,6 +147,7 @@ int prep_pointers(const vs_dims* d, const void* blob, size_t bytes, Prep* P) {
   P->wih_hi = at<_Float16>(b, L.wih_hi);
   P->wih_lo = at<_Float16>(b, L.wih_lo);
   P->lstm_packed = at<float>(b, L.lstm_packed);
+  P->head_packed = (d->math == VS_MATH_BF16 && vs_head_fused_supported(2 * d->H, d->FC1, d->FC2)) ? at<void>(b, L.head_packed) : nullptr;
   return 0;
 }
 
@@ -752,9 +755,8 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // stage 3: head, models/voicesplit/model.py:83-87
 // ---------------------------------------------------------------------------------------------
-int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, void* ws, size_t ws_bytes,
-                float* logits, float* mask, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int head_fwd_impl(const vs_dims* d, const vs_params* p, const float* lstm_out, void* ws, size_t ws_bytes,
+                         float* logits, float* mask, hipStream_t stream, const void* head_packed) {
   vs_ws_layout L;
   if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
   VS_REQUIRE(p && p->fc1_w && p->fc1_b && p->fc2_w && p->fc2_b, "head: NULL parameter");
@@ -763,6 +765,20 @@ int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, voi
   float* h1 = at<float>(ws, L.fc1_out);
   const int M = d->B * d->T;
   ProfScope ps(VS_PROF_HEAD, stream);
+  if (d->math == VS_MATH_BF16 && vs_head_fused_supported(2 * d->H, d->FC1, d->FC2)) {
+    // one launch, h1 in registers between the two contractions (head_fused.hip).  The weights' fragment images come prepared
+    // (vs_prepare_weights) or are packed here into the conv stack's first activation buffer, idle by now (stream order) -- the
+    // same images either way, so the two routes stay bit-identical.  A clip of a frame or two at full width cannot hold them:
+    // the two-launch form below (same roundings, fp32 summation order differs)
+    const size_t need = vs_head_fused_packed_bytes(2 * d->H, d->FC1, d->FC2);
+    const void* img = head_packed;
+    if (!img && L.act1 - L.act0 >= need) {
+      void* scratch = at<void>(ws, L.act0);
+      if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * d->H, d->FC1, d->FC2, scratch, stream)) return rc;
+      img = scratch;
+    }
+    if (img) return vs_head_fused_impl(lstm_out, img, nullptr, logits, mask, M, 2 * d->H, d->FC1, d->FC2, stream);
+  }
   // VS_MATH_BF16: bf16-rounded operands on the bf16 matrix instruction, fp32 accumulate and epilogue
   const auto vs_gemm_nt_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_nt_bf16_impl : ::vs_gemm_nt_impl;
   // relu(lstm) -> fc1 -> relu
@@ -778,6 +794,11 @@ int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, voi
                                  p->fc2_b, nullptr, nullptr, 0, 1, 0, VS_ACT_SIGMOID, stream)) return rc;
   }
   return 0;
+}
+
+int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, void* ws, size_t ws_bytes,
+                float* logits, float* mask, void* stream_) {
+  return head_fwd_impl(d, p, lstm_out, ws, ws_bytes, logits, mask, (hipStream_t)stream_, nullptr);
 }
 
 int vs_forward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
@@ -834,6 +855,10 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
     if (int rc = vs_lstm_split_wih_impl(d->math, p->w_ih[0], p->w_ih[1], d->H, 8 * d->F, 8 * d->F + d->E,
                                         reinterpret_cast<unsigned*>(P.gemm_wscale + 4), P.gemm_wscale, P.wih_hi, P.wih_lo, stream)) return rc;
   }
+  if (P.head_packed) {
+    VS_REQUIRE(p->fc1_w && p->fc1_b && p->fc2_w && p->fc2_b, "prepare_weights: NULL head parameter");
+    if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * d->H, d->FC1, d->FC2, P.head_packed, stream)) return rc;
+  }
   return vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], P.lstm_packed, d->H, stream, d->math);
 }
 
@@ -846,7 +871,7 @@ int vs_forward_prepared(const vs_dims* d, const vs_params* p, const void* prepar
   if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
   if (int rc = conv_stack_impl(d, p, x, conv_act, VS_BN_EVAL, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
   if (int rc = bilstm_impl(d, p, nullptr, dvec, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
-  return vs_head_fwd(d, p, nullptr, ws, ws_bytes, nullptr, mask, stream);
+  return head_fwd_impl(d, p, nullptr, ws, ws_bytes, nullptr, mask, (hipStream_t)stream, P.head_packed);
 }
 
 }  // extern "C"

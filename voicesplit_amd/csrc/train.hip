@@ -293,6 +293,17 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   VsProfScope ps_head(VS_PROF_HEAD, stream);
   const int M = B * T;
   float* h1 = at<float>(tape, L.fc1_out);
+  if (d->math == VS_MATH_BF16 && vs_head_fused_supported(2 * H, d->FC1, d->FC2)) {
+    // one launch, h1 in registers between the two contractions and stored once for the backward pass (head_fused.hip); the weights'
+    // fragment images go into the backward pass's partial-sum scratch, idle during the forward pass
+    const size_t need = vs_head_fused_packed_bytes(2 * H, d->FC1, d->FC2);
+    const size_t room = L.conv_scales - L.partials;
+    if (room >= need) {
+      void* img = at<void>(tape, L.partials);
+      if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * H, d->FC1, d->FC2, img, stream)) return rc;
+      return vs_head_fused_impl(at<float>(tape, L.lstm_out), img, h1, nullptr, mask, M, 2 * H, d->FC1, d->FC2, stream);
+    }
+  }
   const auto vs_gemm_nt_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_nt_bf16_impl : ::vs_gemm_nt_impl;
   if (int rc = vs_gemm_nt_impl(at<float>(tape, L.lstm_out), 2 * H, p->fc1_w, 2 * H, h1, d->FC1, M, d->FC1, 2 * H,
                                p->fc1_b, nullptr, nullptr, 0, 1, 1, VS_ACT_RELU, stream)) return rc;

@@ -163,6 +163,12 @@ int vs_gemm_general_bf16_impl(int layout_a, int layout_w, const float* A, int ld
                          const float* gate, int ldg, int a_relu, int w_relu, int act, int accumulate,
                          int w_shift, int w_group, int splits, float* partials, hipStream_t);
 int vs_gemm_nt_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+// head_fused.hip: relu -> fc1 -> relu -> fc2 -> sigmoid in one launch (VS_MATH_BF16); h1 stays in registers between the two contractions
+bool vs_head_fused_supported(int K1, int FC1, int FC2);
+size_t vs_head_fused_packed_bytes(int K1, int FC1, int FC2);
+int vs_head_fused_pack_impl(const float* w1, const float* b1, const float* w2, const float* b2, int K1, int FC1, int FC2, void* packed, hipStream_t);
+int vs_head_fused_impl(const float* lstm_out, const void* packed, float* h1_out, float* logits, float* mask,
+                       int M, int K1, int FC1, int FC2, hipStream_t);
 int vs_gemm_nt_bf16_impl(const float*, int, const float*, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, float*, int, int, int, int, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 // gemm_bf16.hip: the LSTM contractions of the bf16 configuration (LDS-DMA ring, row / K-major operand forms)
