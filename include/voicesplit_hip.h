@@ -217,6 +217,22 @@ size_t vs_nhwc_conv_packed_bytes(int KT, int KF);
 int vs_nhwc_conv_pack(const float* w, void* packed, int KT, int KF, int transpose_flip, void* stream);
 int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                  int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream);
+/* The same 64 -> 64 convs, FORWARD, in the fp32-class split-f16 arithmetic (VS_MATH_F16X3) on channels-last operands
+ * (csrc/conv_nhwc_f16x3.hip; models/voicesplit/model.py:21-48 under model.eval()).  A tensor is two f16 planes [B][T][F][64]
+ * (hi, lo) and a power-of-two scale pair scale2 = {s, 1/s} in device memory: x = (hi + lo) / s (vs_f16x3_split / vs_f16x3_merge
+ * convert from / to fp32).  vs_nhwc_conv_f16x3_layer runs one layer from fp32 weights w [64][64][KT][KF] and folded BatchNorm
+ * constants (y = act(conv(x) * bn_scale + bn_shift)): it splits and packs the weights into `scratch`
+ * (vs_nhwc_conv_f16x3_scratch_bytes, 256-byte aligned; packed_ready != 0: a previous call with the same weights left them
+ * there), derives the output scale from max |x| (amax_in: n_amax uints holding the bit patterns of non-negative floats, their
+ * maximum = max |x|) and writes out_hi / out_lo / out_scale2 and, when amax_out is not NULL, folds max |y| into
+ * amax_out[VS_AMAX_SLOTS = 1024] (zero it first; it is the next layer's amax_in with n_amax = 1024). */
+size_t vs_nhwc_conv_f16x3_scratch_bytes(int KT, int KF);
+int vs_nhwc_conv_f16x3_layer(const void* in_hi, const void* in_lo, const float* in_scale2, const unsigned* amax_in, int n_amax,
+                             const float* w, const float* bn_scale, const float* bn_shift, void* scratch, int packed_ready,
+                             void* out_hi, void* out_lo, float* out_scale2, unsigned* amax_out,
+                             int B, int T, int F, int KT, int KF, int dil, int act, void* stream);
+int vs_f16x3_split(const float* x, const float* scale2, void* hi, void* lo, long long n, void* stream);
+int vs_f16x3_merge(const void* hi, const void* lo, const float* scale2, float* x, long long n, void* stream);
 /* bf16 GEMM of the same configuration (the three LSTM contractions): C[M][N] (+)= op(A) op(B) (+ rowbias[m / group][n]);
  * A, B bf16; *_kmajor = 0: element (i, k) at i*ld + k, 1: at k*ld + i (no transposed copies: transposing LDS reads).
  * vs_cvt_rows_bf16: fp32 [rows][ld] (K valid columns) -> bf16 [rows][Kp], zero padded.  Row-form operands must be

@@ -105,9 +105,12 @@ def test_stages_match_fp64_oracle(cls_name, act, B, T):
 def test_full_batch_properties():
     """BASELINE config: B=64, [64,301,601] + [64,256], fp32, forward only.  The oracle would take
     ~40 s of CPU for this, so check size-independent properties instead:
-    batch independence (eval BN): row i of the B=64 result == the same utterance run alone (bit
-    exact: no kernel's reduction order depends on B), duplicated utterances give identical masks,
-    outputs are finite and inside (0,1)."""
+    batch independence (eval BN): row i of the B=64 result == the same utterance run alone to fp32 rounding
+    (no kernel's reduction order depends on B, but the split-f16 operands carry one power-of-two scale per
+    TENSOR, derived from the batch's |max|: another scale moves which low parts fall under the f16 subnormal
+    step.  Measured 6e-7 on masks in (0, 1) -- tools/batch_independence_probe.py, both conv routes; the NCHW
+    route of rounds 1-3 is bit-exact only while the batch mates leave every layer's |max| in its binade),
+    duplicated utterances of one batch give identical masks, outputs are finite and inside (0,1)."""
     import voicesplit_amd as V
     dims_d = R.default_dims()
     sd = R.spread_logits(R.build_state_dict(dims_d, 0), 8.0)
@@ -126,7 +129,8 @@ def test_full_batch_properties():
     torch.cuda.synchronize()
     assert big.shape == (64, 301, 601)
     assert torch.isfinite(big).all() and big.min() >= 0 and big.max() <= 1
-    assert torch.equal(big[3], one[0]) and torch.equal(big[7], big[3]) and torch.equal(big[63], last[0])
+    assert torch.equal(big[7], big[3])
+    assert (big[3] - one[0]).abs().max().item() < 2e-6 and (big[63] - last[0]).abs().max().item() < 2e-6
     # and the B=1 result is the one pinned by the upstream golden (vs_full_b1 uses seed 0, x[0])
     g = load_golden("vs_full_b1")
     assert _rel(big[0:1].cpu().numpy(), g["mask"]) < REL_TOL
@@ -141,7 +145,8 @@ def test_library_is_the_loaded_native_code():
 
 def test_long_form_windows_match_per_window_calls():
     """BASELINE configs[4]: a 30 s clip (3001 frames) cut into 10 independent 301-frame windows
-    and run as one batch gives exactly what the module gives window by window."""
+    and run as one batch gives what the module gives window by window -- to fp32 rounding: the split-f16 operands'
+    power-of-two scales are per tensor, i.e. per batch (test_full_batch_properties)."""
     import voicesplit_amd as V
     from voicesplit_amd.streaming import plan_windows, separate_long
     dims_d = R.default_dims()
@@ -158,12 +163,12 @@ def test_long_form_windows_match_per_window_calls():
     assert len(plan) == 10
     with torch.no_grad():
         w3 = m(spec[903:1204][None].contiguous(), dvec[None])          # window 3 on its own
-    assert torch.equal(mask[903:1204], w3[0])
+    assert (mask[903:1204] - w3[0]).abs().max().item() < 2e-6
     last = torch.zeros(1, 301, 601, device="cuda")
     last[0, :292] = spec[2709:]
     with torch.no_grad():
         w9 = m(last, dvec[None])
-    assert torch.equal(mask[2709:], w9[0, :292])
+    assert (mask[2709:] - w9[0, :292]).abs().max().item() < 2e-6
 
 
 def test_exact_long_form_equals_a_whole_clip_pass():

@@ -1,0 +1,101 @@
+"""GPU: the 64 -> 64 convs of models/voicesplit/model.py:21-48 (eval-mode BatchNorm folded, activation fused) in the
+fp32-class split-f16 arithmetic on channels-last hi / lo planes (csrc/conv_nhwc_f16x3.hip), against fp64.
+
+Two comparisons per case: against fp64 on the operands the kernel was GIVEN (x reconstructed from its planes: what is left is the
+weights' split, the dropped lo x lo product, fp32 accumulation and the output split -- 1e-6 of the tensor's range), and against
+fp64 on the original fp32 tensor (adds the input split: the path's contract, REL_TOL = 1e-4 with two orders of margin)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act(y, act):
+    if act == "relu":
+        return y.clamp_min(0)
+    if act == "mish":
+        return y * torch.tanh(F.softplus(y, threshold=20))
+    return y
+
+
+def _merge(hi, lo, s2):
+    return (hi.double() + lo.double()) * s2[1].double()
+
+
+@pytest.mark.parametrize("act", ["mish", "relu", "none"])
+@pytest.mark.parametrize("B,T,Fq,KT,KF,dil", [
+    (2, 37, 53, 5, 5, 1), (1, 61, 40, 5, 5, 2), (3, 30, 17, 5, 5, 16), (2, 33, 70, 7, 1, 1), (1, 5, 16, 5, 5, 1), (1, 2, 3, 7, 1, 1),
+])
+def test_layer_matches_fp64(act, B, T, Fq, KT, KF, dil):
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(T * 10 + dil)
+    x = torch.randn(B, T, Fq, 64, generator=g) * torch.rand(1, 1, 1, 64, generator=g) * 3.0
+    w = torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5
+    sc = (torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.2, -1.0, 1.0)
+    sh = torch.randn(64, generator=g) * 0.5
+    hi, lo, s2 = ops.f16x3_split(x.cuda(), 2.0 ** 7)
+    oh, ol, os2, amax, _ = ops.nhwc_conv_f16x3(hi, lo, s2, w.cuda(), sc.cuda(), sh.cuda(), dil, act)
+    got = _merge(oh, ol, os2).cpu()
+
+    def ref_of(xin):
+        z = F.conv2d(xin.permute(0, 3, 1, 2), w.double(), None, padding=((KT // 2) * dil, KF // 2), dilation=(dil, 1))
+        return _act(z * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), act).permute(0, 2, 3, 1)
+
+    given = ref_of(_merge(hi, lo, s2).cpu())
+    scale = given.abs().max()
+    assert torch.isfinite(got).all()
+    assert ((got - given).abs().max() / scale).item() < 2e-6
+    assert ((got - ref_of(x.double())).abs().max() / scale).item() < 3e-6
+    # the output scale is a power of two that keeps the planes inside f16, and the tracked |max| is the tensor's
+    s = os2[0].item()
+    assert s == 2.0 ** round(torch.log2(torch.tensor(s)).item()) and (oh.float().abs().max() < 32768.0)
+    tracked = amax.view(torch.float32).max().item()
+    assert tracked >= scale.item() * (1 - 1e-6)
+    assert tracked <= max(scale.item(), _act(sh.double(), act).abs().max().item()) * (1 + 1e-5)
+
+
+def test_layers_chain_on_their_own_scales_and_reuse_packed_weights():
+    """Three layers back to back: each consumes the planes, scale pair and tracked |max| the previous one produced; the second
+    call with packed_ready reuses the scratch."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, Fq = 2, 40, 37
+    x = torch.randn(B, T, Fq, 64, generator=g)
+    ws = [torch.randn(64, 64, kt, kf, generator=g) / (64 * kt * kf) ** 0.5 * 1.7 for kt, kf in ((7, 1), (5, 5), (5, 5))]
+    dils = [1, 1, 2]
+    sc = [torch.rand(64, generator=g) + 0.5 for _ in ws]
+    sh = [torch.randn(64, generator=g) * 0.2 for _ in ws]
+    hi, lo, s2 = ops.f16x3_split(x.cuda(), 2.0 ** 9)
+    amax = None
+    ref = x.double()
+    scratches = []
+    for w, d, a, b in zip(ws, dils, sc, sh):
+        hi, lo, s2, amax, scr = ops.nhwc_conv_f16x3(hi, lo, s2, w.cuda(), a.cuda(), b.cuda(), d, "mish", amax_in=amax)
+        scratches.append(scr)
+        kt, kf = w.shape[2], w.shape[3]
+        z = F.conv2d(ref.permute(0, 3, 1, 2), w.double(), None, padding=((kt // 2) * d, kf // 2), dilation=(d, 1))
+        ref = _act(z * a.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1), "mish").permute(0, 2, 3, 1)
+        got = _merge(hi, lo, s2).cpu()
+        assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    # packed_ready: same result, bit for bit
+    h0, l0, s0 = ops.f16x3_split(x.cuda(), 2.0 ** 9)
+    a1 = ops.nhwc_conv_f16x3(h0, l0, s0, ws[0].cuda(), sc[0].cuda(), sh[0].cuda(), 1, "mish")
+    a2 = ops.nhwc_conv_f16x3(h0, l0, s0, ws[0].cuda(), sc[0].cuda(), sh[0].cuda(), 1, "mish", scratch=scratches[0])
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+
+
+def test_full_width_timing_shapes_run():
+    """The metric configuration's layer shape at a reduced batch (B = 4): finite, deterministic, batch-independent."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 301, 601, 64, generator=g)
+    w = torch.randn(64, 64, 5, 5, generator=g) / 40.0
+    sc, sh = torch.ones(64), torch.zeros(64)
+    hi, lo, s2 = ops.f16x3_split(x.cuda(), 2.0 ** 8)
+    a = ops.nhwc_conv_f16x3(hi, lo, s2, w.cuda(), sc.cuda(), sh.cuda(), 4, "mish")
+    b = ops.nhwc_conv_f16x3(hi, lo, s2, w.cuda(), sc.cuda(), sh.cuda(), 4, "mish")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    one = ops.nhwc_conv_f16x3(hi[2:3].contiguous(), lo[2:3].contiguous(), s2, w.cuda(), sc.cuda(), sh.cuda(), 4, "mish",
+                              amax_in=((hi.float() + lo.float()) * s2[1]).abs().max().reshape(1).view(torch.int32))
+    assert torch.equal(one[0][0], a[0][2]) and torch.equal(one[1][0], a[1][2])

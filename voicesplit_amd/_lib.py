@@ -108,6 +108,11 @@ SIGNATURES = {
     "vs_cvt_rows_bf16": (c_int, [_P, c_longlong, c_int, c_int, _P, c_int, _P]),
     "vs_gemm_bf16": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "vs_gemm_bf16_split": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_nhwc_conv_f16x3_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "vs_nhwc_conv_f16x3_layer": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P,
+                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vs_f16x3_split": (c_int, [_P, _P, _P, _P, c_longlong, _P]),
+    "vs_f16x3_merge": (c_int, [_P, _P, _P, _P, c_longlong, _P]),
     "vs_nhwc_conv_first": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_nhwc_first_moments": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vs_nhwc_first_stats": (c_int, [_P, _P, _P, ctypes.c_double, _P, _P]),

@@ -1,6 +1,7 @@
 // extern "C" surface of libvoicesplit_hip.so (declared in include/voicesplit_hip.h) and the
 // orchestration of the forward pass: which kernel runs on which buffer, in which order.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/voicesplit_hip.h"
@@ -63,6 +64,20 @@ int check_dims(const vs_dims* d) {
   return 0;
 }
 
+// packed weights of mid layer i in whichever form the configuration uses (fp32 MFMA fragments are the largest of the NCHW
+// forms; the channels-last split-f16 forward keeps its row norms / scale / per-call plan behind the packed planes)
+size_t conv_packed_bytes(int i) {
+  const size_t a = vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4, b = vs_nhwc_f16x3_layer_scratch_bytes(kMid[i].kt, kMid[i].kf);
+  return a > b ? a : b;
+}
+
+// Eval-mode forward of the fp32-class arithmetic: channels-last hi / lo planes (conv_nhwc_f16x3.hip), or -- VOICESPLIT_F16X3_CONV=nchw,
+// the A/B switch -- the [B][64][T][F] kernels of rounds 1-2, which train mode keeps using (its tape is fp32 NCHW).
+bool split_route() {
+  static const bool nchw = getenv("VOICESPLIT_F16X3_CONV") && !strcmp(getenv("VOICESPLIT_F16X3_CONV"), "nchw");
+  return !nchw;
+}
+
 int layout(const vs_dims* d, vs_ws_layout* L) {
   if (int rc = check_dims(d)) return rc;
   const size_t B = d->B, T = d->T, F = d->F, H = d->H;
@@ -75,7 +90,7 @@ int layout(const vs_dims* d, vs_ws_layout* L) {
   L->xg = take(B * T * 8 * H * 4);
   L->lstm_out = take(B * T * 2 * H * 4);
   L->fc1_out = take(B * T * (size_t)d->FC1 * 4);
-  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(conv_packed_bytes(i));
   L->bn_scale = take(8 * 64 * 4);
   L->bn_shift = take(8 * 64 * 4);
   L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);    // partial slots of one layer at a time (stream-ordered reuse)
@@ -120,7 +135,7 @@ int prep_layout(const vs_dims* d, PrepLayout* L) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   L->bn_scale = take(8 * 64 * 4);
   L->bn_shift = take(8 * 64 * 4);
-  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(conv_packed_bytes(i));
   L->conv_wscale = take(6 * 8 * 4);
   L->gemm_wscale = take(8 * 4);
   const size_t Kp = ((size_t)8 * d->F + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
@@ -367,6 +382,28 @@ int vs_nhwc_conv(const void* in, const void* packed, const float* scale, const f
                  int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, void* stream) {
   VS_REQUIRE(in != out, "nhwc_conv: in-place is not supported");
   return vs_nhwc_conv_impl(in, packed, scale, shift, out, B, T, F, KT, KF, dil, act, bn_stats, (hipStream_t)stream);
+}
+
+size_t vs_nhwc_conv_f16x3_scratch_bytes(int KT, int KF) { return vs_nhwc_f16x3_layer_scratch_bytes(KT, KF); }
+
+int vs_nhwc_conv_f16x3_layer(const void* in_hi, const void* in_lo, const float* in_scale2, const unsigned* amax_in, int n_amax,
+                             const float* w, const float* bn_scale, const float* bn_shift, void* scratch, int packed_ready,
+                             void* out_hi, void* out_lo, float* out_scale2, unsigned* amax_out,
+                             int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
+  VS_REQUIRE(in_hi != out_hi && in_lo != out_lo && in_hi != out_lo && in_lo != out_hi, "nhwc_conv_f16x3: in-place is not supported");
+  VS_REQUIRE(in_scale2 && amax_in && n_amax > 0 && bn_scale && bn_shift && out_scale2, "nhwc_conv_f16x3: NULL argument");
+  VS_REQUIRE(scratch != nullptr, "nhwc_conv_f16x3: NULL scratch");
+  float* plan = reinterpret_cast<float*>(static_cast<char*>(scratch) + vs_nhwc_f16x3_wpart_bytes(KT, KF));
+  return vs_nhwc_f16x3_layer_impl(in_hi, in_lo, in_scale2, amax_in, n_amax, w, bn_scale, bn_shift, scratch, packed_ready, plan, out_hi, out_lo,
+                                  out_scale2, amax_out, B, T, F, KT, KF, dil, act, (hipStream_t)stream);
+}
+
+int vs_f16x3_split(const float* x, const float* scale2, void* hi, void* lo, long long n, void* stream) {
+  return vs_f16x3_split_impl(x, scale2, hi, lo, n, (hipStream_t)stream);
+}
+
+int vs_f16x3_merge(const void* hi, const void* lo, const float* scale2, float* x, long long n, void* stream) {
+  return vs_f16x3_merge_impl(hi, lo, scale2, x, n, (hipStream_t)stream);
 }
 
 int vs_cvt_rows_bf16(const float* src, long long rows, int K, int ld, void* dst, int Kp, void* stream) {
@@ -640,6 +677,39 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
     return 0;
   }
 
+  if (d->math == VS_MATH_F16X3 && !train && split_route()) {
+    // BASELINE configs[1]: activations as channels-last hi / lo f16 planes in the same ping-pong buffers; every layer writes its
+    // output at a scale derived on the device from the tracked |max| of its input (conv_nhwc_f16x3.hip), no host round trip
+    const size_t half = (size_t)B * T * F * 64 * 2;
+    char* plane[2][2] = {{at<char>(ws, L.act0), at<char>(ws, L.act0) + half}, {at<char>(ws, L.act1), at<char>(ws, L.act1) + half}};
+    float* cs = at<float>(ws, L.conv_scales);
+    VS_CHECK_HIP(hipMemsetAsync(cs, 0, 8 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
+    auto slot = [&](int l) { return cs + VS_SCALE_SLOT_FLOATS * l; };          // [0..1]: scale pair of layer l's input; + 8: its |max|
+    {
+      ProfScope ps(VS_PROF_CNN1, stream);
+      if (int rc = vs_absmax_any_impl(x, (long long)B * T * F, vs_amax_slot(slot(0)), stream)) return rc;
+      if (int rc = vs_nhwc_first_plan_impl(vs_amax_slot(slot(0)), 1, p->conv[0].weight, scale, shift, slot(1), stream)) return rc;
+      if (int rc = vs_nhwc_conv_first_split_impl(x, p->conv[0].weight, scale, shift, slot(1), plane[0][0], plane[0][1], vs_amax_slot(slot(1)),
+                                                 B, T, F, layer_act, stream)) return rc;
+    }
+    int c = 0;
+    for (int i = 0; i < 6; ++i) {
+      const int l = i + 1;
+      ProfScope ps(VS_PROF_CNN2 + i, stream);
+      char* mine = at<char>(ws, L.conv_packed[i]);
+      void* wpart = prep ? prep->conv_packed[i] : mine;
+      float* plan = reinterpret_cast<float*>(mine + vs_nhwc_f16x3_wpart_bytes(kMid[i].kt, kMid[i].kf));
+      if (int rc = vs_nhwc_f16x3_layer_impl(plane[c][0], plane[c][1], slot(l), vs_amax_slot(slot(l)), VS_AMAX_SLOTS, p->conv[l].weight,
+                                            scale + 64 * l, shift + 64 * l, wpart, prep ? 1 : 0, plan, plane[c ^ 1][0], plane[c ^ 1][1],
+                                            slot(l + 1), l < 6 ? vs_amax_slot(slot(l + 1)) : nullptr, B, T, F, kMid[i].kt, kMid[i].kf,
+                                            kMid[i].dil, layer_act, stream)) return rc;
+      c ^= 1;
+    }
+    ProfScope ps(VS_PROF_CNN8, stream);
+    return vs_nhwc_conv_last_split_impl(plane[c][0], plane[c][1], slot(7), p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat,
+                                        B, T, F, layer_act, stream);
+  }
+
   int cur = 0;
   // split-f16 convs: every producer of a conv operand folds its |max| into the consumer's slot
   float* cs = at<float>(ws, L.conv_scales);
@@ -837,6 +907,8 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
     const float* w = p->conv[i + 1].weight;
     if (d->math == VS_MATH_BF16) {
       if (int rc = vs_nhwc_pack_impl(w, P.conv_packed[i], kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+    } else if (d->math == VS_MATH_F16X3 && split_route()) {
+      if (int rc = vs_nhwc_f16x3_prepare_wpart_impl(w, P.conv_packed[i], kMid[i].kt, kMid[i].kf, stream)) return rc;
     } else if (d->math != VS_MATH_FP32) {
       float* ws8 = P.conv_wscale + 8 * i;
       if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0,

@@ -986,3 +986,227 @@ int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7,
   VS_LAUNCH_CHECK();
   return vs_reduce_partials_impl(part, (int)nb, 512, dw, stream);
 }
+
+// ---- the same two edges for the channels-last split-f16 forward (conv_nhwc_f16x3.hip: VS_MATH_F16X3, eval BatchNorm) ---------------
+// cnn1 computes in fp32 (7 FMAs per output) and writes y * s_y as hi / lo f16 planes; s_y comes from vs_nhwc_first_plan_impl's bound.
+// cnn8 reads the planes of cnn7's output and contracts them on the f16 matrix pipe with its 8 x 64 weights split the same way.
+namespace {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+// out_scale2 <- {s, 1 / s}, s = the power of two that maps max_c (|scale_c| sum_j |w_cj| max|x| + |shift_c|) (>= max |y|) into [2^14, 2^15)
+__global__ void nhwc_first_plan_kernel(const unsigned* __restrict__ amax_in, int n_amax, const float* __restrict__ w, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float* __restrict__ out_scale2) {
+  const int c = threadIdx.x;                                  // 64 threads
+  unsigned mb = 0;
+  for (int i = c; i < n_amax; i += 64) mb = amax_in[i] > mb ? amax_in[i] : mb;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mb, o, 64); mb = other > mb ? other : mb; }
+  float l1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) l1 += fabsf(w[c * 7 + k]);
+  float bound = fmaxf(fabsf(scale[c]) * l1 * __uint_as_float(mb) + fabsf(shift[c]), 0.3125f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+  if (c == 0) {
+    float s = 1.f, si = 1.f;
+    if (bound > 0.f && bound < 3.0e38f) {
+      int e = 0;
+      (void)frexpf(bound, &e);
+      int k = 15 - e;
+      k = k > 100 ? 100 : (k < -100 ? -100 : k);
+      s = ldexpf(1.f, k);
+      si = ldexpf(1.f, -k);
+    }
+    out_scale2[0] = s;
+    out_scale2[1] = si;
+  }
+}
+
+// max |x| of the path's input (any 4-byte alignment: the mixture may be a slice of a batch), folded into *amax (bits of a float >= 0)
+__global__ __launch_bounds__(256)
+void absmax_any_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ amax) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_conv_first_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const float* __restrict__ out_scale2, unsigned short* __restrict__ out_hi,
+                                  unsigned short* __restrict__ out_lo, unsigned* __restrict__ amax_out, long long npix, int F) {
+  const int piece = threadIdx.x & 7;
+  vs_f32x2 wr[4][7], sc[4], sh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = piece * 8 + 2 * q;
+    sc[q] = vs_f32x2{scale[c0], scale[c0 + 1]};
+    sh[q] = vs_f32x2{shift[c0], shift[c0 + 1]};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wr[q][k] = vs_f32x2{w[c0 * 7 + k], w[(c0 + 1) * 7 + k]};
+  }
+  const float sy = out_scale2[0];
+  float am = 0.f;
+  const long long stride = (long long)gridDim.x * 32;
+  const int sr = (int)(stride % F);
+  long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  int f = (int)(p % F);
+  float mine = p < npix ? load_x7(x + (p - f), f, F, piece) : 0.f;
+  for (; p < npix; p += stride) {
+    int fn = f + sr;
+    if (fn >= F) fn -= F;
+    const long long pn = p + stride;
+    const float mine_next = pn < npix ? load_x7(x + (pn - fn), fn, F, piece) : 0.f;
+    float xv[7];
+    exchange_x7(mine, xv);
+    mine = mine_next;
+    f = fn;
+    u4v ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vs_f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) s2 = __builtin_elementwise_fma(wr[q][k], vs_f32x2{xv[k], xv[k]}, s2);
+      vs_f32x2 y = vs_act_fast2<ACT>(__builtin_elementwise_fma(s2, sc[q], sh[q]));
+      am = fmaxf(am, fmaxf(fabsf(y.x), fabsf(y.y)));
+      y = y * sy;
+      const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y.x, y.y));
+      const h2v h = __builtin_bit_cast(h2v, hb);
+      ph[q] = hb;
+      pl[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y.x - (float)h[0], y.y - (float)h[1]));
+    }
+    __builtin_nontemporal_store(ph, reinterpret_cast<u4v*>(out_hi + p * 64 + piece * 8));
+    __builtin_nontemporal_store(pl, reinterpret_cast<u4v*>(out_lo + p * 64 + piece * 8));
+  }
+  vs_absmax_commit(am, amax_out);
+}
+
+// out[b][t][co][f] = act(scale[co] * sum_ci w[co][ci] x[b][t][f][ci] + shift[co]), co < 8, x = (in_hi + in_lo) / s_x.
+// One wave = 16 pixels per step: B operands = the two planes' pixels as they lie in memory, A = the weights (rows 8..15 zero)
+// split into hi / lo after a power-of-two scale found here (512 values: one wave reduction); three products, fp32 accumulate.
+template <int ACT>
+__global__ __launch_bounds__(256)
+void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const unsigned short* __restrict__ in_lo, const float* __restrict__ in_scale2,
+                                 const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
+                                 float* __restrict__ out, long long nrows, int F) {
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  float wv[2][8], wmax = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wv[kc][j] = n < 8 ? w[n * 64 + kc * 32 + g * 8 + j] : 0.f;
+      wmax = fmaxf(wmax, fabsf(wv[kc][j]));
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+  float sw = 1.f, swi = 1.f;
+  if (wmax > 0.f && wmax < 3.0e38f) {
+    int e = 0;
+    (void)frexpf(wmax, &e);
+    sw = ldexpf(1.f, 10 - e);
+    swi = ldexpf(1.f, e - 10);
+  }
+  h8v wh[2], wl[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = wv[kc][j] * sw;
+      wh[kc][j] = (_Float16)v;
+      wl[kc][j] = (_Float16)(v - (float)wh[kc][j]);
+    }
+  const float inv = in_scale2[1] * swi;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = (g * 4 + r) & 7;
+    sc[r] = scale[co] * inv;
+    sh[r] = shift[co];
+  }
+  const int blocks_per_row = (F + 15) >> 4;
+  const long long nblk = nrows * blocks_per_row;
+  const long long wstride = (long long)gridDim.x * 4;
+  const long long sq = wstride / blocks_per_row;
+  const int sr = (int)(wstride - sq * blocks_per_row);
+  long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  long long row = blk / blocks_per_row;
+  int bc = (int)(blk - row * blocks_per_row);
+  for (; blk < nblk; blk += wstride, row += sq, bc += sr) {
+    if (bc >= blocks_per_row) { bc -= blocks_per_row; ++row; }
+    const int f = bc * 16 + n;
+    const bool ok = f < F;
+    const size_t e0 = (size_t)((row * F + (ok ? f : 0)) << 6);
+    const u4v* sh_ = reinterpret_cast<const u4v*>(in_hi + e0) + g;
+    const u4v* sl_ = reinterpret_cast<const u4v*>(in_lo + e0) + g;
+    const u4v z4 = {0u, 0u, 0u, 0u};
+    const u4v h0 = ok ? __builtin_nontemporal_load(sh_) : z4, h1 = ok ? __builtin_nontemporal_load(sh_ + 4) : z4;
+    const u4v l0 = ok ? __builtin_nontemporal_load(sl_) : z4, l1 = ok ? __builtin_nontemporal_load(sl_ + 4) : z4;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], __builtin_bit_cast(h8v, h0), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1], __builtin_bit_cast(h8v, h1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], __builtin_bit_cast(h8v, l0), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], __builtin_bit_cast(h8v, l1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], __builtin_bit_cast(h8v, h0), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], __builtin_bit_cast(h8v, h1), c, 0, 0, 0);
+    if (ok && g < 2) {
+      float* o = out + (row * 8 + g * 4) * F + f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)r * F] = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r]));
+    }
+  }
+}
+
+}  // namespace
+
+int vs_absmax_any_impl(const float* x, long long n, unsigned* amax, hipStream_t stream) {
+  VS_REQUIRE(x && amax && n > 0, "absmax: bad argument");
+  hipLaunchKernelGGL(absmax_any_kernel, dim3(stream_blocks(256 * 16, n)), dim3(256), 0, stream, x, n, amax);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_nhwc_first_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2,
+                            hipStream_t stream) {
+  VS_REQUIRE(amax_in && n_amax > 0 && w && scale && shift && out_scale2, "nhwc first_plan: bad argument");
+  hipLaunchKernelGGL(nhwc_first_plan_kernel, dim3(1), dim3(64), 0, stream, amax_in, n_amax, w, scale, shift, out_scale2);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_nhwc_conv_first_split_impl(const float* x, const float* w, const float* scale, const float* shift, const float* out_scale2,
+                                  void* out_hi, void* out_lo, unsigned* amax_out, int B, int T, int F, int act, hipStream_t stream) {
+  VS_REQUIRE(x && w && scale && shift && out_scale2 && out_hi && out_lo, "nhwc conv_first_split: NULL argument");
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_first_split: bad shape");
+  const long long npix = (long long)B * T * F;
+  const dim3 grid(stream_blocks(32, npix)), block(256);
+  unsigned short* oh = reinterpret_cast<unsigned short*>(out_hi);
+  unsigned short* ol = reinterpret_cast<unsigned short*>(out_lo);
+  if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_first_split_kernel<VS_ACT_NONE>), grid, block, 0, stream, x, w, scale, shift, out_scale2, oh, ol, amax_out, npix, F);
+  else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_first_split_kernel<VS_ACT_MISH>), grid, block, 0, stream, x, w, scale, shift, out_scale2, oh, ol, amax_out, npix, F);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_first_split_kernel<VS_ACT_RELU>), grid, block, 0, stream, x, w, scale, shift, out_scale2, oh, ol, amax_out, npix, F);
+  else VS_REQUIRE(false, "nhwc conv_first_split: unsupported activation %d", act);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_nhwc_conv_last_split_impl(const void* in_hi, const void* in_lo, const float* in_scale2, const float* w, const float* scale,
+                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t stream) {
+  VS_REQUIRE(in_hi && in_lo && in_scale2 && w && scale && shift && out, "nhwc conv_last_split: NULL argument");
+  VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last_split: bad shape");
+  const long long nrows = (long long)B * T;
+  const long long nblk = nrows * ((F + 15) / 16);
+  const dim3 grid(stream_blocks(4, nblk)), block(256);
+  const unsigned short* ih = reinterpret_cast<const unsigned short*>(in_hi);
+  const unsigned short* il = reinterpret_cast<const unsigned short*>(in_lo);
+  if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_NONE>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
+  else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_MISH>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_RELU>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
+  else VS_REQUIRE(false, "nhwc conv_last_split: unsupported activation %d", act);
+  VS_LAUNCH_CHECK();
+  return 0;
+}

@@ -71,6 +71,30 @@ size_t vs_nhwc_packed_bytes(int KT, int KF);
 int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
+// conv_nhwc_f16x3.hip: the same convs, forward, in the fp32-class split-f16 arithmetic on channels-last hi / lo f16 planes
+size_t vs_nhwc_f16x3_packed_bytes(int KT, int KF);
+int vs_nhwc_f16x3_pack_impl(const float* w, const float* w_scale2, void* packed, float* l1, int KT, int KF, hipStream_t);
+int vs_nhwc_f16x3_plan_impl(const float* in_scale2, const float* w_scale2, const unsigned* amax_in, int n_amax, const float* bn_scale,
+                            const float* bn_shift, const float* l1, float* eff_scale, float* eff_shift, float* out_scale2, hipStream_t);
+int vs_nhwc_conv_f16x3_impl(const void* in_hi, const void* in_lo, const void* packed, const float* scale, const float* shift,
+                            const float* out_scale2, void* out_hi, void* out_lo, unsigned* amax_out,
+                            int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
+int vs_f16x3_split_impl(const float* x, const float* scale2, void* hi, void* lo, long long n, hipStream_t);
+int vs_f16x3_merge_impl(const void* hi, const void* lo, const float* scale2, float* x, long long n, hipStream_t);
+size_t vs_nhwc_f16x3_layer_scratch_bytes(int KT, int KF);
+size_t vs_nhwc_f16x3_wpart_bytes(int KT, int KF);
+int vs_nhwc_f16x3_prepare_wpart_impl(const float* w, void* wpart, int KT, int KF, hipStream_t);
+int vs_nhwc_f16x3_layer_impl(const void* in_hi, const void* in_lo, const float* in_scale2, const unsigned* amax_in, int n_amax,
+                             const float* w, const float* bn_scale, const float* bn_shift, void* wpart, int packed_ready, float* plan,
+                             void* out_hi, void* out_lo, float* out_scale2, unsigned* amax_out,
+                             int B, int T, int F, int KT, int KF, int dil, int act, hipStream_t);
+// nhwc_edge.hip: cnn1 / cnn8 on the same planes
+int vs_absmax_any_impl(const float* x, long long n, unsigned* amax, hipStream_t);
+int vs_nhwc_first_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2, hipStream_t);
+int vs_nhwc_conv_first_split_impl(const float* x, const float* w, const float* scale, const float* shift, const float* out_scale2,
+                                  void* out_hi, void* out_lo, unsigned* amax_out, int B, int T, int F, int act, hipStream_t);
+int vs_nhwc_conv_last_split_impl(const void* in_hi, const void* in_lo, const float* in_scale2, const float* w, const float* scale,
+                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t);
 // wgrad_nhwc.hip: their weight gradient (pairs of workgroups, one partial-sum slab per pair)
 #define VS_NHWC_WGRAD_MAX_PAIRS 128
 size_t vs_nhwc_wgrad_partial_floats(int KT, int KF);

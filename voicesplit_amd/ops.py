@@ -681,6 +681,50 @@ def nhwc_conv(x, w, scale, shift, dil: int, act: str, transpose_flip: bool = Fal
     return (out, st.sum(0)) if stats else out
 
 
+def f16x3_split(x, scale: float):
+    """fp32 tensor -> (hi, lo) f16 planes of x * scale (scale a power of two) and the device scale pair {s, 1/s}."""
+    lib = _lib.load()
+    _dev_check(x, "x")
+    s2 = torch.tensor([scale, 1.0 / scale], dtype=torch.float32, device=x.device)
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi)
+    check(lib.vs_f16x3_split(_p(x), _p(s2), _p(hi), _p(lo), x.numel(), _stream()), "vs_f16x3_split")
+    return hi, lo, s2
+
+
+def f16x3_merge(hi, lo, scale2):
+    lib = _lib.load()
+    x = torch.empty(hi.shape, dtype=torch.float32, device=hi.device)
+    check(lib.vs_f16x3_merge(_p(hi), _p(lo), _p(scale2), _p(x), x.numel(), _stream()), "vs_f16x3_merge")
+    return x
+
+
+def nhwc_conv_f16x3(hi, lo, scale2, w, bn_scale, bn_shift, dil: int, act: str, amax_in=None, scratch=None):
+    """One 64 -> 64 layer in the split-f16 arithmetic on channels-last planes (vs_nhwc_conv_f16x3_layer): hi / lo [B,T,F,64] f16,
+    scale2 the device pair {s, 1/s}; -> (out_hi, out_lo, out_scale2, amax_out [1024] uint32 view as int32, scratch).
+    amax_in: int32 tensor holding float bit patterns whose maximum is max |x| (default: computed here from the planes)."""
+    lib = _lib.load()
+    _dev_check(hi, "hi", torch.float16)
+    _dev_check(lo, "lo", torch.float16)
+    for n, t in (("w", w), ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("scale2", scale2)):
+        _dev_check(t, n)
+    B, T, F, C = hi.shape
+    KT, KF = w.shape[2], w.shape[3]
+    if amax_in is None:
+        m = ((hi.float() + lo.float()) * scale2[1]).abs().max().reshape(1)
+        amax_in = m.view(torch.int32)
+    ready = scratch is not None
+    if scratch is None:
+        scratch = torch.empty(lib.vs_nhwc_conv_f16x3_scratch_bytes(KT, KF), dtype=torch.uint8, device=hi.device)
+    out_hi, out_lo = torch.empty_like(hi), torch.empty_like(lo)
+    out_s2 = torch.empty(2, dtype=torch.float32, device=hi.device)
+    amax_out = torch.zeros(1024, dtype=torch.int32, device=hi.device)
+    check(lib.vs_nhwc_conv_f16x3_layer(_p(hi), _p(lo), _p(scale2), _p(amax_in), amax_in.numel(), _p(w), _p(bn_scale), _p(bn_shift),
+                                       _p(scratch), int(ready), _p(out_hi), _p(out_lo), _p(out_s2), _p(amax_out),
+                                       B, T, F, KT, KF, dil, ACT_CODES[act], _stream()), "vs_nhwc_conv_f16x3_layer")
+    return out_hi, out_lo, out_s2, amax_out, scratch
+
+
 def nhwc_conv_pack(w, transpose_flip: bool = False):
     """w [64,64,KT,KF] fp32 -> the register-fragment order vs_nhwc_conv / vs_nhwc_conv_dy take (uint8 tensor)."""
     lib = _lib.load()
