@@ -35,6 +35,13 @@ def main(name):
         ms = ev[0].elapsed_time(ev[1]) / 5
         fl = 2.0 * 64 * 64 * kt * kf * B * T * Fq
         out[f"{kt}x{kf}_dil{dil}"] = {"ms": round(ms, 3), "tflops_fp32_equiv": round(fl / ms / 1e9, 1)}
+        if int(os.environ.get("VOICESPLIT_SPLITCONV_ABL", "0")) & 32:
+            r = ops.nhwc_conv_f16x3(hi, lo, s2, w, sc, sh, dil, "mish", amax_in=amax_in, scratch=scr)
+            probe = r[3].view(torch.int64)[:4].tolist()          # summed over the launch's waves (1024 at B = 64)
+            waves = 1024
+            out[f"{kt}x{kf}_dil{dil}"]["probe_cycles_per_wave"] = {"total": probe[0] / waves, "vmcnt_wait": probe[1] / waves,
+                                                                     "lgkm_barrier_wait": probe[2] / waves, "groups": probe[3] / waves}
+            print(out[f"{kt}x{kf}_dil{dil}"], flush=True)
         print(kt, kf, dil, ms, flush=True)
     json.dump(out, open(f"gpurun_out/{name}.json", "w"), indent=1)
 

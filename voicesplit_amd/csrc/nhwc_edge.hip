@@ -1136,16 +1136,30 @@ void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const
   long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   long long row = blk / blocks_per_row;
   int bc = (int)(blk - row * blocks_per_row);
-  for (; blk < nblk; blk += wstride, row += sq, bc += sr) {
-    if (bc >= blocks_per_row) { bc -= blocks_per_row; ++row; }
+  const u4v z4 = {0u, 0u, 0u, 0u};
+  // the next block's pixels are loaded before this one is contracted (the loop is otherwise load -> wait -> 6 MFMAs -> store)
+  u4v h0 = z4, h1 = z4, l0 = z4, l1 = z4;
+  auto fetch = [&](long long r, int c, u4v& a0, u4v& a1, u4v& b0, u4v& b1) {
+    const int f = c * 16 + n;
+    if (f < F) {
+      const size_t e0 = (size_t)((r * F + f) << 6);
+      const u4v* sh_ = reinterpret_cast<const u4v*>(in_hi + e0) + g;
+      const u4v* sl_ = reinterpret_cast<const u4v*>(in_lo + e0) + g;
+      a0 = __builtin_nontemporal_load(sh_); a1 = __builtin_nontemporal_load(sh_ + 4);
+      b0 = __builtin_nontemporal_load(sl_); b1 = __builtin_nontemporal_load(sl_ + 4);
+    } else {
+      a0 = a1 = b0 = b1 = z4;
+    }
+  };
+  if (blk < nblk) fetch(row, bc, h0, h1, l0, l1);
+  for (; blk < nblk; blk += wstride) {
+    long long rown = row + sq;
+    int bcn = bc + sr;
+    if (bcn >= blocks_per_row) { bcn -= blocks_per_row; ++rown; }
+    u4v nh0 = z4, nh1 = z4, nl0 = z4, nl1 = z4;
+    if (blk + wstride < nblk) fetch(rown, bcn, nh0, nh1, nl0, nl1);
     const int f = bc * 16 + n;
     const bool ok = f < F;
-    const size_t e0 = (size_t)((row * F + (ok ? f : 0)) << 6);
-    const u4v* sh_ = reinterpret_cast<const u4v*>(in_hi + e0) + g;
-    const u4v* sl_ = reinterpret_cast<const u4v*>(in_lo + e0) + g;
-    const u4v z4 = {0u, 0u, 0u, 0u};
-    const u4v h0 = ok ? __builtin_nontemporal_load(sh_) : z4, h1 = ok ? __builtin_nontemporal_load(sh_ + 4) : z4;
-    const u4v l0 = ok ? __builtin_nontemporal_load(sl_) : z4, l1 = ok ? __builtin_nontemporal_load(sl_ + 4) : z4;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], __builtin_bit_cast(h8v, h0), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1], __builtin_bit_cast(h8v, h1), c, 0, 0, 0);
@@ -1158,6 +1172,8 @@ void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[(size_t)r * F] = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r]));
     }
+    h0 = nh0; h1 = nh1; l0 = nl0; l1 = nl1;
+    row = rown; bc = bcn;
   }
 }
 
