@@ -395,6 +395,14 @@ def main():
                                           "(2345 TF on zero operands): the chip clocks down with operand toggling; 553 TF algorithmic = 0.66 of `peak` "
                                           "is the most any schedule of this arithmetic reaches on random data (profiles/r02_conv_ablation.md)"}
             ksub = "conv64_f16x3_pk_kernel"
+            if not is_train:
+                # eval-mode forward (configs[1], configs[4]): the channels-last split-f16 kernel (csrc/conv_nhwc_f16x3.hip, round 4)
+                kname = "nhwc_conv_f16x3_kernel<5,5> (channels-last hi/lo f16 planes by LDS-DMA, weights in AGPRs, K halves across waves)"
+                ksub = "nhwc_conv_f16x3_kernel<5, 5"
+                extra["mfma_pipe"] = "f16 (v_mfma_f32_16x16x32_f16), 3 MFMA products per fp32 product"
+                extra["launch_ms_includes"] = "the layer's plan kernel (output scale from the tracked |max| of its input); weights come prepared"
+                extra["issue_model"] = ("one wave per SIMD: 16 cycles per MFMA + ~5 cycles for every other instruction, no overlap measured "
+                                        "(s_memtime probes and ablations: profiles/r04_split_conv.md); 450 MFMAs + ~490 other instructions per group of 6 rows")
         else:
             kname, peak, extra, ksub = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel"
         traffic, rnd = committed_pmc_traffic(tag, ksub) if B == 64 else (None, None)

@@ -14,7 +14,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -f csv -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 ONE="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $*"
-KREG="conv64_mfma|conv64_wgrad|conv64_f16|gemm_f16x3|gemm_pre|gemm_bf16|lstm16|lstm_persistent|lstm_bwd_persistent|nhwc_conv_kernel|nhwc_wgrad"
+KREG="conv64_mfma|conv64_wgrad|conv64_f16|gemm_f16x3|gemm_pre|gemm_bf16|lstm16|lstm_persistent|lstm_bwd_persistent|nhwc_conv_kernel|nhwc_conv_f16x3|nhwc_wgrad"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o pmc -f csv -- $ONE > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG|conv_first|conv_last|bn_|nhwc_" --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -f csv -- $ONE > "$OUT/pmc_fetch.log" 2>&1

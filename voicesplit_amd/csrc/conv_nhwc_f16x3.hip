@@ -77,7 +77,7 @@ struct SGeo {
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 
 // ABL: timing ablations (results invalid), tools/split_conv_micro.py: 1 = no window DMA, 2 = no epilogue micro-ops, 4 = no hand-over,
-// 8 = epilogue without its stores, 16 = the stores without the arithmetic, 32 = valid results + s_memtime probes of the group boundary
+// 8 = epilogue without its stores, 16 = the stores without the arithmetic, 64 = the H rows two groups share are not fetched again (what a ring buffer would save), 32 = valid results + s_memtime probes of the group boundary
 // (written over amax_out: tools/split_conv_micro.py prints them)
 template <int KT, int KF, int ACT, int ABL = 0>
 struct SplitWalk {
@@ -197,6 +197,7 @@ struct SplitWalk {
     // into clusters): with nothing left to fetch the unit moves zeros into the idle window buffer
     static_assert(4 * G::UNITS == 2 * G::WIN, "every wave has UNITS units");
     if constexpr (ABL & 1) return;
+    if constexpr ((ABL & 64) && 2 * J < H) { b.pcur += rstep; b.wcur += 2; return; }      // what a ring of rows would save: the H shared rows are not fetched again
     const bool ok = b.live & ((unsigned)b.wcur < (unsigned)b.in_end);
     const u4v d = {(unsigned)b.pcur, (unsigned)(b.pcur >> 32), ok ? (unsigned)a.F * 128u : 0u, 0x00020000u};
     const unsigned dst = b.dst0 + (unsigned)(J * 4 * G::ROWB);
@@ -603,6 +604,7 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
     else if (abl == 4) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 4>), g, block, 0, stream, a);
     else if (abl == 8) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 8>), g, block, 0, stream, a);
     else if (abl == 32) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 32>), g, block, 0, stream, a);
+    else if (abl == 96) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 96>), g, block, 0, stream, a);
     else if (abl == 33) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 33>), g, block, 0, stream, a);
     else if (abl == 34) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 34>), g, block, 0, stream, a);
     else if (abl == 35) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 35>), g, block, 0, stream, a);
