@@ -1,4 +1,6 @@
-"""Times vs_nhwc_conv_f16x3_layer at the metric configuration's layer shapes (B = 64, 301 x 601): the gate of the channels-last
+"""(VOICESPLIT_SPLITCONV_ABL=N selects a timing ablation / the in-kernel probes: needs a library built with
+`make -C voicesplit_amd/csrc ABLATION=1`; the production build ignores it.)
+Times vs_nhwc_conv_f16x3_layer at the metric configuration's layer shapes (B = 64, 301 x 601): the gate of the channels-last
 split-f16 forward (the NCHW kernel it replaces: 6.3-6.5 ms per 5x5 layer, 3.4 ms for the 7x1).  Writes gpurun_out/<name>.json."""
 import json
 import sys

@@ -76,7 +76,7 @@ struct SGeo {
 
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 
-// ABL: timing ablations (results invalid), tools/split_conv_micro.py: 1 = no window DMA, 2 = no epilogue micro-ops, 4 = no hand-over,
+// ABL (instances built with -DVS_ABLATION only, selected by VOICESPLIT_SPLITCONV_ABL): timing ablations (results invalid), tools/split_conv_micro.py: 1 = no window DMA, 2 = no epilogue micro-ops, 4 = no hand-over,
 // 8 = epilogue without its stores, 16 = the stores without the arithmetic, 64 = the H rows two groups share are not fetched again (what a ring buffer would save), 32 = valid results + s_memtime probes of the group boundary
 // (written over amax_out: tools/split_conv_micro.py prints them)
 template <int KT, int KF, int ACT, int ABL = 0>
@@ -597,6 +597,7 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
   if (grid < 16) grid = 16;
   if (want < grid) grid = (int)want;
   const dim3 g((unsigned)grid), block(256);
+#ifdef VS_ABLATION        // timing ablations / in-kernel probes (tools/split_conv_micro.py): make -C voicesplit_amd/csrc ABLATION=1
   static const int abl = getenv("VOICESPLIT_SPLITCONV_ABL") ? atoi(getenv("VOICESPLIT_SPLITCONV_ABL")) : 0;     // timing ablations, Mish only
   if (abl && act == VS_ACT_MISH) {
     if (abl == 1) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 1>), g, block, 0, stream, a);
@@ -609,7 +610,9 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
     else if (abl == 34) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 34>), g, block, 0, stream, a);
     else if (abl == 35) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 35>), g, block, 0, stream, a);
     else hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 16>), g, block, 0, stream, a);
-  } else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
+  } else
+#endif
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
   else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
   else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
   else VS_REQUIRE(false, "nhwc f16x3 conv: unsupported activation %d", act);
