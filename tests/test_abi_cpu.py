@@ -81,6 +81,20 @@ def test_workspace_layout_and_argument_errors():
     one = ctypes.c_void_p(256)
     assert lib.vs_bn_finalize(one, 64, 1000.0, 64, one, one, one, None, 1e-5, 0.1, one, one, None, None, None) != 0 and b"both running" in lib.vs_last_error()
     assert lib.vs_bn_finalize(one, 64, 1000.0, 64, one, one, None, None, 1e-5, 1.5, one, one, None, None, None) != 0 and b"momentum" in lib.vs_last_error()
+    # the channels-last split-f16 layer (round 4): scratch = two packed f16 planes + 1 KiB of row norms / scale / plan, which every
+    # mid-layer region of the workspace has room for; NULL, in-place and foreign kernel shapes are refused before any launch
+    assert lib.vs_nhwc_conv_f16x3_scratch_bytes(5, 5) == 2 * 64 * 64 * 25 * 2 + 1024
+    assert all(lay.conv_packed[i + 1] - lay.conv_packed[i] >= lib.vs_nhwc_conv_f16x3_scratch_bytes(5, 5) for i in range(1, 5))
+    assert lay.conv_packed[1] - lay.conv_packed[0] >= lib.vs_nhwc_conv_f16x3_scratch_bytes(7, 1)
+    assert lib.vs_nhwc_conv_f16x3_layer(None, None, None, None, 1, None, None, None, None, 0, None, None, None, None,
+                                        1, 4, 4, 5, 5, 1, 1, None) != 0 and b"NULL" in lib.vs_last_error()
+    two = ctypes.c_void_p(512)
+    assert lib.vs_nhwc_conv_f16x3_layer(one, two, one, one, 1, one, one, one, one, 0, one, two, one, None,
+                                        1, 4, 4, 5, 5, 1, 1, None) != 0 and b"in-place" in lib.vs_last_error()
+    three, four = ctypes.c_void_p(768), ctypes.c_void_p(1024)
+    assert lib.vs_nhwc_conv_f16x3_layer(one, two, one, one, 1, one, one, one, one, 0, three, four, one, None,
+                                        1, 4, 4, 3, 3, 1, 1, None) != 0 and b"7x1, 5x5" in lib.vs_last_error()
+    assert lib.vs_f16x3_split(None, None, None, None, 8, None) != 0 and lib.vs_f16x3_merge(None, None, None, None, 8, None) != 0
     assert lib.vs_set_lstm_kernel(3) == 0 and lib.vs_set_lstm_kernel(4) != 0 and lib.vs_set_lstm_kernel(0) == 0
     # h ping / pong / flags regions are sized for the 16-wide K chunks of the f16 form (H = 24 -> 32)
     assert lib.vs_lstm_state_floats(3, 24) == 3 * 2 * 32 * 32 + 64 and lib.vs_lstm_state_floats(64, 400) == 3 * 2 * 400 * 64 + 64

@@ -390,8 +390,10 @@ int vs_nhwc_conv_f16x3_layer(const void* in_hi, const void* in_lo, const float* 
                              const float* w, const float* bn_scale, const float* bn_shift, void* scratch, int packed_ready,
                              void* out_hi, void* out_lo, float* out_scale2, unsigned* amax_out,
                              int B, int T, int F, int KT, int KF, int dil, int act, void* stream) {
+  VS_REQUIRE(in_hi && in_lo && out_hi && out_lo && in_scale2 && amax_in && n_amax > 0 && bn_scale && bn_shift && out_scale2,
+             "nhwc_conv_f16x3: NULL argument");
   VS_REQUIRE(in_hi != out_hi && in_lo != out_lo && in_hi != out_lo && in_lo != out_hi, "nhwc_conv_f16x3: in-place is not supported");
-  VS_REQUIRE(in_scale2 && amax_in && n_amax > 0 && bn_scale && bn_shift && out_scale2, "nhwc_conv_f16x3: NULL argument");
+  VS_REQUIRE((KT == 5 && KF == 5) || (KT == 7 && KF == 1), "nhwc_conv_f16x3: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
   VS_REQUIRE(scratch != nullptr, "nhwc_conv_f16x3: NULL scratch");
   float* plan = reinterpret_cast<float*>(static_cast<char*>(scratch) + vs_nhwc_f16x3_wpart_bytes(KT, KF));
   return vs_nhwc_f16x3_layer_impl(in_hi, in_lo, in_scale2, amax_in, n_amax, w, bn_scale, bn_shift, scratch, packed_ready, plan, out_hi, out_lo,
