@@ -402,7 +402,8 @@ def main():
                 extra["mfma_pipe"] = "f16 (v_mfma_f32_16x16x32_f16), 3 MFMA products per fp32 product"
                 extra["launch_ms_includes"] = "the layer's plan kernel (output scale from the tracked |max| of its input); weights come prepared"
                 extra["issue_model"] = ("one wave per SIMD: 16 cycles per MFMA + ~5 cycles for every other instruction, no overlap measured "
-                                        "(s_memtime probes and ablations: profiles/r04_split_conv.md); 450 MFMAs + ~490 other instructions per group of 6 rows")
+                                        "(s_memtime probes and ablations: profiles/r04_split_conv.md); 450 MFMAs + ~350 other instructions per group of 6 rows; cuts of the "
+                                        "instruction count have not moved the time: the clock follows (power-bound)")
         else:
             kname, peak, extra, ksub = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel"
         traffic, rnd = committed_pmc_traffic(tag, ksub) if B == 64 else (None, None)

@@ -41,6 +41,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(3))) const u4v lds_u4v;
 typedef __attribute__((address_space(3))) u4v lds_u4v_rw;
 
+#include "split_mfma_blocks.inc"
+
 constexpr int STRIP = 16;           // output columns per strip = one MFMA column block
 
 struct SplitConvArgs {
@@ -237,7 +239,13 @@ struct SplitWalk {
   static constexpr int NMT = HR * NROW;
   // a micro-op's results pass through an opaque volatile statement: volatile statements keep their order, and the MFMAs are
   // volatile asm -- the arithmetic stays between the two MFMAs it was written between instead of sinking to its first use
-  template <typename V> static __device__ __forceinline__ void pin(V& v) { asm volatile("" : "+v"(v)); }
+  template <typename V> static __device__ __forceinline__ void pin(V& v) {
+#ifdef VS_SPLITCONV_PIN
+    asm volatile("" : "+v"(v));
+#else
+    (void)v;      // the group is one basic block since the DMA units lost their branches: the sched_barriers hold the micro-ops in place, and an
+#endif            // opaque statement costs a hazard s_nop each (45 per group)
+  }
   template <int Q>
   __device__ __forceinline__ void micro() {
     if constexpr (ABL & 2) return;
@@ -306,7 +314,7 @@ struct SplitWalk {
   template <int RV>
   struct GroupState {
     f32x4 acc[RV];
-    h8v bq[4];                         // fragments in flight: read three sub-steps ahead
+    h8v bq[6];                         // fragments in flight: the two planes of this pair-step and of the next two
     unsigned vb[KF];
   };
   // sub-step SI = (window row i, tap column df, plane pl): one fragment read, nm(i) taps x {w_hi, w_lo} (hi plane) / {w_hi} (lo plane)
@@ -329,44 +337,44 @@ struct SplitWalk {
     return __builtin_bit_cast(h8v, *(lds_u4v*)(uintptr_t)(st.vb[df] + (unsigned)((i * 2 + pl) * G::ROWB)));
   }
 
-  template <int RV, int SI, int MM>
-  __device__ __forceinline__ void gmfma(GroupState<RV>& st) {
-    constexpr int df = (SI / 2) % KF, i = SI / (2 * KF);
-    constexpr int lo = r_lo<RV>(i), nm = r_hi<RV>(i) - lo + 1;
-    constexpr int r = lo + MM % nm, which = MM / nm;         // which: 0 = w_hi, 1 = w_lo (hi plane only)
-    constexpr int tap = (i - r) * KF + df;
-    // weights (200 registers) and accumulators live in AGPRs, everything else in VGPRs: as a builtin the compiler kept the
-    // weights in VGPRs and shuttled the epilogue's state through v_accvgpr_read / write in the MFMA stream.  The first MFMA
-    // of an output row (window row r, tap column 0, hi x hi) starts its accumulator from the literal 0.
-    constexpr bool first = (i == r) && df == 0 && (SI % 2 == 0) && which == 0;
-    if constexpr (first) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(st.acc[r]) : "a"(wfh[tap]), "v"(st.bq[SI % 4]));
-    else if constexpr (which) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(st.acc[r]) : "a"(wfl[tap]), "v"(st.bq[SI % 4]));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(st.acc[r]) : "a"(wfh[tap]), "v"(st.bq[SI % 4]));
-    constexpr int SP = NS<RV> >= 4 * G::UNITS ? 4 : 2;       // the next group's window: one (row, plane) per unit
-    static_assert(NS<RV> >= SP * G::UNITS, "every DMA unit needs a step");
-    if constexpr (MM == 0 && SI % SP == 0 && SI / SP < G::UNITS) row_unit<SI / SP>(bt);      // in order: the cursor advances
-    // micro-ops of the previous group's epilogue: spread over this group's MFMAs
-    constexpr int TOT = before<RV>(NS<RV>), ord = before<RV>(SI) + MM;
-    // ... the FIRST part of them: the stores must have retired by the s_waitcnt vmcnt(0) in front of the next group, and the
-    // partner's part (take_partner's LDS reads) needs its latency before the first micro-op
-    constexpr bool early = TOT >= 3 * NMT + 12;
-    constexpr int stride = early ? 3 : TOT >= NMT ? TOT / NMT : 1, off = early ? 12 : 0, per = (NMT + TOT - 1) / TOT;
-    if constexpr (ord >= off && (ord - off) % stride == 0) {
-      constexpr int m0 = ((ord - off) / stride) * per;
+  // Pair-step PS = (window row i, tap column df): the two planes' fragments of pair-step PS + 2 are read, then ALL MFMAs of
+  // (i, df) -- rows lo .. lo + nm - 1, three products each -- issue as one asm statement (split_mfma_blocks.inc: weights and
+  // accumulators in AGPRs; the first MFMA of an output row, at (i = r, df = 0), starts from the literal 0).  As a builtin the
+  // compiler kept the weights in VGPRs and shuttled the epilogue's state through v_accvgpr_read / write in the MFMA stream; one
+  // asm statement per MFMA got an s_nop between most of them and a s_waitcnt per fragment.  Behind the block: the next
+  // group's window, one (row, plane) DMA unit per pair-step, and the previous group's epilogue micro-ops -- from pair-step 1 on
+  // (the partner's part needs its LDS latency) and done early (its stores must have retired by the next group's vmcnt(0)).
+  template <int RV>
+  static constexpr int NPS = (RV + H) * KF;
+  template <int RV, int PS, int... Rs>
+  __device__ __forceinline__ void pblock(GroupState<RV>& st, std::integer_sequence<int, Rs...>) {
+    constexpr int df = PS % KF, i = PS / KF;
+    constexpr int lo = r_lo<RV>(i), nm = sizeof...(Rs);
+    const h8v* wh[nm] = {&wfh[(i - (lo + Rs)) * KF + df]...};
+    const h8v* wl[nm] = {&wfl[(i - (lo + Rs)) * KF + df]...};
+    split_mfma_block<nm, (df == 0 && i < RV)>(&st.acc[lo], wh, wl, st.bq[(2 * PS) % 6], st.bq[(2 * PS + 1) % 6]);
+  }
+  template <int RV, int PS>
+  __device__ __forceinline__ void pstep(GroupState<RV>& st) {
+    constexpr int i = PS / KF;
+    if constexpr (PS + 2 < NPS<RV>) {
+      st.bq[(2 * PS + 4) % 6] = frag<RV>(st, 2 * PS + 4);
+      st.bq[(2 * PS + 5) % 6] = frag<RV>(st, 2 * PS + 5);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pblock<RV, PS>(st, std::make_integer_sequence<int, r_hi<RV>(i) - r_lo<RV>(i) + 1>());
+    constexpr int SPD = NPS<RV> >= 2 * G::UNITS ? 2 : 1;
+    static_assert(NPS<RV> >= SPD * G::UNITS, "every DMA unit needs a pair-step");
+    if constexpr (PS % SPD == 0 && PS / SPD < G::UNITS) row_unit<PS / SPD>(bt);      // in order: the cursor advances
+    constexpr int per = (NMT + NPS<RV> - 2) / (NPS<RV> - 1);
+    if constexpr (PS >= 1) {
+      constexpr int m0 = (PS - 1) * per;
       micros<m0>(std::make_integer_sequence<int, (m0 < NMT ? (NMT - m0 < per ? NMT - m0 : per) : 0)>());
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  template <int RV, int SI, int... MMs>
-  __device__ __forceinline__ void gmfmas(GroupState<RV>& st, std::integer_sequence<int, MMs...>) { (gmfma<RV, SI, MMs>(st), ...); }
-  template <int RV, int SI>
-  __device__ __forceinline__ void sstep(GroupState<RV>& st) {
-    if constexpr (SI + 3 < NS<RV>) st.bq[(SI + 3) % 4] = frag<RV>(st, SI + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    gmfmas<RV, SI>(st, std::make_integer_sequence<int, cnt<RV>(SI)>());
-  }
-  template <int RV, int... SIs>
-  __device__ __forceinline__ void ssteps(GroupState<RV>& st, std::integer_sequence<int, SIs...>) { (sstep<RV, SIs>(st), ...); }
+  template <int RV, int... PSs>
+  __device__ __forceinline__ void psteps(GroupState<RV>& st, std::integer_sequence<int, PSs...>) { (pstep<RV, PSs>(st), ...); }
 
   // Output rows ro .. ro + RV - 1 of item x from window buffer `buf`; `par`: the exchange area of this group.  On return the
   // other K half's share of the accumulators is on its way through LDS, this wave's share sits in fin[] (still without the
@@ -379,7 +387,8 @@ struct SplitWalk {
     st.bq[0] = frag<RV>(st, 0);
     st.bq[1] = frag<RV>(st, 1);
     st.bq[2] = frag<RV>(st, 2);
-    ssteps<RV>(st, std::make_integer_sequence<int, NS<RV>>());
+    st.bq[3] = frag<RV>(st, 3);
+    psteps<RV>(st, std::make_integer_sequence<int, NPS<RV>>());
     // hand-over: K half 0 finishes rows [0, RV / 2), K half 1 rows [RV / 2, RV)
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last MFMAs' results (the compiler does not see MFMAs in the asm statements)
     constexpr int HV = RV / 2;
