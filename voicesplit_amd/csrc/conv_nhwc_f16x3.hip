@@ -14,11 +14,15 @@
 // What differs from conv_nhwc.hip, and why:
 //  * weights in registers are 2 planes x 25 taps: 64 co would need 400 VGPRs per wave.  A WORKGROUP therefore owns 32 output
 //    channels (a launch constant: workgroups w and w + 8 -- same XCD, same L2 -- walk the same tiles for the two halves) and its
-//    4 waves are 2 blocks of 16 channels x 2 HALVES OF K (input channels 0-31 / 32-63): 200 VGPRs of weights per wave;
+//    4 waves are 2 blocks of 16 channels x 2 HALVES OF K (input channels 0-31 / 32-63): 200 registers of weights per wave, kept
+//    in AGPRs with the accumulators (the MFMAs are asm statements with `a` operands, one statement per window row and tap column:
+//    split_mfma_blocks.inc);
 //  * the two K halves of a block are summed across waves once per group of R output rows: each wave of a pair hands the other
 //    half of its accumulators through LDS (16 bytes per lane and row) and finishes the other half of the rows;
 //  * that epilogue (BatchNorm scale / shift, activation, |max|, hi / lo split, two 8-byte stores per pixel) is DEFERRED: cut into
-//    micro-ops that ride on the MFMAs of the next group, so the matrix pipe never waits for it;
+//    micro-ops placed between the MFMA blocks of the next group, spread over its first part (measured: a wave alone on its SIMD
+//    does not overlap its VALU work with its own MFMAs -- profiles/r04_split_conv.md -- so the point of the spreading is that the
+//    stores have retired and the partner's LDS data has arrived, not that the arithmetic is free);
 //  * two planes double the LDS per window row: strips are 16 columns and groups 6 rows (5x5) / 8 rows (7x1); two window
 //    buffers + two exchange areas = 144 KiB.
 // A fragment read (hi or lo plane, this wave's K half) feeds <= KT taps x {w_hi, w_lo} (hi plane) or {w_hi} (lo plane):
@@ -317,20 +321,9 @@ struct SplitWalk {
     h8v bq[6];                         // fragments in flight: the two planes of this pair-step and of the next two
     unsigned vb[KF];
   };
-  // sub-step SI = (window row i, tap column df, plane pl): one fragment read, nm(i) taps x {w_hi, w_lo} (hi plane) / {w_hi} (lo plane)
+  // window row i feeds output rows r_lo(i) .. r_hi(i) of the group (tap row i - r)
   template <int RV> static constexpr int r_lo(int i) { return i - (KT - 1) > 0 ? i - (KT - 1) : 0; }
   template <int RV> static constexpr int r_hi(int i) { return i < RV - 1 ? i : RV - 1; }
-  template <int RV> static constexpr int cnt(int si) {
-    const int i = si / (2 * KF), pl = si % 2;
-    return (r_hi<RV>(i) - r_lo<RV>(i) + 1) * (pl == 0 ? 2 : 1);
-  }
-  template <int RV> static constexpr int before(int si) {
-    int s = 0;
-    for (int k = 0; k < si; ++k) s += cnt<RV>(k);
-    return s;
-  }
-  template <int RV> static constexpr int NS = (RV + H) * KF * 2;
-
   template <int RV>
   __device__ __forceinline__ h8v frag(const GroupState<RV>& st, int si) const {
     const int pl = si % 2, df = (si / 2) % KF, i = si / (2 * KF);
