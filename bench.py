@@ -368,6 +368,30 @@ def main():
         except Exception as exc:                      # RCCL unavailable on this box: report, do not fail the bench
             rccl = {"rccl_ranks": 0, "error": str(exc)[:200]}
 
+    # The pool's boxes differ by several percent on every kernel: one fixed, self-contained launch timed
+    # outside the region says which kind of box this line comes from -- the bf16 LSTM input contraction at the metric shape
+    # (19264 x 3200 x 4808, the same seeded random operands everywhere: the clock of these kernels follows the operands' toggle rate).
+    box = None
+    if rank == 0:
+        try:
+            M_, N_, K_ = 19264, 3200, 4808
+            Kp_ = (K_ + 63) // 64 * 64
+            g_ = torch.Generator(device=dev).manual_seed(1234)
+            a_ = torch.randn(M_, Kp_, generator=g_, device=dev).to(torch.bfloat16)
+            b_ = (torch.randn(N_, Kp_, generator=g_, device=dev) * 0.02).to(torch.bfloat16)
+            ops.gemm_bf16(a_, b_, M_, N_, K_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.gemm_bf16(a_, b_, M_, N_, K_)
+            e1.record()
+            torch.cuda.synchronize()
+            box = {"kernel": "gemm_bf16 19264x3200x4808 on seeded random operands, mean of 10 launches outside the timed region",
+                   "ms": round(e0.elapsed_time(e1) / 10, 4)}
+            del a_, b_
+        except Exception as exc:
+            box = {"error": str(exc)[:200]}
+
     def stage_table(ms_, calls_, steps_):
         return {n: (ms_[i] / steps_ if calls_[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
 
@@ -605,6 +629,8 @@ def main():
             line["fp32_strict"] = strict
         if rccl is not None:
             line["rccl"] = rccl
+        if box is not None:
+            line["box_calibration"] = box
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline("train" if train else "forward")
     if dist:
