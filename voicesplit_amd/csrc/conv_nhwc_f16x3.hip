@@ -411,7 +411,7 @@ struct SplitWalk {
 #pragma unroll
     for (int j = 0; j < HR; ++j) got[j] = __builtin_bit_cast(f32x4, *(lds_u4v*)(uintptr_t)(xr + (unsigned)(j * 1024)));
     if (pro[HR - 1] == kOob) {       // a short group (wave-uniform, rare): rows it did not have hold stale bits in the partner's area --
-#pragma unroll                       // zero them, so that |max| stays a fact about the tensor (their stores are dropped anyway)
+#pragma unroll                       // zero them, so that |max| stays under the plan's bound (their stores are dropped anyway)
       for (int j = 0; j < HR; ++j)
         if (pro[j] == kOob) fin[j] = got[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
