@@ -275,3 +275,22 @@ def test_nchw_route_of_the_fp32_class_forward_still_matches_the_oracle():
     assert out.returncode == 0, out.stderr[-2000:]
     rel = float([ln for ln in out.stdout.splitlines() if ln.startswith("REL")][0].split()[1])
     assert rel < REL_TOL, rel
+
+
+@pytest.mark.parametrize("amp", [0.0, 1e-4, 1e3])
+def test_forward_tracks_the_input_range(amp):
+    """Silence, a spectrogram four decades below and three above unit range: every layer of the fp32-class forward derives its
+    operands' scales from tracked magnitudes on the device, so the mask stays at the oracle's (1e-4) for all of them."""
+    import voicesplit_amd as V
+    dims_d = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 5), 6.0)
+    x, dvec = R.synthetic_inputs(2, 40, dims_d, 5)
+    x = x * amp
+    m = V.VoiceSplit(V.default_config(53, 24, 32, 44, 53)).eval()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    with torch.no_grad():
+        got = m(x.cuda(), dvec.cuda()).double().cpu()
+        ref = R.forward(R.cast_state_dict(sd, torch.float64), x.double(), dvec.double(), act="mish")["mask"]
+    assert torch.isfinite(got).all()
+    assert _rel(got.numpy(), ref.numpy()) < REL_TOL
