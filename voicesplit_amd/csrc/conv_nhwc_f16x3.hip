@@ -356,7 +356,9 @@ struct SplitWalk {
     }
     __builtin_amdgcn_sched_barrier(0);
     pblock<RV, PS>(st, std::make_integer_sequence<int, r_hi<RV>(i) - r_lo<RV>(i) + 1>());
-    constexpr int SPD = NPS<RV> >= 2 * G::UNITS ? 2 : 1;
+    // 7x1: a group is 14 pair-steps = 1.5 us, shorter than a DMA round trip under load: its units go out back to back at the group's start
+    // (spread over the group, the last one cost 7 % of the kernel in s_waitcnt vmcnt(0): s_memtime probes, profiles/r04_split_conv.md)
+    constexpr int SPD = (KF > 1 && NPS<RV> >= 2 * G::UNITS) ? 2 : 1;
     static_assert(NPS<RV> >= SPD * G::UNITS, "every DMA unit needs a pair-step");
     if constexpr (PS % SPD == 0 && PS / SPD < G::UNITS) row_unit<PS / SPD>(bt);      // in order: the cursor advances
     constexpr int per = (NMT + NPS<RV> - 2) / (NPS<RV> - 1);
