@@ -526,12 +526,14 @@ __global__ void nhwc_f16x3_pack_kernel(const float* __restrict__ w, const float*
     out[o] = __builtin_bit_cast(unsigned short, hi);
     out[o + 512] = __builtin_bit_cast(unsigned short, lo);
   }
-  // L1 norm of every output channel's weights (the plan kernel's bound): one block-0 wave per 16 channels would do; keep it simple
-  if (l1 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
-    const int co = threadIdx.x;
+  // L1 norm of every output channel's weights (the plan kernel's bound): block 0, four threads per channel
+  if (l1 != nullptr && blockIdx.x == 0) {
+    const int co = threadIdx.x >> 2, part = threadIdx.x & 3, n = 64 * ntap;
     float t = 0.f;
-    for (int k = 0; k < 64 * ntap; ++k) t += fabsf(w[(size_t)co * 64 * ntap + k]);
-    l1[co] = t;
+    for (int k = part; k < n; k += 4) t += fabsf(w[(size_t)co * n + k]);
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (part == 0) l1[co] = t;
   }
 }
 
