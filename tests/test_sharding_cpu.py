@@ -63,7 +63,7 @@ def test_world2_gloo_sharded_equals_unsharded(B):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -120,7 +120,7 @@ def test_world2_gloo_gradient_bucket_allreduce():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -149,14 +149,14 @@ def test_single_rank_group_under_the_launcher_and_alone(tmp_path):
         "dist.destroy_process_group()\n"
         "print('HOW', how.split(':')[0], round(time.time() - t0, 1))\n")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    alone = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    alone = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert alone.returncode == 0 and "HOW tcp" in alone.stdout, alone.stdout + alone.stderr
     import socket
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                               "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=180)
+                               "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert launched.returncode == 0 and "HOW env" in launched.stdout, launched.stdout + launched.stderr
 
 

@@ -271,7 +271,7 @@ def test_world2_gloo_training_job_equals_one_process_on_the_global_batch(tmp_pat
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
