@@ -168,6 +168,13 @@ def test_tensor_index_follows_the_module_tree_and_transients_stay_out_of_copies(
     m.lstm.weight_hh_l0 = torch.nn.Parameter(torch.zeros_like(m.lstm.weight_hh_l0))   # a replaced tensor is read through the dict
     assert m._tensors()["lstm.weight_hh_l0"] is m.lstm.weight_hh_l0
     assert [k for k, _ in m._named_params()] == [k for k, _ in m.named_parameters()]
+    m.fc1.add_module("probe", torch.nn.Linear(2, 2))                  # a NEW grandchild: no existing link changes
+    assert "fc1.probe.weight" in m._tensors() and list(m._tensors()) == list(m.state_dict())
+    del m.fc1._modules["probe"]
+    assert "fc1.probe.weight" not in m._tensors() and list(m._tensors()) == list(m.state_dict())
+    # the recurrence's error word lives in the tape: with no training forward behind the module (or its tape released) the
+    # status is unknown, never "OK"
+    assert V.VoiceSplit(V.default_config(37, 16, 24, 40, 37)).lstm_status() is None
     # transients
     m.__dict__["_last_tape"] = ("tape", "dims")
     m.set_gradient_sink({"fc1.weight": torch.zeros_like(m.fc1.weight)})

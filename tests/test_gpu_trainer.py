@@ -359,3 +359,37 @@ def test_nccl_world2_data_parallel_step_matches_per_shard_reference():
     for p in procs:
         p.join(timeout=120)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_train_step_after_a_plain_autograd_loop_uses_the_fresh_gradients():
+    """zero_grad(set_to_none=True) + a plain loss.backward() over the trainer's model leaves autograd-made
+    .grad tensors that are not bucket views; the next train_step (gradient sink) must step with ITS gradients, not copy the stale
+    ones over them.  Two identical trainers; one of them takes the detour (forward + backward on another batch, no optimizer
+    step; the other runs the same forward so that the BatchNorm running statistics agree), then both run the same step."""
+    import voicesplit_amd as V
+    from voicesplit_amd import losses
+    from voicesplit_amd.trainer import Trainer
+    c = _cfg("voicesplit")
+    acfg = c.audio["voicefilter"]
+    torch.manual_seed(0)
+    a = Trainer(V.VoiceSplit(c).cuda(), c)
+    torch.manual_seed(0)
+    b = Trainer(V.VoiceSplit(c).cuda(), c)
+    assert a._sink and b._sink
+    B, T = 2, 61
+    emb, target, mixed, seq_len, _tw, phase = _batch(B, T, 5)
+    a.model.train(); b.model.train()
+    a.optimizer.zero_grad(set_to_none=True)
+    losses.sisnr_loss(a.model(mixed, emb), mixed, target, phase, seq_len, acfg).backward()        # plain autograd path
+    stale = {n: p.grad.clone() for n, p in a.model.named_parameters()}
+    assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(a.bucket.params, a.bucket.views))
+    with torch.no_grad():
+        b.model(mixed, emb)                                                                       # same BatchNorm update, no gradients
+    nb = _batch(B, T, 6)
+    la, lb = a.train_step(nb), b.train_step(nb)
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+    for (n, p), q in zip(a.model.named_parameters(), b.model.parameters()):
+        assert p.grad.data_ptr() == dict(zip((id(x) for x in a.bucket.params), a.bucket.views))[id(p)].data_ptr(), n
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-7 * float(q.grad.abs().max())), n
+        assert not torch.allclose(p.grad, stale[n], rtol=1e-3, atol=0.0) or float(stale[n].abs().max()) == 0.0, n
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n

@@ -176,3 +176,28 @@ def test_bucket_reattaches_a_grad_the_sink_wrote_and_zeroes_one_nobody_wrote():
     lin.weight.grad = None
     b.all_reduce(1)
     assert lin.weight.grad is None and float(b.views[0].abs().sum()) == 0.0 and float(b.views[1].sum()) == 9.0
+
+
+def test_written_views_win_over_a_stale_grad_and_frozen_parameters_stay_put():
+    """a plain zero_grad(set_to_none=True) / backward loop over the same model leaves an autograd-made
+    .grad that is NOT a bucket view; on the next sink step the library writes fresh gradients into the views and autograd
+    gets nothing for those keys -- the stale tensor must not be copied over the fresh view.  And (low): a parameter frozen
+    after the bucket was built is not re-attached (the optimizer keeps skipping it) and its slot is zeroed."""
+    from voicesplit_amd.sharding import GradientBucket
+    lin = torch.nn.Linear(5, 3)
+    b = GradientBucket(lin.parameters()).attach()
+    lin.weight.grad = torch.full_like(lin.weight, 7.0)      # what a plain backward() after set_to_none leaves behind
+    b.views[0].fill_(2.0)                                   # the sink's fresh gradient
+    b.views[1].fill_(3.0)
+    b.all_reduce(1, written=True)
+    assert lin.weight.grad.data_ptr() == b.views[0].data_ptr() and float(lin.weight.grad.sum()) == 2.0 * 15
+    # without `written` the old contract holds: a foreign .grad was accumulated by autograd and is copied in
+    lin.weight.grad = torch.full_like(lin.weight, 7.0)
+    b.all_reduce(1)
+    assert lin.weight.grad.data_ptr() == b.views[0].data_ptr() and float(b.views[0].sum()) == 7.0 * 15
+    # frozen after construction
+    lin.bias.requires_grad_(False)
+    lin.bias.grad = None
+    b.views[1].fill_(5.0)                                   # the library writes all gradients into the sink
+    b.all_reduce(1, written=True)
+    assert lin.bias.grad is None and float(b.views[1].abs().sum()) == 0.0

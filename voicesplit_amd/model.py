@@ -123,15 +123,16 @@ class _MaskNet(nn.Module):
 
     def _index_is_current(self) -> bool:
         """Is the module tree still the one the index was built from?  Identity of every child in its parent's
-        ``_modules`` and identity + length of every module's ``_parameters`` / ``_buffers`` dict: ~35 modules, a few
+        ``_modules``, the NUMBER of children of every module (``model.fc1.add_module(...)`` adds one without touching an
+        existing link) and identity + length of every module's ``_parameters`` / ``_buffers`` dict: ~35 modules, a few
         microseconds -- ``model.conv[i] = layer``, ``register_buffer`` / ``register_parameter`` on a child or a replaced
         ``_parameters`` dict all show up here (a replaced TENSOR needs no check: tensors are read through the dicts)."""
         links, dicts = self.__dict__["_tree_check"]
         for parent_modules, name, child in links:
             if parent_modules.get(name) is not child:
                 return False
-        for mod, pd, pl, bd, bl in dicts:
-            if mod._parameters is not pd or len(pd) != pl or mod._buffers is not bd or len(bd) != bl:
+        for mod, pd, pl, bd, bl, ml in dicts:
+            if mod._parameters is not pd or len(pd) != pl or mod._buffers is not bd or len(bd) != bl or len(mod._modules) != ml:
                 return False
         return True
 
@@ -152,7 +153,7 @@ class _MaskNet(nn.Module):
                 for n in mod._buffers:
                     if mod._buffers[n] is not None and n not in mod._non_persistent_buffers_set:
                         index.append((prefix + n, mod._buffers, n))
-                dicts.append((mod, mod._parameters, len(mod._parameters), mod._buffers, len(mod._buffers)))
+                dicts.append((mod, mod._parameters, len(mod._parameters), mod._buffers, len(mod._buffers), len(mod._modules)))
                 for cn, child in mod._modules.items():
                     links.append((mod._modules, cn, child))
             self.__dict__["_tensor_index"] = index
@@ -212,16 +213,20 @@ class _MaskNet(nn.Module):
                         torch.autograd.graph.increment_version(m.running_mean)
                         torch.autograd.graph.increment_version(m.running_var)
 
-    def lstm_status(self) -> int:
+    def lstm_status(self):
         """0 when the persistent BiLSTM kernels of the last training forward / backward completed, 1 when one gave up
-        (its output was NaN-poisoned; see vs_lstm_status).  Synchronises."""
+        (its output was NaN-poisoned; see vs_lstm_status), None when that is no longer knowable: no training forward has
+        run, or its tape has been released since (the error word lives in the tape; the pool keeps ONE recycled tape alive,
+        so the usual call -- right after a step -- finds it and reports the last launch on that buffer; with several forwards
+        outstanding, or a graph freed without its backward, the buffer is gone).  Never reports success it cannot see.
+        Synchronises."""
         last = self.__dict__.get("_last_tape")
         if last is None:
-            return 0
+            return None
         ref, dims = last
         tape = ref()
-        if tape is None:                 # released since: nothing to ask (the pool keeps a recycled tape alive, so the usual
-            return 0                     # call -- right after a step -- finds it; it then reports the LAST launch on that buffer)
+        if tape is None:
+            return None
         return ops.lstm_status(dims, tape=tape)
 
     def long_form_stages(self):

@@ -92,6 +92,8 @@ class GradientBucket:
         self.flat = torch.zeros(self.numel + extra, dtype=p0.dtype, device=p0.device)
         self.extra = self.flat[self.numel:]
         self.views = []
+        self.time_events = False                             # bench.py: record a HIP-event pair around every collective
+        self._events = []
         off = 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -110,23 +112,46 @@ class GradientBucket:
         collective must not be co-scheduled with the persistent LSTM kernels).  force: issue the
         collective even at world 1 (a one-rank RCCL all-reduce: used to exercise the device path).
         written: the views were just written by the producer of the gradients itself (the library's
-        gradient sink, trainer.py) -- a ``.grad`` that someone set to None in between
-        (``zero_grad(set_to_none=True)``) is re-attached, not zeroed."""
+        gradient sink, trainer.py) and are authoritative: every ``.grad`` is re-attached to its view, whatever it held.  Returns
+        the flat bucket; ``last_ms`` (when ``time_events`` is set) = HIP-event time of the collective itself."""
         import torch.distributed as dist
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                if written:
-                    p.grad = v
+            if written:
+                # the views ARE the step's gradients.  Whatever .grad holds instead -- None after zero_grad(set_to_none=True), or a
+                # tensor autograd created for a plain backward() over the same model before this step -- is stale: re-attach, never
+                # copy it in.  A parameter frozen since the bucket was built (requires_grad_(False)) keeps its .grad untouched and its
+                # slot zeroed (the library writes every gradient into the sink), so an optimizer that finds the attached view does nothing.
+                if p.requires_grad:
+                    if p.grad is not v:
+                        p.grad = v
                 else:
                     v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():        # someone re-created .grad: copy in
+            elif p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():        # someone re-created .grad and accumulated into it: copy in
                 v.copy_(p.grad)
                 p.grad = v
         if world > 1 or force:
+            ev = None
+            if self.time_events and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()                               # the current stream waits for the collective: the pair brackets it
+                self._events.append(ev)
             if world > 1:
                 self.flat.div_(world)
         return self.flat
+
+    def collective_ms(self):
+        """HIP-event times (ms) of the all-reduces issued since the last call while ``time_events`` was on (synchronises)."""
+        out = []
+        for e0, e1 in self._events:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        self._events = []
+        return out
 
     def zero(self):
         self.flat.zero_()

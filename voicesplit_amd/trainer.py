@@ -26,6 +26,7 @@ criteria of ``losses.py`` every flop of the step is inside libvoicesplit_hip.so.
 """
 import math
 import os
+import time
 from glob import glob
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence
 
@@ -128,10 +129,20 @@ class Trainer:
             self._sink_map = {names[id(p)]: v for p, v in zip(self.bucket.params, self.bucket.views)}
         self.device = self.bucket.flat.device
         self.step = 0
+        self.time_comm = False          # bench.py's N > 1 line: time the two collectives of a step (set_comm_timing)
+        self.flag_ms = []
         if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
             import torch.distributed as dist
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
+
+    def set_comm_timing(self, on: bool = True):
+        """Self-diagnosis of the N > 1 step: HIP events around the gradient all-reduce (``bucket.collective_ms()``) and the host
+        wall time of the EmptyBatch MIN-reduce (``flag_ms``)."""
+        self.time_comm = bool(on)
+        self.bucket.time_events = bool(on)
+        self.flag_ms = []
+        self.bucket._events = []
 
     # -- checkpoints: train.py:38-60 (load), :125-133 (save) ---------------------------------------
     def load_checkpoint(self, path: str, reinit_layers: Optional[Sequence[str]] = None) -> int:
@@ -180,8 +191,11 @@ class Trainer:
         if self.world > 1:
             import torch.distributed as dist
             flag = torch.tensor([1.0 if have else 0.0], device=self.device)
+            t0 = time.perf_counter() if self.time_comm else 0.0
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             have = bool(flag.item() > 0)
+            if self.time_comm:                                              # host wall time of the flag round trip (it ends in a
+                self.flag_ms.append(1e3 * (time.perf_counter() - t0))       # .item(): collective + device-to-host read)
         if not have:
             raise EmptyBatch("a rank has no items in this step (all filtered by the collate): step skipped on every rank")
         emb, target, mixed, seq_len, _target_wav, phase = batch
@@ -213,7 +227,7 @@ class Trainer:
             # a persistent BiLSTM launch that lost its CUs mid-flight poisons its output with NaN: say so instead of
             # reporting a numerical explosion (the host is synchronised here anyway)
             status = getattr(self.model, "lstm_status", None)
-            if callable(status) and status() != 0:
+            if callable(status) and status() == 1:          # None = not knowable any more: report the explosion as such
                 raise RuntimeError("the persistent BiLSTM kernel gave up waiting for a peer workgroup (another process is using "
                                    "the GPU?): this step's results were NaN-poisoned; rerun, or select the per-step kernels "
                                    "with vs_set_lstm_kernel(1)")
