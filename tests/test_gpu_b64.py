@@ -1,0 +1,221 @@
+"""GPU: the metric batch itself (B = 64 x 301 x 601, BASELINE configs[1] / configs[2]) against references -- VERDICT round 4,
+parity items 2 (b), (c).  bench.py times this batch; the other parity tests stop at B = 8.  What a B = 64 launch adds over B = 8 is
+not arithmetic but SCHEDULE: the tile / segment decode of the persistent conv kernels at 64 x dil x 19 items (nseg = 1), 19 264 GEMM
+rows in 256-row tiles (75.25 tiles), 241 workgroups of the fused head with a ragged last one, 64 utterances = 2 batch tiles of the
+persistent recurrence.  Three tests:
+
+  * eval mode (frozen BatchNorm: utterances are independent), both arithmetics: four scattered utterances of the B = 64 mask against
+    the CPU oracle run on those four alone -- f16x3: <= 1e-4 relative and mask MSE <= 1e-4 (the path's contract), bf16: mask MSE <=
+    1e-4 (BASELINE's bound) and the round's max-abs bound;
+  * train mode (batch statistics couple the utterances, so the oracle would need all 64: ~3 minutes of CPU), bf16: every stage of the
+    B = 64 forward is checked against fp64 ON THE TAPE'S OWN OPERANDS -- the batch statistics and the running-statistic update against
+    fp64 reductions of the z tensors the kernels wrote (cnn1: of fp64 conv(x)), and, for four scattered utterances, every 64 -> 64 conv
+    on a pixel sample, every BatchNorm + Mish apply, cnn8, the BiLSTM and the head on a row sample, each from the tensor the previous
+    stage left in the tape.  A schedule error at B = 64 (a tile skipped, a segment decoded wrongly, a ragged edge) shows up as a
+    wrong pixel or row here whatever the batch mates are.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import reference_forward as R
+from test_gpu_nhwc_f16x3 import _sample_pixels, sampled_conv_fp64
+
+pytestmark = pytest.mark.gpu
+IDX = [1, 22, 41, 63]
+
+
+class _math:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from voicesplit_amd import ops
+        self.prev = ops.get_conv_math()
+        ops.set_conv_math(self.name)
+
+    def __exit__(self, *exc):
+        from voicesplit_amd import ops
+        ops.set_conv_math(self.prev)
+
+
+def _model(seed, gain):
+    import voicesplit_amd as V
+    dims_d = R.default_dims()
+    sd = R.spread_logits(R.build_state_dict(dims_d, seed), gain)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in list(sd):                                       # non-trivial running statistics: eval-mode BatchNorm does something
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    m = V.VoiceSplit(V.default_config())
+    m.load_state_dict(sd)
+    return m.cuda(), sd, dims_d
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16"])
+def test_b64_eval_forward_scattered_utterances_vs_oracle(math):
+    m, sd, dims_d = _model(3, 8.0)
+    m.eval()
+    x, dvec = R.synthetic_inputs(64, 301, dims_d, 11)
+    with _math(math), torch.no_grad():
+        big = m(x.cuda(), dvec.cuda())
+    torch.cuda.synchronize()
+    assert big.shape == (64, 301, 601) and torch.isfinite(big).all()
+    with torch.no_grad():
+        ref = R.forward(sd, x[IDX], dvec[IDX], act="mish")["mask"]
+    got = big[IDX].cpu()
+    err = (got.double() - ref.double()).abs()
+    mse = float((err ** 2).mean())
+    rel = float(err.max() / ref.abs().max())
+    assert ref.min() < 0.05 and ref.max() > 0.95             # the masks are spread over (0, 1): the comparison is not vacuous
+    assert mse <= 1e-4
+    if math == "f16x3":
+        assert rel <= 1e-4, rel
+    else:
+        assert float(err.max()) <= 6e-2, float(err.max())
+
+
+def _mish(y):
+    return y * torch.tanh(F.softplus(y, threshold=20))
+
+
+def _bf16_close(got, ref, what, ulps=2.05, floor=2e-5):
+    """|got - ref| within `ulps` x 2^-8 of the reference value + a floor relative to the tensor's range.  The stored result is ONE
+    bf16 rounding of an fp32 value that agrees with the fp64 one to ~1e-6: error <= 2^-8 relative, or -- when the fp32 value sits on
+    the other side of a rounding boundary -- one bf16 step, 2^-7 relative at the bottom of a binade: hence 2.05."""
+    ref = ref.double()
+    tol = ulps * ref.abs() * 2.0 ** -8 + floor * ref.abs().max()
+    bad = ((got.double() - ref).abs() - tol).max().item()
+    assert bad <= 0, (what, bad, ref.abs().max().item())
+
+
+def test_b64_train_forward_bf16_stagewise_vs_fp64_on_the_tapes_operands():
+    from voicesplit_amd import ops
+    m, sd, dims_d = _model(4, 6.0)
+    m.train()
+    B, T, Fq, H = 64, 301, 601, dims_d["lstm_dim"]
+    x, dvec = R.synthetic_inputs(B, T, dims_d, 12)
+    before = {k: v.clone() for k, v in sd.items() if "running_" in k}
+    xc, dc = x.cuda(), dvec.cuda()
+    with _math("bf16"):
+        mask = m(xc, dc)
+        tape = mask.grad_fn.tape
+        dims = ops.make_dims(B, T, Fq, dims_d["emb_dim"], H, dims_d["fc1_dim"], dims_d["fc2_dim"])
+        lay = ops.tape_layout(dims)
+    torch.cuda.synchronize()
+    assert m.lstm_status() == 0
+    bf = torch.bfloat16
+    act_shape = (B, T, Fq, 64)
+    z = {l: ops.ws_view(tape, lay.z[l], act_shape, bf) for l in range(1, 7)}           # cnn2..cnn7: conv + bias
+    a = {l: ops.ws_view(tape, lay.a[l], act_shape, bf) for l in range(0, 6)}           # cnn1..cnn6: Mish(BN(z))
+    t_scale = ops.ws_view(tape, lay.bn_scale, (8, 64))
+    t_shift = ops.ws_view(tape, lay.bn_shift, (8, 64))
+    t_mean = ops.ws_view(tape, lay.bn_mean, (8, 64))
+    t_invstd = ops.ws_view(tape, lay.bn_invstd, (8, 64))
+    z8 = ops.ws_view(tape, lay.z8, (B, T, 8, Fq))
+    feat = ops.ws_view(tape, lay.feat, (B, T, 8 * Fq))
+    lstm_out = ops.ws_view(tape, lay.lstm_out, (B, T, 2 * H))
+    n = float(B * T * Fq)
+    after = m.state_dict()
+    conv_i = [1, 5, 9, 13, 17, 21, 25, 28]                   # Sequential indices of the conv modules; BatchNorm = + 1
+    sdc = {k: v.cuda() for k, v in sd.items()}
+
+    def check_stats(l, mean64, var64, C):
+        """the tape's batch statistics and the module's running-statistic update against an fp64 reduction"""
+        std = var64.sqrt()
+        assert ((t_mean[l, :C].double() - mean64).abs() / std).max().item() < 1e-4, ("mean", l)
+        assert ((t_invstd[l, :C].double() * (var64 + 1e-5).sqrt()) - 1).abs().max().item() < 1e-4, ("invstd", l)
+        bi = conv_i[l] + 1
+        rm = 0.9 * before[f"conv.{bi}.running_mean"].double().cuda() + 0.1 * mean64
+        rv = 0.9 * before[f"conv.{bi}.running_var"].double().cuda() + 0.1 * var64 * n / (n - 1)
+        assert ((after[f"conv.{bi}.running_mean"].double() - rm).abs() / std).max().item() < 1e-4, ("running_mean", l)
+        assert ((after[f"conv.{bi}.running_var"].double() / rv) - 1).abs().max().item() < 1e-4, ("running_var", l)
+        gamma, beta = sdc[f"conv.{bi}.weight"].double(), sdc[f"conv.{bi}.bias"].double()
+        sc = gamma / (var64 + 1e-5).sqrt()
+        assert ((t_scale[l, :C].double() - sc).abs() / sc.abs()).max().item() < 1e-4, ("scale", l)
+        want_sh = beta - mean64 * sc
+        assert ((t_shift[l, :C].double() - want_sh).abs().max() / (want_sh.abs().max() + 1.0)).item() < 1e-4, ("shift", l)
+
+    # ---- cnn1 (recomputed from x: no z1 in the tape): statistics of fp64 conv(x) + bias over the whole batch, a1 on the sample --------
+    w1, b1 = sdc["conv.1.weight"].double(), sdc["conv.1.bias"].double()
+    s1 = torch.zeros(64, dtype=torch.float64, device="cuda")
+    s2 = torch.zeros(64, dtype=torch.float64, device="cuda")
+    for b0 in range(0, B, 8):
+        z1 = F.conv2d(F.pad(xc[b0:b0 + 8].double().unsqueeze(1), (3, 3)), w1, b1)          # [8, 64, T, F]
+        s1 += z1.sum((0, 2, 3))
+        s2 += (z1 * z1).sum((0, 2, 3))
+        del z1
+    mean1 = s1 / n
+    check_stats(0, mean1, s2 / n - mean1 * mean1, 64)
+    tt, ff = _sample_pixels(T, Fq)
+    ttc, ffc = tt.cuda(), ff.cuda()
+    for b in IDX:
+        z1 = F.conv2d(F.pad(xc[b:b + 1].double().unsqueeze(1), (3, 3)), w1, b1)[0].permute(1, 2, 0)       # [T, F, 64]
+        want = _mish(z1[ttc, ffc] * t_scale[0].double() + t_shift[0].double())
+        _bf16_close(a[0][b][ttc, ffc], want, ("a1", b))
+
+    # ---- cnn2 .. cnn7: conv on the pixel sample from the tape's a, statistics from the tape's z, apply from the tape's z ---------------
+    spec = [(7, 1, 1), (5, 5, 1), (5, 5, 2), (5, 5, 4), (5, 5, 8), (5, 5, 16)]
+    for l in range(1, 7):
+        KT, KF, dil = spec[l - 1]
+        w = sdc[f"conv.{conv_i[l]}.weight"].to(bf).float()                 # the operand the kernel multiplies: bf16-rounded weights
+        bias = sdc[f"conv.{conv_i[l]}.bias"].double()
+        for b in IDX:
+            ref = sampled_conv_fp64(a[l - 1][b:b + 1], w, dil, tt, ff)[0] + bias
+            _bf16_close(z[l][b][ttc, ffc], ref, ("z", l + 1, b))
+        # batch statistics: the kernel sums its fp32 outputs BEFORE rounding them to bf16; the fp64 reduction below sees the rounded
+        # tensor -- unbiased roundings of 2^-9 relative average out over 1.16e7 values per channel (1e-6 of the spread)
+        s1.zero_(); s2.zero_()
+        for b0 in range(0, B, 4):
+            zz = z[l][b0:b0 + 4].double()
+            s1 += zz.sum((0, 1, 2))
+            s2 += (zz * zz).sum((0, 1, 2))
+            del zz
+        mean = s1 / n
+        check_stats(l, mean, s2 / n - mean * mean, 64)
+        if l < 6:                                                           # a7 is formed inside cnn8 (consumer-side apply)
+            for b in IDX:
+                want = _mish(z[l][b][ttc, ffc].double() * t_scale[l].double() + t_shift[l].double())
+                _bf16_close(a[l][b][ttc, ffc], want, ("a", l + 1, b))
+
+    # ---- cnn8 (64 -> 8, reads z7 and applies cnn7's BatchNorm + Mish on the way in), its statistics, the LSTM features ----------------
+    w8 = sdc["conv.28.weight"].to(bf).double().view(8, 64)
+    b8 = sdc["conv.28.bias"].double()
+    for b in IDX:
+        a7 = _mish(z[6][b][ttc, ffc].double() * t_scale[6].double() + t_shift[6].double()).to(bf).double()
+        ref = a7 @ w8.t() + b8                                              # [n, 8]
+        got = z8[b].permute(0, 2, 1)[ttc, ffc]                              # [T, 8, F] -> [T, F, 8]
+        err = ((got.double() - ref).abs() / ref.abs().max()).max().item()
+        assert err < 1e-5, ("z8", b, err)
+    z8d = z8.double()
+    mean8 = z8d.mean((0, 1, 3))
+    var8 = (z8d * z8d).mean((0, 1, 3)) - mean8 * mean8
+    del z8d
+    check_stats(7, mean8, var8, 8)
+    for b in IDX:
+        want = _mish(z8[b].double() * t_scale[7, :8].double().view(1, 8, 1) + t_shift[7, :8].double().view(1, 8, 1)).reshape(T, 8 * Fq)
+        err = ((feat[b].double() - want).abs() / want.abs().max()).max().item()
+        assert err < 1e-5, ("feat", b, err)
+
+    # ---- BiLSTM on four utterances from the tape's features (fp64 nn.LSTM, d-vector concatenated at every frame) ----------------------
+    lstm = torch.nn.LSTM(8 * Fq + dims_d["emb_dim"], H, batch_first=True, bidirectional=True).double().cuda()
+    lstm.load_state_dict({k[len("lstm."):]: v.double() for k, v in sdc.items() if k.startswith("lstm.")})
+    with torch.no_grad():
+        inp = torch.cat([feat[IDX].double(), dc[IDX].double().unsqueeze(1).expand(-1, T, -1)], dim=2)
+        want, _ = lstm(inp)
+    err = (lstm_out[IDX].double() - want).abs().max().item()
+    assert err < 3e-2, ("lstm_out", err)                                  # bf16 GEMM operands, f16 recurrent operands (tests/test_gpu_bf16.py: 8e-2 end to end)
+
+    # ---- head on a row sample (fused kernel: bf16 operands, fp32 accumulate; ragged last workgroup = the last rows) -------------------
+    rows = torch.cat([torch.arange(0, B * T, 37), torch.arange(B * T - 100, B * T)]).cuda()
+    lo_rows = lstm_out.reshape(B * T, 2 * H)[rows]
+    r = lambda t: t.to(bf).double()
+    h1 = (r(lo_rows.clamp_min(0)) @ r(sdc["fc1.weight"]).t() + sdc["fc1.bias"].double()).clamp_min(0)
+    logits = r(h1.float()) @ r(sdc["fc2.weight"]).t() + sdc["fc2.bias"].double()
+    want = torch.sigmoid(logits)
+    got = mask.detach().reshape(B * T, -1)[rows].double()
+    assert (got - want).abs().max().item() < 1.5e-3, (got - want).abs().max().item()     # tests/test_gpu_head.py's MASK_TOL: an h1 element
+    assert (got - want).abs().mean().item() < 2e-5                                       # rounded the other way moves a logit
+    del mask

@@ -132,3 +132,63 @@ def test_scale_plan_follows_the_input_range(amp):
     got0 = _merge(oh, ol, os2).cpu()
     want0 = _act(sh.double(), "mish").view(1, 1, 1, 64).expand_as(got0)
     assert (got0 - want0).abs().max().item() < 1e-5
+
+
+# ---- full width: the metric configuration's layer shapes, against fp64 on a sample of pixels (parity item 1) ----
+def _sample_pixels(T, Fq):
+    """Every row for a few columns (the image's left edge, a strip boundary, the middle, the last -- ragged -- strip of F = 601:
+    columns 592..600) and every column for a few rows (the first / last rows, rows around the first segment boundaries): the strip
+    / segment decode of the launch (nseg, seg_rows, the 38th strip) takes its full-size values only here."""
+    cols = sorted({0, 1, 2, 15, 16, 17, 31, 32, Fq // 2, Fq // 2 + 1} | set(range(max(0, Fq - 11), Fq)))
+    rows = sorted({0, 1, 2, 3, 4, 5, 6, 7, 17, 18, 23, 24, 25, 47, 48, 150, T - 5, T - 4, T - 3, T - 2, T - 1} & set(range(T)))
+    tt = torch.cat([torch.arange(T).repeat_interleave(len(cols)), torch.tensor(rows).repeat_interleave(Fq)])
+    ff = torch.cat([torch.tensor(cols).repeat(T), torch.arange(Fq).repeat(len(rows))])
+    return tt, ff
+
+
+def sampled_conv_fp64(x, w, dil, tt, ff):
+    """fp64 conv output [B, n, 64] at the pixels (tt, ff) of a channels-last input x [B, T, F, 64] (any float dtype, on the
+    device), zero padding, time dilation `dil`: the patches are gathered from a padded fp64 copy, one einsum."""
+    B, T, Fq, C = x.shape
+    KT, KF = w.shape[2], w.shape[3]
+    P, PF = (KT // 2) * dil, KF // 2
+    xp = torch.zeros(B, T + 2 * P, Fq + 2 * PF, C, dtype=torch.float64, device=x.device)
+    xp[:, P:P + T, PF:PF + Fq] = x.double()
+    tt, ff = tt.to(x.device), ff.to(x.device)
+    out = torch.zeros(B, tt.numel(), w.shape[0], dtype=torch.float64, device=x.device)
+    w64 = w.double().to(x.device)
+    for dt in range(KT):
+        for df in range(KF):
+            patch = xp[:, tt + dt * dil, ff + df]                     # [B, n, ci]
+            out += torch.einsum("bnc,oc->bno", patch, w64[:, :, dt, df])
+    return out
+
+
+@pytest.mark.parametrize("KT,KF,dil", [(5, 5, 1), (5, 5, 2), (5, 5, 4), (5, 5, 8), (5, 5, 16), (7, 1, 1)])
+def test_full_width_layer_matches_fp64_on_a_pixel_sample(KT, KF, dil):
+    """B = 2 x 301 x 601 (the metric configuration's image), every dilation of the stack + the 7x1 layer: ~29 000 pixels x 64
+    output channels (both channel halves = both workgroups of a pair) per utterance against fp64, same bounds as the small cases."""
+    from voicesplit_amd import ops
+    B, T, Fq = 2, 301, 601
+    g = torch.Generator().manual_seed(100 * KT + dil)
+    x = torch.randn(B, T, Fq, 64, generator=g) * (torch.rand(1, 1, 1, 64, generator=g) * 2.0 + 0.1)
+    w = torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5
+    sc = (torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.2, -1.0, 1.0)
+    sh = torch.randn(64, generator=g) * 0.5
+    hi, lo, s2 = ops.f16x3_split(x.cuda(), 2.0 ** 6)
+    oh, ol, os2, amax, _ = ops.nhwc_conv_f16x3(hi, lo, s2, w.cuda(), sc.cuda(), sh.cuda(), dil, "mish")
+    got_full = _merge(oh, ol, os2)
+    assert torch.isfinite(got_full).all()
+    tt, ff = _sample_pixels(T, Fq)
+    assert tt.numel() >= 20000
+    got = got_full[:, tt.cuda(), ff.cuda()]
+
+    def ref_of(xin):
+        z = sampled_conv_fp64(xin, w, dil, tt, ff)
+        return _act(z * sc.double().cuda() + sh.double().cuda(), "mish")
+
+    given = ref_of(_merge(hi, lo, s2))
+    scale = given.abs().max()
+    assert ((got - given).abs().max() / scale).item() < 2e-6
+    assert ((got - ref_of(x.cuda())).abs().max() / scale).item() < 3e-6
+    assert amax.view(torch.float32).max().item() >= scale.item() * (1 - 1e-6)
