@@ -44,7 +44,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these are its only exports */
 #endif
 
-#define VS_ABI_VERSION 7
+#define VS_ABI_VERSION 8
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -450,6 +450,35 @@ int vs_set_conv_kernel(int mode);
  * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
  * (a workgroup of the launch was not resident): results are then invalid. */
 int vs_set_lstm_kernel(int mode);
+
+/* Every remaining process-wide switch of the library, behind ONE call (ABI 8): the library itself reads NO environment variable.
+ * All of them exist for A/B timing and cross-checks; every value of every option gives valid results unless the option says
+ * "timing ablation".  vs_set_option returns 0, or -1 for an unknown option / a value outside its range; vs_get_option returns
+ * the current value (-1 for an unknown option).  Not thread-safe against concurrent calls into the library: set options before
+ * work is enqueued.  (The Python package maps the environment variable named beside each option onto this call when it loads
+ * the library: voicesplit_amd/_lib.py.) */
+enum vs_option {
+  VS_OPT_F16X3_CONV_NCHW = 0, /* 0 (default): the fp32-class eval forward runs on channels-last hi / lo f16 planes
+                                 (conv_nhwc_f16x3.hip); 1: the [B][64][T][F] kernels of rounds 1-3.  Changes which form of the conv
+                                 weights vs_prepare_weights writes: set it BEFORE preparing weights and keep it while a prepared
+                                 blob is in use.  VOICESPLIT_F16X3_CONV=nchw */
+  VS_OPT_BWD_DY = 1,          /* 1 (default): bf16 data gradients carry the activation derivative and the BatchNorm-backward sums in
+                                 their epilogue (dy form); 0: plain data gradients + two-pass BatchNorm backward.  VOICESPLIT_BWD_DY */
+  VS_OPT_GEMM_KERNEL = 2,     /* bf16 GEMM: 0 (default) the interleaved kernel, 1 the round-3 kernel (bit-identical).  VOICESPLIT_GEMM_KERNEL=old */
+  VS_OPT_GEMM_DR = 3,         /* bf16 GEMM: three digits (row x row, row x col, col x col), each 4 or 8 = MFMA rows the DMA chunks of a K
+                                 step are issued in; default 888.  VOICESPLIT_GEMM_DR */
+  VS_OPT_GEMM_ABL = 4,        /* bf16 GEMM timing ablations (results INVALID): 0 off; 9 = empty operand descriptors; 1..3 = instances of
+                                 an ABLATION=1 build.  VOICESPLIT_GEMM_ABL */
+  VS_OPT_GEMM_BAND = 5,       /* split-f16 GEMM: tile rows per raster band, default 8.  VOICESPLIT_GEMM_BAND */
+  VS_OPT_WGRAD_ABL = 6,       /* bf16 weight gradient timing ablations of an ABLATION=1 build (results INVALID).  VOICESPLIT_WGRAD_ABL */
+  VS_OPT_SPLITCONV_ABL = 7,   /* split-f16 channels-last conv: timing ablations / in-kernel probes of an ABLATION=1 build.  VOICESPLIT_SPLITCONV_ABL */
+  VS_OPT_CONV_SCALAR_EPILOGUE = 8, /* bf16 channels-last conv (conv_nhwc.hip): 1 = the instances compiled WITHOUT packed-fp32 VALU
+                                 instructions (v_pk_fma_f32 ... become pairs of scalar instructions: same values, bit for bit), 0 = the packed
+                                 ones; default: see vs_get_option.  VOICESPLIT_CONV_SCALAR_EPILOGUE */
+  VS_OPT_COUNT = 9
+};
+int vs_set_option(int option, int value);
+int vs_get_option(int option);
 
 /* Did the persistent BiLSTM kernels of the last vs_forward_train / vs_backward on `tape` and / or the last vs_forward /
  * vs_bilstm_fwd on `workspace` complete?  0 = yes, 1 = a bounded spin gave up (another process took CUs away while the

@@ -24,6 +24,20 @@ def timed(fn, reps=3):
 
 
 def main():
+    # VS_MICRO_EPILOGUE_AB=1: every conv variant twice, packed-fp32 and scalar epilogue builds (vs_set_option), in one process
+    if os.environ.get("VS_MICRO_EPILOGUE_AB"):
+        from voicesplit_amd import _lib
+        out = {}
+        for rnd in range(2):                              # twice: the clock of a fresh box drifts over the first seconds
+            for mode in (0, 1):
+                _lib.set_option("CONV_SCALAR_EPILOGUE", mode)
+                out[f"round{rnd} scalar_epilogue={mode}"] = run()
+        print(json.dumps(out, indent=1), flush=True)
+        return
+    print(json.dumps(run(), indent=1), flush=True)
+
+
+def run():
     B, T, F = int(os.environ.get("VS_B", 64)), 301, 601
     dev = torch.device("cuda:0")
     x = torch.randn(B, T, F, 64, device=dev).to(torch.bfloat16)
@@ -49,7 +63,7 @@ def main():
             continue
         ms = timed(lambda: ops.nhwc_conv_wgrad(x, x, KT, KF, dil))
         res[f"nhwc wgrad {KT}x{KF} dil{dil}"] = {"ms": round(ms, 3), "tflops": round(gflop / ms, 1)}
-    print(json.dumps(res, indent=1), flush=True)
+    return res
 
 
 if __name__ == "__main__":

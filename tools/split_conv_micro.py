@@ -20,6 +20,9 @@ def main(name):
     sc, sh = torch.ones(64).cuda(), torch.zeros(64).cuda()
     out = {}
     import os
+    from voicesplit_amd import _lib
+    if os.environ.get("VS_MICRO_SCALAR") is not None:
+        _lib.set_option("CONV_SCALAR_EPILOGUE", int(os.environ["VS_MICRO_SCALAR"]))
     shapes = ((5, 5, 1), (5, 5, 4), (5, 5, 16), (7, 1, 1)) if not os.environ.get("VOICESPLIT_SPLITCONV_ABL") else ((5, 5, 1), (7, 1, 1))
     for kt, kf, dil in shapes:
         w = (torch.randn(64, 64, kt, kf, generator=g) / (64 * kt * kf) ** 0.5).cuda()

@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class VsDims(Structure):
@@ -158,6 +158,8 @@ SIGNATURES = {
     "vs_set_wgrad_kernel": (c_int, [c_int]),
     "vs_set_conv_kernel": (c_int, [c_int]),
     "vs_set_lstm_kernel": (c_int, [c_int]),
+    "vs_set_option": (c_int, [c_int, c_int]),
+    "vs_get_option": (c_int, [c_int]),
     "vs_set_backward_overlap": (c_int, [c_int]),
     "vs_lstm_status": (c_int, [POINTER(VsDims), _P, c_size_t, _P, c_size_t, _P]),
     "vs_bn_act_bwd_first": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -211,8 +213,48 @@ def load(path: str = None) -> ctypes.CDLL:
         fn.argtypes = argtypes
     if lib.vs_abi_version() != ABI_VERSION:
         raise VoiceSplitHipError(f"{path}: ABI version {lib.vs_abi_version()} != {ABI_VERSION}; rebuild")
+    _apply_env_options(lib)
     _lib = lib
     return lib
+
+
+# enum vs_option of include/voicesplit_hip.h.  The library reads no environment variable; for A/B timing from the shell this
+# package maps the variables below onto vs_set_option ONCE, when it loads the library.
+OPTIONS = {"F16X3_CONV_NCHW": 0, "BWD_DY": 1, "GEMM_KERNEL": 2, "GEMM_DR": 3, "GEMM_ABL": 4, "GEMM_BAND": 5, "WGRAD_ABL": 6,
+           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8}
+_ENV_OPTIONS = {
+    "VOICESPLIT_F16X3_CONV": ("F16X3_CONV_NCHW", lambda v: 1 if v == "nchw" else 0),
+    "VOICESPLIT_BWD_DY": ("BWD_DY", lambda v: 0 if v.startswith("0") else 1),
+    "VOICESPLIT_GEMM_KERNEL": ("GEMM_KERNEL", lambda v: 1 if v.startswith("o") else 0),
+    "VOICESPLIT_GEMM_DR": ("GEMM_DR", int),
+    "VOICESPLIT_GEMM_ABL": ("GEMM_ABL", lambda v: 9 if v.startswith("n") else int(v)),
+    "VOICESPLIT_GEMM_BAND": ("GEMM_BAND", int),
+    "VOICESPLIT_WGRAD_ABL": ("WGRAD_ABL", int),
+    "VOICESPLIT_SPLITCONV_ABL": ("SPLITCONV_ABL", int),
+    "VOICESPLIT_CONV_SCALAR_EPILOGUE": ("CONV_SCALAR_EPILOGUE", int),
+}
+
+
+def _apply_env_options(lib):
+    for var, (name, conv) in _ENV_OPTIONS.items():
+        v = os.environ.get(var)
+        if v is None or v == "":
+            continue
+        if lib.vs_set_option(OPTIONS[name], conv(v)) != 0:
+            msg = lib.vs_last_error()
+            raise VoiceSplitHipError(f"{var}={v}: {msg.decode() if msg else 'rejected by vs_set_option'}")
+
+
+def set_option(name: str, value: int):
+    """vs_set_option by name (see OPTIONS); returns the previous value."""
+    lib = load()
+    prev = lib.vs_get_option(OPTIONS[name])
+    check(lib.vs_set_option(OPTIONS[name], int(value)), f"vs_set_option({name})")
+    return prev
+
+
+def get_option(name: str) -> int:
+    return load().vs_get_option(OPTIONS[name])
 
 
 def check(rc: int, what: str):

@@ -23,6 +23,10 @@ void vs_set_error(const char* fmt, ...) {
 // caller's stream (no synchronisation, ~1 us each).  vs_profile_end() synchronises the events,
 // sums the elapsed time per slot and frees them.  Instrumentation only: process-global, not
 // thread safe, off by default.
+// defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
+int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
+                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 0};
+
 namespace {
 struct Prof {
   bool on = false;
@@ -71,12 +75,9 @@ size_t conv_packed_bytes(int i) {
   return a > b ? a : b;
 }
 
-// Eval-mode forward of the fp32-class arithmetic: channels-last hi / lo planes (conv_nhwc_f16x3.hip), or -- VOICESPLIT_F16X3_CONV=nchw,
+// Eval-mode forward of the fp32-class arithmetic: channels-last hi / lo planes (conv_nhwc_f16x3.hip), or -- vs_set_option(VS_OPT_F16X3_CONV_NCHW, 1),
 // the A/B switch -- the [B][64][T][F] kernels of rounds 1-2, which train mode keeps using (its tape is fp32 NCHW).
-bool split_route() {
-  static const bool nchw = getenv("VOICESPLIT_F16X3_CONV") && !strcmp(getenv("VOICESPLIT_F16X3_CONV"), "nchw");
-  return !nchw;
-}
+bool split_route() { return vs_opt(VS_OPT_F16X3_CONV_NCHW) == 0; }
 
 int layout(const vs_dims* d, vs_ws_layout* L) {
   if (int rc = check_dims(d)) return rc;
@@ -278,6 +279,27 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
 extern "C" {
 
 int vs_abi_version(void) { return VS_ABI_VERSION; }
+
+int vs_set_option(int option, int value) {
+  VS_REQUIRE(option >= 0 && option < VS_OPT_COUNT, "vs_set_option: unknown option %d", option);
+  bool ok = true;
+  switch (option) {
+    case VS_OPT_F16X3_CONV_NCHW: case VS_OPT_BWD_DY: case VS_OPT_GEMM_KERNEL: case VS_OPT_CONV_SCALAR_EPILOGUE: ok = value == 0 || value == 1; break;
+    case VS_OPT_GEMM_DR: {
+      const int a = value / 100, b = (value / 10) % 10, c = value % 10;
+      ok = (a == 4 || a == 8) && (b == 4 || b == 8) && (c == 4 || c == 8);
+      break;
+    }
+    case VS_OPT_GEMM_ABL: ok = (value >= 0 && value <= 3) || value == 9; break;
+    case VS_OPT_GEMM_BAND: ok = value >= 1 && value <= 1024; break;
+    default: ok = value >= 0; break;
+  }
+  VS_REQUIRE(ok, "vs_set_option: value %d is outside the range of option %d", value, option);
+  g_vs_options[option] = value;
+  return 0;
+}
+
+int vs_get_option(int option) { return (option >= 0 && option < VS_OPT_COUNT) ? g_vs_options[option] : -1; }
 
 int vs_profile_begin(int max_calls) {
   VS_REQUIRE(!g_prof.on, "profile: already enabled");

@@ -493,11 +493,9 @@ struct ConvWalk {
   }
 };
 
-template <int KT, int KF, int ACT, bool STATS, bool DY = false>
-__global__ __launch_bounds__(256, 1)
-void nhwc_conv_kernel(NhwcConvArgs a) {
+template <int KT, int KF, int ACT, bool STATS, bool DY>
+__device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsigned char* smem) {
   using G = Geo<KT, KF>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];      // the only LDS object of the kernel
   ConvWalk<KT, KF, ACT, STATS, DY> wk(a, (const lds_byte*)smem);
 
   // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
@@ -541,6 +539,24 @@ void nhwc_conv_kernel(NhwcConvArgs a) {
     }
   }
   wk.flush_stats();
+}
+
+// Two builds of every instance: with the packed-fp32 VALU instructions the epilogue's pair arithmetic compiles to (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32), and -- PK = false -- with that subtarget feature switched off for the kernel, so that every pair
+// operation becomes two scalar instructions (same values, bit for bit).  MI355X_MICROARCH.md prices a packed-fp32 instruction
+// beside MFMAs at +22..26 cycles over the two scalar ones it replaces ("an anti-lever beside MFMAs"); vs_set_option(
+// VS_OPT_CONV_SCALAR_EPILOGUE) picks the build, the measurement is in profiles/r05_conv_epilogue_ab.md.
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
+__global__ __launch_bounds__(256, 1)
+void nhwc_conv_kernel(NhwcConvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];      // the only LDS object of the kernel
+  nhwc_conv_body<KT, KF, ACT, STATS, DY>(a, smem);
+}
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
+__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
+void nhwc_conv_scalar_kernel(NhwcConvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
+  nhwc_conv_body<KT, KF, ACT, STATS, DY>(a, smem);
 }
 
 // w [co][ci][KT][KF] fp32 -> per-wave A fragments: [q][tap][kc][lane][j] = w'[16q + (lane&15)][32kc + 8(lane>>4) + j][tap]
@@ -591,11 +607,14 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   const dim3 grid((unsigned)(n_items < cus ? n_items : cus)), block(256);
   const size_t lds = 0;   // static LDS: Geo::LDS_BYTES
   const bool stats = a.bn_stats != nullptr;
-#define VS_NHWC_LAUNCH(A, S) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S>), grid, block, lds, stream, a)
+  const bool scalar = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE) != 0;
+#define VS_NHWC_LAUNCH3(A, S, D) do { if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
+                                      else hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); } while (0)
+#define VS_NHWC_LAUNCH(A, S) VS_NHWC_LAUNCH3(A, S, false)
   if (a.z2) {            // data gradient with the activation-derivative epilogue: act = the activation whose derivative is taken
     VS_REQUIRE(stats && a.bn2_scale && a.bn2_shift && a.bn2_mean && a.bn2_invstd, "nhwc conv: the dy epilogue needs statistics slots and BatchNorm constants");
-    if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, VS_ACT_MISH, false, true>), grid, block, lds, stream, a);
-    else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, VS_ACT_RELU, false, true>), grid, block, lds, stream, a);
+    if (act == VS_ACT_MISH) VS_NHWC_LAUNCH3(VS_ACT_MISH, false, true);
+    else if (act == VS_ACT_RELU) VS_NHWC_LAUNCH3(VS_ACT_RELU, false, true);
     else VS_REQUIRE(false, "nhwc conv: dy epilogue for activation %d", act);
   } else if (stats) {
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv: fused statistics go with no activation");
@@ -605,6 +624,7 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   else if (act == VS_ACT_RELU) VS_NHWC_LAUNCH(VS_ACT_RELU, false);
   else VS_REQUIRE(false, "nhwc conv: unsupported activation %d", act);
 #undef VS_NHWC_LAUNCH
+#undef VS_NHWC_LAUNCH3
   VS_LAUNCH_CHECK();
   return 0;
 }

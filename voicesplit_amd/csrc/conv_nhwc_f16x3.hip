@@ -421,12 +421,10 @@ struct SplitWalk {
   __device__ __forceinline__ void flush_epilogue() { micros<0>(std::make_integer_sequence<int, NMT>()); }
 };
 
-template <int KT, int KF, int ACT, int ABL = 0>
-__global__ __launch_bounds__(256, 1)
-void nhwc_conv_f16x3_kernel(SplitConvArgs a) {
+template <int KT, int KF, int ACT, int ABL>
+__device__ __forceinline__ void nhwc_conv_f16x3_body(const SplitConvArgs& a, const unsigned char* smem) {
   using G = SGeo<KT, KF>;
   constexpr int R = G::R;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
   SplitWalk<KT, KF, ACT, ABL> wk(a, (const lds_byte*)smem);
   // workgroups w and w + 8 (one XCD) are a pair: the same tiles, the two halves of the output channels
   const int slot = (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7);
@@ -505,6 +503,20 @@ void nhwc_conv_f16x3_kernel(SplitConvArgs a) {
     }
   } else
   vs_absmax_commit(wk.am * a.out_scale2[1], a.amax_out);
+}
+
+// (the _scalar build: no packed-fp32 VALU instructions in the epilogue -- conv_nhwc.hip has the reason; vs_set_option(VS_OPT_CONV_SCALAR_EPILOGUE))
+template <int KT, int KF, int ACT, int ABL = 0>
+__global__ __launch_bounds__(256, 1)
+void nhwc_conv_f16x3_kernel(SplitConvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SGeo<KT, KF>::LDS_BYTES];
+  nhwc_conv_f16x3_body<KT, KF, ACT, ABL>(a, smem);
+}
+template <int KT, int KF, int ACT>
+__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
+void nhwc_conv_f16x3_scalar_kernel(SplitConvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SGeo<KT, KF>::LDS_BYTES];
+  nhwc_conv_f16x3_body<KT, KF, ACT, 0>(a, smem);
 }
 
 // w [co][ci][KT][KF] fp32 -> [co half][wave = (block m, K half kh)][tap][plane][lane][j] f16:
@@ -604,7 +616,7 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
   if (want < grid) grid = (int)want;
   const dim3 g((unsigned)grid), block(256);
 #ifdef VS_ABLATION        // timing ablations / in-kernel probes (tools/split_conv_micro.py): make -C voicesplit_amd/csrc ABLATION=1
-  static const int abl = getenv("VOICESPLIT_SPLITCONV_ABL") ? atoi(getenv("VOICESPLIT_SPLITCONV_ABL")) : 0;     // timing ablations, Mish only
+  const int abl = vs_opt(VS_OPT_SPLITCONV_ABL);     // timing ablations, Mish only
   if (abl && act == VS_ACT_MISH) {
     if (abl == 1) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 1>), g, block, 0, stream, a);
     else if (abl == 2) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 2>), g, block, 0, stream, a);
@@ -618,6 +630,12 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
     else hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 16>), g, block, 0, stream, a);
   } else
 #endif
+  if (vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE)) {
+    if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
+    else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
+    else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
+    else VS_REQUIRE(false, "nhwc f16x3 conv: unsupported activation %d", act);
+  } else
   if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
   else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
   else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);

@@ -625,18 +625,18 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   const dim3 grid((unsigned)nwg), block(256);
   const int form = (!a_kmajor && !b_kmajor) ? 0 : (!a_kmajor && b_kmajor) ? 1 : (a_kmajor && b_kmajor) ? 2 : 3;
   VS_REQUIRE(form != 3, "gemm_bf16: the col x row form is not used by the path");
-  // round 4: the interleaved kernel (side work in the slots behind the MFMAs); VOICESPLIT_GEMM_KERNEL=old selects the round-3
+  // round 4: the interleaved kernel (side work in the slots behind the MFMAs); vs_set_option(VS_OPT_GEMM_KERNEL, 1) selects the round-3
   // kernel for A/B timing (same arithmetic, same summation order: bit-identical results)
-  static const bool use_old = [] { const char* e = getenv("VOICESPLIT_GEMM_KERNEL"); return e && e[0] == 'o'; }();
+  const bool use_old = vs_opt(VS_OPT_GEMM_KERNEL) == 1;
   if (!use_old) {
-    // VOICESPLIT_GEMM_DR: three digits (row x row, row x col, col x col), each 4 or 8 = rows the DMA chunks are issued in (A/B timing)
-    static const int dr_cfg = [] { const char* e = getenv("VOICESPLIT_GEMM_DR"); return (e && e[0] && e[1] && e[2]) ? (e[0] - '0') * 100 + (e[1] - '0') * 10 + (e[2] - '0') : 888; }();
-    static const bool nodma = [] { const char* e = getenv("VOICESPLIT_GEMM_ABL"); return e && e[0] == 'n'; }();
+    // VS_OPT_GEMM_DR: three digits (row x row, row x col, col x col), each 4 or 8 = rows the DMA chunks are issued in (A/B timing)
+    const int dr_cfg = vs_opt(VS_OPT_GEMM_DR);
+    const bool nodma = vs_opt(VS_OPT_GEMM_ABL) == 9;
     if (nodma) g.accumulate = -1;                          // timing ablation: results are meaningless
     const int dr = form == 0 ? dr_cfg / 100 : form == 1 ? (dr_cfg / 10) % 10 : dr_cfg % 10;
-    VS_REQUIRE(dr == 4 || dr == 8, "gemm_bf16: VOICESPLIT_GEMM_DR digit %d", dr);
+    VS_REQUIRE(dr == 4 || dr == 8, "gemm_bf16: VS_OPT_GEMM_DR digit %d", dr);
 #ifdef VS_ABLATION
-    static const int abl = [] { const char* e = getenv("VOICESPLIT_GEMM_ABL"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }();
+    const int abl = vs_opt(VS_OPT_GEMM_ABL) <= 3 ? vs_opt(VS_OPT_GEMM_ABL) : 0;
     if (abl && form == 0) {
       if (abl == 1) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 1>), grid, block, 0, stream, g);
       else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 2>), grid, block, 0, stream, g);

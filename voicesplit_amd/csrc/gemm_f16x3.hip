@@ -28,7 +28,7 @@
 // would need transposed split copies of dxg and feat (~0.45 ms) to save ~1 ms.
 #include <stdlib.h>
 
-#include "vs_common.h"
+#include "vs_internal.h"
 
 namespace {
 
@@ -491,13 +491,7 @@ void gemm_pre_kernel(GemmPreArgs g) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int gemm_band() {
-  static const int band = [] {
-    const char* e = getenv("VOICESPLIT_GEMM_BAND");
-    return e ? atoi(e) : 8;
-  }();
-  return band;
-}
+int gemm_band() { return vs_opt(VS_OPT_GEMM_BAND); }
 
 }  // namespace
 

@@ -566,9 +566,9 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
-    // A/B switch (VOICESPLIT_BWD_DY=0): the data gradients of cnn3..cnn7 as plain convs, the activation derivative and the
+    // A/B switch (vs_set_option(VS_OPT_BWD_DY, 0)): the data gradients of cnn3..cnn7 as plain convs, the activation derivative and the
     // BatchNorm-backward sums taken by the two-pass BatchNorm backward beside the weight gradient instead (round 2's form)
-    static const bool dy_form = [] { const char* e = getenv("VOICESPLIT_BWD_DY"); return !(e && e[0] == '0'); }();
+    const bool dy_form = vs_opt(VS_OPT_BWD_DY) != 0;
     bool have_dy = true;               // gb[c] holds dy (activation derivative applied, sums in `stats`) -- cnn8's backward above produced it
     for (int i = 5; i >= 0; --i) {
       const int l = i + 1;

@@ -8,6 +8,14 @@
 
 #define VS_WAVE 64
 
+// A kernel built without gfx950's packed-fp32 VALU instructions (v_pk_fma_f32 ...: pairs of scalar instructions instead; same values).
+// The attribute names a device subtarget feature: the host pass of the same translation unit does not know it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VS_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define VS_NO_PACKED_FP32
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -10,6 +10,10 @@ struct VsProfScope {
   ~VsProfScope();
 };
 
+// capi.hip: the option table behind vs_set_option / vs_get_option (the library reads no environment variable)
+extern int g_vs_options[VS_OPT_COUNT];
+inline int vs_opt(int o) { return g_vs_options[o]; }
+
 // conv_mfma.hip
 int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_conv64_fwd_impl(const float* in, const float* wp, const float* scale, const float* shift, float* out,

@@ -559,7 +559,7 @@ int vs_nhwc_wgrad_impl(const void* dz, const void* a_in, float* part, float* dw,
   WgradArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(a_in), part, B, T, F, dil,
               (F + STRIP - 1) / STRIP, 1, 0, 0, 0};
 #ifdef VS_ABLATION
-  if (const char* e = getenv("VOICESPLIT_WGRAD_ABL")) a.abl = atoi(e);
+  a.abl = vs_opt(VS_OPT_WGRAD_ABL);
 #endif
   if (KT == 5 && KF == 5) return launch_wgrad<5, 5>(a, dw, stream);
   if (KT == 7 && KF == 1) return launch_wgrad<7, 1>(a, dw, stream);
