@@ -61,20 +61,38 @@ MATH_LABEL = {"fp32": "fp32 MFMA", "f16x3": "fp32 I/O, split-f16 MFMA (3 f16 pro
               "bf16": "channels-last bf16 activations / tape, bf16 MFMA, fp32 accumulate / statistics / master weights"}
 
 
-def committed_pmc_traffic(tag, kernel_substr, instance=None):
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def committed_pmc_traffic(tag, kernel_substr, instance=None, source=None):
     """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/<tag>_rocprof/pmc_per_kernel.csv, written by tools/profile_gpu.sh + summarize_prof.py in
     separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE, in GB.  The x2 is calibrated, not assumed: a 1 GiB
     read reports FETCH_SIZE = 0.5 GiB for dword and for 16-byte loads alike on this chip and tool version, and a
     1 GiB write reports WRITE_SIZE = 1 GiB (profiles/r02_calibration/).  bench.py itself cannot collect
-    counters; None when the file is absent.  instance: a substring of the template arguments that picks ONE
-    instantiation of the kernel (the forward conv and the dy-form data gradient are two instances of nhwc_conv_kernel
-    with different traffic); without it the instance with the most dispatches."""
+    counters.  instance: a substring of the template arguments that picks ONE instantiation of the kernel (the forward
+    conv and the dy-form data gradient are two instances of nhwc_conv_kernel with different traffic); without it the
+    instance with the most dispatches.  source: the kernel's file under voicesplit_amd/csrc/ -- the figure is reported only
+    while that file is byte-identical to the one the counters were collected on (sources.sha256 beside the CSV, written
+    on the GPU box by tools/profile_gpu.sh); a profile without that record, or of an older source, gives (None, why).
+    Returns (GB or None, provenance string)."""
     import csv
-    for rnd in ("r04", "r03", "r02"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_rocprof", "pmc_per_kernel.csv")
+    for rnd in ("r05", "r04", "r03", "r02"):
+        d = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_rocprof")
+        path = os.path.join(d, "pmc_per_kernel.csv")
         if not os.path.isfile(path):
             continue
+        if source is not None:
+            rec = os.path.join(d, "sources.sha256")
+            if not os.path.isfile(rec):
+                return None, f"{rnd}: no sources.sha256 beside the counters (profile predates the record)"
+            want = {ln.split()[1].lstrip("*"): ln.split()[0] for ln in open(rec) if ln.strip()}
+            cur = os.path.join(ROOT, "voicesplit_amd", "csrc", source)
+            if want.get(source) != (_sha256(cur) if os.path.isfile(cur) else None):
+                return None, f"{rnd}: {source} has changed since the counters were collected"
         best = None
         for r in csv.DictReader(open(path)):
             if kernel_substr in r["kernel"] and (instance is None or instance in r["kernel"]) and r.get("fetch_GB_x2") and r.get("write_GB"):
@@ -83,7 +101,7 @@ def committed_pmc_traffic(tag, kernel_substr, instance=None):
                     best = (n, float(r["fetch_GB_x2"]) + float(r["write_GB"]))
         if best is not None:
             return round(best[1], 2), rnd
-    return None, None
+    return None, "no committed profile of this command"
 
 
 def _pick_threads():
@@ -148,13 +166,26 @@ def cpu_baseline(mode, seconds_budget=14.0):
 
     n1, el1 = run(1, seconds_budget)
     n4, el4 = run(4, seconds_budget * 0.6)
-    return {"value": round(n1 / el1, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
-            "metric": ("utterances/sec fwd+bwd with a stand-in loss (the model's share of the step: the SI-SNR head is not timed on the CPU)"
-                       if mode == "train" else "utterances/sec forward"),
-            "value_b4": round(4 * n4 / el4, 4),
-            "sample": f"{n1} x {what} of one [1,301,601] utterance in {el1:.1f} s (value) and {n4} x the same at B=4 in "
-                      f"{el4:.1f} s (value_b4), fp32, torch {torch.__version__} CPU ops, {threads} threads "
-                      f"(fastest of a 4..256 sweep; {avail} logical cores visible)"}
+    fwd_b1 = None
+    if mode == "train":
+        # BASELINE configs[0]: the reference's own CPU-runnable case -- ONE 3 s utterance, forward only (what test.py / validation() run)
+        mode_keep, mode = mode, "forward"
+        try:
+            nf, elf = run(1, seconds_budget * 0.4)
+        finally:
+            mode = mode_keep
+        fwd_b1 = {"value": round(nf / elf, 4), "unit": "utterances/s",
+                  "sample": f"BASELINE configs[0]: {nf} x forward of one [1,301,601] utterance in {elf:.1f} s, same threads"}
+    out = {"value": round(n1 / el1, 4), "unit": "utterances/s", "cores": threads, "kind": "port",
+           "metric": ("utterances/sec fwd+bwd with a stand-in loss (the model's share of the step: the SI-SNR head is not timed on the CPU)"
+                      if mode == "train" else "utterances/sec forward"),
+           "value_b4": round(4 * n4 / el4, 4),
+           "sample": f"{n1} x {what} of one [1,301,601] utterance in {el1:.1f} s (value) and {n4} x the same at B=4 in "
+                     f"{el4:.1f} s (value_b4), fp32, torch {torch.__version__} CPU ops, {threads} threads "
+                     f"(fastest of a 4..256 sweep; {avail} logical cores visible)"}
+    if fwd_b1 is not None:
+        out["forward_b1"] = fwd_b1
+    return out
 
 
 def self_launch(args):
@@ -299,19 +330,22 @@ def main():
         def step():
             return streaming.separate_long_many(model, long_spec, long_dvec, window=T_FRAMES, max_batch=B)
 
-    def timed(fn, steps, warmup, profile):
+    elapsed_local = [0.0]
+
+    def timed(fn, steps, warmup, profile, calls_per_step=None):
         for _ in range(warmup):
             out_ = fn()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         if profile and rank == 0:
-            _lib.check(lib.vs_profile_begin(steps * (6 if args.mode == "longform" else 1)), "vs_profile_begin")
+            _lib.check(lib.vs_profile_begin(steps * (calls_per_step or (6 if args.mode == "longform" else 1))), "vs_profile_begin")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             out_ = fn()
         torch.cuda.synchronize()
+        elapsed_local[0] = time.perf_counter() - t0               # this rank alone, before the closing barrier
         if dist:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -327,9 +361,32 @@ def main():
             _lib.check(lib.vs_profile_end(ms, calls), "vs_profile_end")
         return el, ms, calls
 
+    if train and world > 1:
+        # N > 1 self-diagnosis: HIP events around every gradient all-reduce, host time of the EmptyBatch MIN-reduce; the communicator's
+        # first collectives (ring setup, buffer registration) run in the warm-up -- at least one warm-up step even with --warmup 0
+        if args.warmup < 1:
+            step()
+        trainer.set_comm_timing(True)
     elapsed, ms, calls = timed(step, args.steps, args.warmup, True)
     if train:
         assert torch.isfinite(bucket.flat).all()
+    comm = None
+    if train and world > 1:
+        ar = bucket.collective_ms()[-args.steps:]
+        fl = trainer.flag_ms[-args.steps:]
+        trainer.set_comm_timing(False)
+        mine = torch.tensor([elapsed_local[0] / args.steps * 1e3, sum(ar) / max(1, len(ar)), max(ar) if ar else 0.0,
+                             sum(fl) / max(1, len(fl))], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu()
+        comm = {"step_ms_per_rank_min": round(float(rows[:, 0].min()), 3), "step_ms_per_rank_max": round(float(rows[:, 0].max()), 3),
+                "allreduce_ms": round(float(rows[:, 1].mean()), 3), "allreduce_ms_max_over_ranks_and_steps": round(float(rows[:, 2].max()), 3),
+                "flag_ms": round(float(rows[:, 3].mean()), 3),
+                "note": "allreduce_ms: HIP-event time of the flat 75.5 MB gradient all-reduce per step (bucket.all_reduce, trainer.py), mean over ranks "
+                        "and timed steps; it includes waiting for the slowest rank's backward.  flag_ms: host wall time of the EmptyBatch MIN-reduce "
+                        "(a 4-byte all-reduce + .item()) in front of every step.  step_ms_per_rank_*: each rank's own clock around its timed steps "
+                        "(before the closing barrier)"}
 
     # ---- RCCL leg (outside the timed region) ---------------------------------------------------------
     # N > 1: every rank must hold the same bucket after the step's all-reduce (a checksum per rank, gathered).
@@ -346,6 +403,8 @@ def main():
                 same = all(torch.equal(allc[0], c) for c in allc)
                 assert same, "gradient buckets differ between ranks after the all-reduce"
                 rccl = {"rccl_ranks": world, "bucket_identical_on_all_ranks": True, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1)}
+                if comm:
+                    rccl.update(comm)
             else:
                 # (under torch.distributed.run the group has to come from the launcher's store: see the helper)
                 from voicesplit_amd.sharding import init_single_rank_group
@@ -386,8 +445,11 @@ def main():
                 ops.gemm_bf16(a_, b_, M_, N_, K_)
             e1.record()
             torch.cuda.synchronize()
+            cal_ms = e0.elapsed_time(e1) / 10
             box = {"kernel": "gemm_bf16 19264x3200x4808 on seeded random operands, mean of 10 launches outside the timed region",
-                   "ms": round(e0.elapsed_time(e1) / 10, 4)}
+                   "ms": round(cal_ms, 4), "tflops": round(2.0 * M_ * N_ * K_ / cal_ms / 1e9, 1),
+                   "note": "the same launch on every box: its TFLOP/s is a proxy of the clock this box sustains under a matrix-pipe load "
+                           "(the pool's boxes differ by +-3.5 %); compare two lines at equal calibration"}
             del a_, b_
         except Exception as exc:
             box = {"error": str(exc)[:200]}
@@ -395,19 +457,24 @@ def main():
     def stage_table(ms_, calls_, steps_):
         return {n: (ms_[i] / steps_ if calls_[i] else None) for i, n in enumerate(_lib.PROF_NAMES)}
 
-    def conv_roofline(stage_ms, math, is_train, tag):
-        """The dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training)."""
+    def conv_roofline(stage_ms, math, is_train, tag, nbatch=None, batch=None):
+        """The dominant kernel: the 5x5 64->64 conv (cnn3..cnn7 forward, + their data gradients in training).
+        nbatch: forward batches per timed step (long-form: the windows of a step go through in several batches), batch: their
+        mean size -- the stage timers hold the sum over a step's batches."""
+        if nbatch is None:
+            nbatch = 5 if args.mode == "longform" else 1      # --mode longform: 1280 windows = 5 forward batches of 256 per step
+        B = args.batch if batch is None else batch
         launches = [stage_ms[f"cnn{i}"] for i in range(3, 8)]
         if is_train:
             launches += [stage_ms[f"dgrad_cnn{i}"] for i in range(3, 8)]
-        launches = [v / (5 if args.mode == "longform" else 1) for v in launches]      # longform: 5 forward batches per step
+        launches = [v / nbatch for v in launches]
         mean_launch_ms = sum(launches) / len(launches)
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
         act_bytes = 2 if math == "bf16" else 4
         if math == "bf16":
             kname, peak = "nhwc_conv_kernel<5,5> (channels-last bf16, LDS-DMA window buffers, register-resident weights)", PEAK_F16_MFMA_TFLOPS
             extra = {"mfma_pipe": "bf16 (v_mfma_f32_16x16x32_bf16), one MFMA product per product", "mfma_peak_tflops": PEAK_F16_MFMA_TFLOPS}
-            ksub = "nhwc_conv_kernel"
+            ksub, ksrc = "nhwc_conv_kernel", "conv_nhwc.hip"
         elif math == "f16x3":
             # every fp32 product is three f16 MFMA products (csrc/conv_f16x3.hip): the pipe-level
             # ceiling for ALGORITHMIC flops is the dense f16 MFMA peak / 3
@@ -418,27 +485,28 @@ def main():
                      "empirical_ceiling": "a stream of nothing but this layer's MFMAs reaches 1659 TF on the f16 pipe with its real operand values "
                                           "(2345 TF on zero operands): the chip clocks down with operand toggling; 553 TF algorithmic = 0.66 of `peak` "
                                           "is the most any schedule of this arithmetic reaches on random data (profiles/r02_conv_ablation.md)"}
-            ksub = "conv64_f16x3_pk_kernel"
+            ksub, ksrc = "conv64_f16x3_pk_kernel", "conv_f16x3_pk.hip"
             if not is_train:
                 # eval-mode forward (configs[1], configs[4]): the channels-last split-f16 kernel (csrc/conv_nhwc_f16x3.hip, round 4)
                 kname = "nhwc_conv_f16x3_kernel<5,5> (channels-last hi/lo f16 planes by LDS-DMA, weights in AGPRs, K halves across waves)"
-                ksub = "nhwc_conv_f16x3_kernel<5, 5"
+                ksub, ksrc = "nhwc_conv_f16x3_kernel<5, 5", "conv_nhwc_f16x3.hip"
                 extra["mfma_pipe"] = "f16 (v_mfma_f32_16x16x32_f16), 3 MFMA products per fp32 product"
                 extra["launch_ms_includes"] = "the layer's plan kernel (output scale from the tracked |max| of its input); weights come prepared"
                 extra["issue_model"] = ("one wave per SIMD: 16 cycles per MFMA + ~5 cycles for every other instruction, no overlap measured "
                                         "(s_memtime probes and ablations: profiles/r04_split_conv.md); 450 MFMAs + ~350 other instructions per group of 6 rows; cuts of the "
                                         "instruction count have not moved the time: the clock follows (power-bound)")
         else:
-            kname, peak, extra, ksub = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel"
-        traffic, rnd = committed_pmc_traffic(tag, ksub) if B == 64 else (None, None)
+            kname, peak, extra, ksub, ksrc = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel", "conv_mfma.hip"
+        no64 = (None, "counters were collected at B = 64 only")
+        traffic, rnd = committed_pmc_traffic(tag, ksub, source=ksrc) if B == 64 else no64
         algo_gb = B * 2 * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
         by_instance = None
         if math == "bf16" and is_train:
             # two instances of the kernel share the 10 launches: the forward conv (reads a, writes z: 2 tensors) and the dy-form
             # data gradient (reads dz and the lower layer's z, writes dy: 3 tensors) -- each against ITS algorithmic bytes
             one = B * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
-            t_f, r_f = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "true, false>") if B == 64 else (None, None)
-            t_d, r_d = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "false, true>") if B == 64 else (None, None)
+            t_f, r_f = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "true, false>", source=ksrc) if B == 64 else no64
+            t_d, r_d = committed_pmc_traffic(tag, "nhwc_conv_kernel<5, 5", "false, true>", source=ksrc) if B == 64 else no64
             by_instance = {"forward": {"launches_per_step": 5, "algorithmic_gb": round(2 * one, 2), "traffic_gb": t_f},
                            "dy_form_data_gradient": {"launches_per_step": 5, "algorithmic_gb": round(3 * one, 2), "traffic_gb": t_d}}
             algo_gb = 2.5 * one                                                 # mean over the 10 launches
@@ -449,9 +517,11 @@ def main():
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "traffic": traffic,
-                "traffic_unit": f"GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
-                                f"(profiles/{rnd or 'rNN'}_{tag}_rocprof/pmc_per_kernel.csv; not measured in this run: bench.py cannot collect counters); "
-                                f"algorithmic bytes {algo_gb:.2f} GB" + (" (mean over the two instances: traffic_by_instance)" if by_instance else ""),
+                "traffic_unit": (f"GB per launch: 2 x FETCH_SIZE (calibrated: profiles/r02_calibration) + WRITE_SIZE from the committed --pmc passes of this command "
+                                 f"(profiles/{rnd}_{tag}_rocprof/pmc_per_kernel.csv, collected on a byte-identical {ksrc}: sources.sha256 there; not measured "
+                                 f"in this run: bench.py cannot collect counters); " if traffic is not None else
+                                 f"null: no committed counters that belong to this binary ({rnd}); ")
+                                + f"algorithmic bytes {algo_gb:.2f} GB" + (" (mean over the two instances: traffic_by_instance)" if by_instance else ""),
                 "launches_per_step": len(launches), "launch_ms": [round(v, 3) for v in launches],
                 "hbm_frac_of_same_kernel": round(algo_gb / (mean_launch_ms / 1e3) / PEAK_HBM_GBS, 4)}
         roof.update(extra)
@@ -471,7 +541,7 @@ def main():
                                               "(vs_set_backward_overlap, DESIGN.md 6.7)"
                                               if not args.serial_backward else "serial schedule: the kernel alone")}
         if stage_ms.get("lstm_gemm"):
-            nl = 5 if args.mode == "longform" else 1
+            nl = nbatch
             gemm_peak = PEAK_F16_MFMA_TFLOPS if math == "bf16" else PEAK_F16_MFMA_TFLOPS / 3.0 if math == "f16x3" else PEAK_FP32_MFMA_TFLOPS
             lg = B * GFLOP_LSTM_GEMM / (stage_ms["lstm_gemm"] / nl)
             roof["lstm_input_gemm"] = {"stage_ms": round(stage_ms["lstm_gemm"] / nl, 3), "achieved": round(lg, 1), "peak": round(gemm_peak, 1),
@@ -480,6 +550,12 @@ def main():
         return roof
 
     # ---- BASELINE configs[1] next to the training line: forward only, eval-mode BatchNorm ---------------
+    def leg_roofline(ms_, calls_, steps_, math, tag, nbatch=1, batch=None):
+        """`roofline` + per-stage times of a forward / long-form sub-leg from its own stage timers (rank 0)."""
+        st_ms = stage_table(ms_, calls_, steps_)
+        roof = conv_roofline(st_ms, math, False, tag, nbatch=nbatch, batch=batch)
+        return roof, {k: round(v / nbatch, 3) for k, v in st_ms.items() if v is not None}
+
     def forward_leg(m, math):
         m.eval()
         prev = ops.get_conv_math()
@@ -490,13 +566,16 @@ def main():
             def f():
                 with torch.no_grad():
                     return m(spec, dvec)
-            fel, _, _ = timed(f, FK, 2, False)
+            fel, fms, fcalls = timed(f, FK, 2, True)
         finally:
             ops.set_conv_math(prev)
             m.train()
-        return {"metric": f"utterances/sec (3 s clips, B={B}/GPU) forward only, eval BatchNorm (BASELINE configs[1]), " + MATH_LABEL[math],
-                "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
-                "ms_per_step": round(1e3 * fel / FK, 3)}
+        leg = {"metric": f"utterances/sec (3 s clips, B={B}/GPU) forward only, eval BatchNorm (BASELINE configs[1]), " + MATH_LABEL[math],
+               "value": round(world * B * FK / fel, 2), "unit": "utterances/s", "steps": FK, "warmup": 2,
+               "ms_per_step": round(1e3 * fel / FK, 3)}
+        if fms is not None:
+            leg["roofline"], leg["stage_ms"] = leg_roofline(fms, fcalls, FK, math, "forward" + ("" if math == "f16x3" else "_" + math))
+        return leg
 
     # ---- BASELINE configs[4] next to the training line: 30 s clips as independent 301-frame windows, 256 per forward batch ----
     def longform_leg(m, math, clips=51, steps=2):
@@ -513,15 +592,21 @@ def main():
 
             def f():
                 return streaming.separate_long_many(m, ls, ld, window=T_FRAMES, max_batch=256)
-            lel, _, _ = timed(f, steps, 1, False)
+            lel, lms, lcalls = timed(f, steps, 1, True, calls_per_step=-(-nwin // 256) + 1)
             del ls
         finally:
             ops.set_conv_math(prev)
             m.train()
-        return {"metric": "windows/sec = utterances/sec (30 s clips cut into independent 301-frame windows, 256 windows per forward batch, eval "
-                          "BatchNorm: BASELINE configs[4]), " + MATH_LABEL[math],
-                "value": round(world * nwin * steps / lel, 2), "unit": "utterances/s", "clips_per_s": round(world * clips * steps / lel, 2),
-                "clips_per_gpu_and_step": clips, "windows_per_step": nwin, "steps": steps, "warmup": 1, "ms_per_step": round(1e3 * lel / steps, 3)}
+        leg = {"metric": "windows/sec = utterances/sec (30 s clips cut into independent 301-frame windows, 256 windows per forward batch, eval "
+                         "BatchNorm: BASELINE configs[4]), " + MATH_LABEL[math],
+               "value": round(world * nwin * steps / lel, 2), "unit": "utterances/s", "clips_per_s": round(world * clips * steps / lel, 2),
+               "clips_per_gpu_and_step": clips, "windows_per_step": nwin, "steps": steps, "warmup": 1, "ms_per_step": round(1e3 * lel / steps, 3)}
+        if lms is not None:
+            nb_ = -(-nwin // 256)                                   # forward batches per step; the roofline is per launch at their mean size
+            leg["roofline"], leg["stage_ms"] = leg_roofline(lms, lcalls, steps, math, "forward" + ("" if math == "f16x3" else "_" + math),
+                                                            nbatch=nb_, batch=nwin / nb_)
+            leg["stage_ms_note"] = f"per forward batch ({nb_} batches of {nwin / nb_:.0f} windows per step)"
+        return leg
 
     # ---- the same training step in another arithmetic (own model, own trainer, same inputs) ----------------
     def train_leg(math, steps, warmup):
@@ -594,7 +679,8 @@ def main():
         line = {
             "metric": (f"utterances/sec (3 s clips, B={B}/GPU) " + {"train": "fwd+bwd, ", "forward": "forward, ",
                                                                    "longform": "forward over 301-frame windows of 30 s clips, "}[args.mode]
-                       + MATH_LABEL[conv_math]),
+                       + MATH_LABEL[conv_math]
+                       + (f" [box calibration GEMM: {box['tflops']:.0f} TF]" if box and "tflops" in box else "")),
             "value": round(value, 2), "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),

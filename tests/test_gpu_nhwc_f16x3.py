@@ -139,8 +139,8 @@ def _sample_pixels(T, Fq):
     """Every row for a few columns (the image's left edge, a strip boundary, the middle, the last -- ragged -- strip of F = 601:
     columns 592..600) and every column for a few rows (the first / last rows, rows around the first segment boundaries): the strip
     / segment decode of the launch (nseg, seg_rows, the 38th strip) takes its full-size values only here."""
-    cols = sorted({0, 1, 2, 15, 16, 17, 31, 32, Fq // 2, Fq // 2 + 1} | set(range(max(0, Fq - 11), Fq)))
-    rows = sorted({0, 1, 2, 3, 4, 5, 6, 7, 17, 18, 23, 24, 25, 47, 48, 150, T - 5, T - 4, T - 3, T - 2, T - 1} & set(range(T)))
+    cols = sorted(({0, 1, 2, 15, 16, 17, 31, 32, 47, 48, 63, 64, Fq // 2, Fq // 2 + 1} & set(range(Fq))) | set(range(max(0, Fq - 11), Fq)))
+    rows = sorted({0, 1, 2, 3, 4, 5, 6, 7, 17, 18, 23, 24, 25, 47, 48, 95, 96, 150, 200, 201, T - 5, T - 4, T - 3, T - 2, T - 1} & set(range(T)))
     tt = torch.cat([torch.arange(T).repeat_interleave(len(cols)), torch.tensor(rows).repeat_interleave(Fq)])
     ff = torch.cat([torch.tensor(cols).repeat(T), torch.arange(Fq).repeat(len(rows))])
     return tt, ff

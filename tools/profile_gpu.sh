@@ -9,6 +9,8 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# which kernel sources these counters belong to: bench.py reports a committed `traffic` only while the kernel's source file is unchanged
+(cd "$REPO/voicesplit_amd/csrc" && sha256sum *.hip *.h *.inc) > "$OUT/sources.sha256"
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -f csv -- $BENCH > "$OUT/trace.log" 2>&1

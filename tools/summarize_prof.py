@@ -27,6 +27,8 @@ def main():
     dst = os.path.join(ROOT, "profiles", f"{tag}_rocprof")
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    if os.path.isfile(os.path.join(src, "sources.sha256")):
+        shutil.copy(os.path.join(src, "sources.sha256"), os.path.join(dst, "sources.sha256"))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
