@@ -475,7 +475,10 @@ enum vs_option {
   VS_OPT_CONV_SCALAR_EPILOGUE = 8, /* bf16 channels-last conv (conv_nhwc.hip): 1 = the instances compiled WITHOUT packed-fp32 VALU
                                  instructions (v_pk_fma_f32 ... become pairs of scalar instructions: same values, bit for bit), 0 = the packed
                                  ones; default: see vs_get_option.  VOICESPLIT_CONV_SCALAR_EPILOGUE */
-  VS_OPT_COUNT = 9
+  VS_OPT_MFMA_PRIO = 9,       /* bit 0: the bf16 weight-gradient kernel, bit 1: the bf16 channels-last conv raise their wave priority (s_setprio 3), so that
+                                 the HBM-bound BatchNorm pass co-resident on the same SIMDs (vs_backward's side stream) gets the issue slots they leave,
+                                 not the other way round.  Same results.  VOICESPLIT_MFMA_PRIO */
+  VS_OPT_COUNT = 10
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

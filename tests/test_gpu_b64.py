@@ -188,7 +188,9 @@ def test_b64_train_forward_bf16_stagewise_vs_fp64_on_the_tapes_operands():
         ref = a7 @ w8.t() + b8                                              # [n, 8]
         got = z8[b].permute(0, 2, 1)[ttc, ffc]                              # [T, 8, F] -> [T, F, 8]
         err = ((got.double() - ref).abs() / ref.abs().max()).max().item()
-        assert err < 1e-5, ("z8", b, err)
+        # fp32 accumulation is ~1e-6; what is left is an a7 element whose fp32 Mish sits on the other side of a bf16 rounding
+        # boundary than the fp64 one: one bf16 step of ONE of the 64 operands of a pixel (measured 3e-5 of the range)
+        assert err < 1e-4, ("z8", b, err)
     z8d = z8.double()
     mean8 = z8d.mean((0, 1, 3))
     var8 = (z8d * z8d).mean((0, 1, 3)) - mean8 * mean8

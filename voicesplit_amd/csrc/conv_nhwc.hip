@@ -72,6 +72,7 @@ struct NhwcConvArgs {
   const float* bn2_scale; const float* bn2_shift; const float* bn2_mean; const float* bn2_invstd;   // [64] each
   int B, T, F, dil;
   int nstrip, nseg, seg_rows, n_items;
+  int prio;                         // != 0: the waves raise their priority (VS_OPT_MFMA_PRIO bit 1)
 };
 
 // XOR swizzle of the 16-byte pieces of a staged pixel (128 bytes = half a bank row; pixel parity picks the half): a
@@ -496,6 +497,7 @@ struct ConvWalk {
 template <int KT, int KF, int ACT, bool STATS, bool DY>
 __device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsigned char* smem) {
   using G = Geo<KT, KF>;
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   ConvWalk<KT, KF, ACT, STATS, DY> wk(a, (const lds_byte*)smem);
 
   // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
@@ -653,7 +655,7 @@ int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, co
              (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nhwc conv: buffers must be 16-byte aligned");
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(in), reinterpret_cast<const unsigned short*>(packed), scale, shift,
                  reinterpret_cast<unsigned short*>(out), bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
@@ -674,7 +676,7 @@ int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const voi
              (reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 7) == 0, "nhwc conv dy: buffer alignment");
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(packed), bn_scale, bn_shift,
                  reinterpret_cast<unsigned short*>(dy), bn_stats, reinterpret_cast<const unsigned short*>(z), bn_scale, bn_shift, bn_mean, bn_invstd,
-                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0};
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv dy: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
