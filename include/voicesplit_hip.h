@@ -478,7 +478,10 @@ enum vs_option {
   VS_OPT_MFMA_PRIO = 9,       /* bit 0: the bf16 weight-gradient kernel, bit 1: the bf16 channels-last conv raise their wave priority (s_setprio 3), so that
                                  the HBM-bound BatchNorm pass co-resident on the same SIMDs (vs_backward's side stream) gets the issue slots they leave,
                                  not the other way round.  Same results.  VOICESPLIT_MFMA_PRIO */
-  VS_OPT_COUNT = 10
+  VS_OPT_CONV8 = 10,          /* the 5x5 bf16 channels-last convs on the eight-wave kernel (conv_nhwc8.hip: two waves per SIMD, K halves across waves):
+                                 bit 0 = forward / plain data gradient, bit 1 = the dy-form data gradient; 0 = the four-wave kernel (conv_nhwc.hip).
+                                 Same operands, fp32 accumulation in another order (two halves of K).  VOICESPLIT_CONV8 */
+  VS_OPT_COUNT = 11
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

@@ -25,7 +25,7 @@ void vs_set_error(const char* fmt, ...) {
 // thread safe, off by default.
 // defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
 int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
-                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 0, /*MFMA_PRIO*/ 0};
+                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 0, /*MFMA_PRIO*/ 0, /*CONV8*/ 0};
 
 namespace {
 struct Prof {
@@ -292,7 +292,7 @@ int vs_set_option(int option, int value) {
     }
     case VS_OPT_GEMM_ABL: ok = (value >= 0 && value <= 3) || value == 9; break;
     case VS_OPT_GEMM_BAND: ok = value >= 1 && value <= 1024; break;
-    case VS_OPT_MFMA_PRIO: ok = value >= 0 && value <= 3; break;
+    case VS_OPT_MFMA_PRIO: case VS_OPT_CONV8: ok = value >= 0 && value <= 3; break;
     default: ok = value >= 0; break;
   }
   VS_REQUIRE(ok, "vs_set_option: value %d is outside the range of option %d", value, option);

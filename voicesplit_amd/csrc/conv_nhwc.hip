@@ -656,6 +656,8 @@ int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, co
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(in), reinterpret_cast<const unsigned short*>(packed), scale, shift,
                  reinterpret_cast<unsigned short*>(out), bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr,
                  B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
+  if (KT == 5 && KF == 5 && (vs_opt(VS_OPT_CONV8) & 1))
+    return vs_nhwc_conv8_impl(in, packed, scale, shift, out, bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, F, dil, act, stream);
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
@@ -677,6 +679,8 @@ int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const voi
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(packed), bn_scale, bn_shift,
                  reinterpret_cast<unsigned short*>(dy), bn_stats, reinterpret_cast<const unsigned short*>(z), bn_scale, bn_shift, bn_mean, bn_invstd,
                  B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
+  if (KT == 5 && KF == 5 && (vs_opt(VS_OPT_CONV8) & 2))
+    return vs_nhwc_conv8_impl(dz, packed, bn_scale, bn_shift, dy, bn_stats, z, bn_scale, bn_shift, bn_mean, bn_invstd, B, T, F, dil, act, stream);
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv dy: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);

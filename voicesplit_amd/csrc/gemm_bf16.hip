@@ -327,6 +327,15 @@ void gemm_bf16_kernel(GemmBf16Args g) {
 //  * the per-step bubble is gone: the step's barrier sits in front of the LAST row -- by then every fragment of the stage
 //    has been read into registers and the next stage's DMA was issued more than a thousand cycles ago -- and the first nine
 //    fragment reads of the next step (8 B + 1 A, into the registers of the finished k-half) ride on the last row's MFMAs.
+// An accumulator tile leaves the AGPRs HERE, as four explicit reads: left to the compiler, the copies of all 64 tiles were hoisted to the
+// loop exit and ~90 of the 256 registers they needed went to scratch around the epilogue of every tile.
+__device__ __forceinline__ f32x4 acc_read(const f32x4& t) {
+  f32x4 v;
+  asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "a"(t[0]), "a"(t[1]), "a"(t[2]), "a"(t[3]));
+  return v;
+}
+
 // DR: the 16 DMA chunks of a step are issued in the first DR rows (8: chunk a of both operands in row a; 4: chunks 2a, 2a+1 in row a
 // -- 4 more rows for the lines to arrive before the step's barrier)
 // ABL (timing ablations, built with -DVS_ABLATION only; results are meaningless): 1 = no fragment reads inside the K loop (the MFMAs
@@ -409,16 +418,8 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
 
   int cstage = 0;
   vs_bf16x8 bf[2][WB], afc, afn;
-  {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    unsigned fa = lds0 + fbA, fb = lds0 + (unsigned)A_BYTES + fbB;
-    asm volatile("" : "+v"(fa), "+v"(fb));
-#pragma unroll
-    for (int b = 0; b < WB; ++b) bf[0][b] = OB::frag(fb, b * 16, 0);
-    afc = OA::frag(fa, 0, 0);
-    afn = afc;
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   for (int j = 0; tile_ok(j); ++j) {
     int tm, tn;
     if (!tile_of(g, tile_id(j), tm, tn)) break;
@@ -427,6 +428,17 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
     for (int a = 0; a < WA; ++a)
 #pragma unroll
       for (int b = 0; b < WB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // the tile's first fragments.  (The last K step of the previous tile has read them already -- its row 15 does not know it is
+      // the last -- but re-reading them here ends their live range in front of the epilogue, which needs the registers: with the
+      // 36 of them live across it the allocator spilled ~90 registers per tile.  The stage is complete: the step barrier.)
+      unsigned fa = lds0 + (unsigned)(cstage * STAGE_BYTES) + fbA, fb = lds0 + (unsigned)(cstage * STAGE_BYTES + A_BYTES) + fbB;
+      asm volatile("" : "+v"(fa), "+v"(fb));
+#pragma unroll
+      for (int b = 0; b < WB; ++b) bf[0][b] = OB::frag(fb, b * 16, 0);
+      afc = OA::frag(fa, 0, 0);
+      afn = afc;
+    }
     for (int ks = 0; ks < nk; ++ks) {
       // !plive (end of the job): empty descriptors stay empty.  (plive is wave-uniform but lives in a vector register: made
       // scalar explicitly, or the descriptors it touches would leave the scalar registers the DMA instruction needs them in)
@@ -532,7 +544,7 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
       if (whole) {
         f32x4 v[WB];
 #pragma unroll
-        for (int b = 0; b < WB; ++b) v[b] = acc[a][b];
+        for (int b = 0; b < WB; ++b) v[b] = acc_read(acc[a][b]);
         if (rb) {
 #pragma unroll
           for (int b = 0; b < WB; ++b) v[b] += bias_nx[b];
@@ -549,19 +561,20 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
 #pragma unroll
         for (int b = 0; b < WB; ++b) *reinterpret_cast<f32x4*>(crow + 16 * b) = v[b];
       } else if (m < g.M) {
+        // a tile that sticks out of the matrix: the same 16-byte accesses under a per-lane predicate (N is a multiple of 4 and the
+        // leading dimensions are 16-byte multiples here -- vec_ok; the launcher sends everything else to gemm_bf16_kernel, whose
+        // epilogue works element by element: with that path unrolled in THIS kernel the allocator spilled 91 registers around it)
 #pragma unroll
-        for (int b = 0; b < WB; ++b)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = n0 + 16 * b + e;
-            if (n < g.N) {
-              float v = acc[a][b][e];
-              if (rb) v += rb[16 * b + e];
-              if (g.accumulate > 0) v += crow[16 * b + e];
-              crow[16 * b + e] = v;
-            }
+        for (int b = 0; b < WB; ++b) {
+          if (n0 + 16 * b < g.N) {
+            f32x4 v = acc_read(acc[a][b]);
+            if (rb) v += *reinterpret_cast<const f32x4*>(rb + 16 * b);
+            if (g.accumulate > 0) v += *reinterpret_cast<const f32x4*>(crow + 16 * b);
+            *reinterpret_cast<f32x4*>(crow + 16 * b) = v;
           }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);      // one row block at a time: hoisting the next blocks' loads across this point is what spilled
     }
   }
 }
@@ -627,7 +640,7 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   VS_REQUIRE(form != 3, "gemm_bf16: the col x row form is not used by the path");
   // round 4: the interleaved kernel (side work in the slots behind the MFMAs); vs_set_option(VS_OPT_GEMM_KERNEL, 1) selects the round-3
   // kernel for A/B timing (same arithmetic, same summation order: bit-identical results)
-  const bool use_old = vs_opt(VS_OPT_GEMM_KERNEL) == 1;
+  const bool use_old = vs_opt(VS_OPT_GEMM_KERNEL) == 1 || !g.vec_ok;      // the interleaved kernel's epilogue moves 16 bytes at a time
   if (!use_old) {
     // VS_OPT_GEMM_DR: three digits (row x row, row x col, col x col), each 4 or 8 = rows the DMA chunks are issued in (A/B timing)
     const int dr_cfg = vs_opt(VS_OPT_GEMM_DR);

@@ -75,6 +75,10 @@ size_t vs_nhwc_packed_bytes(int KT, int KF);
 int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
+// conv_nhwc8.hip: the 5x5 layers of the two calls above on the eight-wave kernel (two waves per SIMD); z != NULL: the dy form
+int vs_nhwc_conv8_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out, double* bn_stats,
+                       const void* z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                       int B, int T, int F, int dil, int act, hipStream_t);
 // conv_nhwc_f16x3.hip: the same convs, forward, in the fp32-class split-f16 arithmetic on channels-last hi / lo f16 planes
 size_t vs_nhwc_f16x3_packed_bytes(int KT, int KF);
 int vs_nhwc_f16x3_pack_impl(const float* w, const float* w_scale2, void* packed, float* l1, int KT, int KF, hipStream_t);
