@@ -481,7 +481,13 @@ enum vs_option {
   VS_OPT_CONV8 = 10,          /* the 5x5 bf16 channels-last convs on the eight-wave kernel (conv_nhwc8.hip: two waves per SIMD, K halves across waves):
                                  bit 0 = forward / plain data gradient, bit 1 = the dy-form data gradient; 0 = the four-wave kernel (conv_nhwc.hip).
                                  Same operands, fp32 accumulation in another order (two halves of K).  VOICESPLIT_CONV8 */
-  VS_OPT_COUNT = 11
+  VS_OPT_BN_FUSED_FINALIZE = 11, /* the bf16 training step folds the BatchNorm partial-sum slots, finalizes and clears the scratch in ONE launch per
+                                 layer: 1 (default) in the forward pass, 2 in the backward pass too, 0 nowhere (fold kernel + finalize kernel + a
+                                 memset in front of every producer: rounds 1-4).  Same values; in the backward pass the fused form is SLOWER
+                                 (it takes away the weight gradient's head start on the side stream: DESIGN.md 6.7).  VOICESPLIT_BN_FUSED_FINALIZE */
+  VS_OPT_SIDE_PRIO = 12,      /* priority of the library's side stream (weight gradients beside the BatchNorm backward passes): 0 normal (default),
+                                 1 high, 2 low.  Read when the stream is created (the first vs_backward on a device).  VOICESPLIT_SIDE_PRIO */
+  VS_OPT_COUNT = 13
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

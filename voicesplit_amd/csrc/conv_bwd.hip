@@ -668,9 +668,44 @@ __global__ void bn_bwd_fold_slots_kernel(double* __restrict__ stats, int n, int 
 
 // stats: [slots][C][2] doubles {sum dy, sum dy*xhat} (slots > 1: folded into slot 0 first) -> parameter gradients and
 // the three per-channel coefficients of the apply pass
+namespace {
+// one launch: fold the slots, the coefficients, clear the scratch (vs_fold_slots; the arithmetic of bn_bwd_finalize_kernel, to the letter)
+__global__ __launch_bounds__(VS_FOLD_THREADS)
+void bn_bwd_fold_finalize_kernel(double* __restrict__ stats, int slots, int rezero, double count, int train, int C,
+                                 const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ coef) {
+  __shared__ double part[8 * 128], tot[128];
+  vs_fold_slots(stats, 2 * C, slots, rezero, part, tot);
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double s1 = tot[2 * c], s2 = tot[2 * c + 1];
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  const double sc = scale[c];
+  if (train) {
+    const double k1 = s1 / count, k2 = s2 / count, is = invstd[c], mu = mean[c];
+    coef[c] = (float)sc;
+    coef[C + c] = (float)(-sc * k2 * is);
+    coef[2 * C + c] = (float)(-sc * k1 + sc * k2 * is * mu);
+    if (dbias) dbias[c] = 0.f;
+  } else {
+    coef[c] = (float)sc;
+    coef[C + c] = 0.f;
+    coef[2 * C + c] = 0.f;
+    if (dbias) dbias[c] = (float)(sc * s1);
+  }
+}
+}  // namespace
+
 int vs_bn_bwd_finalize_impl(double* stats, int slots, double count, int train, int C, const float* scale, const float* mean,
-                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t stream) {
+                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t stream, int rezero_doubles) {
   VS_REQUIRE(stats && coef && C > 0 && count > 0, "bn_bwd_finalize: bad argument");
+  if (rezero_doubles > 0 && C <= 64) {
+    hipLaunchKernelGGL(bn_bwd_fold_finalize_kernel, dim3(1), dim3(VS_FOLD_THREADS), 0, stream, stats, slots, rezero_doubles, count, train, C,
+                       scale, mean, invstd, dgamma, dbeta, dbias, coef);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   if (slots > 1) hipLaunchKernelGGL(bn_bwd_fold_slots_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, slots);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, train, C,
                      scale, mean, invstd, dgamma, dbeta, dbias, coef);

@@ -368,11 +368,42 @@ int vs_bn_train_impl(const float* x, float* y, int B, int C, int plane, const fl
 // Train-mode BatchNorm constants from accumulated statistics: stats = [slots][C][2] doubles {sum, sum of squares}
 // (slots > 1: partial sums of the conv epilogues, folded here) over `count` values per channel -> scale / shift of the
 // apply pass, mean / invstd for the backward pass, running buffers updated like nn.BatchNorm2d.
+// rezero_doubles > 0 (the training orchestration, C <= 64): ONE launch folds the slots, finalizes and clears that many doubles of the
+// scratch behind itself (vs_fold_slots); slot 0 does not receive the totals then.
+static __global__ __launch_bounds__(VS_FOLD_THREADS)
+void bn_fold_finalize_kernel(double* __restrict__ stats, int slots, int rezero, double count,
+                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int C,
+                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                             float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  __shared__ double part[8 * 128], tot[128];
+  vs_fold_slots(stats, 2 * C, slots, rezero, part, tot);
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double mean = tot[2 * c] / count;               // (the arithmetic of bn_finalize_kernel, to the letter)
+  double var = tot[2 * c + 1] / count - mean * mean;
+  if (var < 0) var = 0;
+  const float is = 1.0f / sqrtf((float)var + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = is;
+  const double unb = count > 1 ? var * (count / (count - 1)) : var;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+}
+
 int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float eps, float momentum,
-                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t stream) {
+                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t stream, int rezero_doubles) {
   VS_REQUIRE(stats && C > 0 && count > 0 && slots >= 1, "bn_finalize: bad argument (stats %p, slots %d, C %d, count %g)", (void*)stats, slots, C, count);
   VS_REQUIRE(gamma && beta && scale && shift, "bn_finalize: NULL gamma / beta / scale / shift");
+  if (rezero_doubles > 0 && C <= 64) {
+    hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3(1), dim3(VS_FOLD_THREADS), 0, stream, stats, slots, rezero_doubles, count, gamma, beta,
+                       eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);
+    VS_LAUNCH_CHECK();
+    return 0;
+  }
   if (slots > 1) hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, stream, stats, 2 * C, slots);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, gamma, beta,
                      eps, momentum, C, running_mean, running_var, scale, shift, mean_out, invstd_out);

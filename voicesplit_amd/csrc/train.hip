@@ -166,13 +166,17 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   if (nhwc) {
     // BASELINE configs[2]: channels-last bf16 z / a (conv_nhwc.hip, nhwc_edge.hip); statistics from the conv epilogues
     const long long npix = (long long)B * T * F;
+    // the statistics scratch is cleared ONCE here; every finalize below folds the slots and clears the scratch behind itself in the
+    // same launch (vs_fold_slots): no memset kernel in front of the conv launches
+    const int kStatsDoubles = vs_opt(VS_OPT_BN_FUSED_FINALIZE) ? VS_BN_STAT_SLOTS * 128 : 0;      // 0: the A/B form (memset per producer)
+    if (train && kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
     auto bn16 = [&](int l) -> int {
       VsProfScope ps(VS_PROF_FWD_BN, stream);
       const vs_conv_layer& c = p->conv[l];
       float *sc = scale + 64 * l, *sh = shift + 64 * l, *mu = mean + 64 * l, *is = invstd + 64 * l;
       if (train) {
         if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean,
-                                         c.bn_running_var, kBnEps, kBnMomentum, sc, sh, mu, is, stream)) return rc;
+                                         c.bn_running_var, kBnEps, kBnMomentum, sc, sh, mu, is, stream, kStatsDoubles)) return rc;
       } else {
         if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, 64, sc, sh, mu, is, stream)) return rc;
       }
@@ -189,7 +193,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       if (train) {
         if (int rc = vs_nhwc_first_stats_impl(mom, c.weight, c.bias, (double)npix, stats, stream)) return rc;
         if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
-                                         kBnMomentum, scale, shift, mean, invstd, stream)) return rc;
+                                         kBnMomentum, scale, shift, mean, invstd, stream, kStatsDoubles)) return rc;
       } else {
         if (int rc = vs_bn_eval_consts_impl(c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps, 64, scale, shift, mean, invstd, stream)) return rc;
       }
@@ -202,7 +206,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       VsProfScope ps(VS_PROF_FWD_BN, stream);
       const vs_conv_layer& c = p->conv[l];
       return vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
-                                 kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, mean + 64 * l, invstd + 64 * l, stream);
+                                 kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, mean + 64 * l, invstd + 64 * l, stream, kStatsDoubles);
     };
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;
@@ -210,7 +214,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       {
         VsProfScope ps(VS_PROF_CNN2 + i, stream);
         if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
-        if (train) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+        if (train && !kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
         if (int rc = vs_nhwc_conv_impl(at<void>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<void>(tape, L.z[l]), B, T, F,
                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, train ? stats : nullptr, stream)) return rc;
       }
@@ -220,7 +224,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     {
       VsProfScope ps(VS_PROF_CNN8, stream);
       if (train) {
-        VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 16, stream));
+        if (!kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 16, stream));
         if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.z[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream,
                                             stats, scale + 64 * 6, shift + 64 * 6, conv_act)) return rc;
       } else if (int rc = vs_nhwc_conv_last_impl(at<void>(tape, L.a[6]), p->conv[7].weight, ones, p->conv[7].bias, at<float>(tape, L.z8), B, T, F, VS_ACT_NONE, stream)) return rc;
@@ -257,7 +261,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     VsProfScope ps(VS_PROF_FWD_BN, stream);
     const vs_conv_layer& c = p->conv[7];
     if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)B * T * F, 8, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
-                                     kBnEps, kBnMomentum, scale + 64 * 7, shift + 64 * 7, mean + 64 * 7, invstd + 64 * 7, stream)) return rc;
+                                     kBnEps, kBnMomentum, scale + 64 * 7, shift + 64 * 7, mean + 64 * 7, invstd + 64 * 7, stream,
+                                     vs_opt(VS_OPT_BN_FUSED_FINALIZE) ? VS_BN_STAT_SLOTS * 128 : 0)) return rc;
     // ... which also writes the bf16 row-form copy of the features the LSTM GEMMs read
     const VsLstmBf16Layout Lf = vs_lstm_bf16_layout((long long)B * T, 8 * F, H);
     if (int rc = vs_bn_apply_feat_bf16_impl(at<float>(tape, L.z8), at<float>(tape, L.feat), at<char>(tape, L.lstm_bf16) + Lf.feat, Lf.Kp, B, T, F, conv_act,
@@ -350,7 +355,10 @@ int side_stream(SideStream** out) {
   VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
   SideStream& ss = g_side[dev];
   if (!ss.s) {
-    VS_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    int lo = 0, hi = 0;                                  // (numerically: hi <= lo, hi = the greatest priority)
+    VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int pr = vs_opt(VS_OPT_SIDE_PRIO) == 1 ? hi : vs_opt(VS_OPT_SIDE_PRIO) == 2 ? lo : (lo + hi) / 2;
+    VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, pr));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
   }
@@ -551,13 +559,15 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     // Every kernel that produces a layer's input gradient (cnn8's backward, the data-gradient convs) applies the
     // activation derivative of the layer below on the spot and accumulates the BatchNorm backward sums (the dy forms):
     // the BatchNorm backward proper is then finalize + one pass.
-    auto zero_stats = [&]() -> int {
-      VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
-      return 0;
-    };
+    // (the scratch is cleared once, in front of cnn8's backward; every finalize then clears it behind itself: vs_fold_slots)
+    // BACKWARD: off by default (VS_OPT_BN_FUSED_FINALIZE = 2 turns it on).  Measured (profiles/r05_bn_finalize_ab.md): the 25 us the
+    // one-thread-per-value fold kernel takes in front of the BatchNorm pass are what lets the weight gradient on the side stream get
+    // its 256 workgroups resident FIRST; with the fused finalize the HBM-bound pass fills the CUs first, the weight gradient's workgroups
+    // (139 KB of LDS, 384 registers) wait for its blocks to leave, and every layer's pair takes 2.5 ms instead of 2.05 (+1.6 ms per step).
+    const int kStatsDoubles = vs_opt(VS_OPT_BN_FUSED_FINALIZE) >= 2 ? VS_BN_STAT_SLOTS * 128 : 0;
     {
       VsProfScope ps(VS_PROF_BWD_EDGE, stream);
-      if (int rc = zero_stats()) return rc;
+      VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
       // partial sums in the idle second gradient buffer: `part` may still be in use by the LSTM leaf GEMMs on the side stream
       // train mode: a7 was never written (see vs_forward_train): recomputed from z7 by the kernel
       if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, train ? nullptr : at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
@@ -577,7 +587,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
         if (have_dy) {
           if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
                                                    invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                                   stats, coef, stream)) return rc;
+                                                   stats, coef, stream, kStatsDoubles)) return rc;
         } else {
           if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
                                                mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
@@ -599,7 +609,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
           have_dy = false;
         } else {
           have_dy = true;
-          if (int rc = zero_stats()) return rc;
+          if (!kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
           if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
                                             shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
                                             B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;

@@ -268,3 +268,29 @@ void vs_set_error(const char* fmt, ...);
   } while (0)
 
 #define VS_LAUNCH_CHECK() VS_CHECK_HIP(hipGetLastError())
+
+// ---- partial-sum slots of the BatchNorm statistics (forward: {sum, sum of squares}, backward: {sum dy, sum dy xhat}) --------------------
+// stats = [slots][n] doubles, n = 2 C <= 128.  ONE block of 1024 threads folds the slots (8 groups of threads, independent loads:
+// the one-thread-per-value loop of rounds 1-4 was 64 dependent L2 round trips = 17-24 us per layer on the critical path), leaves the
+// totals in tot[] (LDS, 128 doubles) and, after every read, zeroes `rezero` doubles of the scratch for the next producer (the memset
+// in front of every conv launch of a training step -- its own ~5 us kernel + a launch gap -- goes away).
+#define VS_FOLD_THREADS 1024
+__device__ __forceinline__ void vs_fold_slots(double* stats, int n, int slots, int rezero, double* part /* LDS [8][128] */, double* tot /* LDS [128] */) {
+  const int tid = threadIdx.x, i = tid & 127, sg = tid >> 7;
+  double v0 = 0.0, v1 = 0.0;
+  if (i < n) {
+    int k = sg;
+    for (; k + 8 < slots; k += 16) { v0 += stats[(size_t)k * n + i]; v1 += stats[(size_t)(k + 8) * n + i]; }
+    if (k < slots) v0 += stats[(size_t)k * n + i];
+  }
+  part[sg * 128 + i] = v0 + v1;
+  __syncthreads();
+  if (tid < 128) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += part[q * 128 + tid];
+    tot[tid] = t;
+  }
+  __syncthreads();                                   // every load of stats has returned: the scratch may be cleared
+  for (int j = tid; j < rezero; j += VS_FOLD_THREADS) stats[j] = 0.0;
+}

@@ -139,18 +139,19 @@ int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const voi
                          int B, int T, int F, int KT, int KF, int dil, hipStream_t stream);
 int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long long npix, int train,
                                 const float* scale, const float* mean, const float* invstd,
-                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream);
+                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream, int rezero_doubles = 0);
 int vs_nhwc_bn_bwd_first_from_dy_impl(const void* dy, const void* z, const float* x, int B, int T, int F, int train,
                                       const float* scale, const float* mean, const float* invstd,
                                       float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc,
                                       hipStream_t stream);
 // conv_bwd.hip: coefficients of the BatchNorm backward apply pass from the folded sums
 int vs_bn_bwd_finalize_impl(double* stats, int slots, double count, int train, int C, const float* scale, const float* mean,
-                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t);
+                            const float* invstd, float* dgamma, float* dbeta, float* dbias, float* coef, hipStream_t,
+                            int rezero_doubles = 0 /* > 0: one fused launch that also clears that much of the scratch behind itself */);
 // conv_edge.hip
 int vs_bn_finalize_impl(double* stats, int slots, double count, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float eps, float momentum,
-                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t);
+                        float* scale, float* shift, float* mean_out, float* invstd_out, hipStream_t, int rezero_doubles = 0);
 int vs_bn_fold_impl(const float*, const float*, const float*, const float*, const float*, float, int, float*, float*, hipStream_t);
 int vs_conv_first_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, unsigned* amax_out, hipStream_t);
 int vs_conv_last_fwd_impl(const float*, const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
