@@ -487,7 +487,9 @@ enum vs_option {
                                  (it takes away the weight gradient's head start on the side stream: DESIGN.md 6.7).  VOICESPLIT_BN_FUSED_FINALIZE */
   VS_OPT_SIDE_PRIO = 12,      /* priority of the library's side stream (weight gradients beside the BatchNorm backward passes): 0 normal (default),
                                  1 high, 2 low.  Read when the stream is created (the first vs_backward on a device).  VOICESPLIT_SIDE_PRIO */
-  VS_OPT_COUNT = 13
+  VS_OPT_BWD_APPLY_BLOCKS = 13, /* grid of the BatchNorm-backward pass that runs beside the weight gradient (dz = cA dy + cB z + cC): 0 = default
+                                 (one block of 256 threads per CU: 256), else that many blocks (the pass alone uses 2048).  VOICESPLIT_BWD_APPLY_BLOCKS */
+  VS_OPT_COUNT = 14
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

@@ -25,7 +25,7 @@ void vs_set_error(const char* fmt, ...) {
 // thread safe, off by default.
 // defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
 int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
-                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 0, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0};
+                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 0, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0};
 
 namespace {
 struct Prof {

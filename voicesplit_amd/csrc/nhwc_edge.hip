@@ -904,10 +904,18 @@ int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long n
 // epilogue, cnn8's backward below): stats holds the per-channel sums; parameter gradients + dz = cA dy + cB z + cC
 int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long long npix, int train,
                                 const float* scale, const float* mean, const float* invstd,
-                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream, int rezero_doubles) {
+                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream, int rezero_doubles,
+                                int beside_wgrad) {
   VS_REQUIRE(dy && z && dz && scale && mean && invstd && stats && coef && npix > 0, "nhwc bn_bwd_from_dy: bad argument");
   const long long npieces = npix * 8;
-  const dim3 grid(stream_blocks(512, npieces)), block(256);
+  int nb = stream_blocks(512, npieces);
+  // beside the weight gradient on the side stream (vs_backward): ONE block per CU.  The pass then takes 1.8 ms instead of 1.2 -- still
+  // inside the weight gradient's 1.95 -- and takes less from it (2.06 -> 1.94 ms per layer, -0.4 ms per step: profiles/r05_bn_finalize_ab.md)
+  if (beside_wgrad) {
+    const int want = vs_opt(VS_OPT_BWD_APPLY_BLOCKS) > 0 ? vs_opt(VS_OPT_BWD_APPLY_BLOCKS) : 256;
+    if (want < nb) nb = want;
+  }
+  const dim3 grid(nb), block(256);
   if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream,
                                        rezero_doubles)) return rc;
   hipLaunchKernelGGL(nhwc_bn_bwd_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, reinterpret_cast<const u4v*>(dy), reinterpret_cast<const u4v*>(z),

@@ -587,7 +587,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
         if (have_dy) {
           if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
                                                    invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                                   stats, coef, stream, kStatsDoubles)) return rc;
+                                                   stats, coef, stream, kStatsDoubles, pending ? 1 : 0)) return rc;
         } else {
           if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
                                                mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,

@@ -139,7 +139,8 @@ int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const voi
                          int B, int T, int F, int KT, int KF, int dil, hipStream_t stream);
 int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long long npix, int train,
                                 const float* scale, const float* mean, const float* invstd,
-                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream, int rezero_doubles = 0);
+                                float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t stream, int rezero_doubles = 0,
+                                int beside_wgrad = 0 /* the pass shares the CUs with a matrix-pipe kernel on another stream: a small grid */);
 int vs_nhwc_bn_bwd_first_from_dy_impl(const void* dy, const void* z, const float* x, int B, int T, int F, int train,
                                       const float* scale, const float* mean, const float* invstd,
                                       float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc,
