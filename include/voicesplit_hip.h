@@ -445,7 +445,9 @@ int vs_set_conv_kernel(int mode);
 /* which BiLSTM recurrence / BPTT runs: 0 = default (the persistent kernels whenever all their workgroups
  * fit on the device at once, else one launch per time step), 1 = one launch per step (always the fp32 MFMA products),
  * 2 = persistent (error when the grid cannot be resident), 3 = persistent with the fp32 MFMA products whatever dims.math
- * says (A/B of the f16 / bf16 products).  In VS_MATH_FP32 both forms give bit-identical results.  Process-wide.
+ * says (A/B of the f16 / bf16 products), 4 = persistent with the flag hand-off of rounds 2-4 where the default is the tagged-data
+ * hand-off (the f16 / split-f16 forward recurrence: same arithmetic), 5 = the tagged-data hand-off in the bf16 BPTT as well
+ * (default there: flags).  In VS_MATH_FP32 both forms give bit-identical results.  Process-wide.
  * The persistent kernels keep an error word in the caller's state buffer (the first of its last 64
  * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
  * (a workgroup of the launch was not resident): results are then invalid. */

@@ -168,3 +168,44 @@ def test_fp32_selector_overrides_the_math():
         lib.vs_set_lstm_kernel(0)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B", [64, 2])
+def test_tagged_handoff_soak_and_agrees_with_the_flag_handoff(B):
+    """Round 5: the persistent forward recurrence hands the hidden vector over as its own flag (four exchange buffers armed with a
+    sentinel, lstm16_tagged_kernel; the bf16 BPTT has the same hand-off behind vs_set_lstm_kernel(5)).  A protocol error shows as a
+    wrong or poisoned sequence, possibly only once in many launches: 1000 forward (+ 300 tagged BPTT) launches in the bf16
+    configuration's arithmetic and 200 in the split-f16 one, at the metric batch (two batch tiles, 200 resident workgroups) and at
+    B = 2: every launch bit-identical to the first of its kind, the error word 0 throughout (ops raises on 1), and the result the
+    flag hand-off's of rounds 2-4 (bit for bit in the f16 / bf16 kernels; the split-f16 pair differs by fp32 roundings: 4e-7)."""
+    from voicesplit_amd import _lib, ops
+    lib = _lib.load()
+    T, H = 301, 400
+    g = torch.Generator().manual_seed(3 + B)
+    xg = torch.randn(B, T, 8 * H, generator=g).to(dev())
+    whh = [(torch.randn(4 * H, H, generator=g) * (1.5 / H ** 0.5)).to(dev()) for _ in range(2)]
+    dout = torch.randn(B, T, 2 * H, generator=g).to(dev())
+    try:
+        for math in (_lib.MATH_BF16, _lib.MATH_F16X3):
+            assert lib.vs_set_lstm_kernel(4) == 0                    # the flag hand-off everywhere
+            out_f, gates_f, c_f = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
+            dxg_f = ops.bilstm_recurrent_bwd(gates_f, c_f, dout, whh[0], whh[1], math=math)
+            assert lib.vs_set_lstm_kernel(5) == 0                    # tagged forward and (bf16) tagged BPTT
+            first = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
+            if math == _lib.MATH_BF16:
+                assert all(torch.equal(a, b) for a, b in zip(first, (out_f, gates_f, c_f)))
+            else:
+                assert all((a - b).abs().max().item() <= 3e-6 for a, b in zip(first, (out_f, gates_f, c_f)))
+            n = 1000 if math == _lib.MATH_BF16 else 200
+            for it in range(n):
+                got = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
+                if it % 50 == 0 or it == n - 1:
+                    assert all(torch.equal(a, b) for a, b in zip(got, first)), (int(math), it)
+            assert torch.equal(ops.bilstm_recurrent(xg, whh[0], whh[1], math=math), first[0])
+            if math == _lib.MATH_BF16:
+                for it in range(300):
+                    dxg = ops.bilstm_recurrent_bwd(gates_f, c_f, dout, whh[0], whh[1], math=math)
+                    if it % 50 == 0 or it == 299:
+                        assert torch.equal(dxg, dxg_f), it
+    finally:
+        lib.vs_set_lstm_kernel(0)

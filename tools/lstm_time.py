@@ -18,7 +18,8 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for mode, math, name in ((1, None, "one launch per step"), (2, None, "persistent, fp32 MFMA products"),
-                         (2, _lib.MATH_F16X3, "persistent, split-f16 fwd / fp32 BPTT"), (2, _lib.MATH_BF16, "persistent, f16 fwd / bf16 BPTT")):
+                         (4, _lib.MATH_F16X3, "flag hand-off, split-f16 fwd / fp32 BPTT"), (4, _lib.MATH_BF16, "flag hand-off, f16 fwd / bf16 BPTT"),
+                         (2, _lib.MATH_F16X3, "tagged fwd, split-f16 fwd / fp32 BPTT"), (2, _lib.MATH_BF16, "tagged fwd, f16 fwd / bf16 BPTT")):
     assert lib.vs_set_lstm_kernel(mode) == 0
     out, gates, c = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
     f = timeit(lambda: ops.bilstm_recurrent(xg, whh[0], whh[1], math=math))

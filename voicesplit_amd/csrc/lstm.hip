@@ -977,6 +977,193 @@ void lstm16_persistent_kernel(Lstm16Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same recurrence with the hidden vector as its OWN flag (round 5): one agent-scope round trip per step instead
+// of two.  The flag protocol above costs, per step and on the critical path: store h (write-through) -> wait for the store to
+// drain -> store the flag -> [consumer] see the flag -> load h: two dependent round trips plus the drain.  Here:
+//   * FOUR exchange buffers; h_s lives in buffer s % 4.  A slot that has not been written yet holds the SENTINEL 0x7FFF7FFF in
+//     every dword -- two 16-bit NaNs, a pattern no finite h (hi or lo plane; bf16 gate gradient in the BPTT) produces;
+//   * a consumer wave polls the chunks IT multiplies (sc1 loads, as before) until no dword of them is the sentinel: a dword is
+//     written by one store instruction, so it is either old (sentinel) or complete; no flag word, no workgroup barrier in front
+//     of the MFMAs;
+//   * the producer of a slot re-arms it.  At step s, behind the workgroup barrier of the K reduction -- EVERY wave's poll of h_s has
+//     succeeded, so every member of the group has published h_s, i.e. has finished step s - 1 and with it every read of buffer
+//     (s - 1) % 4 -- it waits for its older stores (the re-arming store of the previous step among them: a whole step old, the
+//     wait is free), stores the sentinel to ITS slot of buffer (s - 1) % 4 = (s + 3) % 4, does the gate arithmetic and stores
+//     h_{s+1} into buffer (s + 1) % 4 with nothing behind it.  Why nobody can read stale data: buffer X % 4 is polled for h_X by a
+//     consumer that has finished step X - 1, for which it needed this workgroup's h_{X-1}; that was stored at step X - 2 behind the
+//     wait that acknowledged the re-arming store of step X - 3, whose target was (X - 3 + 3) % 4 = X % 4.  (Three buffers would do
+//     with the acknowledgement exposed inside the step; a re-arm by a wave that has only seen ITS chunks arrive -- the first version
+//     -- is a race: a slow member may still be reading the slot.)
+// Every spin is bounded and reports through *err (NaN poison + vs_lstm_status as before).  H <= 448 (all chunks register-resident);
+// larger hidden sizes take the flag kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned kSentinel = 0x7FFF7FFFu;
+
+template <int NP>
+__global__ __launch_bounds__(256)
+void lstm16_tagged_kernel(Lstm16Args a, void* hbuf2, void* hbuf3) {
+  __shared__ float sRed[2][3 * 16 * 64];      // by step parity: no barrier separates wave 0's reads of step s from the other waves' writes of step s + 1
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HQ = a.H / 8;
+  const int NC = (a.H + 15) / 16;
+  const int NBT = a.Bpad / 32;
+  const int jg = blockIdx.x % HQ;
+  const int bt = a.bt0 + blockIdx.x / HQ;
+  const int dir = blockIdx.y;
+  const int b = bt * 32 + l31;
+  if (tid == 0) sDead = 0;
+
+  const u32x4_t* wq = a.wp + ((size_t)(dir * HQ + jg) * NC * NP) * 64 + lane;
+  f16x8 w[kMaxC][NP];
+  bool owned[kMaxC];                     // does a producer write this lane's half-chunk?  (the upper half of the last chunk when H % 16 == 8: never)
+#pragma unroll
+  for (int i = 0; i < kMaxC; ++i) {
+    const int c = wave + 4 * i;
+    owned[i] = c < NC && 16 * c + 8 * half < a.H;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      w[i][p] = __builtin_bit_cast(f16x8, c < NC ? wq[(size_t)(c * NP + p) * 64] : u32x4_t{0u, 0u, 0u, 0u});
+  }
+  const float inv = a.hdr[0];
+  const size_t group = (size_t)dir * NBT + bt;
+  const unsigned hbytes = (unsigned)((size_t)2 * NBT * NC * NP * 1024);
+  __amdgpu_buffer_rsrc_t hrs[4] = {__builtin_amdgcn_make_buffer_rsrc(a.hbuf0, 0, hbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.hbuf1, 0, hbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(hbuf2, 0, hbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(hbuf3, 0, hbytes, 0x00020000)};
+  // this lane's slot (wave 0 stores it): chunk jg >> 1, k-half jg & 1, plane = lane half (NP == 2) / lower half-wave only (NP == 1)
+  const unsigned plane = NP == 2 ? (unsigned)half : 0u;
+  const unsigned slot_off = (unsigned)((((group * NC + (jg >> 1)) * NP + plane) * 64 + (jg & 1) * 32 + l31) * 16);
+  const bool storer = NP == 2 || half == 0;
+  float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? (a.T - 1 - s) : s;
+    const int rb = s & 3, wb = (s + 1) & 3, zb = (s + 3) & 3;            // h_s is read from rb, h_{s+1} goes to wb, zb (= h_{s-1}'s) is re-armed
+    float xgv[16];
+    if (wave == 0) {
+      const bool ok = b < a.B;
+      const float* xrow = a.xg + ((size_t)(ok ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xgv[r] = ok ? xrow[(r >> 2) * a.H + (r & 3)] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      const unsigned hoff = (unsigned)((group * NC * NP * 64 + lane) * 16);
+      f16x8 h[kMaxC][NP];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < kMaxC; ++i) {
+          const int c = wave + 4 * i;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            u32x4_t v = c < NC ? __builtin_amdgcn_raw_buffer_load_b128(hrs[rb], hoff + (unsigned)(c * NP + p) * 1024u, 0, 16 /* sc1 */)
+                               : u32x4_t{0u, 0u, 0u, 0u};
+            if (!owned[i]) v = u32x4_t{0u, 0u, 0u, 0u};
+            ok = ok && v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel;
+            h[i][p] = __builtin_bit_cast(f16x8, v);
+          }
+        }
+        if (__all(ok)) break;
+        if (++spins > kSpinLimit || *(volatile int*)&sDead) {
+          if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxC; ++i) {
+        if (wave + 4 * i < NC) {          // wave-uniform
+          if (NP == 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][NP - 1], h[i][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][0], h[i][NP - 1], acc, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i][0], h[i][0], acc, 0, 0, 0);
+        }
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sRed[s & 1][((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    // wave 1 is the re-arming wave (wave 0's store queue carries h: a sentinel store in front of it would delay it).  Its re-arming
+    // store of the previous step is acknowledged HERE, in front of the barrier behind which wave 0 stores this step's h (see the header)
+    if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // every wave's poll has succeeded: the group is done with buffer zb
+    if (wave == 1 && s > 0 && storer)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{kSentinel, kSentinel, kSentinel, kSentinel}, hrs[zb], slot_off, 0, 16);
+    if (wave == 0) {
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sRed[s & 1][(w3 * 16 + r) * 64 + lane];
+      float hv[4], cnew[4], gact[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float gi = vs_sigmoid_fast(fmaf(acc[0 + u], inv, xgv[0 + u]));
+        const float gf = vs_sigmoid_fast(fmaf(acc[4 + u], inv, xgv[4 + u]));
+        const float gg = vs_tanh_fast(fmaf(acc[8 + u], inv, xgv[8 + u]));
+        const float go = vs_sigmoid_fast(fmaf(acc[12 + u], inv, xgv[12 + u]));
+        const float cn = gf * cprev[u] + gi * gg;
+        hv[u] = go * vs_tanh_fast(cn);
+        cnew[u] = cn;
+        cprev[u] = cn;
+        gact[0][u] = gi; gact[1][u] = gf; gact[2][u] = gg; gact[3][u] = go;
+      }
+      {
+        float full[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float o = __shfl_xor(hv[u], 32, 64);
+          full[u] = half ? o : hv[u];
+          full[4 + u] = half ? hv[u] : o;
+        }
+        u32x4_t v;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (NP == 2) {
+            const float x0 = full[2 * j] * kHScale, x1 = full[2 * j + 1] * kHScale;
+            const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+            const unsigned lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]));
+            v[j] = half ? lo : __builtin_bit_cast(unsigned, hh);
+          } else {
+            const h2 hh = {(_Float16)full[2 * j], (_Float16)full[2 * j + 1]};
+            v[j] = __builtin_bit_cast(unsigned, hh);
+          }
+        }
+        if (storer) __builtin_amdgcn_raw_buffer_store_b128(v, hrs[wb], slot_off, 0, 16 /* sc1: write-through */);
+      }
+      if (b < a.B) {
+        float4* o = reinterpret_cast<float4*>(a.out + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+        *o = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (a.c_save) {
+          float4* cs = reinterpret_cast<float4*>(a.c_save + ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + jg * 8 + 4 * half);
+          *cs = make_float4(cnew[0], cnew[1], cnew[2], cnew[3]);
+        }
+        if (a.gates_save) {
+          float* grow = a.gates_save + ((size_t)b * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + jg * 8 + 4 * half;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(grow + gq * a.H) = make_float4(gact[gq][0], gact[gq][1], gact[gq][2], gact[gq][3]);
+        }
+      }
+    }
+  }
+}
+
 struct Lstm16BwdArgs {
   const u32x4_t* wpt;    // lstm_pack16_t_kernel
   void* gbuf0;           // bf16 gate gradients [2 dir][NBT][H/4][64 lane] x 16 bytes
@@ -1145,6 +1332,166 @@ void lstm16_bwd_persistent_kernel(Lstm16BwdArgs a) {
   }
 }
 
+// The persistent BPTT with the gate gradients as their own flags: lstm16_tagged_kernel's hand-off (four exchange buffers, sentinel
+// slots, re-arming behind the K reduction's barrier).  4H <= 8 * 13 * 16 = 1664 (all chunks register-resident), else the flag kernel.
+__global__ __launch_bounds__(512)
+void lstm16_bwd_tagged_kernel(Lstm16BwdArgs a, void* gbuf2, void* gbuf3) {
+  __shared__ float sRed[2][8 * 16 * 64];      // by step parity (lstm16_tagged_kernel)
+  __shared__ int sDead;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int NCt = a.H / 4;
+  const int NUT = (a.H + 31) / 32;
+  const int NBT = a.Bpad / 32;
+  const int ut = blockIdx.x % NUT;
+  const int bt = a.bt0 + blockIdx.x / NUT;
+  const int dir = blockIdx.y;
+  if (tid == 0) sDead = 0;
+
+  const int b31 = tid & 31, ug = (tid >> 5) & 7;
+  const int b = bt * 32 + b31;
+  const int u0 = ut * 32 + 4 * ug;
+  const bool units_ok = tid < 256 && u0 < a.H;          // wave-uniform (H % 8 == 0)
+  const bool item = units_ok && b < a.B;
+
+  const u32x4_t* wq = a.wpt + ((size_t)(dir * NUT + ut) * NCt) * 64 + lane;
+  bf16x8 w[kBwdRes16];
+#pragma unroll
+  for (int i = 0; i < kBwdRes16; ++i) {
+    const int c = wave + 8 * i;
+    w[i] = __builtin_bit_cast(bf16x8, c < NCt ? wq[(size_t)c * 64] : u32x4_t{0u, 0u, 0u, 0u});
+  }
+  const size_t group = (size_t)dir * NBT + bt;
+  const unsigned gbytes = (unsigned)((size_t)2 * NBT * NCt * 1024);
+  __amdgpu_buffer_rsrc_t grs[4] = {__builtin_amdgcn_make_buffer_rsrc(a.gbuf0, 0, gbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(a.gbuf1, 0, gbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(gbuf2, 0, gbytes, 0x00020000),
+                                   __builtin_amdgcn_make_buffer_rsrc(gbuf3, 0, gbytes, 0x00020000)};
+  // the four slots this lane stores per step (waves 0-3, lower half-wave): gate g's half-chunk of rows g * H + ut * 32 + 8 * wave .. + 7
+  unsigned slot_off[4];
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) {
+    const int r0 = gate * a.H + ut * 32 + 8 * (wave & 3);
+    slot_off[gate] = (unsigned)(((group * NCt + (r0 >> 4)) * 64 + ((r0 >> 3) & 1) * 32 + b31) * 16);
+  }
+  const bool rearmer = tid >= 256 && u0 < a.H && half == 0;      // wave w + 4 re-arms the slots of wave w (same lane -> same slots)
+  float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < a.T; ++s) {
+    const int t = dir ? s : (a.T - 1 - s);
+    const int tp = dir ? t + 1 : t - 1;                 // forward-order predecessor (c_{t-1})
+    float4 gi4, gf4, gg4, go4, c4, cp4, dh4;
+    gi4 = gf4 = gg4 = go4 = c4 = cp4 = dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* grow = a.gates + ((size_t)(item ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + (item ? u0 : 0);
+    if (item) {
+      gi4 = *reinterpret_cast<const float4*>(grow);
+      gf4 = *reinterpret_cast<const float4*>(grow + a.H);
+      gg4 = *reinterpret_cast<const float4*>(grow + 2 * a.H);
+      go4 = *reinterpret_cast<const float4*>(grow + 3 * a.H);
+      const size_t so = ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + u0;
+      c4 = *reinterpret_cast<const float4*>(a.c_all + so);
+      dh4 = *reinterpret_cast<const float4*>(a.dout + so);
+      if (tp >= 0 && tp < a.T)
+        cp4 = *reinterpret_cast<const float4*>(a.c_all + ((size_t)b * a.T + tp) * (2 * a.H) + (size_t)dir * a.H + u0);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int rb = s & 3, wb = (s + 1) & 3, zb = (s + 3) & 3;          // lstm16_tagged_kernel's protocol
+    if (s > 0) {
+      const unsigned goff = (unsigned)((group * NCt * 64 + lane) * 16);
+      bf16x8 g[kBwdRes16];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < kBwdRes16; ++i) {
+          const int c = wave + 8 * i;
+          const u32x4_t v = c < NCt ? __builtin_amdgcn_raw_buffer_load_b128(grs[rb], goff + (unsigned)c * 1024u, 0, 16 /* sc1 */)
+                                    : u32x4_t{0u, 0u, 0u, 0u};
+          ok = ok && v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel;
+          g[i] = __builtin_bit_cast(bf16x8, v);
+        }
+        if (__all(ok)) break;
+        if (++spins > kSpinLimit || *(volatile int*)&sDead) {
+          if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int i = 0; i < kBwdRes16; ++i) {
+        if (wave + 8 * i < NCt)        // wave-uniform
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i], g[i], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[s & 1][(wave * 16 + r) * 64 + lane] = acc[r];
+    // waves 4-7 re-arm (the storing waves' queues carry the gradients); their previous re-arming stores are acknowledged in front of the barrier
+    if (tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s > 0 && rearmer) {       // every wave's poll has succeeded: the group is done with buffer zb
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{kSentinel, kSentinel, kSentinel, kSentinel}, grs[zb], slot_off[gate], 0, 16);
+    }
+    if (tid < 256) {
+      float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += sRed[s & 1][(w8 * 16 + 4 * wave + u) * 64 + lane];
+      const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+      const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+      float dg4[4][4];        // [gate i,f,g,o][unit]
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float tc = vs_tanh_fast(cc[u]);
+        dg4[3][u] = dh[u] * tc * go[u] * (1.f - go[u]);
+        const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
+        dg4[0][u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
+        dg4[1][u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
+        dg4[2][u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
+        dcc[u] = dc * gf[u];
+      }
+      if (!item) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dg4[gate][u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dcc[u] = 0.f;
+      }
+      // next step's operand: rows gate*H + ut*32 + 8*wave .. +7 = one half-chunk; this lane computed 4*half .. 4*half+3 of them
+      if (units_ok) {
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+          bf16x8 v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float o = __shfl_xor(dg4[gate][u], 32, 64);
+            v[u] = (__bf16)(half ? o : dg4[gate][u]);
+            v[4 + u] = (__bf16)(half ? dg4[gate][u] : o);
+          }
+          if (half == 0)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), grs[wb], slot_off[gate], 0, 16 /* sc1 */);
+        }
+      }
+      if (item) {           // the batched GEMMs' operand, in place of the saved gates
+        *reinterpret_cast<float4*>(grow) = make_float4(dg4[0][0], dg4[0][1], dg4[0][2], dg4[0][3]);
+        *reinterpret_cast<float4*>(grow + a.H) = make_float4(dg4[1][0], dg4[1][1], dg4[1][2], dg4[1][3]);
+        *reinterpret_cast<float4*>(grow + 2 * a.H) = make_float4(dg4[2][0], dg4[2][1], dg4[2][2], dg4[2][3]);
+        *reinterpret_cast<float4*>(grow + 3 * a.H) = make_float4(dg4[3][0], dg4[3][1], dg4[3][2], dg4[3][3]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // packed recurrent weights: the fp32 fragment form (every arithmetic: the step kernels use it), then room for the f16
@@ -1152,10 +1499,11 @@ void lstm16_bwd_persistent_kernel(Lstm16BwdArgs a) {
 static size_t lstm_packed_fp32_floats(int H) { return (size_t)2 * (H / 8) * (H / 8) * 256; }
 static size_t lstm_packed_f16_floats(int H) { return (size_t)2 * (H / 8) * ((H + 15) / 16) * 2 * 256; }
 extern "C" size_t vs_lstm_packed_floats(int H) { return lstm_packed_fp32_floats(H) + lstm_packed_f16_floats(H) + 64; }
-// h ping, h pong, flags / c: three regions of 2 * Hp * Bpad floats (Hp = H rounded up to the f16 form's 16-wide K chunk)
-// + 64: the persistent kernel's error word lives in the last 64 floats (never touched by the step kernels)
+// h ping, h pong, flags / c, + a fourth: four regions of 2 * Hp * Bpad floats (Hp = H rounded up to the f16 form's 16-wide K chunk; the
+// tagged-data hand-off uses all four as exchange buffers) + 64: the persistent kernels' error word lives in the last 64 floats
+// (never touched by the step kernels)
 static size_t lstm_state_region(int B, int H) { return (size_t)2 * ((H + 15) / 16 * 16) * (((size_t)B + 31) / 32 * 32); }
-extern "C" size_t vs_lstm_state_floats(int B, int H) { return 3 * lstm_state_region(B, H) + 64; }
+extern "C" size_t vs_lstm_state_floats(int B, int H) { return 4 * lstm_state_region(B, H) + 64; }
 
 // math: the dims.math of the call the weights are packed for (VS_MATH_CODE_*); it selects the f16 form written behind
 // the fp32 one
@@ -1185,10 +1533,12 @@ int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, 
 
 // which recurrence runs: 0 = persistent when its grid is resident (default), 1 = one launch per step (fp32 MFMA),
 // 2 = persistent (error if it cannot be), 3 = persistent with the fp32 MFMA products whatever dims.math says (A/B of
-// the f16 / bf16 products).  Test / A-B switch, process-global.
+// the f16 / bf16 products), 4 = persistent with the flag protocol of rounds 2-4 where the default is the tagged-data hand-off
+// (lstm16_tagged_kernel: the f16 forward recurrence), 5 = the tagged-data hand-off in the bf16 BPTT too (correct, measured 5 % slower
+// than its flag kernel: every wave polls 13 KB of gradients per round).  Test / A-B switch, process-global.
 static int g_lstm_kernel = 0;
 extern "C" int vs_set_lstm_kernel(int mode) {
-  VS_REQUIRE(mode >= 0 && mode <= 3, "vs_set_lstm_kernel: mode %d", mode);
+  VS_REQUIRE(mode >= 0 && mode <= 5, "vs_set_lstm_kernel: mode %d", mode);
   g_lstm_kernel = mode;
   return 0;
 }
@@ -1231,9 +1581,13 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
   const int bt_per_launch = cus / (2 * HQ);
   const bool persistent = g_lstm_kernel != 1 && bt_per_launch >= 1;
   VS_REQUIRE(g_lstm_kernel != 2 || persistent, "lstm: persistent recurrence needs 2*H/8 = %d workgroups <= %d CUs", 2 * HQ, cus);
+  // the tagged-data hand-off of the f16 forward recurrence: three exchange buffers (the regions of h ping, h pong and of the flags),
+  // the second and third armed with the sentinel
+  const bool tagged = persistent && math != VS_MATH_CODE_FP32 && g_lstm_kernel != 4 && (H + 15) / 16 <= 4 * kMaxC;
+  if (tagged) VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + per), (int)kSentinel, 3 * per, stream));
   if (persistent) {
     unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * per);      // zeroed above
-    unsigned* err = reinterpret_cast<unsigned*>(state + 3 * per);         // first of the 64 trailing words
+    unsigned* err = reinterpret_cast<unsigned*>(state + 4 * per);         // first of the 64 trailing words
     bool launched = true;
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
@@ -1246,6 +1600,14 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
         const float* w16 = wp + lstm_packed_fp32_floats(H);
         Lstm16Args a{xg, reinterpret_cast<const u32x4_t*>(w16), w16 + lstm_packed_f16_floats(H), hbuf[0], hbuf[1], flags, err, out,
                      gates_save, c_save, B, T, H, Bpad, bt0};
+        if (tagged) {
+          void* hb2 = state + 2 * per;
+          void* hb3 = state + 3 * per;
+          void* params[] = {&a, &hb2, &hb3};
+          e = hipLaunchCooperativeKernel(math == VS_MATH_CODE_BF16 ? reinterpret_cast<const void*>(&lstm16_tagged_kernel<1>)
+                                                                   : reinterpret_cast<const void*>(&lstm16_tagged_kernel<2>),
+                                         dim3(HQ * nbt, 2), dim3(256), params, 0, stream);
+        } else
         e = math == VS_MATH_CODE_BF16
                 ? launch_resident(reinterpret_cast<const void*>(&lstm16_persistent_kernel<1>), dim3(HQ * nbt, 2), dim3(256), a, stream)
                 : launch_resident(reinterpret_cast<const void*>(&lstm16_persistent_kernel<2>), dim3(HQ * nbt, 2), dim3(256), a, stream);
@@ -1264,6 +1626,7 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
       return 0;
     }
   }
+  if (tagged) VS_CHECK_HIP(hipMemsetAsync(state, 0, vs_lstm_state_floats(B, H) * sizeof(float), stream));      // refused: un-arm the buffers
   float* c = state + 2 * per;
   dim3 grid(HQ * NBT, 2), block(256);
   for (int s = 0; s < T; ++s) {
@@ -1315,6 +1678,9 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
   const int bt_per_launch = cus / (2 * NUT);
   const bool persistent = g_lstm_kernel != 1 && bt_per_launch >= 1;
   VS_REQUIRE(g_lstm_kernel != 2 || persistent, "lstm_bwd: persistent recurrence needs %d workgroups <= %d CUs", 2 * NUT, cus);
+  // tagged-data hand-off (bf16 BPTT): buffers 1..3 armed with the sentinel, buffer 0 (no gradient from beyond the sequence) is never read
+  const bool tagged = persistent && math == VS_MATH_CODE_BF16 && g_lstm_kernel == 5 && H / 4 <= 8 * kBwdRes16;
+  if (tagged) VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + frag / 2), (int)kSentinel, frag + frag / 2, stream));
   if (persistent) {
     unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * frag);      // 2*Bpad*H words available, 2*NBT*NUT*4 used
     unsigned* err = reinterpret_cast<unsigned*>(state + 2 * frag + (size_t)2 * Bpad * H);
@@ -1322,7 +1688,15 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
       hipError_t e;
-      if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
+      if (math == VS_MATH_CODE_BF16 && tagged) {
+        // four bf16 exchange buffers in the room of the two fp32-sized fragment regions
+        Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), state, state + frag / 2, flags, err, gates, c_all, dout,
+                        B, T, H, Bpad, bt0};
+        void* g2 = state + frag;
+        void* g3 = state + frag + frag / 2;
+        void* params[] = {&a, &g2, &g3};
+        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm16_bwd_tagged_kernel), dim3(NUT * nbt, 2), dim3(512), params, 0, stream);
+      } else if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
         Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), gbuf[0], gbuf[1], flags, err, gates, c_all, dout,
                         B, T, H, Bpad, bt0};
         e = launch_resident(reinterpret_cast<const void*>(&lstm16_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
