@@ -491,7 +491,10 @@ enum vs_option {
                                  1 high, 2 low.  Read when the stream is created (the first vs_backward on a device).  VOICESPLIT_SIDE_PRIO */
   VS_OPT_BWD_APPLY_BLOCKS = 13, /* grid of the BatchNorm-backward pass that runs beside the weight gradient (dz = cA dy + cB z + cC): 0 = default
                                  (one block of 256 threads per CU: 256), else that many blocks (the pass alone uses 2048).  VOICESPLIT_BWD_APPLY_BLOCKS */
-  VS_OPT_COUNT = 14
+  VS_OPT_FWD_PROLOGUE = 14,   /* 1 (default): vs_forward_train (bf16) runs the weight-only launches of the step (conv weight packs, bf16 W_ih, d-vector fold,
+                                 recurrent / head weight images) on the library's side stream beside cnn1; 0: in place, in front of their consumers.
+                                 Needs vs_set_backward_overlap(1).  Same values.  VOICESPLIT_FWD_PROLOGUE */
+  VS_OPT_COUNT = 15
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

@@ -101,6 +101,52 @@ int check_params(const vs_params* p) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients on a side stream.  Layer l's weight gradient needs dz_l and the tape's a_{l-1}; nothing on the
+// data-gradient chain (BatchNorm backward of layer l-1 -> data gradient of layer l-1 -> ...) needs ITS result.  It
+// is a matrix-pipe kernel with one workgroup per CU and an idle memory system; the two BatchNorm backward passes
+// of the next layer are pure HBM streams with idle matrix pipes (2.65 ms per layer, 16 ms per step).  So the weight
+// gradient of layer l is launched on a second stream right after the data gradient of layer l and runs beside the
+// BatchNorm backward of layer l-1; the data gradient of layer l-1 -- which overwrites dz_l -- waits for it.
+// Same kernels, same order of every sum: results are bit-identical to the one-stream schedule.
+// One side stream + event pair per device, created on first use; the caller's stream is joined before vs_backward
+// returns, so the fork is invisible outside (and legal under stream capture).
+// ---------------------------------------------------------------------------------------------
+int g_bwd_overlap = 1;
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream g_side[16];
+// Every exit path of vs_backward after the fork -- the error returns included -- orders the caller's stream after what
+// the side stream has been given (it writes gradients and the shared partial-sum scratch), and leaves no unjoined fork
+// behind in a stream capture.  The normal path joins explicitly and disarms the guard.
+struct SideJoin {
+  SideStream* side = nullptr;
+  hipStream_t stream = nullptr;
+  bool forked = false;
+  ~SideJoin() {
+    if (!side || !forked) return;
+    if (hipEventRecord(side->join, side->s) == hipSuccess) (void)hipStreamWaitEvent(stream, side->join, 0);
+  }
+};
+// the side stream and its two events are shared by every caller on the device: one vs_backward enqueues at a time
+// (host threads driving different caller streams would otherwise re-record an event another call is about to wait on)
+std::mutex g_side_mutex;
+int side_stream(SideStream** out) {
+  int dev = 0;
+  VS_CHECK_HIP(hipGetDevice(&dev));
+  VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
+  SideStream& ss = g_side[dev];
+  if (!ss.s) {
+    int lo = 0, hi = 0;                                  // (numerically: hi <= lo, hi = the greatest priority)
+    VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int pr = vs_opt(VS_OPT_SIDE_PRIO) == 1 ? hi : vs_opt(VS_OPT_SIDE_PRIO) == 2 ? lo : (lo + hi) / 2;
+    VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, pr));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +209,42 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   };
 
   const bool nhwc = d->math == VS_MATH_BF16;
+  // ---- weight-only work of the step on the side stream (bf16 configuration) -----------------------------------------------------
+  // Packing the six conv weights, the bf16 copy of W_ih, the d-vector fold, the recurrent and head weight images depend on nothing the
+  // conv stack produces: 14 launches of 5-45 us that used to sit, with their launch gaps, in front of their consumers on the one
+  // stream (~0.25 ms of a step).  They now run beside cnn1; the caller's stream joins in front of cnn2.
+  SideStream* side = nullptr;
+  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  const int K = 8 * F, KE = K + d->E;
+  float* dvbias = at<float>(tape, L.dvbias);
+  const VsLstmBf16Layout Lpre = vs_lstm_bf16_layout((long long)B * T, K, H);
+  const bool head_fused = nhwc && vs_head_fused_supported(2 * H, d->FC1, d->FC2) &&
+                          L.conv_scales - L.partials >= vs_head_fused_packed_bytes(2 * H, d->FC1, d->FC2);
+  bool prologue = false;
+  SideJoin pro_join;
+  if (nhwc && g_bwd_overlap && vs_opt(VS_OPT_FWD_PROLOGUE)) {
+    side_lock.lock();
+    if (int rc = side_stream(&side)) return rc;
+    pro_join.side = side;
+    pro_join.stream = stream;
+    VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+    VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    pro_join.forked = true;
+    hipStream_t ps = side->s;
+    for (int i = 0; i < 6; ++i)
+      if (int rc = vs_nhwc_pack_impl(p->conv[i + 1].weight, at<void>(tape, L.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0, ps)) return rc;
+    for (int dir = 0; dir < 2; ++dir) {
+      if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
+                                   p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, ps)) return rc;
+      if (int rc = vs_cvt_rows_bf16_impl(p->w_ih[dir], 4 * H, K, KE, at<char>(tape, L.lstm_bf16) + Lpre.wih + (size_t)dir * 4 * H * Lpre.Kp * 2, Lpre.Kp, ps)) return rc;
+    }
+    if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], at<float>(tape, L.lstm_packed), H, ps, d->math)) return rc;
+    if (head_fused) {
+      if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * H, d->FC1, d->FC2, at<void>(tape, L.partials), ps)) return rc;
+    }
+    VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+    prologue = true;
+  }
   if (nhwc) {
     // BASELINE configs[2]: channels-last bf16 z / a (conv_nhwc.hip, nhwc_edge.hip); statistics from the conv epilogues
     const long long npix = (long long)B * T * F;
@@ -208,12 +290,17 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       return vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
                                  kBnEps, kBnMomentum, scale + 64 * l, shift + 64 * l, mean + 64 * l, invstd + 64 * l, stream, kStatsDoubles);
     };
+    if (prologue) {      // the weight images are needed from here on
+      VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
+      pro_join.forked = false;
+      side_lock.unlock();
+    }
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;
       void* packed = at<void>(tape, L.conv_packed[i]);
       {
         VsProfScope ps(VS_PROF_CNN2 + i, stream);
-        if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+        if (!prologue) { if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc; }
         if (train && !kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
         if (int rc = vs_nhwc_conv_impl(at<void>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<void>(tape, L.z[l]), B, T, F,
                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, train ? stats : nullptr, stream)) return rc;
@@ -271,23 +358,25 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   } else if (int rc = bn(7, at<float>(tape, L.z8), at<float>(tape, L.feat), 8, true)) return rc;
 
   // BiLSTM (d-vector folded into a per-utterance row bias), gates and cell states kept
-  const int K = 8 * F, KE = K + d->E;
-  float* dvbias = at<float>(tape, L.dvbias);
   float* xg = at<float>(tape, L.gates);
   {
     VsProfScope ps(VS_PROF_LSTM_GEMM, stream);
-    for (int dir = 0; dir < 2; ++dir) {
-      if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
-                                   p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+    if (!prologue) {
+      for (int dir = 0; dir < 2; ++dir) {
+        if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
+                                     p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, stream)) return rc;
+      }
     }
-    // the backward pass's gradient buffers are idle during the forward pass
+    // the backward pass's gradient buffers are idle during the forward pass.  (prologue: the bf16 W_ih is already in its place in the
+    // tape -- handed over as "prepared" so that the contraction does not convert it again)
+    const _Float16* wih_ready = prologue ? reinterpret_cast<const _Float16*>(at<char>(tape, L.lstm_bf16) + Lpre.wih) : nullptr;
     if (int rc = vs_lstm_input_gemm_impl(d->math, at<float>(tape, L.feat), K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
                                          at<float>(tape, L.gemm_scales), nhwc ? at<char>(tape, L.lstm_bf16) : at<char>(tape, L.grad0),
-                                         nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream, nullptr, nullptr, nullptr,
+                                         nhwc ? L.total_bytes - L.lstm_bf16 : 2 * (L.grad1 - L.grad0), stream, nullptr, wih_ready, nullptr,
                                          feat_bf16_ready)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
-  if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc;
+  if (!prologue) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc; }
   {
     VsProfScope ps(VS_PROF_LSTM_REC, stream);
     if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
@@ -305,7 +394,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     const size_t room = L.conv_scales - L.partials;
     if (room >= need) {
       void* img = at<void>(tape, L.partials);
-      if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * H, d->FC1, d->FC2, img, stream)) return rc;
+      if (!prologue) { if (int rc = vs_head_fused_pack_impl(p->fc1_w, p->fc1_b, p->fc2_w, p->fc2_b, 2 * H, d->FC1, d->FC2, img, stream)) return rc; }
       return vs_head_fused_impl(at<float>(tape, L.lstm_out), img, h1, nullptr, mask, M, 2 * H, d->FC1, d->FC2, stream);
     }
   }
@@ -319,54 +408,6 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// Weight gradients on a side stream.  Layer l's weight gradient needs dz_l and the tape's a_{l-1}; nothing on the
-// data-gradient chain (BatchNorm backward of layer l-1 -> data gradient of layer l-1 -> ...) needs ITS result.  It
-// is a matrix-pipe kernel with one workgroup per CU and an idle memory system; the two BatchNorm backward passes
-// of the next layer are pure HBM streams with idle matrix pipes (2.65 ms per layer, 16 ms per step).  So the weight
-// gradient of layer l is launched on a second stream right after the data gradient of layer l and runs beside the
-// BatchNorm backward of layer l-1; the data gradient of layer l-1 -- which overwrites dz_l -- waits for it.
-// Same kernels, same order of every sum: results are bit-identical to the one-stream schedule.
-// One side stream + event pair per device, created on first use; the caller's stream is joined before vs_backward
-// returns, so the fork is invisible outside (and legal under stream capture).
-// ---------------------------------------------------------------------------------------------
-namespace {
-int g_bwd_overlap = 1;
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-SideStream g_side[16];
-// Every exit path of vs_backward after the fork -- the error returns included -- orders the caller's stream after what
-// the side stream has been given (it writes gradients and the shared partial-sum scratch), and leaves no unjoined fork
-// behind in a stream capture.  The normal path joins explicitly and disarms the guard.
-struct SideJoin {
-  SideStream* side = nullptr;
-  hipStream_t stream = nullptr;
-  bool forked = false;
-  ~SideJoin() {
-    if (!side || !forked) return;
-    if (hipEventRecord(side->join, side->s) == hipSuccess) (void)hipStreamWaitEvent(stream, side->join, 0);
-  }
-};
-// the side stream and its two events are shared by every caller on the device: one vs_backward enqueues at a time
-// (host threads driving different caller streams would otherwise re-record an event another call is about to wait on)
-std::mutex g_side_mutex;
-int side_stream(SideStream** out) {
-  int dev = 0;
-  VS_CHECK_HIP(hipGetDevice(&dev));
-  VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
-  SideStream& ss = g_side[dev];
-  if (!ss.s) {
-    int lo = 0, hi = 0;                                  // (numerically: hi <= lo, hi = the greatest priority)
-    VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const int pr = vs_opt(VS_OPT_SIDE_PRIO) == 1 ? hi : vs_opt(VS_OPT_SIDE_PRIO) == 2 ? lo : (lo + hi) / 2;
-    VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, pr));
-    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
-    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
-  }
-  *out = &ss;
-  return 0;
-}
-}  // namespace
-
 extern "C" int vs_set_backward_overlap(int on) {
   if (on != 0 && on != 1) return -1;
   g_bwd_overlap = on;
