@@ -474,9 +474,10 @@ enum vs_option {
   VS_OPT_GEMM_BAND = 5,       /* split-f16 GEMM: tile rows per raster band, default 8.  VOICESPLIT_GEMM_BAND */
   VS_OPT_WGRAD_ABL = 6,       /* bf16 weight gradient timing ablations of an ABLATION=1 build (results INVALID).  VOICESPLIT_WGRAD_ABL */
   VS_OPT_SPLITCONV_ABL = 7,   /* split-f16 channels-last conv: timing ablations / in-kernel probes of an ABLATION=1 build.  VOICESPLIT_SPLITCONV_ABL */
-  VS_OPT_CONV_SCALAR_EPILOGUE = 8, /* bf16 channels-last conv (conv_nhwc.hip): 1 = the instances compiled WITHOUT packed-fp32 VALU
+  VS_OPT_CONV_SCALAR_EPILOGUE = 8, /* channels-last convs (conv_nhwc.hip, conv_nhwc_f16x3.hip): 1 = the instances compiled WITHOUT packed-fp32 VALU
                                  instructions (v_pk_fma_f32 ... become pairs of scalar instructions: same values, bit for bit), 0 = the packed
-                                 ones; default: see vs_get_option.  VOICESPLIT_CONV_SCALAR_EPILOGUE */
+                                 ones, 2 (default) = per instance what measured faster: scalar for the split-f16 conv and for the bf16 conv's
+                                 activation epilogue (1-2 %), packed for the dy form (neutral).  VOICESPLIT_CONV_SCALAR_EPILOGUE */
   VS_OPT_MFMA_PRIO = 9,       /* bit 0: the bf16 weight-gradient kernel, bit 1: the bf16 channels-last conv raise their wave priority (s_setprio 3), so that
                                  the HBM-bound BatchNorm pass co-resident on the same SIMDs (vs_backward's side stream) gets the issue slots they leave,
                                  not the other way round.  Same results.  VOICESPLIT_MFMA_PRIO */

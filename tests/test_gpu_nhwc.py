@@ -547,7 +547,7 @@ def test_scalar_and_packed_epilogue_builds_agree_bit_for_bit(KT, KF, dil):
     prev = _lib.get_option("CONV_SCALAR_EPILOGUE")
     try:
         for mode in (0, 1):
-            _lib.set_option("CONV_SCALAR_EPILOGUE", mode)
+            _lib.set_option("CONV_SCALAR_EPILOGUE", mode)      # (2, the default, picks one of the two per instance)
             a = ops.nhwc_conv(x, w, sc, sh, dil, "mish")
             b, st = ops.nhwc_conv(x, w, one, sh, dil, "none", stats=True)
             dy, st2 = ops.nhwc_conv_dy(x, packed, z, "mish", sc, sh, zero, one, KT, KF, dil)

@@ -609,7 +609,9 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   const dim3 grid((unsigned)(n_items < cus ? n_items : cus)), block(256);
   const size_t lds = 0;   // static LDS: Geo::LDS_BYTES
   const bool stats = a.bn_stats != nullptr;
-  const bool scalar = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE) != 0;
+  // 2 (default): per instance what measured faster -- scalar for the activation epilogues of the forward, packed for the dy form
+  const int sopt = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE);
+  const bool scalar = sopt == 1 || (sopt == 2 && !a.z2 && act != VS_ACT_NONE);
 #define VS_NHWC_LAUNCH3(A, S, D) do { if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
                                       else hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); } while (0)
 #define VS_NHWC_LAUNCH(A, S) VS_NHWC_LAUNCH3(A, S, false)

@@ -630,7 +630,7 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
     else hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 16>), g, block, 0, stream, a);
   } else
 #endif
-  if (vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE)) {
+  if (vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE)) {      // 1, or 2 = per instance what measured faster: this kernel's scalar build (1-1.5 %)
     if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
     else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
     else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
