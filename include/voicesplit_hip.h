@@ -15,15 +15,15 @@
  *    allocates device memory and keeps no caller pointer after return.
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
  *    synchronisation except where an entry point says so (vs_profile_end, vs_lstm_status).
- *  - library-owned state (all of it): (1) ONE side stream + two events per device, created on the first
- *    vs_backward and used to run weight gradients beside the BatchNorm backward passes; every vs_backward
- *    joins it before returning, and the enqueue phase of concurrent vs_backward calls on one device is
- *    serialised by a mutex while it is in use (vs_set_backward_overlap(0) turns it off); (2) the
- *    process-wide kernel-selection switches vs_set_conv_kernel / vs_set_wgrad_kernel / vs_set_lstm_kernel /
- *    vs_set_backward_overlap (A/B timing and cross-checks; every choice gives the same results) and the
- *    opt-in profiler vs_profile_begin / _end; (3) the error word of the persistent recurrence behind
- *    vs_lstm_status and a 64-byte zero page in device memory (static __device__ data of the bf16 GEMM: source
- *    of out-of-range operand pieces).  Calls on different streams with disjoint buffers are otherwise independent.
+ *  - library-owned state (all of it): (1) ONE side stream + two events per device, created on first use: vs_backward runs the
+ *    weight gradients there beside the BatchNorm backward passes, vs_forward_train (VS_MATH_BF16) the weight-only launches of the
+ *    step beside cnn1; both join it before they return, and the enqueue phase of concurrent calls on one device is serialised by a
+ *    mutex while it is in use (vs_set_backward_overlap(0) turns it off); (2) the process-wide switches: vs_set_conv_kernel /
+ *    vs_set_wgrad_kernel / vs_set_lstm_kernel / vs_set_backward_overlap and the option table behind vs_set_option (enum vs_option
+ *    lists every one of them; A/B timing and cross-checks: every choice gives the same results unless the option says "ablation";
+ *    the library reads NO environment variable), and the opt-in profiler vs_profile_begin / _end; (3) the error word of the
+ *    persistent recurrence behind vs_lstm_status and a 64-byte zero page in device memory (static __device__ data of the bf16 GEMM:
+ *    source of out-of-range operand pieces).  Calls on different streams with disjoint buffers are otherwise independent.
  *  - return 0 on success, <0 on error (-1 bad argument, -2 HIP runtime error); the message is
  *    available from vs_last_error() (thread-local).  No exceptions cross the ABI.
  *  - tensors are dense row-major with the reference's layouts: spectrogram [B][T][F]
