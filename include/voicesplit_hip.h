@@ -495,7 +495,9 @@ enum vs_option {
   VS_OPT_FWD_PROLOGUE = 14,   /* 1 (default): vs_forward_train (bf16) runs the weight-only launches of the step (conv weight packs, bf16 W_ih, d-vector fold,
                                  recurrent / head weight images) on the library's side stream beside cnn1; 0: in place, in front of their consumers.
                                  Needs vs_set_backward_overlap(1).  Same values.  VOICESPLIT_FWD_PROLOGUE */
-  VS_OPT_COUNT = 15
+  VS_OPT_HEAD_LEAF_SIDE = 15, /* 1: the head's two weight gradients (leaves of vs_backward) on the side stream beside the BPTT; 0: in front of it.
+                                 Default 1 (-0.3 ms per step).  Same values.  VOICESPLIT_HEAD_LEAF_SIDE */
+  VS_OPT_COUNT = 16
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

@@ -1,8 +1,8 @@
 # Round-end GPU script (one gpurun call): full -m gpu suite, smoke(), the bench lines, the probes, the rocprofv3 profile.
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/final_round.sh r04'
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/final_round.sh r05'
 # Results land in gpurun_out/final/; copy what is to be kept into profiles/ (tools/collect_final.sh <round>).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 mkdir -p gpurun_out/final
 export TMPDIR=/tmp
 O=gpurun_out/final
@@ -21,10 +21,11 @@ timeout 200 python tools/edge_micro.py > $O/${R}_edge_micro.json 2>/dev/null
 timeout 200 python tools/gemm_epilogue_probe.py > $O/${R}_gemm_epilogue_probe.json 2>/dev/null
 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_torchrun_n1.json; cut -c1-160 $O/${R}_bench_train_torchrun_n1.json
 VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.json 2>/dev/null
-{ for p in gemm_issue_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
+{ for p in gemm_issue_probe occupancy_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
 { timeout 200 python tools/lstm_time.py 64; timeout 200 python tools/lstm_time.py 2; } 2>/dev/null | grep "B=" > $O/${R}_lstm_time.txt
 [ -f voicesplit_amd/libvoicesplit_hip_abl.so ] && timeout 300 python tools/wgrad_ablation.py > $O/${R}_wgrad_ablation.json 2>/dev/null
 PYTHONPATH=. timeout 200 python tools/split_conv_micro.py final/${R}_split_conv_micro > /dev/null 2>&1
+VS_MICRO_CONV8_AB=1 VS_MICRO_WGRAD=0 timeout 300 python tools/nhwc_micro.py > $O/${R}_nhwc_micro_conv8_ab.json 2>/dev/null
 bash tools/profile_gpu.sh ${R}_forward --mode forward 2>&1 | tail -2
 bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
 # device idle gaps of one training step, from the kernel trace of the profile run

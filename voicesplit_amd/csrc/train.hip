@@ -130,6 +130,14 @@ struct SideJoin {
 // the side stream and its two events are shared by every caller on the device: one vs_backward enqueues at a time
 // (host threads driving different caller streams would otherwise re-record an event another call is about to wait on)
 std::mutex g_side_mutex;
+// (not std::unique_lock: its lock() / unlock() are out-of-line template members that libstdc++ marks default-visible, i.e. they would
+// become exports of the library -- tests/test_abi_cpu.py compares the dynamic symbol table with the header)
+struct SideLock {
+  bool held = false;
+  void lock() { g_side_mutex.lock(); held = true; }
+  void unlock() { if (held) { g_side_mutex.unlock(); held = false; } }
+  ~SideLock() { unlock(); }
+};
 int side_stream(SideStream** out) {
   int dev = 0;
   VS_CHECK_HIP(hipGetDevice(&dev));
@@ -214,7 +222,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   // conv stack produces: 14 launches of 5-45 us that used to sit, with their launch gaps, in front of their consumers on the one
   // stream (~0.25 ms of a step).  They now run beside cnn1; the caller's stream joins in front of cnn2.
   SideStream* side = nullptr;
-  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  SideLock side_lock;
   const int K = 8 * F, KE = K + d->E;
   float* dvbias = at<float>(tape, L.dvbias);
   const VsLstmBf16Layout Lpre = vs_lstm_bf16_layout((long long)B * T, K, H);
@@ -417,7 +425,7 @@ extern "C" int vs_set_backward_overlap(int on) {
 int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
                 void* tape, size_t tape_bytes, const float* mask, const float* dmask, const vs_grads* g, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  SideLock side_lock;
   if (g_bwd_overlap) side_lock.lock();
   vs_tape_layout L;
   if (int rc = check_tape(d, tape, tape_bytes, &L)) return rc;
@@ -440,6 +448,12 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   float* ones = at<float>(tape, L.consts);
   float* zeros = ones + 64;
 
+  // the side stream: the leaves of the backward pass (weight gradients of the head, of the LSTM, of the convs) run there
+  SideStream* side = nullptr;
+  if (g_bwd_overlap) { if (int rc = side_stream(&side)) return rc; }
+  SideJoin side_join;
+  side_join.side = side;
+  side_join.stream = stream;
   // ---- head: sigmoid, fc2, relu, fc1, relu (models/voicesplit/model.py:83-87 backwards) ----
   float* dlogits = at<float>(tape, L.dlogits);
   float* h1 = at<float>(tape, L.fc1_out);
@@ -450,20 +464,29 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   VsProfScope ps(VS_PROF_BWD_HEAD, stream);
   // VS_MATH_BF16: the four head contractions on bf16-rounded operands (fp32 accumulate, fp32 split-K partials)
   const auto vs_gemm_general_impl = d->math == VS_MATH_BF16 ? ::vs_gemm_general_bf16_impl : ::vs_gemm_general_impl;
+  // [r5] The two weight gradients of the head are leaves: with VS_OPT_HEAD_LEAF_SIDE they go to the side stream, where they run beside
+  // the BPTT -- a latency-bound launch that leaves the CUs' arithmetic idle -- instead of in front of it (same kernels, same sums).
+  const bool leaf_side = side != nullptr && vs_opt(VS_OPT_HEAD_LEAF_SIDE) != 0;
+  hipStream_t hs = leaf_side ? side->s : stream;
   if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp, FC2, stream)) return rc;
   if (int rc = vs_colsum_impl(tmp, FC2, 1, B, FC2, g->fc2_b, FC2, stream)) return rc;
-  // dW2 = dlogits^T @ h1
-  if (int rc = vs_gemm_general_impl(1, 1, dlogits, FC2, h1, nullptr, 0x7fffffff, FC1, g->fc2_w, FC1, FC2, FC1, M,
-                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, kSplitK, part, stream)) return rc;
   // dfc1 = (dlogits @ W2) * (h1 > 0)
   if (int rc = vs_gemm_general_impl(0, 1, dlogits, FC2, p->fc2_w, nullptr, 0x7fffffff, FC1, dfc1, FC1, M, FC1, FC2,
                                     nullptr, nullptr, nullptr, 0, 1, h1, FC1, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  if (leaf_side) {
+    VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+    VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    side_join.forked = true;
+  }
+  // dW2 = dlogits^T @ h1
+  if (int rc = vs_gemm_general_impl(1, 1, dlogits, FC2, h1, nullptr, 0x7fffffff, FC1, g->fc2_w, FC1, FC2, FC1, M,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, kSplitK, part, hs)) return rc;
   if (int rc = vs_colsum_impl(dfc1, FC1, B, T, FC1, tmp, FC1, stream)) return rc;
   if (int rc = vs_colsum_impl(tmp, FC1, 1, B, FC1, g->fc1_b, FC1, stream)) return rc;
   // dW1 = dfc1^T @ relu(lstm_out)
   if (int rc = vs_gemm_general_impl(1, 1, dfc1, FC1, lstm_out, nullptr, 0x7fffffff, 2 * H, g->fc1_w, 2 * H, FC1, 2 * H, M,
-                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 1, VS_ACT_NONE, 0, 0, 0, kSplitK, part, stream)) return rc;
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 1, VS_ACT_NONE, 0, 0, 0, kSplitK, part, hs)) return rc;
   // dlstm_out = (dfc1 @ W1) * (lstm_out > 0)
   if (int rc = vs_gemm_general_impl(0, 1, dfc1, FC1, p->fc1_w, nullptr, 0x7fffffff, 2 * H, dlstm, 2 * H, M, 2 * H, FC1,
                                     nullptr, nullptr, nullptr, 0, 1, lstm_out, 2 * H, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
@@ -484,8 +507,6 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // Only dfeat continues down the conv stack; the LSTM's own parameter gradients (dW_ih, dW_hh, biases, d-vector)
   // are leaves.  They go to the side stream (see vs_set_backward_overlap above) and run beside the HBM-bound
   // cnn8 / BatchNorm backward kernels that follow the dfeat GEMMs on the caller's stream.
-  SideStream* side = nullptr;
-  if (g_bwd_overlap) { if (int rc = side_stream(&side)) return rc; }
   float* gsc = at<float>(tape, L.gemm_scales);
   const bool f16g = d->math != VS_MATH_FP32;
   {
@@ -506,9 +527,6 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
   }
   hipStream_t ls = stream;
-  SideJoin side_join;
-  side_join.side = side;
-  side_join.stream = stream;
   if (side) {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
