@@ -468,6 +468,7 @@ def main():
         if is_train:
             launches += [stage_ms[f"dgrad_cnn{i}"] for i in range(3, 8)]
         launches = [v / nbatch for v in launches]
+        kinst = None
         mean_launch_ms = sum(launches) / len(launches)
         achieved = B * GFLOP_CONV5X5 / mean_launch_ms           # algorithmic GFLOP / ms == TFLOP/s
         act_bytes = 2 if math == "bf16" else 4
@@ -489,7 +490,7 @@ def main():
             if not is_train:
                 # eval-mode forward (configs[1], configs[4]): the channels-last split-f16 kernel (csrc/conv_nhwc_f16x3.hip, round 4)
                 kname = "nhwc_conv_f16x3_kernel<5,5> (channels-last hi/lo f16 planes by LDS-DMA, weights in AGPRs, K halves across waves)"
-                ksub, ksrc = "nhwc_conv_f16x3_kernel<5, 5", "conv_nhwc_f16x3.hip"
+                ksub, ksrc, kinst = "nhwc_conv_f16x3", "conv_nhwc_f16x3.hip", "<5, 5"      # (_kernel or _scalar_kernel: the build vs_set_option picks)
                 extra["mfma_pipe"] = "f16 (v_mfma_f32_16x16x32_f16), 3 MFMA products per fp32 product"
                 extra["launch_ms_includes"] = "the layer's plan kernel (output scale from the tracked |max| of its input); weights come prepared"
                 extra["issue_model"] = ("one wave per SIMD: 16 cycles per MFMA + ~5 cycles for every other instruction, no overlap measured "
@@ -498,7 +499,7 @@ def main():
         else:
             kname, peak, extra, ksub, ksrc = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel", "conv_mfma.hip"
         no64 = (None, "counters were collected at B = 64 only")
-        traffic, rnd = committed_pmc_traffic(tag, ksub, source=ksrc) if B == 64 else no64
+        traffic, rnd = committed_pmc_traffic(tag, ksub, kinst, source=ksrc) if B == 64 else no64
         algo_gb = B * 2 * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
         by_instance = None
         if math == "bf16" and is_train:

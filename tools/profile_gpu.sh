@@ -27,6 +27,6 @@ timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc SQ_LDS
 echo "pmc_lds rc=$?"
 find "$OUT" -name "*.csv" | head -40
 # keep the merged-back payload small: drop everything but csv/log
-find "$OUT" -type f ! -name "*.csv" ! -name "*.log" -delete
+find "$OUT" -type f ! -name "*.csv" ! -name "*.log" ! -name "sources.sha256" -delete
 find "$OUT" -name "*agent_info*" -delete
 du -sh "$OUT"
