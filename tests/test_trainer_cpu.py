@@ -112,6 +112,12 @@ def test_train_step_is_zero_grad_backward_adam_step():
         assert torch.allclose(p, q, rtol=1e-6, atol=1e-8)
     # gradients still live in the flat bucket (no per-step re-allocation)
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.bucket.params, tr.bucket.views))
+    # bench.py's N > 1 self-diagnosis switch: harmless at world 1 / on the CPU (no collective, no events), and it resets its records
+    tr.set_comm_timing(True)
+    tr.train_step(_batch(4, 7))
+    assert tr.time_comm and tr.bucket.time_events and tr.flag_ms == [] and tr.bucket.collective_ms() == []
+    tr.set_comm_timing(False)
+    assert not tr.time_comm and not tr.bucket.time_events
 
 
 def test_loss_explosion_follows_train_py_order_and_fit_leaves_the_epoch():

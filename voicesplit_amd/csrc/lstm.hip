@@ -1076,7 +1076,7 @@ void lstm16_tagged_kernel(Lstm16Args a, void* hbuf2, void* hbuf3) {
           }
         }
         if (__all(ok)) break;
-        if (++spins > kSpinLimit || *(volatile int*)&sDead) {
+        if (++spins > kSpinLimit / 4 || *(volatile int*)&sDead) {      // (a poll round here is 7-13 loads, not one: the same give-up time as the flag kernels')
           if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           break;
         }
@@ -1417,7 +1417,7 @@ void lstm16_bwd_tagged_kernel(Lstm16BwdArgs a, void* gbuf2, void* gbuf3) {
           g[i] = __builtin_bit_cast(bf16x8, v);
         }
         if (__all(ok)) break;
-        if (++spins > kSpinLimit || *(volatile int*)&sDead) {
+        if (++spins > kSpinLimit / 4 || *(volatile int*)&sDead) {      // (a poll round here is 7-13 loads, not one: the same give-up time as the flag kernels')
           if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           break;
         }
