@@ -497,7 +497,11 @@ enum vs_option {
                                  Needs vs_set_backward_overlap(1).  Same values.  VOICESPLIT_FWD_PROLOGUE */
   VS_OPT_HEAD_LEAF_SIDE = 15, /* 1: the head's two weight gradients (leaves of vs_backward) on the side stream beside the BPTT; 0: in front of it.
                                  Default 1 (-0.3 ms per step).  Same values.  VOICESPLIT_HEAD_LEAF_SIDE */
-  VS_OPT_COUNT = 16
+  VS_OPT_FEAT_ROWS = 16,      /* VS_MATH_F16X3 whole-path eval forward (vs_forward, vs_forward_prepared): 1 = cnn8 writes the LSTM input
+                                 GEMM's split-f16 A operand itself, at a scale planned from the tracked |max| of its input (no fp32
+                                 features in the workspace, no |max| / split passes over them); 0 = fp32 features, then the passes.  Default 1.
+                                 Same values unless a lo half underflows (both scales are powers of two).  VOICESPLIT_FEAT_ROWS */
+  VS_OPT_COUNT = 17
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

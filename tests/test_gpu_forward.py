@@ -46,7 +46,7 @@ def _thin(name, arr, full):
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_module_matches_upstream_golden(name):
     """Every stage the fixture recorded: cnn8 (conv stack), lstm_out, logits, mask."""
-    from voicesplit_amd import ops
+    from voicesplit_amd import _lib, ops
     g = load_golden(name)
     m, sd = _module(g)
     m.train(g["training"])
@@ -60,7 +60,18 @@ def test_module_matches_upstream_golden(name):
     ws = ops.get_workspace(dims, x.cuda().device)
     full = d["num_freq"] > 100
     B, T, Fq, H = g["B"], g["T"], d["num_freq"], d["lstm_dim"]
-    feat = ops.ws_view(ws, lay.feat, (B, T, 8, Fq)).cpu().permute(0, 2, 1, 3).numpy()     # -> [B,8,T,F]
+    if not g["training"] and ops.get_conv_math() == "f16x3" and _lib.get_option("FEAT_ROWS"):
+        # the whole-path eval forward of this arithmetic holds the features only as the LSTM input GEMM's split operand (cnn8 writes it):
+        # hi and lo f16 rows [B T][Kp] in the second ping-pong buffer, scale pair in gemm_scales; the K padding must be zero
+        Kp = (8 * Fq + 63) // 64 * 64
+        na = (B * T * Kp * 2 + 255) // 256 * 256
+        hi = ops.ws_view(ws, lay.act1, (B * T, Kp), torch.float16).float()
+        lo = ops.ws_view(ws, lay.act1 + na, (B * T, Kp), torch.float16).float()
+        assert not hi[:, 8 * Fq:].any() and not lo[:, 8 * Fq:].any()
+        inv = ops.ws_view(ws, lay.gemm_scales, (2,))[1]
+        feat = ((hi + lo) * inv)[:, :8 * Fq].reshape(B, T, 8, Fq).cpu().permute(0, 2, 1, 3).numpy()
+    else:
+        feat = ops.ws_view(ws, lay.feat, (B, T, 8, Fq)).cpu().permute(0, 2, 1, 3).numpy()     # -> [B,8,T,F]
     lstm_out = ops.ws_view(ws, lay.lstm_out, (B, T, 2 * H)).cpu().numpy()
     assert _rel(_thin("cnn8", feat, full), g["cnn8"]) < REL_TOL
     assert _rel(_thin("lstm_out", lstm_out, full), g["lstm_out"]) < REL_TOL
@@ -294,3 +305,36 @@ def test_forward_tracks_the_input_range(amp):
         ref = R.forward(R.cast_state_dict(sd, torch.float64), x.double(), dvec.double(), act="mish")["mask"]
     assert torch.isfinite(got).all()
     assert _rel(got.numpy(), ref.numpy()) < REL_TOL
+
+
+@pytest.mark.parametrize("F,B,T", [(53, 3, 45), (601, 2, 40), (16, 1, 5)])
+def test_cnn8_writing_the_gemm_operand_agrees_with_the_separate_passes(F, B, T):
+    """vs_set_option(VS_OPT_FEAT_ROWS): the fp32-class whole-path forward lets cnn8 write the LSTM input GEMM's split A operand (rows
+    padded to the GEMM's K block, scale planned from a bound) instead of fp32 features + a |max| pass + a split pass.  Both forms
+    stay at the oracle's 1e-4; the two scales are powers of two, so the halves are the same numbers unless a lo half underflows
+    (usually bit-identical masks); prepared and unprepared weights take the same route."""
+    import voicesplit_amd as V
+    from voicesplit_amd import _lib, ops
+    dims_d = dict(num_freq=F, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=F)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 31), 6.0)
+    x, dvec = R.synthetic_inputs(B, T, dims_d, 31)
+    m = V.VoiceSplit(V.default_config(F, 24, 32, 44, F)).eval()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert ops.get_conv_math() == "f16x3"
+    prev = _lib.get_option("FEAT_ROWS")
+    got = {}
+    try:
+        for mode in (1, 0):
+            _lib.set_option("FEAT_ROWS", mode)
+            with torch.no_grad():
+                t = {k: v.detach() for k, v in m._tensors().items()}
+                direct = ops.forward(t, x.cuda(), dvec.cuda(), m._dims(B, T), m.conv_act, training=False)
+                prepared = m(x.cuda(), dvec.cuda())
+            assert torch.equal(direct, prepared)
+            got[mode] = prepared.double().cpu()
+    finally:
+        _lib.set_option("FEAT_ROWS", prev)
+    ref = R.forward(R.cast_state_dict(sd, torch.float64), x.double(), dvec.double(), act="mish")["mask"]
+    assert _rel(got[1].numpy(), ref.numpy()) < REL_TOL and _rel(got[0].numpy(), ref.numpy()) < REL_TOL
+    assert _rel(got[1].numpy(), got[0].numpy()) < 2e-6

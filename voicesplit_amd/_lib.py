@@ -221,7 +221,7 @@ def load(path: str = None) -> ctypes.CDLL:
 # enum vs_option of include/voicesplit_hip.h.  The library reads no environment variable; for A/B timing from the shell this
 # package maps the variables below onto vs_set_option ONCE, when it loads the library.
 OPTIONS = {"F16X3_CONV_NCHW": 0, "BWD_DY": 1, "GEMM_KERNEL": 2, "GEMM_DR": 3, "GEMM_ABL": 4, "GEMM_BAND": 5, "WGRAD_ABL": 6,
-           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15}
+           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16}
 _ENV_OPTIONS = {
     "VOICESPLIT_F16X3_CONV": ("F16X3_CONV_NCHW", lambda v: 1 if v == "nchw" else 0),
     "VOICESPLIT_BWD_DY": ("BWD_DY", lambda v: 0 if v.startswith("0") else 1),
@@ -239,6 +239,7 @@ _ENV_OPTIONS = {
     "VOICESPLIT_BWD_APPLY_BLOCKS": ("BWD_APPLY_BLOCKS", int),
     "VOICESPLIT_FWD_PROLOGUE": ("FWD_PROLOGUE", int),
     "VOICESPLIT_HEAD_LEAF_SIDE": ("HEAD_LEAF_SIDE", int),
+    "VOICESPLIT_FEAT_ROWS": ("FEAT_ROWS", int),
 }
 
 

@@ -25,7 +25,7 @@ void vs_set_error(const char* fmt, ...) {
 // thread safe, off by default.
 // defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
 int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
-                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 2, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0, /*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1};
+                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 2, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0, /*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1, /*FEAT_ROWS*/ 1};
 
 namespace {
 struct Prof {
@@ -168,9 +168,9 @@ int prep_pointers(const vs_dims* d, const void* blob, size_t bytes, Prep* P) {
 }
 
 int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
-                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep);
+                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep, bool* feat_rows = nullptr);
 int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
-                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep);
+                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep, bool feat_rows = false);
 
 }  // namespace
 
@@ -212,11 +212,21 @@ int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int
   return vs_split_rows_impl(w_ih1, 4 * H, K, KE, w_scale2, Wh + (size_t)4 * H * Kp, Wl + (size_t)4 * H * Kp, 0, stream, math);
 }
 
+// whether the split-operand form of the LSTM input GEMM runs out of `scratch` (the condition vs_lstm_input_gemm_impl applies below):
+// cnn8 may then write its output as that form's A operand (hi rows at scratch, lo rows at scratch + na)
+bool vs_lstm_rows_fit(int M, int K, int H, const void* scratch, size_t scratch_bytes, bool prepared) {
+  const size_t Kp = (size_t)(K + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
+  const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
+  if (!scratch || (reinterpret_cast<uintptr_t>(scratch) & 255) != 0) return false;
+  if (prepared) return 2 * na <= scratch_bytes;
+  return scratch_bytes >= vs_gemm_presplit_bytes(M, 8 * H, K) && 2 * na + 2 * nw <= scratch_bytes;
+}
+
 // prep_* != NULL: W_ih arrives prepared (vs_prepare_weights): its scale and split halves are read, not rebuilt
 int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_ih0, const float* w_ih1, int H, int KE,
                             float* xg, int M, const float* rowbias, int T, float* gs, void* scratch, size_t scratch_bytes,
                             hipStream_t stream, const float* prep_wscale2, const _Float16* prep_wh, const _Float16* prep_wl,
-                            bool feat_bf16_ready) {
+                            bool feat_bf16_ready, bool feat_rows_ready) {
   // the bf16 configuration's own GEMM (gemm_bf16.hip): feat and W_ih as bf16 arrays that the backward pass reuses.  It needs
   // room for the bf16 copy of feat, and for the bf16 W_ih unless that arrives prepared (vs_prepare_weights keeps it in the
   // prepared blob): a B = 1 clip of a second has room for the first but not for the 31 MB of the second.
@@ -244,7 +254,10 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
   }
   if (math != VS_MATH_FP32) {
     unsigned* amax = reinterpret_cast<unsigned*>(gs + 4);
-    if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc;
+    // feat_rows_ready: cnn8 wrote the split A operand and its scale (gs[0..1]) itself (conv_stack_impl, the whole-path eval forward)
+    VS_REQUIRE(!feat_rows_ready || (math == VS_MATH_F16X3 && vs_lstm_rows_fit(M, K, H, scratch, scratch_bytes, prep_wscale2 != nullptr)),
+               "lstm input gemm: the split feature rows were announced but do not fit");
+    if (!feat_rows_ready) { if (int rc = vs_pow2_scale_impl(feat, (long long)M * K, amax, gs, stream)) return rc; }
     const size_t Kp = (size_t)(K + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
     const size_t na = ((size_t)M * Kp * 2 + 255) / 256 * 256, nw = ((size_t)8 * H * Kp * 2 + 255) / 256 * 256;
     const bool aligned = scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0;
@@ -253,7 +266,7 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
     _Float16* Al = reinterpret_cast<_Float16*>(base + na);
     if (prep_wscale2) {
       if (aligned && 2 * na <= scratch_bytes) {
-        if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc;
+        if (!feat_rows_ready) { if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc; }
         return vs_gemm_presplit_impl(Ah, Al, prep_wh, prep_wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
                                      VS_ACT_NONE, 0, gs, prep_wscale2, stream, math);
       }
@@ -265,7 +278,7 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
     _Float16* Wl = reinterpret_cast<_Float16*>(base + 2 * na + nw);
     if (int rc = vs_lstm_split_wih_impl(math, w_ih0, w_ih1, H, K, KE, amax + 1, gs + 2, presplit ? Wh : nullptr, Wl, stream)) return rc;
     if (presplit) {
-      if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc;
+      if (!feat_rows_ready) { if (int rc = vs_split_rows_impl(feat, M, K, K, gs, Ah, Al, 0, stream, math)) return rc; }
       return vs_gemm_presplit_impl(Ah, Al, Wh, Wl, (int)Kp, xg, 8 * H, M, 8 * H, nullptr, nullptr, rowbias, 8 * H, T,
                                    VS_ACT_NONE, 0, gs, gs + 2, stream, math);
     }
@@ -284,7 +297,7 @@ int vs_set_option(int option, int value) {
   VS_REQUIRE(option >= 0 && option < VS_OPT_COUNT, "vs_set_option: unknown option %d", option);
   bool ok = true;
   switch (option) {
-    case VS_OPT_F16X3_CONV_NCHW: case VS_OPT_BWD_DY: case VS_OPT_GEMM_KERNEL: case VS_OPT_FWD_PROLOGUE: case VS_OPT_HEAD_LEAF_SIDE: ok = value == 0 || value == 1; break;
+    case VS_OPT_F16X3_CONV_NCHW: case VS_OPT_BWD_DY: case VS_OPT_GEMM_KERNEL: case VS_OPT_FWD_PROLOGUE: case VS_OPT_HEAD_LEAF_SIDE: case VS_OPT_FEAT_ROWS: ok = value == 0 || value == 1; break;
     case VS_OPT_CONV_SCALAR_EPILOGUE: ok = value >= 0 && value <= 2; break;
     case VS_OPT_SIDE_PRIO: case VS_OPT_BN_FUSED_FINALIZE: ok = value >= 0 && value <= 2; break;
     case VS_OPT_GEMM_DR: {
@@ -618,8 +631,9 @@ int vs_conv_stack_fwd(const vs_dims* d, const vs_params* p, const float* x, int 
 
 namespace {
 int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int conv_act, int bn_mode,
-                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep) {
+                    void* ws, const vs_ws_layout& L, float* feat, hipStream_t stream, const Prep* prep, bool* feat_rows) {
   VS_REQUIRE(p && x, "conv_stack: NULL argument");
+  if (feat_rows) *feat_rows = false;
   VS_REQUIRE(conv_act == VS_ACT_MISH || conv_act == VS_ACT_RELU, "conv_stack: conv_act must be MISH or RELU");
   VS_REQUIRE(bn_mode == VS_BN_EVAL || bn_mode == VS_BN_TRAIN, "conv_stack: unknown bn_mode %d", bn_mode);
   if (!feat) feat = at<float>(ws, L.feat);
@@ -719,6 +733,12 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
       if (int rc = vs_nhwc_conv_first_split_impl(x, p->conv[0].weight, scale, shift, slot(1), plane[0][0], plane[0][1], vs_amax_slot(slot(1)),
                                                  B, T, F, layer_act, stream)) return rc;
     }
+    // the whole-path forward (feat_rows != NULL: nobody reads the fp32 features): cnn8 writes the LSTM input GEMM's split A operand
+    // into the idle ping-pong buffer, at a scale planned from the tracked |max| of its input -- no fp32 features, no |max| and split passes
+    const size_t act_bytes = (size_t)B * 64 * T * F * sizeof(float);
+    const int Kp = (8 * F + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
+    const bool rows = feat_rows && vs_opt(VS_OPT_FEAT_ROWS) != 0 &&
+                      vs_lstm_rows_fit(B * T, 8 * F, d->H, at<char>(ws, L.act1), act_bytes, prep != nullptr);
     int c = 0;
     for (int i = 0; i < 6; ++i) {
       const int l = i + 1;
@@ -728,11 +748,20 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
       float* plan = reinterpret_cast<float*>(mine + vs_nhwc_f16x3_wpart_bytes(kMid[i].kt, kMid[i].kf));
       if (int rc = vs_nhwc_f16x3_layer_impl(plane[c][0], plane[c][1], slot(l), vs_amax_slot(slot(l)), VS_AMAX_SLOTS, p->conv[l].weight,
                                             scale + 64 * l, shift + 64 * l, wpart, prep ? 1 : 0, plan, plane[c ^ 1][0], plane[c ^ 1][1],
-                                            slot(l + 1), l < 6 ? vs_amax_slot(slot(l + 1)) : nullptr, B, T, F, kMid[i].kt, kMid[i].kf,
+                                            slot(l + 1), (l < 6 || rows) ? vs_amax_slot(slot(l + 1)) : nullptr, B, T, F, kMid[i].kt, kMid[i].kf,
                                             kMid[i].dil, layer_act, stream)) return rc;
       c ^= 1;
     }
     ProfScope ps(VS_PROF_CNN8, stream);
+    if (rows) {      // six layers: c == 0, the input planes fill act0 and act1 is idle
+      float* gs = at<float>(ws, L.gemm_scales);
+      char* rows_hi = at<char>(ws, L.act1);
+      const size_t na = ((size_t)B * T * Kp * 2 + 255) / 256 * 256;
+      if (int rc = vs_nhwc_last_plan_impl(vs_amax_slot(slot(7)), VS_AMAX_SLOTS, p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, gs, stream)) return rc;
+      *feat_rows = true;
+      return vs_nhwc_conv_last_split_impl(plane[c][0], plane[c][1], slot(7), p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, nullptr,
+                                          B, T, F, layer_act, stream, rows_hi, rows_hi + na, Kp, gs);
+    }
     return vs_nhwc_conv_last_split_impl(plane[c][0], plane[c][1], slot(7), p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat,
                                         B, T, F, layer_act, stream);
   }
@@ -815,7 +844,7 @@ int vs_bilstm_fwd(const vs_dims* d, const vs_params* p, const float* feat, const
 
 namespace {
 int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const float* dvec,
-                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep) {
+                void* ws, const vs_ws_layout& L, float* lstm_out, hipStream_t stream, const Prep* prep, bool feat_rows) {
   VS_REQUIRE(p && dvec, "bilstm: NULL argument");
   if (!feat) feat = at<float>(ws, L.feat);
   if (!lstm_out) lstm_out = at<float>(ws, L.lstm_out);
@@ -834,11 +863,12 @@ int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const f
   // both directions in one launch (N = 8H): twice the workgroups, half the tail quantisation
   // the conv stack is done: its activation ping-pong is idle (feat may be the caller's own buffer)
   const size_t act_bytes = (size_t)B * 64 * T * d->F * sizeof(float);
+  // feat_rows: cnn8 left the split A operand in the second ping-pong buffer (conv_stack_impl)
   if (int rc = vs_lstm_input_gemm_impl(d->math, feat, K, p->w_ih[0], p->w_ih[1], H, KE, xg, B * T, dvbias, T,
-                                       at<float>(ws, L.gemm_scales), at<char>(ws, L.act0),
-                                       L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes, stream,
+                                       at<float>(ws, L.gemm_scales), at<char>(ws, feat_rows ? L.act1 : L.act0),
+                                       feat_rows ? act_bytes : (L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes), stream,
                                        prep ? prep->gemm_wscale : nullptr, prep ? prep->wih_hi : nullptr,
-                                       prep ? prep->wih_lo : nullptr)) return rc;
+                                       prep ? prep->wih_lo : nullptr, false, feat_rows)) return rc;
   }
   float* packed = prep ? prep->lstm_packed : at<float>(ws, L.lstm_packed);
   if (!prep) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc; }
@@ -901,8 +931,11 @@ int vs_head_fwd(const vs_dims* d, const vs_params* p, const float* lstm_out, voi
 int vs_forward(const vs_dims* d, const vs_params* p, const float* x, const float* dvec, int conv_act, int bn_mode,
                void* ws, size_t ws_bytes, float* mask, void* stream) {
   VS_REQUIRE(mask != nullptr, "forward: mask is NULL");
-  if (int rc = vs_conv_stack_fwd(d, p, x, conv_act, bn_mode, ws, ws_bytes, nullptr, stream)) return rc;
-  if (int rc = vs_bilstm_fwd(d, p, nullptr, dvec, ws, ws_bytes, nullptr, stream)) return rc;
+  vs_ws_layout L;
+  if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
+  bool feat_rows = false;
+  if (int rc = conv_stack_impl(d, p, x, conv_act, bn_mode, ws, L, nullptr, (hipStream_t)stream, nullptr, &feat_rows)) return rc;
+  if (int rc = bilstm_impl(d, p, nullptr, dvec, ws, L, nullptr, (hipStream_t)stream, nullptr, feat_rows)) return rc;
   return vs_head_fwd(d, p, nullptr, ws, ws_bytes, nullptr, mask, stream);
 }
 
@@ -968,8 +1001,9 @@ int vs_forward_prepared(const vs_dims* d, const vs_params* p, const void* prepar
   if (int rc = prep_pointers(d, prepared, prepared_bytes, &P)) return rc;
   vs_ws_layout L;
   if (int rc = check_ws(d, ws, ws_bytes, &L)) return rc;
-  if (int rc = conv_stack_impl(d, p, x, conv_act, VS_BN_EVAL, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
-  if (int rc = bilstm_impl(d, p, nullptr, dvec, ws, L, nullptr, (hipStream_t)stream, &P)) return rc;
+  bool feat_rows = false;
+  if (int rc = conv_stack_impl(d, p, x, conv_act, VS_BN_EVAL, ws, L, nullptr, (hipStream_t)stream, &P, &feat_rows)) return rc;
+  if (int rc = bilstm_impl(d, p, nullptr, dvec, ws, L, nullptr, (hipStream_t)stream, &P, feat_rows)) return rc;
   return head_fwd_impl(d, p, nullptr, ws, ws_bytes, nullptr, mask, (hipStream_t)stream, P.head_packed);
 }
 

@@ -192,7 +192,10 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
   const long long wstride = (long long)gridDim.x * 4;
   const long long sq = wstride / blocks_per_row;          // (row, block column) are carried along: one division per launch
   const int sr = (int)(wstride - sq * blocks_per_row);
-  long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // workgroups go round the 8 XCDs: the ones of an XCD take neighbouring blocks, so that the 64-byte pieces of an output line meet in one L2
+  const int per_xcd = gridDim.x >> 3;
+  const int vblock = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long blk = (long long)vblock * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   long long row = blk / blocks_per_row;
   int bc = (int)(blk - row * blocks_per_row);
   for (; blk < nblk; blk += wstride, row += sq, bc += sr) {
@@ -1004,18 +1007,21 @@ namespace {
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
-// out_scale2 <- {s, 1 / s}, s = the power of two that maps max_c (|scale_c| sum_j |w_cj| max|x| + |shift_c|) (>= max |y|) into [2^14, 2^15)
+// out_scale2 <- {s, 1 / s}, s = the power of two that maps max_c (|scale_c| sum_j |w_cj| max|x| + |shift_c|) (>= max |y|) into [2^14, 2^15);
+// w = [nco][taps] (cnn1: 64 x 7, cnn8: 8 x 64)
 __global__ void nhwc_first_plan_kernel(const unsigned* __restrict__ amax_in, int n_amax, const float* __restrict__ w, const float* __restrict__ scale,
-                                       const float* __restrict__ shift, float* __restrict__ out_scale2) {
+                                       const float* __restrict__ shift, float* __restrict__ out_scale2, int nco, int taps) {
   const int c = threadIdx.x;                                  // 64 threads
   unsigned mb = 0;
   for (int i = c; i < n_amax; i += 64) mb = amax_in[i] > mb ? amax_in[i] : mb;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(mb, o, 64); mb = other > mb ? other : mb; }
-  float l1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) l1 += fabsf(w[c * 7 + k]);
-  float bound = fmaxf(fabsf(scale[c]) * l1 * __uint_as_float(mb) + fabsf(shift[c]), 0.3125f);
+  float bound = 0.3125f;
+  if (c < nco) {
+    float l1 = 0.f;
+    for (int k = 0; k < taps; ++k) l1 += fabsf(w[c * taps + k]);
+    bound = fmaxf(fabsf(scale[c]) * l1 * __uint_as_float(mb) + fabsf(shift[c]), 0.3125f);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
   if (c == 0) {
@@ -1095,20 +1101,23 @@ void nhwc_conv_first_split_kernel(const float* __restrict__ x, const float* __re
 }
 
 // out[b][t][co][f] = act(scale[co] * sum_ci w[co][ci] x[b][t][f][ci] + shift[co]), co < 8, x = (in_hi + in_lo) / s_x.
-// One wave = 16 pixels per step: B operands = the two planes' pixels as they lie in memory, A = the weights (rows 8..15 zero)
+// One wave = 16 pixels per step: B operands = the two planes' pixels as they lie in memory, A = the weights (rows 8..15 repeat rows 0..7)
 // split into hi / lo after a power-of-two scale found here (512 values: one wave reduction); three products, fp32 accumulate.
-template <int ACT>
+// ROWS: the output goes out as the LSTM input GEMM's A operand instead -- hi / lo f16 rows [nrows][Kp] of out * out_scale2[0] (element
+// co * F + f of row (b, t): the feature order of the fp32 form), columns 8 F .. Kp zeroed by the workgroups that own a row's first block.
+template <int ACT, bool ROWS>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const unsigned short* __restrict__ in_lo, const float* __restrict__ in_scale2,
                                  const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
-                                 float* __restrict__ out, long long nrows, int F) {
+                                 float* __restrict__ out, long long nrows, int F,
+                                 unsigned short* __restrict__ row_hi, unsigned short* __restrict__ row_lo, int Kp, const float* __restrict__ out_scale2) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
   float wv[2][8], wmax = 0.f;
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      wv[kc][j] = n < 8 ? w[n * 64 + kc * 32 + g * 8 + j] : 0.f;
+      wv[kc][j] = w[(n & 7) * 64 + kc * 32 + g * 8 + j];      // A rows 8..15 repeat 0..7: accumulator rows g >= 2 repeat g - 2
       wmax = fmaxf(wmax, fabsf(wv[kc][j]));
     }
 #pragma unroll
@@ -1137,12 +1146,17 @@ void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const
     sc[r] = scale[co] * inv;
     sh[r] = shift[co];
   }
+  const float so = ROWS ? out_scale2[0] : 1.f;
   const int blocks_per_row = (F + 15) >> 4;
   const long long nblk = nrows * blocks_per_row;
   const long long wstride = (long long)gridDim.x * 4;
   const long long sq = wstride / blocks_per_row;
   const int sr = (int)(wstride - sq * blocks_per_row);
-  long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // workgroups go round the 8 XCDs: the ones of an XCD take neighbouring blocks, so that the 32- and 64-byte pieces of an output
+  // line meet in ONE L2 instead of leaving eight of them as partial writes
+  const int per_xcd = gridDim.x >> 3;
+  const int vblock = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long blk = (long long)vblock * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   long long row = blk / blocks_per_row;
   int bc = (int)(blk - row * blocks_per_row);
   const u4v z4 = {0u, 0u, 0u, 0u};
@@ -1176,7 +1190,24 @@ void nhwc_conv_last_split_kernel(const unsigned short* __restrict__ in_hi, const
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], __builtin_bit_cast(h8v, l1), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], __builtin_bit_cast(h8v, h0), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], __builtin_bit_cast(h8v, h1), c, 0, 0, 0);
-    if (ok && g < 2) {
+    if (ROWS) {
+      if (ok) {                                                 // lanes g < 2 write the hi halves, their repeats (g >= 2) the lo halves
+        unsigned short* dst = (g < 2 ? row_hi : row_lo) + (size_t)row * Kp + (size_t)((g & 1) * 4) * F + f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r])) * so;
+          const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.f))[0];
+          const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.f))[0];
+          dst[(size_t)r * F] = __builtin_bit_cast(unsigned short, g < 2 ? vh : vl);
+        }
+      }
+      if (bc == 0) {                                            // this wave owns the row's padding
+        for (int k = 8 * F + lane; k < Kp; k += 64) {
+          row_hi[(size_t)row * Kp + k] = 0;
+          row_lo[(size_t)row * Kp + k] = 0;
+        }
+      }
+    } else if (ok && g < 2) {
       float* o = out + (row * 8 + g * 4) * F + f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[(size_t)r * F] = vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r]));
@@ -1198,7 +1229,16 @@ int vs_absmax_any_impl(const float* x, long long n, unsigned* amax, hipStream_t 
 int vs_nhwc_first_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2,
                             hipStream_t stream) {
   VS_REQUIRE(amax_in && n_amax > 0 && w && scale && shift && out_scale2, "nhwc first_plan: bad argument");
-  hipLaunchKernelGGL(nhwc_first_plan_kernel, dim3(1), dim3(64), 0, stream, amax_in, n_amax, w, scale, shift, out_scale2);
+  hipLaunchKernelGGL(nhwc_first_plan_kernel, dim3(1), dim3(64), 0, stream, amax_in, n_amax, w, scale, shift, out_scale2, 64, 7);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same for cnn8 (8 output channels x 64 taps) when its output is written as the LSTM input GEMM's split operand
+int vs_nhwc_last_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2,
+                           hipStream_t stream) {
+  VS_REQUIRE(amax_in && n_amax > 0 && w && scale && shift && out_scale2, "nhwc last_plan: bad argument");
+  hipLaunchKernelGGL(nhwc_first_plan_kernel, dim3(1), dim3(64), 0, stream, amax_in, n_amax, w, scale, shift, out_scale2, 8, 64);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -1220,18 +1260,28 @@ int vs_nhwc_conv_first_split_impl(const float* x, const float* w, const float* s
 }
 
 int vs_nhwc_conv_last_split_impl(const void* in_hi, const void* in_lo, const float* in_scale2, const float* w, const float* scale,
-                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t stream) {
-  VS_REQUIRE(in_hi && in_lo && in_scale2 && w && scale && shift && out, "nhwc conv_last_split: NULL argument");
+                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t stream,
+                                 void* row_hi, void* row_lo, int Kp, const float* out_scale2) {
+  VS_REQUIRE(in_hi && in_lo && in_scale2 && w && scale && shift && (out || row_hi), "nhwc conv_last_split: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last_split: bad shape");
+  VS_REQUIRE(!row_hi || (row_lo && out_scale2 && Kp >= 8 * F), "nhwc conv_last_split: bad row-form arguments (Kp = %d)", Kp);
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
   const dim3 grid(stream_blocks(4, nblk)), block(256);
   const unsigned short* ih = reinterpret_cast<const unsigned short*>(in_hi);
   const unsigned short* il = reinterpret_cast<const unsigned short*>(in_lo);
-  if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_NONE>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
-  else if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_MISH>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<VS_ACT_RELU>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F);
+  unsigned short* rh = reinterpret_cast<unsigned short*>(row_hi);
+  unsigned short* rl = reinterpret_cast<unsigned short*>(row_lo);
+#define VS_LAST_SPLIT(A)                                                                                                                   \
+  do {                                                                                                                                     \
+    if (rh) hipLaunchKernelGGL((nhwc_conv_last_split_kernel<A, true>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F, rh, rl, Kp, out_scale2); \
+    else hipLaunchKernelGGL((nhwc_conv_last_split_kernel<A, false>), grid, block, 0, stream, ih, il, in_scale2, w, scale, shift, out, nrows, F, rh, rl, Kp, out_scale2);  \
+  } while (0)
+  if (act == VS_ACT_NONE) VS_LAST_SPLIT(VS_ACT_NONE);
+  else if (act == VS_ACT_MISH) VS_LAST_SPLIT(VS_ACT_MISH);
+  else if (act == VS_ACT_RELU) VS_LAST_SPLIT(VS_ACT_RELU);
   else VS_REQUIRE(false, "nhwc conv_last_split: unsupported activation %d", act);
+#undef VS_LAST_SPLIT
   VS_LAUNCH_CHECK();
   return 0;
 }

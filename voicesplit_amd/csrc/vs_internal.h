@@ -43,7 +43,9 @@ int vs_lstm_input_gemm_impl(int math, const float* feat, int K, const float* w_i
                             float* xg, int M, const float* rowbias, int T, float* gemm_scales,
                             void* scratch, size_t scratch_bytes, hipStream_t, const float* prep_wscale2 = nullptr,
                             const _Float16* prep_wh = nullptr, const _Float16* prep_wl = nullptr,
-                            bool feat_bf16_ready = false /* VS_MATH_BF16: the bf16 copy of feat is already in scratch */);
+                            bool feat_bf16_ready = false /* VS_MATH_BF16: the bf16 copy of feat is already in scratch */,
+                            bool feat_rows_ready = false /* VS_MATH_F16X3: cnn8 wrote the split A operand + its scale (vs_lstm_rows_fit) */);
+bool vs_lstm_rows_fit(int M, int K, int H, const void* scratch, size_t scratch_bytes, bool prepared);
 int vs_lstm_split_wih_impl(int math, const float* w_ih0, const float* w_ih1, int H, int K, int KE, unsigned* amax1,
                            float* w_scale2, _Float16* Wh, _Float16* Wl, hipStream_t);
 int vs_conv64_pack_f16_impl(const float* w, _Float16* wp, int KT, int KF, int transpose_flip, unsigned* amax_scratch,
@@ -101,8 +103,11 @@ int vs_absmax_any_impl(const float* x, long long n, unsigned* amax, hipStream_t)
 int vs_nhwc_first_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2, hipStream_t);
 int vs_nhwc_conv_first_split_impl(const float* x, const float* w, const float* scale, const float* shift, const float* out_scale2,
                                   void* out_hi, void* out_lo, unsigned* amax_out, int B, int T, int F, int act, hipStream_t);
+int vs_nhwc_last_plan_impl(const unsigned* amax_in, int n_amax, const float* w, const float* scale, const float* shift, float* out_scale2, hipStream_t);
+// row_hi != NULL: the output as the LSTM input GEMM's split A operand [B T][Kp] (scale out_scale2 from vs_nhwc_last_plan_impl), `out` unused
 int vs_nhwc_conv_last_split_impl(const void* in_hi, const void* in_lo, const float* in_scale2, const float* w, const float* scale,
-                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t);
+                                 const float* shift, float* out, int B, int T, int F, int act, hipStream_t,
+                                 void* row_hi = nullptr, void* row_lo = nullptr, int Kp = 0, const float* out_scale2 = nullptr);
 // wgrad_nhwc.hip: their weight gradient (pairs of workgroups, one partial-sum slab per pair)
 #define VS_NHWC_WGRAD_MAX_PAIRS 128
 size_t vs_nhwc_wgrad_partial_floats(int KT, int KF);
