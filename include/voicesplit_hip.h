@@ -245,6 +245,11 @@ int vs_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, int lda, const void*
  * col x col contraction over K = B*T (dxg^T @ feat, M = 8H: rows < 4H -> lstm.weight_ih_l0.grad, the rest -> _reverse). */
 int vs_gemm_bf16_split(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, float* C2, int ldc, int split_m,
                        int M, int N, int K, int accumulate, void* stream);
+/* The same contraction under a relu mask: C[m][n] = (op(A) op(B))[m][n] where gate[m * ldg + n] > 0, else 0.  This is how vs_backward
+ * runs the head's two data gradients (models/voicesplit/model.py:83-85 backwards): dfc1 = (dlogits @ W2) * (h1 > 0) and
+ * dlstm_out = (dfc1 @ W1) * (lstm_out > 0), A = the bf16 row copy of the incoming gradient, B = the bf16 weight in K-major form. */
+int vs_gemm_bf16_gated(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                       const float* gate, int ldg, void* stream);
 /* the memory-bound kernels around them.  cnn1: x [B][T][F] fp32 -> [B][T][F][64] bf16 (bn_stats as above);
  * BatchNorm + activation apply a = act(z * scale[c] + shift[c]) over npix pixels (a may alias z); cnn8 + transpose/view:
  * [B][T][F][64] bf16 -> [B][T][8][F] fp32. */
@@ -501,7 +506,15 @@ enum vs_option {
                                  GEMM's split-f16 A operand itself, at a scale planned from the tracked |max| of its input (no fp32
                                  features in the workspace, no |max| / split passes over them); 0 = fp32 features, then the passes.  Default 1.
                                  Same values unless a lo half underflows (both scales are powers of two).  VOICESPLIT_FEAT_ROWS */
-  VS_OPT_COUNT = 17
+  VS_OPT_HEAD_BWD_GEMM = 17,  /* VS_MATH_BF16 vs_backward: 1 = the head's two data-gradient contractions (dfc1, dlstm_out) on the LSTM
+                                 contractions' LDS-DMA kernel over bf16 copies of their operands (relu mask in the epilogue); 0 = the generic
+                                 kernel (in-flight conversion).  Default 1.  Same operand roundings, fp32 summation order differs.
+                                 VOICESPLIT_HEAD_BWD_GEMM */
+  VS_OPT_LSTM_LEAF_LATE = 18, /* VS_MATH_BF16 vs_backward with the side stream: where the LSTM's leaf contractions (dW_ih, dW_hh, d-vector) start
+                                 on it.  0 = right behind the BPTT (beside the dfeat contraction and the features' BatchNorm backward);
+                                 1 = behind that BatchNorm backward (beside cnn8's backward); 2 = behind cnn8's backward.  Same values.
+                                 VOICESPLIT_LSTM_LEAF_LATE */
+  VS_OPT_COUNT = 19
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

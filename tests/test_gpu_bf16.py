@@ -290,3 +290,67 @@ def test_bf16_gradients_sit_inside_the_ideal_bf16_envelope():
 def test_bf16_is_never_the_default():
     from voicesplit_amd import ops
     assert ops.get_conv_math() in ("f16x3", "fp32")
+
+
+def test_head_data_gradients_on_the_lstm_gemm_kernel_agree_with_the_generic_kernel():
+    """vs_set_option(VS_OPT_HEAD_BWD_GEMM): dfc1 = (dlogits @ W2) * (h1 > 0) and dlstm_out = (dfc1 @ W1) * (lstm_out > 0) on
+    gemm_bf16.hip's kernel (bf16 copies of the operands, relu mask in the epilogue) against the generic kernel that converts the
+    same operands to bf16 while it stages them: same products, another fp32 summation order -- the head's own gradients agree to
+    fp32 rounding, everything below the BPTT to the bf16 storage rounding a changed last bit can flip."""
+    import voicesplit_amd as V
+    from voicesplit_amd import _lib
+    dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=32, fc1_dim=48, fc2_dim=601)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 5), 6.0)
+    x, dvec = R.synthetic_inputs(3, 70, dims_d, 5)
+    w = torch.randn(3, 70, 601, generator=torch.Generator().manual_seed(9)).cuda()
+    prev = _lib.get_option("HEAD_BWD_GEMM")
+    got = {}
+    try:
+        with _math("bf16"):
+            for mode in (1, 0):
+                _lib.set_option("HEAD_BWD_GEMM", mode)
+                m = V.VoiceSplit(V.default_config(601, 256, 32, 48, 601))
+                m.load_state_dict(sd, strict=True)
+                m = m.cuda().train(True)
+                (m(x.cuda(), dvec.cuda()) * w).sum().backward()
+                torch.cuda.synchronize()
+                got[mode] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        _lib.set_option("HEAD_BWD_GEMM", prev)
+    for k in got[1]:
+        assert torch.isfinite(got[1][k]).all(), k
+        tol = 1e-5 if k.startswith("fc2") else (2e-4 if k.startswith("fc1") else 2e-2)
+        assert _rel(got[1][k], got[0][k]) < tol, (k, _rel(got[1][k], got[0][k]))
+
+
+def test_where_the_lstm_leaf_contractions_start_does_not_change_a_gradient():
+    """vs_set_option(VS_OPT_LSTM_LEAF_LATE): the LSTM's leaf contractions start on the side stream behind the BPTT (0), behind the
+    features' BatchNorm backward (1) or behind cnn8's backward (2) -- the same launches on the same operands: bit-identical gradients,
+    twice per mode to catch a missing fork or join."""
+    import voicesplit_amd as V
+    from voicesplit_amd import _lib
+    dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=32, fc1_dim=48, fc2_dim=601)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 5), 6.0)
+    x, dvec = R.synthetic_inputs(3, 70, dims_d, 5)
+    w = torch.randn(3, 70, 601, generator=torch.Generator().manual_seed(9)).cuda()
+    prev = _lib.get_option("LSTM_LEAF_LATE")
+    got = {}
+    try:
+        with _math("bf16"):
+            for mode in (0, 1, 2):
+                _lib.set_option("LSTM_LEAF_LATE", mode)
+                m = V.VoiceSplit(V.default_config(601, 256, 32, 48, 601))
+                m.load_state_dict(sd, strict=True)
+                m = m.cuda().train(True)
+                got[mode] = []
+                for _ in range(2):
+                    m.zero_grad(set_to_none=True)
+                    (m(x.cuda(), dvec.cuda()) * w).sum().backward()
+                    torch.cuda.synchronize()
+                    got[mode].append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    finally:
+        _lib.set_option("LSTM_LEAF_LATE", prev)
+    for mode in (1, 2):
+        for a, b in zip(got[0], got[mode]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (mode, k)

@@ -152,3 +152,24 @@ def test_gemm_bf16_split_store(M, N, K, split):
     from voicesplit_amd import _lib
     with pytest.raises(_lib.VoiceSplitHipError, match="split_m"):
         ops.gemm_bf16_split(Ab, Bb, M, N, K, M)
+
+
+@pytest.mark.parametrize("M,N,K", [(2408, 600, 601), (2408, 800, 600), (135, 44, 53), (135, 64, 44), (300, 601, 600)])
+def test_gemm_bf16_gated_head_shapes(M, N, K):
+    """vs_gemm_bf16_gated = the head's two data gradients of vs_backward: row-form gradient (K = 601 / 600: a K tail inside a 64-step,
+    zero padded) x K-major weight [K][N padded to 8], relu mask in the epilogue; N = 601 (not a multiple of 4) takes the element-wise
+    kernel.  Against fp64 on the same bf16-rounded operands."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    Kp, Np = (K + 63) // 64 * 64, (N + 7) // 8 * 8
+    dy = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) * 0.05).cuda()                     # fc weight [out = K of this contraction][in = N]
+    gate = torch.randn(M, N, generator=g).cuda()
+    gate[::7, ::3] = 0.0                                                    # (relu'(0) = 0)
+    db, wb = ops.cvt_rows_bf16(dy, K, Kp), ops.cvt_rows_bf16(w, N, Np)
+    got = ops.gemm_bf16_gated(db, wb, gate, M, N, K, b_kmajor=True)
+    ref = (db[:, :K].double() @ wb[:, :N].double()) * (gate > 0).double()
+    assert _rel(got.double(), ref) < 2e-5
+    assert torch.equal(got == 0, ~(gate > 0) | (ref == 0))
+    plain = ops.gemm_bf16(db, wb, M, N, K, b_kmajor=True)
+    assert torch.equal(got, torch.where(gate > 0, plain, torch.zeros_like(plain)))

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vs_nhwc_conv": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vs_cvt_rows_bf16": (c_int, [_P, c_longlong, c_int, c_int, _P, c_int, _P]),
     "vs_gemm_bf16": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "vs_gemm_bf16_gated": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "vs_gemm_bf16_split": (c_int, [c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vs_nhwc_conv_f16x3_scratch_bytes": (c_size_t, [c_int, c_int]),
     "vs_nhwc_conv_f16x3_layer": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P,
@@ -221,7 +222,7 @@ def load(path: str = None) -> ctypes.CDLL:
 # enum vs_option of include/voicesplit_hip.h.  The library reads no environment variable; for A/B timing from the shell this
 # package maps the variables below onto vs_set_option ONCE, when it loads the library.
 OPTIONS = {"F16X3_CONV_NCHW": 0, "BWD_DY": 1, "GEMM_KERNEL": 2, "GEMM_DR": 3, "GEMM_ABL": 4, "GEMM_BAND": 5, "WGRAD_ABL": 6,
-           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16}
+           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16, "HEAD_BWD_GEMM": 17, "LSTM_LEAF_LATE": 18}
 _ENV_OPTIONS = {
     "VOICESPLIT_F16X3_CONV": ("F16X3_CONV_NCHW", lambda v: 1 if v == "nchw" else 0),
     "VOICESPLIT_BWD_DY": ("BWD_DY", lambda v: 0 if v.startswith("0") else 1),
@@ -240,6 +241,8 @@ _ENV_OPTIONS = {
     "VOICESPLIT_FWD_PROLOGUE": ("FWD_PROLOGUE", int),
     "VOICESPLIT_HEAD_LEAF_SIDE": ("HEAD_LEAF_SIDE", int),
     "VOICESPLIT_FEAT_ROWS": ("FEAT_ROWS", int),
+    "VOICESPLIT_HEAD_BWD_GEMM": ("HEAD_BWD_GEMM", int),
+    "VOICESPLIT_LSTM_LEAF_LATE": ("LSTM_LEAF_LATE", int),
 }
 
 

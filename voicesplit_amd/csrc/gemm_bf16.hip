@@ -50,6 +50,7 @@ struct GemmBf16Args {
   const float* rowbias; int ldrb, group;
   int accumulate;
   int tiles_m, tiles_n, band;
+  const float* gate; int ldg;         // C = the product where gate[m][n] > 0, else 0 (the relu mask of a backward contraction); or NULL
   int vec_ok;                         // C (C2, rowbias) 16-byte aligned with leading dimensions that are multiples of 4: 16-byte epilogue accesses
 };
 
@@ -305,6 +306,7 @@ void gemm_bf16_kernel(GemmBf16Args g) {
             float v = acc[a][b][r];
             if (rb) v += rb[n];
             if (g.accumulate) v += crow[n];
+            if (g.gate) v = g.gate[(size_t)m * g.ldg + n] > 0.f ? v : 0.f;
             crow[n] = v;
           }
         }
@@ -558,6 +560,15 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
 #pragma unroll
           for (int b = 0; b < WB; ++b) v[b] += *reinterpret_cast<const f32x4*>(crow + 16 * b);
         }
+        if (g.gate) {
+          const float* gr = g.gate + (size_t)mc * g.ldg + n0;
+#pragma unroll
+          for (int b = 0; b < WB; ++b) {
+            const f32x4 gt = *reinterpret_cast<const f32x4*>(gr + 16 * b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[b][e] = gt[e] > 0.f ? v[b][e] : 0.f;
+          }
+        }
 #pragma unroll
         for (int b = 0; b < WB; ++b) *reinterpret_cast<f32x4*>(crow + 16 * b) = v[b];
       } else if (m < g.M) {
@@ -570,6 +581,11 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
             f32x4 v = acc_read(acc[a][b]);
             if (rb) v += *reinterpret_cast<const f32x4*>(rb + 16 * b);
             if (g.accumulate > 0) v += *reinterpret_cast<const f32x4*>(crow + 16 * b);
+            if (g.gate) {
+              const f32x4 gt = *reinterpret_cast<const f32x4*>(g.gate + (size_t)mc * g.ldg + n0 + 16 * b);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+            }
             *reinterpret_cast<f32x4*>(crow + 16 * b) = v;
           }
         }
@@ -618,18 +634,22 @@ int vs_cvt_rows_bf16_impl(const float* src, long long rows, int K, int ld, void*
 // C[M][N] (+)= opA(A) opB(B) + rowbias[m / group][n]; a_kmajor / b_kmajor: 0 = element (i, k) at i*ld + k, 1 = at k*ld + i.
 // Operands bf16, 16-byte aligned, ld a multiple of 8; row-form operands must be readable (zero padded) up to the next
 // multiple of 64 in k.  C2 / split_m: rows >= split_m are written to C2 (two output matrices stacked along M).
+// gate [M][ldg] (or NULL): elements where gate <= 0 are written as 0 (the relu mask of the head's backward contractions).
 int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* C2, int split_m,
-                      int M, int N, int K, const float* rowbias, int ldrb, int group, int accumulate, hipStream_t stream) {
+                      int M, int N, int K, const float* rowbias, int ldrb, int group, int accumulate, hipStream_t stream,
+                      const float* gate, int ldg) {
   VS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_bf16: bad argument");
   VS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
              "gemm_bf16: operands must be 16-byte aligned with ld a multiple of 8");
   VS_REQUIRE(!rowbias || (group > 0 && ldrb >= N), "gemm_bf16: rowbias needs group > 0 and ldrb >= N");
+  VS_REQUIRE(!gate || (ldg >= N && !C2), "gemm_bf16: gate needs ldg >= N and a single output");
   VS_REQUIRE(a_kmajor || lda >= (K + BK - 1) / BK * BK, "gemm_bf16: row-form A must be padded to a multiple of %d in k", BK);
   VS_REQUIRE(b_kmajor || ldb >= (K + BK - 1) / BK * BK, "gemm_bf16: row-form B must be padded to a multiple of %d in k", BK);
   GemmBf16Args g{reinterpret_cast<const unsigned short*>(A), lda, reinterpret_cast<const unsigned short*>(B), ldb, C, ldc, C2, split_m,
-                 M, N, K, rowbias, ldrb, group > 0 ? group : 1, accumulate, (M + TM - 1) / TM, (N + TN - 1) / TN, 8, 0};
+                 M, N, K, rowbias, ldrb, group > 0 ? group : 1, accumulate, (M + TM - 1) / TM, (N + TN - 1) / TN, 8, gate, ldg, 0};
   g.vec_ok = ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
-             (!rowbias || (ldrb % 4 == 0 && (reinterpret_cast<uintptr_t>(rowbias) & 15) == 0));
+             (!rowbias || (ldrb % 4 == 0 && (reinterpret_cast<uintptr_t>(rowbias) & 15) == 0)) &&
+             (!gate || (ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gate) & 15) == 0));
   static int cus = gemm_cus();
   const long long ntiles = (long long)g.tiles_m * g.tiles_n;
   long long nwg = cus / 8 * 8;

@@ -13,6 +13,28 @@ void sigmoid_bwd_kernel(const float* __restrict__ dmask, const float* __restrict
   }
 }
 
+// the same, and a bf16 row copy of dlogits [rows][Kp] (zero padded) beside it: the A operand of the head's first backward contraction
+// on gemm_bf16.hip (vs_backward, VS_MATH_BF16) without a conversion pass; a thread = 2 consecutive columns of a row (lanes side by side)
+__global__ __launch_bounds__(256)
+void sigmoid_bwd_rows_kernel(const float* __restrict__ dmask, const float* __restrict__ mask, float* __restrict__ dlogits, long long rows, int N,
+                             unsigned* __restrict__ rows_bf16, int Kp) {
+  const int pairs = Kp >> 1;
+  const long long total = rows * pairs;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / pairs;
+    const int k = (int)(i - r * pairs) * 2;
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (k + e < N) {
+        const float m = mask[r * N + k + e];
+        v[e] = dmask[r * N + k + e] * m * (1.f - m);
+        dlogits[r * N + k + e] = v[e];
+      }
+    rows_bf16[i] = vs_pack_bf16(v[0], v[1]);
+  }
+}
+
 // out[g][n] = sum_{r < rows} X[(g*rows + r)*ld + n]: one thread per column, rows walked serially
 // (coalesced across the 256 columns of a block).  Used twice for a full column sum: per
 // utterance (g = b, rows = T), then over the utterances.
@@ -39,6 +61,17 @@ int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, l
   VS_REQUIRE(n > 0, "sigmoid_bwd: n=%lld", n);
   const long long nb = (n + 255) / 256;
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, stream, dmask, mask, dlogits, n);
+  VS_LAUNCH_CHECK();
+  return 0;
+}
+
+int vs_sigmoid_bwd_rows_impl(const float* dmask, const float* mask, float* dlogits, long long rows, int N, void* rows_bf16, int Kp,
+                             hipStream_t stream) {
+  VS_REQUIRE(rows > 0 && N > 0 && rows_bf16 && Kp >= N && Kp % 8 == 0 && (reinterpret_cast<uintptr_t>(rows_bf16) & 15) == 0,
+             "sigmoid_bwd_rows: bad argument");
+  const long long nb = (rows * (Kp >> 1) + 255) / 256;
+  hipLaunchKernelGGL(sigmoid_bwd_rows_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, stream, dmask, mask, dlogits, rows, N,
+                     reinterpret_cast<unsigned*>(rows_bf16), Kp);
   VS_LAUNCH_CHECK();
   return 0;
 }

@@ -64,7 +64,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   L->bn_stats = take((size_t)VS_BN_STAT_SLOTS * 64 * 2 * 8);
   L->bn_coef = take(3 * 64 * 4);
   L->first_acc = take((64 + VS_FIRST_BWD_SCRATCH_DOUBLES) * 8);      // [cnn1's input moments (forward -> backward)][backward scratch]
-  L->colsum_tmp = take(B * max3(8 * H, d->FC1, d->FC2) * 4);
+  L->colsum_tmp = take(2 * B * max3(8 * H, d->FC1, d->FC2) * 4);      // two halves: the caller's stream, the side stream's leaves
   // one scratch region, reused by the stream-ordered consumers: conv wgrad partial sums,
   // cnn8 wgrad partials, split-K partials of the fc / W_hh weight gradients
   size_t part = vs_conv64_wgrad_partial_floats(5, 5);
@@ -468,28 +468,53 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // the BPTT -- a latency-bound launch that leaves the CUs' arithmetic idle -- instead of in front of it (same kernels, same sums).
   const bool leaf_side = side != nullptr && vs_opt(VS_OPT_HEAD_LEAF_SIDE) != 0;
   hipStream_t hs = leaf_side ? side->s : stream;
-  if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
-  if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp, FC2, stream)) return rc;
-  if (int rc = vs_colsum_impl(tmp, FC2, 1, B, FC2, g->fc2_b, FC2, stream)) return rc;
+  // [r5] The two data-gradient contractions of the head (the serial ones) on gemm_bf16.hip's kernel: bf16 row copies of dlogits / dfc1
+  // and bf16 copies of the two weights in the idle gradient buffer of the conv stack (its backward has not begun), the relu mask in
+  // the epilogue.  Same operand roundings as the generic kernel's in-flight conversion.
+  auto up256 = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const int K2p = (FC2 + 63) / 64 * 64, K1p = (FC1 + 63) / 64 * 64, N1p = (FC1 + 7) / 8 * 8, N2p = (2 * H + 7) / 8 * 8;
+  const size_t o_df = up256((size_t)M * K2p * 2), o_w2 = o_df + up256((size_t)M * K1p * 2), o_w1 = o_w2 + up256((size_t)FC2 * N1p * 2);
+  const size_t head_need = o_w1 + up256((size_t)FC1 * N2p * 2);
+  const bool head_bf16 = d->math == VS_MATH_BF16 && vs_opt(VS_OPT_HEAD_BWD_GEMM) != 0 && FC1 % 4 == 0 && (2 * H) % 4 == 0 &&
+                         head_need <= L.grad1 - L.grad0;
+  char* hb = at<char>(tape, L.grad0);
+  // the bias gradients (column sums) are leaves as well: on the side stream they use the second half of the column-sum scratch
+  float* tmp_leaf = leaf_side ? tmp + (size_t)B * max3(8 * H, FC1, FC2) : tmp;
   // dfc1 = (dlogits @ W2) * (h1 > 0)
-  if (int rc = vs_gemm_general_impl(0, 1, dlogits, FC2, p->fc2_w, nullptr, 0x7fffffff, FC1, dfc1, FC1, M, FC1, FC2,
-                                    nullptr, nullptr, nullptr, 0, 1, h1, FC1, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  if (head_bf16) {
+    if (int rc = vs_cvt_rows_bf16_impl(p->fc2_w, FC2, FC1, FC1, hb + o_w2, N1p, stream)) return rc;
+    if (int rc = vs_cvt_rows_bf16_impl(p->fc1_w, FC1, 2 * H, 2 * H, hb + o_w1, N2p, stream)) return rc;
+    if (int rc = vs_sigmoid_bwd_rows_impl(dmask, mask, dlogits, M, FC2, hb, K2p, stream)) return rc;
+    if (int rc = vs_gemm_bf16_impl(0, 1, hb, K2p, hb + o_w2, N1p, dfc1, FC1, nullptr, 0, M, FC1, FC2, nullptr, 0, 1, 0, stream, h1, FC1)) return rc;
+  } else {
+    if (int rc = vs_sigmoid_bwd_impl(dmask, mask, dlogits, (long long)M * FC2, stream)) return rc;
+    if (int rc = vs_gemm_general_impl(0, 1, dlogits, FC2, p->fc2_w, nullptr, 0x7fffffff, FC1, dfc1, FC1, M, FC1, FC2,
+                                      nullptr, nullptr, nullptr, 0, 1, h1, FC1, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  }
   if (leaf_side) {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
     side_join.forked = true;
   }
+  if (int rc = vs_colsum_impl(dlogits, FC2, B, T, FC2, tmp_leaf, FC2, hs)) return rc;
+  if (int rc = vs_colsum_impl(tmp_leaf, FC2, 1, B, FC2, g->fc2_b, FC2, hs)) return rc;
   // dW2 = dlogits^T @ h1
   if (int rc = vs_gemm_general_impl(1, 1, dlogits, FC2, h1, nullptr, 0x7fffffff, FC1, g->fc2_w, FC1, FC2, FC1, M,
                                     nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, kSplitK, part, hs)) return rc;
-  if (int rc = vs_colsum_impl(dfc1, FC1, B, T, FC1, tmp, FC1, stream)) return rc;
-  if (int rc = vs_colsum_impl(tmp, FC1, 1, B, FC1, g->fc1_b, FC1, stream)) return rc;
+  if (int rc = vs_colsum_impl(dfc1, FC1, B, T, FC1, tmp_leaf, FC1, hs)) return rc;
+  if (int rc = vs_colsum_impl(tmp_leaf, FC1, 1, B, FC1, g->fc1_b, FC1, hs)) return rc;
   // dW1 = dfc1^T @ relu(lstm_out)
   if (int rc = vs_gemm_general_impl(1, 1, dfc1, FC1, lstm_out, nullptr, 0x7fffffff, 2 * H, g->fc1_w, 2 * H, FC1, 2 * H, M,
                                     nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 1, VS_ACT_NONE, 0, 0, 0, kSplitK, part, hs)) return rc;
   // dlstm_out = (dfc1 @ W1) * (lstm_out > 0)
+  if (head_bf16) {
+    if (int rc = vs_cvt_rows_bf16_impl(dfc1, M, FC1, FC1, hb + o_df, K1p, stream)) return rc;
+    if (int rc = vs_gemm_bf16_impl(0, 1, hb + o_df, K1p, hb + o_w1, N2p, dlstm, 2 * H, nullptr, 0, M, 2 * H, FC1, nullptr, 0, 1, 0, stream,
+                                   lstm_out, 2 * H)) return rc;
+  } else {
   if (int rc = vs_gemm_general_impl(0, 1, dfc1, FC1, p->fc1_w, nullptr, 0x7fffffff, 2 * H, dlstm, 2 * H, M, 2 * H, FC1,
                                     nullptr, nullptr, nullptr, 0, 1, lstm_out, 2 * H, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
+  }
   }
 
   // ---- BiLSTM: BPTT, then the batched weight / input gradients ------------------------------
@@ -527,10 +552,18 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
   }
   hipStream_t ls = stream;
-  if (side) {
+  // [r5] VS_OPT_LSTM_LEAF_LATE (bf16 configuration): the LSTM's leaf contractions start on the side stream not here, beside the dfeat
+  // contraction and the HBM-bound BatchNorm backward of the features (which they slow down 3x: every CU holds a persistent GEMM
+  // workgroup), but behind that BatchNorm backward (1) or behind cnn8's backward (2) -- beside VALU-bound kernels
+  const int leaf_late = (side && bf16g) ? vs_opt(VS_OPT_LSTM_LEAF_LATE) : 0;
+  auto fork_leaves = [&]() -> int {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
     side_join.forked = true;
+    return 0;
+  };
+  if (side) {
+    if (!leaf_late) { if (int rc = fork_leaves()) return rc; }
     ls = side->s;
   }
   if (bf16g) {
@@ -553,7 +586,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       }
     }
   }
-  {
+  auto lstm_leaves = [&]() -> int {
     VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, ls);
     for (int dir = 0; dir < 2; ++dir) {
       VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
@@ -586,7 +619,9 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                           B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, ls)) return rc;
       }
     }
-  }
+    return 0;
+  };
+  if (!leaf_late) { if (int rc = lstm_leaves()) return rc; }
 
   // ---- conv stack, cnn8 .. cnn1 (models/voicesplit/model.py:15-52 backwards) ------------------
   float* scale = at<float>(tape, L.bn_scale);
@@ -608,6 +643,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   };
   // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
   if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
+  if (leaf_late == 1) {
+    if (int rc = fork_leaves()) return rc;
+    if (int rc = lstm_leaves()) return rc;
+  }
   if (d->math == VS_MATH_BF16) {
     // BASELINE configs[2]: the conv stack backward on channels-last bf16 tensors (nhwc_edge.hip, conv_nhwc.hip,
     // wgrad_nhwc.hip).  Same chain and the same side-stream schedule as below: layer l's weight gradient runs beside
@@ -632,6 +671,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       if (int rc = vs_nhwc_conv_last_bwd_impl(dfeat, p->conv[7].weight, train ? nullptr : at<void>(tape, L.a[6]), gb[c], at<float>(tape, L.grad1),
                                               g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
                                               mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
+    }
+    if (leaf_late == 2) {
+      if (int rc = fork_leaves()) return rc;
+      if (int rc = lstm_leaves()) return rc;
     }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;

@@ -213,7 +213,8 @@ int vs_gemm_nt2_impl(const float*, int, const float*, const float*, int, int, fl
 // gemm_bf16.hip: the LSTM contractions of the bf16 configuration (LDS-DMA ring, row / K-major operand forms)
 int vs_cvt_rows_bf16_impl(const float* src, long long rows, int K, int ld, void* dst, int Kp, hipStream_t);
 int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const void* B, int ldb, float* C, int ldc, float* C2, int split_m,
-                      int M, int N, int K, const float* rowbias, int ldrb, int group, int accumulate, hipStream_t);
+                      int M, int N, int K, const float* rowbias, int ldrb, int group, int accumulate, hipStream_t,
+                      const float* gate = nullptr, int ldg = 0);
 // layout of the three bf16 operand arrays inside one scratch region (256-byte aligned pieces): feat [M][Kp], W_ih [8H][Kp], dxg [M][8H]
 struct VsLstmBf16Layout { size_t feat, wih, dxg, total; int Kp; };
 inline VsLstmBf16Layout vs_lstm_bf16_layout(long long M, int K, int H) {
@@ -237,4 +238,5 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
                                  int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
 // reduce.hip
 int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, long long n, hipStream_t);
+int vs_sigmoid_bwd_rows_impl(const float* dmask, const float* mask, float* dlogits, long long rows, int N, void* rows_bf16, int Kp, hipStream_t);
 int vs_colsum_impl(const float* x, int ld, int groups, int rows, int N, float* out, int ldo, hipStream_t);

@@ -957,6 +957,18 @@ def gemm_bf16(A, B, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bo
     return C
 
 
+def gemm_bf16_gated(A, B, gate, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False):
+    """C = op(A) op(B) where gate > 0, else 0 (vs_gemm_bf16_gated: the head's data gradients of vs_backward); gate fp32 [M, ldg >= N]."""
+    lib = _lib.load()
+    _dev_check(A, "A", torch.bfloat16)
+    _dev_check(B, "B", torch.bfloat16)
+    _dev_check(gate, "gate", torch.float32)
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(lib.vs_gemm_bf16_gated(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), N, M, N, K,
+                                 _p(gate), gate.shape[1], _stream()), "vs_gemm_bf16_gated")
+    return C
+
+
 def gemm_bf16_split(A, B, M: int, N: int, K: int, split_m: int, a_kmajor: bool = False, b_kmajor: bool = False, ldc: Optional[int] = None):
     """The same contraction stored into two matrices stacked along M (vs_gemm_bf16_split: the dW_ih store of vs_backward):
     returns (C [split_m, ldc], C2 [M - split_m, ldc]); columns >= N are left untouched (NaN-filled here so a test sees a
