@@ -715,6 +715,15 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
       if (train) { if (int rc = bn_train(l, abuf[c])) return rc; }
     }
     ProfScope ps(VS_PROF_CNN8, stream);
+    // the whole-path eval forward (feat_rows != NULL: nobody reads the fp32 features): cnn8 writes the bf16 A operand of the LSTM input
+    // GEMM into the idle ping-pong buffer itself (six layers: abuf[c] is act0) -- no fp32 features, no conversion pass
+    const size_t act_bytes = (size_t)B * 64 * T * F * sizeof(float);
+    const VsLstmBf16Layout Lb = vs_lstm_bf16_layout((long long)B * T, 8 * F, d->H);
+    if (!train && feat_rows && vs_opt(VS_OPT_FEAT_ROWS) != 0 && c == 0 && act_bytes >= (prep ? Lb.wih : Lb.dxg)) {
+      *feat_rows = true;
+      return vs_nhwc_conv_last_impl(abuf[c], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, nullptr, B, T, F, layer_act, stream, nullptr,
+                                    nullptr, nullptr, VS_ACT_NONE, at<char>(ws, L.act1) + Lb.feat, Lb.Kp);
+    }
     if (int rc = vs_nhwc_conv_last_impl(abuf[c], p->conv[7].weight, scale + 64 * 7, shift + 64 * 7, feat, B, T, F, layer_act, stream)) return rc;
     if (train) {
       if (int rc = vs_bn_train_feat_impl(feat, feat, B, T, F, p->conv[7].bn_weight, p->conv[7].bn_bias, p->conv[7].bn_running_mean,
@@ -874,7 +883,8 @@ int bilstm_impl(const vs_dims* d, const vs_params* p, const float* feat, const f
                                        at<float>(ws, L.gemm_scales), at<char>(ws, feat_rows ? L.act1 : L.act0),
                                        feat_rows ? act_bytes : (L.act1 == L.act0 + act_bytes ? 2 * act_bytes : act_bytes), stream,
                                        prep ? prep->gemm_wscale : nullptr, prep ? prep->wih_hi : nullptr,
-                                       prep ? prep->wih_lo : nullptr, false, feat_rows)) return rc;
+                                       prep ? prep->wih_lo : nullptr, feat_rows && d->math == VS_MATH_BF16,
+                                       feat_rows && d->math == VS_MATH_F16X3)) return rc;
   }
   float* packed = prep ? prep->lstm_packed : at<float>(ws, L.lstm_packed);
   if (!prep) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc; }

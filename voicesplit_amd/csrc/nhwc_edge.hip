@@ -160,7 +160,10 @@ template <int ACT, bool STATS = false, int PRE = -1>
 __global__ __launch_bounds__(256)
 void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ out, long long nrows /* B*T */, int F,
-                           double* __restrict__ stats, const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr) {
+                           double* __restrict__ stats, const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr,
+                           unsigned short* __restrict__ rows_bf16 = nullptr, int Kp = 0) {
+  // rows_bf16 != NULL (eval forward, whole path): the output goes out as the bf16 A operand of the LSTM input GEMM instead -- rows
+  // [nrows][Kp] (element co * F + f of row (b, t), the K padding zeroed by the wave that owns a row's first block), `out` unused
   __shared__ float red[4 * 16];
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
@@ -216,7 +219,15 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], __builtin_bit_cast(vs_bf16x8, b0), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], __builtin_bit_cast(vs_bf16x8, b1), c, 0, 0, 0);
-    if (ok && g < 2) {
+    if (!STATS && PRE < 0 && rows_bf16) {
+      if (ok && g < 2) {
+        unsigned short* o = rows_bf16 + (size_t)row * Kp + (size_t)(g * 4) * F + f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(size_t)r * F] = (unsigned short)(vs_pack_bf16(vs_act_fast<ACT>(fmaf(c[r], sc[r], sh[r])), 0.f) & 0xffffu);
+      }
+      if (bc == 0)
+        for (int k = 8 * F + lane; k < Kp; k += 64) rows_bf16[(size_t)row * Kp + k] = 0;
+    } else if (ok && g < 2) {
       float* o = out + (row * 8 + g * 4) * F + f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -847,8 +858,10 @@ int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const
 
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t stream, double* bn_stats,
-                           const float* pre_scale, const float* pre_shift, int pre_act) {
-  VS_REQUIRE(in && w && scale && shift && out, "nhwc conv_last: NULL argument");
+                           const float* pre_scale, const float* pre_shift, int pre_act, void* rows_bf16, int Kp) {
+  VS_REQUIRE(in && w && scale && shift && (out || rows_bf16), "nhwc conv_last: NULL argument");
+  VS_REQUIRE(!rows_bf16 || (!bn_stats && !pre_scale && Kp >= 8 * F), "nhwc conv_last: the row form is the plain eval layer's (Kp = %d)", Kp);
+  unsigned short* rb = reinterpret_cast<unsigned short*>(rows_bf16);
   VS_REQUIRE(!pre_scale == !pre_shift, "nhwc conv_last: pre_scale and pre_shift come together");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
@@ -871,9 +884,10 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
     VS_LAUNCH_CHECK();
     return 0;
   }
-  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_MISH>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_RELU>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
-  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_NONE>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr);
+  const float* nof = nullptr;
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_MISH>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr, nof, nof, rb, Kp);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_RELU>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr, nof, nof, rb, Kp);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_conv_last_kernel<VS_ACT_NONE>, grid, block, 0, stream, i, w, scale, shift, out, nrows, F, (double*)nullptr, nof, nof, rb, Kp);
   else VS_REQUIRE(false, "nhwc conv_last: unsupported activation %d", act);
   VS_LAUNCH_CHECK();
   return 0;

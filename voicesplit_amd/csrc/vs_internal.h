@@ -128,7 +128,9 @@ int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr,
-                           const float* pre_scale = nullptr, const float* pre_shift = nullptr, int pre_act = VS_ACT_NONE);
+                           const float* pre_scale = nullptr, const float* pre_shift = nullptr, int pre_act = VS_ACT_NONE,
+                           void* rows_bf16 = nullptr /* eval: the output as bf16 rows [B T][Kp] (the LSTM input GEMM's A operand) instead of `out` */,
+                           int Kp = 0);
 int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);
