@@ -510,10 +510,11 @@ enum vs_option {
                                  contractions' LDS-DMA kernel over bf16 copies of their operands (relu mask in the epilogue); 0 = the generic
                                  kernel (in-flight conversion).  Default 1.  Same operand roundings, fp32 summation order differs.
                                  VOICESPLIT_HEAD_BWD_GEMM */
-  VS_OPT_LSTM_LEAF_LATE = 18, /* VS_MATH_BF16 vs_backward with the side stream: where the LSTM's leaf contractions (dW_ih, dW_hh, d-vector) start
-                                 on it.  0 = right behind the BPTT (beside the dfeat contraction and the features' BatchNorm backward);
-                                 1 = behind that BatchNorm backward (beside cnn8's backward); 2 = behind cnn8's backward.  Same values.
-                                 VOICESPLIT_LSTM_LEAF_LATE */
+  VS_OPT_LSTM_LEAF_LATE = 18, /* VS_MATH_BF16 vs_backward with the side stream: where / in which order the LSTM's leaf contractions (dW_ih, dW_hh,
+                                 d-vector) run on it.  0 = right behind the BPTT, dW_ih first; 1 = behind the features' BatchNorm backward
+                                 (beside cnn8's backward); 2 = behind cnn8's backward; 3 = behind the BPTT as 0, but dW_ih -- one persistent
+                                 workgroup per CU -- LAST, behind the small leaves.  Default 3 (-0.13 ms per step against 0; 1, 2: slower).
+                                 Same values.  VOICESPLIT_LSTM_LEAF_LATE */
   VS_OPT_COUNT = 19
 };
 int vs_set_option(int option, int value);

@@ -325,8 +325,8 @@ def test_head_data_gradients_on_the_lstm_gemm_kernel_agree_with_the_generic_kern
 
 def test_where_the_lstm_leaf_contractions_start_does_not_change_a_gradient():
     """vs_set_option(VS_OPT_LSTM_LEAF_LATE): the LSTM's leaf contractions start on the side stream behind the BPTT (0), behind the
-    features' BatchNorm backward (1) or behind cnn8's backward (2) -- the same launches on the same operands: bit-identical gradients,
-    twice per mode to catch a missing fork or join."""
+    features' BatchNorm backward (1) or behind cnn8's backward (2), or behind the BPTT with dW_ih last (3, the default) -- the same
+    launches on the same operands: bit-identical gradients, twice per mode to catch a missing fork or join."""
     import voicesplit_amd as V
     from voicesplit_amd import _lib
     dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=32, fc1_dim=48, fc2_dim=601)
@@ -337,7 +337,7 @@ def test_where_the_lstm_leaf_contractions_start_does_not_change_a_gradient():
     got = {}
     try:
         with _math("bf16"):
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 _lib.set_option("LSTM_LEAF_LATE", mode)
                 m = V.VoiceSplit(V.default_config(601, 256, 32, 48, 601))
                 m.load_state_dict(sd, strict=True)
@@ -350,7 +350,7 @@ def test_where_the_lstm_leaf_contractions_start_does_not_change_a_gradient():
                     got[mode].append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
     finally:
         _lib.set_option("LSTM_LEAF_LATE", prev)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for a, b in zip(got[0], got[mode]):
             for k in a:
                 assert torch.equal(a[k], b[k]), (mode, k)

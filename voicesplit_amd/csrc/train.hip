@@ -552,10 +552,12 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
   }
   hipStream_t ls = stream;
-  // [r5] VS_OPT_LSTM_LEAF_LATE (bf16 configuration): the LSTM's leaf contractions start on the side stream not here, beside the dfeat
-  // contraction and the HBM-bound BatchNorm backward of the features (which they slow down 3x: every CU holds a persistent GEMM
-  // workgroup), but behind that BatchNorm backward (1) or behind cnn8's backward (2) -- beside VALU-bound kernels
-  const int leaf_late = (side && bf16g) ? vs_opt(VS_OPT_LSTM_LEAF_LATE) : 0;
+  // [r5] VS_OPT_LSTM_LEAF_LATE (bf16 configuration): the LSTM's leaf contractions start on the side stream here (0, 3), beside the dfeat
+  // contraction and the HBM-bound BatchNorm backward of the features (which dW_ih slows down 3x: every CU holds one of its persistent
+  // workgroups) -- or behind that BatchNorm backward (1) / behind cnn8's backward (2), beside VALU-bound kernels: measured slower
+  const int leaf_opt = (side && bf16g) ? vs_opt(VS_OPT_LSTM_LEAF_LATE) : 0;
+  const bool wih_last = leaf_opt == 3;      // (3): start behind the BPTT as (0), but dW_ih -- the persistent contraction -- goes last
+  const int leaf_late = wih_last ? 0 : leaf_opt;
   auto fork_leaves = [&]() -> int {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
@@ -595,7 +597,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       // dW_ih[:, :8F] = dxg_d^T @ feat
       if (bf16g) {
         // both directions in one col x col contraction over K = B*T: rows < 4H -> dW_ih, the rest -> dW_ih_reverse
-        if (dir == 0) {
+        if (dir == 0 && !wih_last) {
           if (int rc = vs_gemm_bf16_impl(1, 1, bfb + Lb.dxg, 8 * H, bfb + Lb.feat, Lb.Kp, g->w_ih[0], KE, g->w_ih[1], 4 * H, 8 * H, K8, M,
                                          nullptr, 0, 1, 0, ls)) return rc;
         }
@@ -618,6 +620,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
         if (int rc = vs_gemm_general_impl(0, 1, dsum + (size_t)dir * 4 * H, 8 * H, p->w_ih[dir] + K8, nullptr, 0x7fffffff, KE, g->dvec, E,
                                           B, E, 4 * H, nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, dir, 0, 0, 1, nullptr, ls)) return rc;
       }
+    }
+    if (bf16g && wih_last) {      // (3): the one-workgroup-per-CU contraction behind the small leaves
+      if (int rc = vs_gemm_bf16_impl(1, 1, bfb + Lb.dxg, 8 * H, bfb + Lb.feat, Lb.Kp, g->w_ih[0], KE, g->w_ih[1], 4 * H, 8 * H, K8, M,
+                                     nullptr, 0, 1, 0, ls)) return rc;
     }
     return 0;
   };
