@@ -302,7 +302,10 @@ def main():
         cfg.loss["loss_name"] = {"sisnr": "si_snr", "powerlaw": "power_law_compression", "fixed": "si_snr"}[args.loss]
         cfg.train_config["learning_rate"] = 1e-4                    # random data: keep the weights finite
         fixed = (lambda mask, mixed, tgt, sl, ph: (mask * dmask).sum()) if args.loss == "fixed" else None
-        return Trainer(m, cfg, rank, world, criterion=fixed)
+        tr = Trainer(m, cfg, rank, world, criterion=fixed)
+        if os.environ.get("VOICESPLIT_EARLY_LOSS") == "0":           # A/B: the blocking loss.item() behind optimizer.step()
+            tr.early_loss_read = False
+        return tr
 
     units_per_step = B                                              # utterances (windows) per rank and step
     if train:

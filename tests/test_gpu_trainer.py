@@ -393,3 +393,33 @@ def test_train_step_after_a_plain_autograd_loop_uses_the_fresh_gradients():
         assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-7 * float(q.grad.abs().max())), n
         assert not torch.allclose(p.grad, stale[n], rtol=1e-3, atol=0.0) or float(stale[n].abs().max()) == 0.0, n
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+
+
+def test_early_loss_read_returns_the_same_values_and_still_raises():
+    """One rank on a GPU: train_step copies the loss to pinned memory as soon as the criterion has run and reads it behind
+    optimizer.step() without draining the device (the blocking loss.item() of train.py:114 costs 0.3 ms of idle device per step).
+    Same returned values as the blocking read, step by step, and LossExploded still fires in the step whose loss exploded."""
+    import voicesplit_amd as V
+    from oracle import reference_forward as R
+    from voicesplit_amd.trainer import LossExploded, Trainer
+    dims_d = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53)
+    sd = R.spread_logits(R.build_state_dict(dims_d, 3), 4.0)
+    x, dvec = R.synthetic_inputs(3, 40, dims_d, 3)
+    w = torch.randn(3, 40, 53, generator=torch.Generator().manual_seed(1)).cuda()
+    batch = (dvec.cuda(), x.cuda(), x.cuda(), None, None, x.cuda())
+
+    def run(early, scale=1.0):
+        m = V.VoiceSplit(V.default_config(53, 24, 32, 44, 53))
+        m.load_state_dict(sd, strict=True)
+        cfg = V.default_config(53, 24, 32, 44, 53)
+        tr = Trainer(m.cuda(), cfg, criterion=lambda mask, mixed, tgt, sl, ph: ((mask * w).sum().abs() + 1.0) * scale)
+        assert tr.early_loss_read
+        tr.early_loss_read = early
+        return [tr.train_step(batch) for _ in range(4)], tr
+
+    a, tr = run(True)
+    b, _ = run(False)
+    assert a == b and all(v == v for v in a)
+    assert tr._loss_event.query()
+    with pytest.raises(LossExploded):
+        run(True, scale=1e12)

@@ -131,6 +131,14 @@ class Trainer:
         self.step = 0
         self.time_comm = False          # bench.py's N > 1 line: time the two collectives of a step (set_comm_timing)
         self.flag_ms = []
+        # train.py:114 reads loss.item() behind optimizer.step(): a device-to-host read that drains the device -- 0.3 ms of idle
+        # device per step until the next step's first launches arrive.  One rank on a GPU: the value is final as soon as the
+        # criterion has run, so it is copied to pinned memory THEN (beside the backward pass) and read at the reference's point
+        # without draining anything; the guard fires on the same value at the same place.  (Several ranks read the rank-averaged
+        # value, which exists only behind the gradient all-reduce: they keep the blocking read.)
+        self.early_loss_read = world == 1 and self.device.type == "cuda"
+        self._loss_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.early_loss_read else None
+        self._loss_event = torch.cuda.Event() if self.early_loss_read else None
         if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
             import torch.distributed as dist
             for t in list(model.parameters()) + list(model.buffers()):
@@ -207,6 +215,10 @@ class Trainer:
             self.model.train()                                              # is 0.1 ms of host time with an idle device)
         mask = self.model(mixed, emb)                                       # train.py:94
         loss = self.criterion(mask, mixed, target, seq_len, phase)          # :95-108
+        early = self.early_loss_read and loss.is_cuda and loss.dtype == torch.float32
+        if early:
+            self._loss_host.copy_(loss.detach().reshape(1), non_blocking=True)
+            self._loss_event.record()
         if not self._sink:
             self.bucket.zero()                                              # optimizer.zero_grad()
             loss.backward()                                                 # :110
@@ -220,7 +232,11 @@ class Trainer:
         self.bucket.all_reduce(self.world, written=self._sink)              # the one exchange step
         self.optimizer.step()                                               # :111
         self.step += 1                                                      # :112
-        value = float(self.bucket.extra[0].item())                          # :114 (the reference syncs here too)
+        if early:
+            self._loss_event.synchronize()                                  # long since complete: the host does not wait for the backward
+            value = float(self._loss_host[0])                               # :114
+        else:
+            value = float(self.bucket.extra[0].item())                      # :114 (the reference syncs here too)
         # :115-117, in the reference's order: the update has been applied and counted when the guard
         # fires, so step numbering and checkpoint cadence after an explosion match train.py
         if value > 1e8 or math.isnan(value):
