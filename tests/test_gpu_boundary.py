@@ -173,3 +173,32 @@ def test_gemm_bf16_gated_head_shapes(M, N, K):
     assert torch.equal(got == 0, ~(gate > 0) | (ref == 0))
     plain = ops.gemm_bf16(db, wb, M, N, K, b_kmajor=True)
     assert torch.equal(got, torch.where(gate > 0, plain, torch.zeros_like(plain)))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 601, 600), (257, 77, 130), (520, 254, 64)])
+def test_gemm_bf16_n_not_a_multiple_of_4_with_an_aligned_leading_dimension_leaves_the_padding_alone(M, N, K):
+    """with N % 4 != 0 but ldc % 4 == 0 the interleaved kernel's partial-tile epilogue (16 bytes per lane,
+    checked by the group's first column) wrote up to three columns past N and read rowbias / gate there.  Such shapes now take the
+    element-wise epilogue: the columns >= N of C stay as they were (NaN here), in the plain, the row-bias, the split and the gated entry."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + N)
+    Kp, ldc = (K + 63) // 64 * 64, (N + 3) // 4 * 4 + 4
+    A, Bm = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    Ab, Bb = ops.cvt_rows_bf16(A, K, Kp), ops.cvt_rows_bf16(Bm, K, Kp)
+    ref = Ab[:, :K].double() @ Bb[:, :K].double().t()
+    rb = torch.full((2, ldc), float("nan"), device="cuda")
+    rb[:, :N] = torch.randn(2, N, generator=g).cuda()
+    nan = lambda: torch.full((M, ldc), float("nan"), dtype=torch.float32, device="cuda")
+    out = ops.gemm_bf16(Ab, Bb, M, N, K, out=nan())
+    assert _rel(out[:, :N].double(), ref) < 2e-5 and torch.isnan(out[:, N:]).all()
+    group = (M + 1) // 2
+    out = ops.gemm_bf16(Ab, Bb, M, N, K, rowbias=rb, group=group, out=nan())
+    want = ref + rb[:, :N].double().repeat_interleave(group, 0)[:M]
+    assert _rel(out[:, :N].double(), want) < 2e-5 and torch.isnan(out[:, N:]).all()
+    c0, c1 = ops.gemm_bf16_split(Ab, Bb, M, N, K, M // 3, ldc=ldc)
+    assert _rel(torch.cat((c0[:, :N], c1[:, :N])).double(), ref) < 2e-5
+    assert torch.isnan(c0[:, N:]).all() and torch.isnan(c1[:, N:]).all()
+    gate = torch.full((M, ldc), float("nan"), device="cuda")
+    gate[:, :N] = torch.randn(M, N, generator=g).cuda()
+    out = ops.gemm_bf16_gated(Ab, Bb, gate, M, N, K, out=nan())
+    assert _rel(out[:, :N].double(), ref * (gate[:, :N] > 0).double()) < 2e-5 and torch.isnan(out[:, N:]).all()

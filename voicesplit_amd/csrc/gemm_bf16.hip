@@ -647,7 +647,9 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   VS_REQUIRE(b_kmajor || ldb >= (K + BK - 1) / BK * BK, "gemm_bf16: row-form B must be padded to a multiple of %d in k", BK);
   GemmBf16Args g{reinterpret_cast<const unsigned short*>(A), lda, reinterpret_cast<const unsigned short*>(B), ldb, C, ldc, C2, split_m,
                  M, N, K, rowbias, ldrb, group > 0 ? group : 1, accumulate, (M + TM - 1) / TM, (N + TN - 1) / TN, 8, gate, ldg, 0};
-  g.vec_ok = ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
+  // N % 4: the partial-tile epilogue of the interleaved kernel checks a 4-column group by its first column only (ADVICE round 5:
+  // with N % 4 != 0 it wrote up to 3 columns past N and read rowbias / gate there)
+  g.vec_ok = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
              (!rowbias || (ldrb % 4 == 0 && (reinterpret_cast<uintptr_t>(rowbias) & 15) == 0)) &&
              (!gate || (ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(gate) & 15) == 0));
   static int cus = gemm_cus();

@@ -1143,6 +1143,9 @@ void lstm16_tagged_kernel(Lstm16Args a, void* hbuf2, void* hbuf3) {
             const h2 hh = {(_Float16)full[2 * j], (_Float16)full[2 * j + 1]};
             v[j] = __builtin_bit_cast(unsigned, hh);
           }
+          // A diverged step (h = NaN with an all-ones payload in both halves) must not look like an unwritten slot: the consumers
+          // would spin to their bound and report "gave up" instead of carrying the NaN to the loss guard.
+          v[j] = v[j] == kSentinel ? 0x7FFF7E00u : v[j];
         }
         if (storer) __builtin_amdgcn_raw_buffer_store_b128(v, hrs[wb], slot_off, 0, 16 /* sc1: write-through */);
       }

@@ -957,14 +957,15 @@ def gemm_bf16(A, B, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bo
     return C
 
 
-def gemm_bf16_gated(A, B, gate, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False):
-    """C = op(A) op(B) where gate > 0, else 0 (vs_gemm_bf16_gated: the head's data gradients of vs_backward); gate fp32 [M, ldg >= N]."""
+def gemm_bf16_gated(A, B, gate, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, out=None):
+    """C = op(A) op(B) where gate > 0, else 0 (vs_gemm_bf16_gated: the head's data gradients of vs_backward); gate fp32 [M, ldg >= N];
+    out: a preallocated [M, ldc >= N] fp32 result (columns >= N are left untouched)."""
     lib = _lib.load()
     _dev_check(A, "A", torch.bfloat16)
     _dev_check(B, "B", torch.bfloat16)
     _dev_check(gate, "gate", torch.float32)
-    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    check(lib.vs_gemm_bf16_gated(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), N, M, N, K,
+    C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(lib.vs_gemm_bf16_gated(int(a_kmajor), int(b_kmajor), _p(A), A.shape[1], _p(B), B.shape[1], _p(C), C.shape[1], M, N, K,
                                  _p(gate), gate.shape[1], _stream()), "vs_gemm_bf16_gated")
     return C
 
