@@ -44,7 +44,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these are its only exports */
 #endif
 
-#define VS_ABI_VERSION 8
+#define VS_ABI_VERSION 9
 
 /* activation codes */
 #define VS_ACT_RELU 0     /* VoiceFilter conv stack (models/voicefilter/model.py:21..54), head */
@@ -377,6 +377,12 @@ typedef struct vs_grads {
   float* b_hh[2];             /* [4H]       */
   float* fc1_w; float* fc1_b; float* fc2_w; float* fc2_b;
   float* dvec;                /* [B][E] d/d speaker embedding, may be NULL */
+  void* leaves_event;         /* ABI 9.  NULL, or a hipEvent_t of the caller: vs_backward records it when every gradient of the head and
+                                 the BiLSTM (fc1 / fc2 / w_ih / w_hh / b_ih / b_hh: 73 of the 75.5 MB at config.json's sizes) is final --
+                                 about 5 ms into the backward pass at B = 64, the conv stack's 25 ms still ahead.  A data-parallel caller
+                                 lets its collective stream wait for it and starts the all-reduce of that part of its gradient bucket
+                                 beside the conv backward (voicesplit_amd/trainer.py).  The event is recorded on the
+                                 library's side stream when the backward overlap is on, else on `stream`. */
 } vs_grads;
 
 /* Byte offsets inside the caller-provided training tape.  vs_forward_train fills the "saved"

@@ -310,7 +310,7 @@ def _nccl_dp_worker(rank, world, port, q):
         sl = slice(rank * Bl, (rank + 1) * Bl)
         tr = trainer.Trainer(make(), c, rank, world, criterion=crit)
         loss = tr.train_step((dvec[sl].to(dev), tgt[sl].to(dev), x[sl].to(dev), None, None, None))
-        grads = tr.bucket.flat[:tr.bucket.numel].clone()
+        grads = tr.bucket.grads.clone()
         # reference on THIS device: both shards through one replica each (per-shard BatchNorm statistics, as DP has
         # them), gradients averaged, the same Adam step
         ref = make()

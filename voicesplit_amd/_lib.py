@@ -19,7 +19,7 @@ PROF_NAMES = ("cnn1", "cnn2", "cnn3", "cnn4", "cnn5", "cnn6", "cnn7", "cnn8", "l
               "fwd_bn", "bwd_head", "bwd_lstm_rec", "bwd_lstm_gemm", "bwd_bn",
               "wgrad_cnn2", "wgrad_cnn3", "wgrad_cnn4", "wgrad_cnn5", "wgrad_cnn6", "wgrad_cnn7",
               "dgrad_cnn2", "dgrad_cnn3", "dgrad_cnn4", "dgrad_cnn5", "dgrad_cnn6", "dgrad_cnn7", "bwd_edge")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class VsDims(Structure):
@@ -64,6 +64,7 @@ class VsGrads(Structure):
         ("w_ih", c_void_p * 2), ("w_hh", c_void_p * 2), ("b_ih", c_void_p * 2), ("b_hh", c_void_p * 2),
         ("fc1_w", c_void_p), ("fc1_b", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p),
         ("dvec", c_void_p),
+        ("leaves_event", c_void_p),
     ]
 
 

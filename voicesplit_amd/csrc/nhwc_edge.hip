@@ -897,10 +897,15 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
 int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             float* dgamma, float* dbeta, float* dbias, double* stats /* [VS_BN_STAT_SLOTS][64][2] */, float* coef,
-                            hipStream_t stream) {
+                            hipStream_t stream, int beside_wgrad) {
   VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef && npix > 0, "nhwc bn_act_bwd: bad argument");
   const long long npieces = npix * 8;
-  const dim3 grid(stream_blocks(512, npieces)), block(256);
+  int nb = stream_blocks(512, npieces);
+  if (beside_wgrad) {      // both passes throttled like vs_nhwc_bn_bwd_from_dy_impl's (the round-6 re-run of the two-pass A/B, VS_OPT_BWD_DY = 0)
+    const int want = vs_opt(VS_OPT_BWD_APPLY_BLOCKS) > 0 ? vs_opt(VS_OPT_BWD_APPLY_BLOCKS) : 256;
+    if (want < nb) nb = want;
+  }
+  const dim3 grid(nb), block(256);
   const u4v* g = reinterpret_cast<const u4v*>(da);
   const u4v* zz = reinterpret_cast<const u4v*>(z);
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));

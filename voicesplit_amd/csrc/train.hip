@@ -627,7 +627,13 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     }
     return 0;
   };
-  if (!leaf_late) { if (int rc = lstm_leaves()) return rc; }
+  // ABI 9: the caller's event for "head + BiLSTM gradients are final" (vs_grads.leaves_event): recorded behind the last leaf launch,
+  // on the stream the leaves ran on (the head's leaves were enqueued earlier on the same stream, or on `stream` ahead of the fork)
+  auto leaves_done = [&]() -> int {
+    if (g->leaves_event) VS_CHECK_HIP(hipEventRecord((hipEvent_t)g->leaves_event, ls));
+    return 0;
+  };
+  if (!leaf_late) { if (int rc = lstm_leaves()) return rc; if (int rc = leaves_done()) return rc; }
 
   // ---- conv stack, cnn8 .. cnn1 (models/voicesplit/model.py:15-52 backwards) ------------------
   float* scale = at<float>(tape, L.bn_scale);
@@ -652,6 +658,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   if (leaf_late == 1) {
     if (int rc = fork_leaves()) return rc;
     if (int rc = lstm_leaves()) return rc;
+    if (int rc = leaves_done()) return rc;
   }
   if (d->math == VS_MATH_BF16) {
     // BASELINE configs[2]: the conv stack backward on channels-last bf16 tensors (nhwc_edge.hip, conv_nhwc.hip,
@@ -681,6 +688,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (leaf_late == 2) {
       if (int rc = fork_leaves()) return rc;
       if (int rc = lstm_leaves()) return rc;
+      if (int rc = leaves_done()) return rc;
     }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
@@ -699,7 +707,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
         } else {
           if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
                                                mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                               stats, coef, stream)) return rc;
+                                               stats, coef, stream, pending ? 1 : 0)) return rc;
         }
       }
       if (pending) {                 // the previous layer's weight gradient still reads the buffer this data gradient writes

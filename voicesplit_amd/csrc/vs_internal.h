@@ -133,7 +133,7 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
                            int Kp = 0);
 int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long npix, int act, int train,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
-                            float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t);
+                            float* dgamma, float* dbeta, float* dbias, double* stats, float* coef, hipStream_t, int beside_wgrad = 0);
 int vs_nhwc_bn_act_bwd_first_impl(const void* da, const void* z, const float* x, int B, int T, int F, int act, int train,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
                                   float* dgamma, float* dbeta, float* dbias, float* dw, double* stats, float* coef, double* acc, hipStream_t);

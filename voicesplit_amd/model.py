@@ -70,7 +70,8 @@ class _MaskForward(torch.autograd.Function):
         sd = module._tensors()
         sink = module.__dict__.get("_grad_sink")
         grads = ops.backward(sd, x, dvec, ctx.dims, module.conv_act, ctx.training, ctx.tape, mask,
-                             grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2], sink=sink)
+                             grad_mask.contiguous(), want_dvec=ctx.needs_input_grad[2], sink=sink,
+                             leaves_event=module.__dict__.get("_leaves_event"))
         ops.recycle_tape(ctx.tape)                           # 49 GB at B=64: back to the pool for the next forward
         ctx.tape = None
         out = [None, None, grads.get("speaker_embedding")]
@@ -105,7 +106,7 @@ class _MaskNet(nn.Module):
         m = self.config.model
         return ops.make_dims(B, T, self.audio["num_freq"], m["emb_dim"], m["lstm_dim"], m["fc1_dim"], m["fc2_dim"])
 
-    _TRANSIENT = ("_last_tape", "_grad_sink", "_tensor_index", "_tree_check", "_prepared")
+    _TRANSIENT = ("_last_tape", "_grad_sink", "_leaves_event", "_tensor_index", "_tree_check", "_prepared")
 
     def __getstate__(self):
         # copy.deepcopy / torch.save(model): caches and views into other objects' memory (the last tape, a trainer's
@@ -172,6 +173,23 @@ class _MaskNet(nn.Module):
             self.__dict__.pop("_grad_sink", None)
         else:
             self.__dict__["_grad_sink"] = dict(sink)
+
+    def set_leaves_event(self, event):
+        """event: a ``torch.cuda.Event`` (already recorded once, so that its handle exists) or None.  While set, every backward
+        through this module records it when the gradients of the head and the BiLSTM are final (vs_grads.leaves_event): a
+        data-parallel trainer starts the all-reduce of that part of its bucket there, beside the conv stack's backward.  Hidden
+        state like the gradient sink: whoever installs it removes it."""
+        if event is None:
+            self.__dict__.pop("_leaves_event", None)
+        else:
+            handle = int(event.cuda_event)
+            if not handle:
+                raise ValueError("set_leaves_event: record the event once before installing it (its handle is created lazily)")
+            self.__dict__["_leaves_event"] = handle
+
+    def leaf_parameter_names(self):
+        """state_dict keys of the parameters whose gradients are final at the leaves event, in named_parameters() order."""
+        return [n for n, _ in self._named_params() if not n.startswith("conv.")]
 
     def _named_params(self):
         """[(key, parameter)] in named_parameters() order, from the same index (no module-tree walk)."""

@@ -419,10 +419,13 @@ GRAD_KEYS_BN = (("bn_weight", "weight"), ("bn_bias", "bias"))
 
 
 def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: torch.Tensor, mask, dmask,
-             want_dvec: bool = False, sink: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+             want_dvec: bool = False, sink: Optional[Dict[str, torch.Tensor]] = None,
+             leaves_event: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """d(loss)/d(parameters) for dmask = d(loss)/d(mask); returns {state_dict key: gradient}
     (+ 'speaker_embedding' when want_dvec).  sink: {key: preallocated tensor} the library writes those gradients into
-    (overwriting, vs_backward never accumulates) instead of fresh tensors -- the trainer's flat all-reduce bucket."""
+    (overwriting, vs_backward never accumulates) instead of fresh tensors -- the trainer's flat all-reduce bucket.
+    leaves_event: raw hipEvent_t handle (``torch.cuda.Event.cuda_event``) the library records when the head's and the BiLSTM's
+    gradients are final (vs_grads.leaves_event, ABI 9)."""
     lib = _lib.load()
     _dev_check(dmask, "grad_mask")
     _dev_check(mask, "mask")
@@ -453,6 +456,8 @@ def backward(sd, x, dvec, dims: VsDims, conv_act: str, training: bool, tape: tor
     if want_dvec:
         out["speaker_embedding"] = torch.empty_like(dvec)
         grads.dvec = out["speaker_embedding"].data_ptr()
+    if leaves_event:
+        grads.leaves_event = int(leaves_event)
     with torch.cuda.device(x.device):
         rc = lib.vs_backward(ctypes.byref(dims), ctypes.byref(params), _p(x), _p(dvec), ACT_CODES[conv_act],
                              BN_TRAIN if training else BN_EVAL, _p(tape), tape.numel(), _p(mask), _p(dmask),

@@ -107,50 +107,125 @@ def make_optimizer(c, params):
 # ---------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------
+class _FlagOfStep:
+    """A skip decision that is still on its way: slot of the host ring the step that carried the flag copied its extra slots to."""
+
+    def __init__(self, slot: int):
+        self.slot = slot
+
+
+_END = object()
+
+
 class Trainer:
     """One rank of the training job.  ``model``: VoiceSplit / VoiceFilter on this rank's GPU (any
-    ``nn.Module`` with the same ``forward(mixed, emb) -> mask`` works: the CPU tests use one)."""
+    ``nn.Module`` with the same ``forward(mixed, emb) -> mask`` works: the CPU tests use one).
+
+    The N > 1 step (round 6; SURVEY.md 8(e) asks for ONE exchange step and nothing else on the path):
+      * no per-step flag collective: ``fit`` looks two batches ahead and lets "my batch k + 2 is empty" ride in the second spare
+        slot of step k's gradient bucket; the verdict is read from pinned memory two steps later, when it is long complete
+        (``train_step(batch)`` called directly keeps the blocking MIN-reduce: it cannot look ahead);
+      * the rank-averaged loss is read through pinned memory + an event recorded right behind the all-reduce, not by an
+        ``.item()`` behind ``optimizer.step()``; ``loss_lag = 1`` returns the value of the step BEFORE (the guard of train.py:115-117
+        then fires one step late) and the host never waits for the device at all;
+      * ``split_allreduce``: the gradients of the BiLSTM and the head (73 of 75.5 MB) are final ~5 ms into the backward pass
+        (vs_grads.leaves_event): their all-reduce starts there, on a side stream beside the conv stack's backward, and the
+        collective behind the backward moves the conv stack's 2.2 MB + the two spare slots only.
+    ``force_collectives``: run exactly that code at world 1 over a one-rank group (tests, bench.py's N = 1 A/B of the path)."""
 
     def __init__(self, model: torch.nn.Module, c, rank: int = 0, world: int = 1, group=None,
-                 criterion: Optional[Callable] = None, optimizer: Optional[torch.optim.Optimizer] = None):
+                 criterion: Optional[Callable] = None, optimizer: Optional[torch.optim.Optimizer] = None,
+                 force_collectives: bool = False, split_allreduce: Optional[bool] = None, loss_lag: int = 0):
         self.model, self.c, self.rank, self.world, self.group = model, c, rank, world, group
         self.criterion = criterion if criterion is not None else make_criterion(c)
         self.optimizer = optimizer if optimizer is not None else make_optimizer(c, model.parameters())
-        self.bucket = GradientBucket(model.parameters(), group, extra=1).attach()
+        self._force = bool(force_collectives)
+        self._comm = world > 1 or self._force
+        params = list(model.parameters())
+        on_cuda = len(params) > 0 and params[0].is_cuda
+        can_sink = hasattr(model, "set_gradient_sink") and on_cuda
+        early = None
+        if self._comm and can_sink and hasattr(model, "leaf_parameter_names") and (split_allreduce is None or split_allreduce):
+            leaf = set(model.leaf_parameter_names())
+            early = [p for n, p in model.named_parameters() if n in leaf and p.requires_grad]
+        # two spare slots: [0] the loss value (every rank logs / guards the rank average), [1] "a rank has no batch two steps ahead"
+        self.bucket = GradientBucket(params, group, extra=2, early=early).attach()
         # the HIP modules write their gradients straight into the bucket's .grad views (no `grad += new` per parameter,
         # no zeroing per step); any other module goes through autograd's accumulation into the zeroed bucket
         # (the sink is installed around train_step's own backward only: a plain zero_grad / backward / step loop over the
         # same model, before or after this trainer existed, gets its gradients through autograd as usual; parameters whose
         # requires_grad is switched on after construction are in neither the bucket nor the sink -- build a new Trainer)
-        self._sink = hasattr(model, "set_gradient_sink") and self.bucket.flat.is_cuda
+        self._sink = can_sink and self.bucket.flat.is_cuda
         self._sink_map = None
         if self._sink:
             names = {id(p): n for n, p in model.named_parameters()}
             self._sink_map = {names[id(p)]: v for p, v in zip(self.bucket.params, self.bucket.views)}
         self.device = self.bucket.flat.device
         self.step = 0
-        self.time_comm = False          # bench.py's N > 1 line: time the two collectives of a step (set_comm_timing)
+        self.time_comm = False          # bench.py's N > 1 line: time the collectives of a step (set_comm_timing)
         self.flag_ms = []
+        self.split_allreduce = bool(self._sink and self.bucket.has_early)
+        self._comm_stream = self._leaves_event = None
+        if self.split_allreduce:
+            self._comm_stream = torch.cuda.Stream(self.device)
+            self._leaves_event = torch.cuda.Event()
+            self._leaves_event.record()                                     # the handle the library records is created by the first record
         # train.py:114 reads loss.item() behind optimizer.step(): a device-to-host read that drains the device -- 0.3 ms of idle
         # device per step until the next step's first launches arrive.  One rank on a GPU: the value is final as soon as the
         # criterion has run, so it is copied to pinned memory THEN (beside the backward pass) and read at the reference's point
-        # without draining anything; the guard fires on the same value at the same place.  (Several ranks read the rank-averaged
-        # value, which exists only behind the gradient all-reduce: they keep the blocking read.)
-        self.early_loss_read = world == 1 and self.device.type == "cuda"
+        # without draining anything; the guard fires on the same value at the same place.  Several ranks read the rank-averaged
+        # value, which exists only behind the gradient all-reduce: copied to pinned memory there, read through an event.
+        cuda = self.device.type == "cuda"
+        self.early_loss_read = not self._comm and cuda
         self._loss_host = torch.zeros(1, dtype=torch.float32).pin_memory() if self.early_loss_read else None
         self._loss_event = torch.cuda.Event() if self.early_loss_read else None
+        self.loss_lag = int(loss_lag)
+        if self.loss_lag not in (0, 1):
+            raise ValueError("loss_lag must be 0 or 1")
+        self._ring = self._ring_ev = None
+        self._slot = 0                                                      # steps that copied their spare slots to the host ring
+        self._last_value = None
+        if self._comm:                                                      # (gloo on the CPU: plain tensors, nothing to wait for)
+            self._ring = [torch.zeros(2, dtype=torch.float32).pin_memory() if cuda else torch.zeros(2) for _ in range(4)]
+            self._ring_ev = [torch.cuda.Event() for _ in range(4)] if cuda else None
         if world > 1:           # every replica starts from rank 0's weights (train.py has one process)
             import torch.distributed as dist
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
 
     def set_comm_timing(self, on: bool = True):
-        """Self-diagnosis of the N > 1 step: HIP events around the gradient all-reduce (``bucket.collective_ms()``) and the host
-        wall time of the EmptyBatch MIN-reduce (``flag_ms``)."""
+        """Self-diagnosis of the N > 1 step: HIP events around the gradient all-reduces (``bucket.collective_ms()``, ``early=True``
+        for the BiLSTM + head segment) and the host wall time of the blocking EmptyBatch MIN-reduces (``flag_ms``: one per step when
+        ``train_step`` is called without a decision, one per epoch under ``fit``)."""
         self.time_comm = bool(on)
         self.bucket.time_events = bool(on)
         self.flag_ms = []
         self.bucket._events = []
+        self.bucket._early_events = []
+
+    @staticmethod
+    def _has(batch) -> bool:
+        return batch is not None and batch is not _END and batch[0] is not None and len(batch[0]) > 0
+
+    def _agree(self, haves: Sequence[bool]) -> List[bool]:
+        """One blocking MIN-reduce: entry i is True when EVERY rank has its batch i."""
+        if not self._comm:
+            return [bool(h) for h in haves]
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if h else 0.0 for h in haves], device=self.device)
+        t0 = time.perf_counter() if self.time_comm else 0.0
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        out = [v > 0 for v in flag.tolist()]
+        if self.time_comm:                                                  # host wall time of the flag round trip (it ends in a
+            self.flag_ms.append(1e3 * (time.perf_counter() - t0))           # device-to-host read: collective + drain)
+        return out
+
+    def _read_slot(self, slot: int, index: int) -> float:
+        if self._ring is None:
+            raise RuntimeError("no host ring on this trainer")
+        if self._ring_ev is not None:
+            self._ring_ev[slot % 4].synchronize()
+        return float(self._ring[slot % 4][index])
 
     # -- checkpoints: train.py:38-60 (load), :125-133 (save) ---------------------------------------
     def load_checkpoint(self, path: str, reinit_layers: Optional[Sequence[str]] = None) -> int:
@@ -187,23 +262,21 @@ class Trainer:
         return path
 
     # -- one step: train.py:86-117 ---------------------------------------------------------------------
-    def train_step(self, batch) -> float:
+    def train_step(self, batch, have: Optional[bool] = None, next_missing: float = 0.0) -> float:
         """batch = (emb, target, mixed, seq_len, target_wav, spec_phase) as train_collate_fn returns
         it (utils/dataset.py:84-114).  Returns the loss averaged over ranks; raises LossExploded on
-        every rank at once."""
+        every rank at once.
+        have: None = decide here whether every rank has a batch (one blocking MIN-reduce per step at N > 1); True / False = the
+        decision the ranks already share (``fit`` carries it in the gradient bucket two steps ahead).  next_missing: this rank's
+        1.0 / 0.0 for "I have no batch two steps from now", summed over ranks in the bucket's second spare slot."""
         # utils/dataset.py:93-95 drops items whose embedding is [0]; a rank whose whole slice was dropped
         # has nothing to run.  With several ranks that must be a collective decision (a rank that
         # raised or skipped alone would leave the others blocked in the gradient all-reduce): every
         # rank contributes "I have a batch", and the step is skipped everywhere unless all do.
-        have = batch is not None and batch[0] is not None and len(batch[0]) > 0
-        if self.world > 1:
-            import torch.distributed as dist
-            flag = torch.tensor([1.0 if have else 0.0], device=self.device)
-            t0 = time.perf_counter() if self.time_comm else 0.0
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            have = bool(flag.item() > 0)
-            if self.time_comm:                                              # host wall time of the flag round trip (it ends in a
-                self.flag_ms.append(1e3 * (time.perf_counter() - t0))       # .item(): collective + device-to-host read)
+        if have is None:
+            have = self._has(batch)
+            if self._comm:
+                have = self._agree([have])[0]
         if not have:
             raise EmptyBatch("a rank has no items in this step (all filtered by the collate): step skipped on every rank")
         emb, target, mixed, seq_len, _target_wav, phase = batch
@@ -219,24 +292,56 @@ class Trainer:
         if early:
             self._loss_host.copy_(loss.detach().reshape(1), non_blocking=True)
             self._loss_event.record()
+        split = False
         if not self._sink:
             self.bucket.zero()                                              # optimizer.zero_grad()
             loss.backward()                                                 # :110
         else:
+            # (a parameter frozen since the bucket was built gets its slot zeroed by reattach: not beside a running collective)
+            split = self.split_allreduce and self.bucket.all_frozen_free()
             self.model.set_gradient_sink(self._sink_map)
+            if split:
+                self.model.set_leaves_event(self._leaves_event)
             try:
                 loss.backward()                                             # :110, written straight into the bucket views
             finally:
                 self.model.set_gradient_sink(None)
+                if split:
+                    self.model.set_leaves_event(None)
         self.bucket.extra[0] = loss.detach()
-        self.bucket.all_reduce(self.world, written=self._sink)              # the one exchange step
+        if self._comm:
+            self.bucket.extra[1] = float(next_missing)
+        self.bucket.reattach(written=self._sink)
+        work = None
+        if split:
+            # the BiLSTM + head segment: final at the library's event (~5 ms into the backward pass), summed on the side stream beside
+            # the conv stack's backward; the caller's stream picks it up in front of the small collective below
+            self._comm_stream.wait_event(self._leaves_event)
+            with torch.cuda.stream(self._comm_stream):
+                work = self.bucket.all_reduce_early(self.world, force=self._force)
+            if work is not None:
+                work.wait()
+        self.bucket.all_reduce(self.world, force=self._force, early_done=work is not None, reattached=True)      # the one exchange step
+        ring = self._ring is not None
+        if ring:                                                            # the two spare slots to the host, behind the collective
+            slot = self._slot % 4
+            self._ring[slot].copy_(self.bucket.extra, non_blocking=True)
+            if self._ring_ev is not None:
+                self._ring_ev[slot].record()
+            self._slot += 1
         self.optimizer.step()                                               # :111
         self.step += 1                                                      # :112
         if early:
             self._loss_event.synchronize()                                  # long since complete: the host does not wait for the backward
             value = float(self._loss_host[0])                               # :114
+        elif ring:
+            if self.loss_lag and self._slot >= 2:
+                value = self._read_slot(self._slot - 2, 0)                  # the step before: its event completed a step ago
+            else:
+                value = self._read_slot(self._slot - 1, 0)                  # waits for this step's all-reduce, not for the optimizer
         else:
             value = float(self.bucket.extra[0].item())                      # :114 (the reference syncs here too)
+        self._last_value = value
         # :115-117, in the reference's order: the update has been applied and counted when the guard
         # fires, so step numbering and checkpoint cadence after an explosion match train.py
         if value > 1e8 or math.isnan(value):
@@ -273,6 +378,46 @@ class Trainer:
         self.model.train()
         return float(acc[0] / acc[1]) if acc[1] > 0 else float("nan")
 
+    def _with_decisions(self, batches: Iterable):
+        """Yields (batch, have, next_missing) for ``train_step``.  One rank: have = None (decided in the step, no collective).
+        Several ranks: the epoch's first two decisions come from ONE blocking MIN-reduce; from then on every rank's "my batch k + 2 is
+        empty" rides in step k's gradient bucket (``next_missing``) and the verdict for batch k + 2 is read from the host ring when its
+        turn comes -- two steps after the collective that carried it, so the read waits for nothing.  A step that is skipped has no
+        gradient collective to ride on: its flag gets a small blocking reduce of its own (empty batches are rare:
+        utils/dataset.py:93-95).  Every rank must see the same number of batches (``EpochShard`` guarantees it)."""
+        if not self._comm or self._ring is None:
+            for batch in batches:
+                yield batch, None, 0.0
+            return
+        it = iter(batches)
+        ahead = []
+
+        def pull():
+            try:
+                ahead.append(next(it))
+            except StopIteration:
+                ahead.append(_END)
+
+        pull()
+        pull()
+        decided = list(self._agree([b is _END or self._has(b) for b in ahead]))
+        while ahead[0] is not _END:
+            batch, d = ahead.pop(0), decided.pop(0)
+            pull()                                                          # ahead = [batch k + 1, batch k + 2]
+            nxt = ahead[1]
+            miss = 0.0 if (nxt is _END or self._has(nxt)) else 1.0
+            have = d if isinstance(d, bool) else self._read_slot(d.slot, 1) < 0.5
+            slot_before = self._slot
+            if have:
+                yield batch, True, miss                                     # the consumer runs train_step now
+            if have and self._slot == slot_before + 1:
+                decided.append(_FlagOfStep(slot_before))
+            else:
+                # skipped here, or the step raised before its collective (LossExploded leaves the epoch: the generator is dropped)
+                if not have:
+                    yield batch, False, 0.0                                 # train_step raises EmptyBatch on every rank
+                decided.append(self._agree([miss == 0.0])[0])
+
     def fit(self, batches_for_epoch: Callable[[int], Iterable], epochs: Optional[int] = None, log_dir: Optional[str] = None,
             on_log: Optional[Callable[[int, float], None]] = None, validation_batches: Optional[Callable[[], Iterable]] = None):
         """train.py:81-135.  ``batches_for_epoch(e)`` yields this rank's batches of epoch e."""
@@ -283,9 +428,9 @@ class Trainer:
                 v = self.validate(validation_batches())
                 if on_log and self.rank == 0:
                     on_log(-self.step, v)
-            for batch in batches_for_epoch(e):
+            for batch, have, miss in self._with_decisions(batches_for_epoch(e)):
                 try:
-                    loss = self.train_step(batch)
+                    loss = self.train_step(batch, have=have, next_missing=miss)
                 except EmptyBatch:
                     continue
                 except LossExploded as err:                                 # :115-117: leave this epoch
