@@ -521,7 +521,11 @@ enum vs_option {
                                  (beside cnn8's backward); 2 = behind cnn8's backward; 3 = behind the BPTT as 0, but dW_ih -- one persistent
                                  workgroup per CU -- LAST, behind the small leaves.  Default 3 (-0.13 ms per step against 0; 1, 2: slower).
                                  Same values.  VOICESPLIT_LSTM_LEAF_LATE */
-  VS_OPT_COUNT = 19
+  VS_OPT_CONV_EPILOGUE = 19,  /* VS_MATH_BF16 64 -> 64 convs (csrc/conv_nhwc.hip): how the epilogue is cut into micro-ops behind the MFMAs.
+                                 0 = round 3's (up to four dependent instructions behind every second MFMA), 1 = round 6's (one scalar
+                                 instruction per channel behind every MFMA, no packed-fp32 instructions: tools/epilogue_slot_probe.hip).
+                                 Same arithmetic.  VOICESPLIT_CONV_EPILOGUE */
+  VS_OPT_COUNT = 20
 };
 int vs_set_option(int option, int value);
 int vs_get_option(int option);

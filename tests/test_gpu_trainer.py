@@ -423,3 +423,85 @@ def test_early_loss_read_returns_the_same_values_and_still_raises():
     assert tr._loss_event.query()
     with pytest.raises(LossExploded):
         run(True, scale=1e12)
+
+
+def test_n_gt_1_step_on_one_rank_split_allreduce_pinned_loss_and_no_device_drain():
+    """The N > 1 code path of Trainer.train_step on the one GPU there is (force_collectives over a one-rank RCCL group): the BiLSTM +
+    head segment of the bucket all-reduced on the side stream from the library's leaves event (vs_grads.leaves_event, ABI 9), the
+    rest + the two spare slots behind the backward pass, the loss value read through pinned memory.
+      * same losses and the same weights as the plain one-rank trainer (a sum over one rank is the identity), bf16 configuration;
+      * no Tensor.item() / tolist() on a device tensor anywhere in a step (the N > 1 step used to have two);
+      * with loss_lag = 1 the host does not wait for the device at all: when train_step returns, the step's last kernel has not run yet
+        (and the value it returns is the step before's); fit() makes its skip decisions without a per-step collective."""
+    import socket
+    import torch.distributed as dist
+    import voicesplit_amd as V
+    from voicesplit_amd.trainer import Trainer
+    dims = dict(num_freq=601, emb_dim=256, lstm_dim=400, fc1_dim=600, fc2_dim=601)
+    B, T = 16, 301
+    c = V.default_config(**dims)
+    c.train_config["learning_rate"] = 1e-4
+    acfg = c.audio["voicefilter"]
+    batches = [_loss_batch(B, T, dims["num_freq"], dims["emb_dim"], acfg["hop_length"], 20 + i, False) for i in range(3)]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+
+    def make(**kw):
+        torch.manual_seed(11)
+        return Trainer(V.VoiceSplit(c).cuda(), c, **kw)
+
+    real_item, real_tolist = torch.Tensor.item, torch.Tensor.tolist
+    try:
+        with _math("bf16"):
+            plain = make()
+            want = [plain.train_step(batches[i % 3]) for i in range(5)]
+            tr = make(force_collectives=True)
+            assert tr.split_allreduce and tr.bucket.has_early and tr._ring is not None and not tr.early_loss_read
+            n_early = tr.bucket.flat.numel() - tr.bucket.split
+            assert n_early == sum(p.numel() for n, p in tr.model.named_parameters() if not n.startswith("conv."))
+            tr.train_step(batches[0], have=True)                # warm-up outside the guard below (lazy initialisations)
+
+            def guard(name, real):
+                def f(self, *a, **k):
+                    if self.is_cuda:
+                        raise AssertionError(f"Tensor.{name}() on a device tensor inside the N > 1 step")
+                    return real(self, *a, **k)
+                return f
+            torch.Tensor.item, torch.Tensor.tolist = guard("item", real_item), guard("tolist", real_tolist)
+            tr.set_comm_timing(True)
+            got = [want[0]] + [tr.train_step(batches[i % 3], have=True, next_missing=0.0) for i in range(1, 5)]
+            torch.Tensor.item, torch.Tensor.tolist = real_item, real_tolist
+            torch.cuda.synchronize()
+            assert len(tr.bucket.collective_ms()) == 4 and len(tr.bucket.collective_ms(early=True)) == 4
+            tr.set_comm_timing(False)
+            assert got == want, (got, want)
+            for p, q in zip(tr.model.parameters(), plain.model.parameters()):
+                assert torch.equal(p, q)
+            # loss_lag = 1: the host runs ahead -- train_step returns while the device still works on the step
+            lag = make(force_collectives=True, loss_lag=1)
+            vals = []
+            end = torch.cuda.Event()
+            busy = []
+            for i in range(5):
+                vals.append(lag.train_step(batches[i % 3], have=True))
+                end.record()
+                busy.append(not end.query())
+            torch.cuda.synchronize()
+            assert vals[0] == want[0] and vals[1:] == want[:4], (vals, want)
+            assert all(busy[1:]), busy
+            for p, q in zip(lag.model.parameters(), plain.model.parameters()):
+                assert torch.equal(p, q)
+            # fit(): skip decisions ride in the bucket -- one blocking flag reduce per epoch, one more for the skipped step
+            ft = make(force_collectives=True)
+            ft.set_comm_timing(True)
+            seq = [batches[0], batches[1], (None,) * 6, batches[2], batches[0]]
+            ft.fit(lambda e: iter(seq), epochs=1)
+            assert ft.step == 4 and len(ft.flag_ms) == 2
+            early_ms = ft.bucket.collective_ms(early=True)
+            assert len(early_ms) == 4 and len(ft.bucket.collective_ms()) == 4
+    finally:
+        torch.Tensor.item, torch.Tensor.tolist = real_item, real_tolist
+        dist.destroy_process_group()

@@ -203,6 +203,91 @@ def test_spec_wav_dataset_reads_the_reference_layout(tmp_path):
         SpecWavDataset(c)
 
 
+def _write_dataset(tmp_path, n, seed=0, samples=4800, T=31, Fq=601):
+    from scipy.io import wavfile
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    for i in range(n):
+        stem = str(tmp_path / ("%06d" % i))
+        torch.save(torch.randn(256, generator=g) if i != 3 else torch.tensor([0]), stem + "-emb.pt")      # item 3: "no embedding" (dataset.py:93-95)
+        torch.save(torch.rand(T, Fq, generator=g), stem + "-target.pt")
+        wavfile.write(stem + "-mixed.wav", 16000, (rng.standard_normal(samples) * 0.1).astype(np.float32))
+        wavfile.write(stem + "-target.wav", 16000, (rng.standard_normal(samples) * 0.1).astype(np.float32))
+    c = _cfg(num_workers=2)
+    c.dataset = {"train_dir": str(tmp_path), "test_dir": str(tmp_path),
+                 "format": {"emb": "*-emb.pt", "mixed": "*-mixed.pt", "target": "*-target.pt",
+                            "target_wav": "*-target.wav", "mixed_wav": "*-mixed.wav"}}
+    return c
+
+
+def test_batch_feeder_worker_processes_yield_exactly_the_epoch_shards_batches(tmp_path):
+    """BatchFeeder.host_batches: a DataLoader with worker processes whose batch sampler is the rank's EpochShard -- the same items
+    in the same order as the synchronous ``[ds[i] for i in idx]`` loop it replaces, filtered items dropped, a batch with nothing left
+    reported as None; the same for both ranks of a world-2 sharding."""
+    from voicesplit_amd.trainer import BatchFeeder, host_collate
+    c = _write_dataset(tmp_path, 13)
+    ds = SpecWavDataset(c)
+    for rank in (0, 1):
+        shard = EpochShard(len(ds), 2, rank, 2, seed=4)
+        feeder = BatchFeeder(ds, shard, "cpu")
+        assert feeder.num_workers == 2
+        for e in (0, 1):
+            got = list(feeder.host_batches(e))
+            want = [host_collate([ds[i] for i in idx]) for idx in shard.epoch(e)]
+            assert len(got) == len(want) == 3
+            for g_, w_, idx in zip(got, want, shard.epoch(e)):
+                assert (g_ is None) == (w_ is None)
+                if g_ is None:
+                    continue
+                assert len(g_[0]) == len([i for i in idx if i != 3])
+                assert all(torch.equal(a, b) for a, b in zip(g_, w_))
+    # a batch made of the filtered item alone
+    one = BatchFeeder(ds, EpochShard(len(ds), 1, 0, 1, shuffle=False), "cpu", num_workers=0)
+    hb = list(one.host_batches(0))
+    assert hb[3] is None and sum(b is None for b in hb) == 1 and len(hb) == 13
+
+
+def test_gradient_bucket_layout_spare_slots_in_front_and_an_early_segment():
+    """flat = [extra | late parameters | early parameters]: the views cover it exactly once, .grad is the view, the early segment
+    is contiguous at the end and the spare slots sit in front of the small segment (sharding.GradientBucket)."""
+    from voicesplit_amd.sharding import GradientBucket
+    m = _Standin()
+    params = list(m.parameters())                     # a.weight, a.bias, b.weight, b.bias
+    early = [m.b.weight, m.b.bias]
+    bk = GradientBucket(params, extra=2, early=early).attach()
+    n_late = m.a.weight.numel() + m.a.bias.numel()
+    assert bk.flat.numel() == 2 + sum(p.numel() for p in params) and bk.split == 2 + n_late and bk.has_early
+    assert bk.extra.data_ptr() == bk.flat.data_ptr() and bk.extra.numel() == 2 and bk.grads.numel() == bk.numel
+    off = {id(p): (v.data_ptr() - bk.flat.data_ptr()) // 4 for p, v in zip(bk.params, bk.views)}
+    assert off[id(m.a.weight)] == 2 and off[id(m.a.bias)] == 2 + m.a.weight.numel()
+    assert off[id(m.b.weight)] == bk.split and off[id(m.b.bias)] == bk.split + m.b.weight.numel()
+    assert all(p.grad is v and v.shape == p.shape for p, v in zip(bk.params, bk.views))
+    for i, v in enumerate(bk.views):
+        v.fill_(float(i + 1))
+    order = {id(p): i for i, p in enumerate(params)}           # (list.index would compare tensors element-wise)
+    want = torch.cat([torch.zeros(2)] + [torch.full((p.numel(),), float(order[id(p)] + 1)) for p in (m.a.weight, m.a.bias, m.b.weight, m.b.bias)])
+    assert torch.equal(bk.flat, want)
+    # no early segment: the old layout but for the spare slots in front
+    bk2 = GradientBucket(params, extra=1)
+    assert not bk2.has_early and bk2.split == bk2.flat.numel() and bk2.all_reduce_early(1) is None
+    assert bk.all_frozen_free()
+    m.a.bias.requires_grad_(False)
+    assert not bk.all_frozen_free()
+
+
+def test_fit_on_one_rank_is_the_plain_loop():
+    """world 1: no collective, no look-ahead -- fit() feeds train_step batch by batch, an empty batch is skipped locally"""
+    c = _cfg(epochs=1)
+    tr = Trainer(_Standin(), c, criterion=_mse)
+    ref = Trainer(_Standin(), c, criterion=_mse)
+    seq = [_batch(2, 0), (None,) * 6, _batch(2, 1), _batch(2, 2)]
+    logged = []
+    tr.fit(lambda e: iter(seq), on_log=lambda s, l: logged.append((s, l)))
+    want = [ref.train_step(b) for b in (seq[0], seq[2], seq[3])]
+    assert tr.step == 3 and [l for _, l in logged] == want
+    assert all(torch.equal(p, q) for p, q in zip(tr.model.parameters(), ref.model.parameters()))
+
+
 # ---- world 2 over gloo ------------------------------------------------------------------------------
 
 def _dp_worker(rank, world, port, tmp, q):
@@ -255,6 +340,48 @@ def _dp_worker(rank, world, port, tmp, q):
     with torch.no_grad():      # the NaN update went into the weights (as in the reference): restore for the rest
         for p_, b_ in zip(tr.model.parameters(), before):
             p_.copy_(b_)
+    # ---- round 6: fit() carries the skip decision in the gradient bucket (no per-step flag collective) ---------------------------
+    # five global batches; rank 1's slice of batch 2 was filtered out entirely: both ranks skip it together, and the job equals one
+    # process that never saw that global batch.  Blocking flag reduces: one at the epoch's start + one at the skipped step.
+    tr2 = Trainer(_Standin(), c, rank, world, criterion=_mse)
+    shard5 = EpochShard(20, b, rank, world, seed=3)
+    data5 = _batch(20, 321)
+    pick5 = lambda idx: tuple(None if t is None else t[idx] for t in data5)
+    mine = [pick5(idx) for idx in shard5.epoch(0)]
+    if rank == 1:
+        mine[2] = (None,) * 6
+    tr2.set_comm_timing(True)
+    seen = []
+    tr2.fit(lambda e: iter(mine), epochs=1, on_log=lambda s, l: seen.append((s, l)))
+    ref2 = Trainer(_Standin(), c, criterion=_mse)
+    full5 = [pick5(idx) for idx in EpochShard(20, b * world, 0, 1, seed=3).epoch(0)]
+    want5 = [ref2.train_step(full5[k]) for k in (0, 1, 3, 4)]
+    ok = ok and tr2.step == 4 and len(tr2.flag_ms) == 2
+    ok = ok and all(torch.allclose(p, r, rtol=1e-5, atol=1e-7) for p, r in zip(tr2.model.parameters(), ref2.model.parameters()))
+    if rank == 0:
+        ok = ok and len(seen) == 4 and all(abs(l - w_) < 1e-6 for (_, l), w_ in zip(seen, want5))
+    # loss_lag = 1: the value returned is the step before's (the guard fires one step late), the weights are the same
+    tr3 = Trainer(_Standin(), c, rank, world, criterion=_mse, loss_lag=1)
+    lag = []
+    tr3.fit(lambda e: iter(mine), epochs=1, on_log=lambda s, l: lag.append(l))
+    ok = ok and all(torch.equal(p, r) for p, r in zip(tr3.model.parameters(), tr2.model.parameters()))
+    if rank == 0:
+        ok = ok and len(lag) == 4 and abs(lag[0] - want5[0]) < 1e-6 and all(abs(lag[k] - want5[k - 1]) < 1e-6 for k in (1, 2, 3))
+    # the early segment: summed on its own + the rest == one all-reduce of the whole bucket
+    from voicesplit_amd.sharding import GradientBucket
+    m4 = _Standin()
+    bk = GradientBucket(list(m4.parameters()), None, extra=2, early=[m4.b.weight, m4.b.bias]).attach()
+    g4 = torch.Generator().manual_seed(50 + rank)
+    bk.flat.copy_(torch.randn(bk.flat.numel(), generator=g4))
+    mine4 = bk.flat.clone()
+    both = [torch.empty_like(mine4) for _ in range(world)]
+    dist.all_gather(both, mine4)
+    work = bk.all_reduce_early(world)
+    ok = ok and work is not None
+    work.wait()
+    ok = ok and torch.equal(bk.flat[:bk.split], mine4[:bk.split])           # the small segment is untouched so far
+    bk.all_reduce(world, early_done=True)
+    ok = ok and torch.allclose(bk.flat, (both[0] + both[1]) / world, rtol=0, atol=1e-6)
     # validation mean over ranks
     tr.criterion = _mse
     v = tr.validate([pick([2 * rank, 2 * rank + 1])])

@@ -36,6 +36,15 @@ def main():
                 out[f"round{rnd} scalar_epilogue={mode}"] = run()
         print(json.dumps(out, indent=1), flush=True)
         return
+    if os.environ.get("VS_MICRO_FINE_AB"):                # round 6: one-scalar-micro-op-per-MFMA epilogue (VS_OPT_CONV_EPILOGUE) against round 3's
+        out = {}
+        modes = [int(v) for v in os.environ["VS_MICRO_FINE_AB"].split(",")] if "," in os.environ["VS_MICRO_FINE_AB"] else [0, 1]
+        for rnd in range(2):
+            for mode in modes:
+                _lib.set_option("CONV_EPILOGUE", mode)
+                out[f"round{rnd} conv_epilogue={mode}"] = run()
+        print(json.dumps(out, indent=1), flush=True)
+        return
     if os.environ.get("VS_MICRO_CONV8_AB"):
         out = {}
         for rnd in range(2):

@@ -223,7 +223,7 @@ def load(path: str = None) -> ctypes.CDLL:
 # enum vs_option of include/voicesplit_hip.h.  The library reads no environment variable; for A/B timing from the shell this
 # package maps the variables below onto vs_set_option ONCE, when it loads the library.
 OPTIONS = {"F16X3_CONV_NCHW": 0, "BWD_DY": 1, "GEMM_KERNEL": 2, "GEMM_DR": 3, "GEMM_ABL": 4, "GEMM_BAND": 5, "WGRAD_ABL": 6,
-           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16, "HEAD_BWD_GEMM": 17, "LSTM_LEAF_LATE": 18}
+           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16, "HEAD_BWD_GEMM": 17, "LSTM_LEAF_LATE": 18, "CONV_EPILOGUE": 19}
 _ENV_OPTIONS = {
     "VOICESPLIT_F16X3_CONV": ("F16X3_CONV_NCHW", lambda v: 1 if v == "nchw" else 0),
     "VOICESPLIT_BWD_DY": ("BWD_DY", lambda v: 0 if v.startswith("0") else 1),
@@ -244,6 +244,7 @@ _ENV_OPTIONS = {
     "VOICESPLIT_FEAT_ROWS": ("FEAT_ROWS", int),
     "VOICESPLIT_HEAD_BWD_GEMM": ("HEAD_BWD_GEMM", int),
     "VOICESPLIT_LSTM_LEAF_LATE": ("LSTM_LEAF_LATE", int),
+    "VOICESPLIT_CONV_EPILOGUE": ("CONV_EPILOGUE", int),
 }
 
 
@@ -252,7 +253,11 @@ def _apply_env_options(lib):
         v = os.environ.get(var)
         if v is None or v == "":
             continue
-        if lib.vs_set_option(OPTIONS[name], conv(v)) != 0:
+        try:
+            value = conv(v)
+        except ValueError as err:
+            raise VoiceSplitHipError(f"{var}={v}: not a value of this switch ({err})") from None
+        if lib.vs_set_option(OPTIONS[name], value) != 0:
             msg = lib.vs_last_error()
             raise VoiceSplitHipError(f"{var}={v}: {msg.decode() if msg else 'rejected by vs_set_option'}")
 

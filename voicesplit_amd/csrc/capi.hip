@@ -25,7 +25,7 @@ void vs_set_error(const char* fmt, ...) {
 // thread safe, off by default.
 // defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
 int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
-                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 2, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0, /*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1, /*FEAT_ROWS*/ 1, /*HEAD_BWD_GEMM*/ 1, /*LSTM_LEAF_LATE*/ 3};
+                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 2, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0, /*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1, /*FEAT_ROWS*/ 1, /*HEAD_BWD_GEMM*/ 1, /*LSTM_LEAF_LATE*/ 3, /*CONV_EPILOGUE*/ 0};
 
 namespace {
 struct Prof {
@@ -301,6 +301,7 @@ int vs_set_option(int option, int value) {
     case VS_OPT_CONV_SCALAR_EPILOGUE: ok = value >= 0 && value <= 2; break;
     case VS_OPT_SIDE_PRIO: case VS_OPT_BN_FUSED_FINALIZE: ok = value >= 0 && value <= 2; break;
     case VS_OPT_LSTM_LEAF_LATE: ok = value >= 0 && value <= 3; break;
+    case VS_OPT_CONV_EPILOGUE: ok = value >= 0 && value <= 2; break;
     case VS_OPT_GEMM_DR: {
       const int a = value / 100, b = (value / 10) % 10, c = value % 10;
       ok = (a == 4 || a == 8) && (b == 4 || b == 8) && (c == 4 || c == 8);

@@ -106,7 +106,12 @@ struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 // accumulates the two sums of the BatchNorm backward (sum dy, sum dy * xhat) like the STATS epilogue accumulates the
 // forward's, and stores dy: the separate statistics pass over (da, z) disappears and the apply pass needs no activation
 // derivative (dz = cA dy + cB z + cC).  ACT is then the activation whose derivative is taken.
-template <int KT, int KF, int ACT, bool STATS, bool DY = false>
+// EP: how the epilogue is cut into micro-ops.  0 = round 3's: up to four DEPENDENT (partly packed-fp32) instructions behind every second
+// MFMA.  1 = round 6's (tools/epilogue_slot_probe.hip: behind an MFMA one or two INDEPENDENT scalar VALU instructions are nearly
+// free -- 17.4 / 18.5 cycles per MFMA against 16.5 -- a third costs 7 cycles, a dependent chain of three 16, and ONE v_pk_fma_f32
+// 17): every micro-op is the same scalar instruction on the two channels of a pair (or one transcendental, or one store), one
+// micro-op per MFMA; built without packed-fp32 instructions.
+template <int KT, int KF, int ACT, bool STATS, bool DY = false, int EP = 0>
 struct ConvWalk {
   using G = Geo<KT, KF>;
   static constexpr int P = G::P, PF = G::PF, H = G::H, NTAP = G::NTAP;
@@ -253,14 +258,18 @@ struct ConvWalk {
     u2v zq[3][NB];                     // DY: z of the output row being finished and the next two (4 channels of one pixel each)
     float cok[NB], mk[NB];             // DY: 1 for a column inside the image, else 0; the same for the row being finished
     f2v tz, ty, tu, tn, tr, tw;        // DY: one channel pair in flight through the stages of the activation derivative
+    f2v tp, tq, da;                    // EP = 1: further stage registers
+    u2v pk[NB];                        // EP = 1: the packed pixel on its way to the store
     unsigned vb[KF][2];                // B-fragment read bases of this group's window buffer (column shift, k-chunk); row, column block: immediates
     int ro;
   };
   // micro-ops of one output row.  Plain: NB*4 values + NB stores.  DY: z loads of a later row, NB*2 channel pairs x NSTAGE
   // stages (packed fp32 math: one v_pk_* per two channels; at most three of them or one transcendental per micro-op, which
   // is what fits behind one MFMA without holding up the next), NB stores.
-  static constexpr int NSTAGE = DY ? 9 : ACT == VS_ACT_MISH ? 7 : 1;
-  static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + NB;
+  static constexpr int NSTAGE = EP == 0 ? (DY ? 9 : ACT == VS_ACT_MISH ? 7 : 1)
+                                        : (DY ? (ACT == VS_ACT_MISH ? 19 : 7) : ACT == VS_ACT_MISH ? 12 : ACT == VS_ACT_RELU ? 2 : STATS ? 4 : 1);
+  static constexpr int NSTORE = EP == 0 ? NB : 2 * NB;               // EP = 1: pack and store are two micro-ops
+  static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + NSTORE;
 
   template <int RV>
   __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
@@ -295,9 +304,134 @@ struct ConvWalk {
   }
 
   // micro-op q of the epilogue of output row r of the group
+  // ---- EP = 1 ------------------------------------------------------------------------------------------------------------------------
+  // Every stage is ONE scalar instruction per channel of the pair (x, y: independent of each other), or one transcendental.  The
+  // instructions are volatile inline assembly: as C++ expressions the compiler contracted and re-associated them across stages (a
+  // stage's two instructions ended up beside the next stage's, the slot behind the following MFMA empty), which is exactly the
+  // clustering this form exists to avoid.
+#ifndef VS_EP_ASM_VALU
+#define VS_EP_ASM_VALU 0
+#endif
+#if VS_EP_ASM_VALU
+  static __device__ __forceinline__ float i_fma(float a, float b, float c) { float d; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+  static __device__ __forceinline__ float i_mul(float a, float b) { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+  static __device__ __forceinline__ float i_add(float a, float b) { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+  static __device__ __forceinline__ float i_add2(float a) { float d; asm volatile("v_add_f32 %0, 2.0, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_exp2(float a) { float d; asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_rcp(float a) { float d; asm volatile("v_rcp_f32 %0, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_max0(float a) { float d; asm volatile("v_max_f32 %0, 0, %1" : "=v"(d) : "v"(a)); return d; }
+  // literal operands (VOP2 encodings take a 32-bit literal): 20 log2(e), 20, log2(e), 4 ln 2
+  static __device__ __forceinline__ float i_min_20log2e(float a) { float d; asm volatile("v_min_f32 %0, 0x41e6d4ca, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_min_20(float a) { float d; asm volatile("v_min_f32 %0, 0x41a00000, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_mul_log2e(float a) { float d; asm volatile("v_mul_f32 %0, 0x3fb8aa3b, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_mul_4ln2(float a) { float d; asm volatile("v_mul_f32 %0, 0x40317218, %1" : "=v"(d) : "v"(a)); return d; }
+  static __device__ __forceinline__ float i_bf_lo(unsigned u) { float d; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(d) : "v"(u)); return d; }
+  static __device__ __forceinline__ float i_bf_hi(unsigned u) { float d; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(u)); return d; }
+#else
+  // (as volatile assembly the compiler's hazard recognizer, which cannot look inside, put an s_nop in front of every statement that
+  // reads a register the statement before wrote: 349 per group)
+  static __device__ __forceinline__ float i_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+  static __device__ __forceinline__ float i_mul(float a, float b) { return a * b; }
+  static __device__ __forceinline__ float i_add(float a, float b) { return a + b; }
+  static __device__ __forceinline__ float i_add2(float a) { return a + 2.0f; }
+  static __device__ __forceinline__ float i_exp2(float a) { return __builtin_amdgcn_exp2f(a); }
+  static __device__ __forceinline__ float i_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+  static __device__ __forceinline__ float i_max0(float a) { return fmaxf(a, 0.f); }
+  static __device__ __forceinline__ float i_min_20log2e(float a) { return fminf(a, 20.0f * kLog2e); }
+  static __device__ __forceinline__ float i_min_20(float a) { return fminf(a, 20.0f); }
+  static __device__ __forceinline__ float i_mul_log2e(float a) { return a * kLog2e; }
+  static __device__ __forceinline__ float i_mul_4ln2(float a) { return a * (4.0f * 0.69314718055994530942f); }
+  static __device__ __forceinline__ float i_bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+  static __device__ __forceinline__ float i_bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
+
+  template <int RV, int r, int q>
+  __device__ __forceinline__ void micro_fine(const Item& x, GroupState<RV>& st) {
+    constexpr bool mish = ACT == VS_ACT_MISH;
+    constexpr int Q0 = DY ? 1 : 0;
+    if constexpr (DY && q == 0) {
+      if constexpr (r + 2 < RV) load_z<RV>(x, st, r + 2);
+#pragma unroll
+      for (int nb2 = 0; nb2 < NB; ++nb2) st.mk[nb2] = (st.ro + r < x.o1) ? st.cok[nb2] : 0.f;
+    } else if constexpr (q < Q0 + NB * 2 * NSTAGE) {
+      constexpr int v = (q - Q0) / NSTAGE, sg = (q - Q0) % NSTAGE, nb2 = v / 2, pr = v % 2;
+      if constexpr (DY) {
+        if constexpr (sg == 0) {
+          const unsigned u = st.zq[r % 3][nb2][pr];
+          st.tz.x = i_bf_lo(u); st.tz.y = i_bf_hi(u);
+        } else if constexpr (sg == 1) {
+          st.ty.x = i_fma(st.tz.x, csc[pr].x, csh[pr].x); st.ty.y = i_fma(st.tz.y, csc[pr].y, csh[pr].y);
+        } else if constexpr (mish) {
+          if constexpr (sg == 2) { st.ty.x = i_min_20log2e(st.ty.x); st.ty.y = i_min_20log2e(st.ty.y); }
+          else if constexpr (sg == 3) st.tu.x = i_exp2(st.ty.x);
+          else if constexpr (sg == 4) st.tu.y = i_exp2(st.ty.y);
+          else if constexpr (sg == 5) { st.tw.x = i_add2(st.tu.x); st.tw.y = i_add2(st.tu.y); }
+          else if constexpr (sg == 6) { st.tn.x = i_mul(st.tu.x, st.tw.x); st.tn.y = i_mul(st.tu.y, st.tw.y); }
+          else if constexpr (sg == 7) { st.tw.x = i_add2(st.tn.x); st.tw.y = i_add2(st.tn.y); }
+          else if constexpr (sg == 8) st.tr.x = i_rcp(st.tw.x);
+          else if constexpr (sg == 9) st.tr.y = i_rcp(st.tw.y);
+          else if constexpr (sg == 10) { st.tp.x = i_fma(st.tu.x, st.tu.x, st.tu.x); st.tp.y = i_fma(st.tu.y, st.tu.y, st.tu.y); }          // u (u + 1)
+          else if constexpr (sg == 11) { st.tp.x = i_mul(st.tp.x, st.ty.x); st.tp.y = i_mul(st.tp.y, st.ty.y); }
+          else if constexpr (sg == 12) { st.tq.x = i_mul_4ln2(st.tr.x); st.tq.y = i_mul_4ln2(st.tr.y); }                                  // y was scaled by log2(e)
+          else if constexpr (sg == 13) { st.tn.x = i_fma(st.tp.x, st.tq.x, st.tn.x); st.tn.y = i_fma(st.tp.y, st.tq.y, st.tn.y); }
+          else if constexpr (sg == 14) { st.tw.x = i_mul(st.tr.x, st.tn.x); st.tw.y = i_mul(st.tr.y, st.tn.y); }                          // Mish'
+          else if constexpr (sg == 15) { st.ty.x = i_mul(st.acc[r][nb2][2 * pr], st.tw.x); st.ty.y = i_mul(st.acc[r][nb2][2 * pr + 1], st.tw.y); }
+          else if constexpr (sg == 16) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
+          else if constexpr (sg == 17) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
+          else {
+            a2[pr].x = i_fma(st.tp.x, st.tz.x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.tz.y, a2[pr].y);
+            st.y[nb2][pr] = st.ty;
+          }
+        } else {                       // ReLU (ACT_NONE is not a dy instance)
+          if constexpr (sg == 2) st.ty.x = st.ty.x > 0.f ? st.acc[r][nb2][2 * pr] : 0.f;
+          else if constexpr (sg == 3) st.ty.y = st.ty.y > 0.f ? st.acc[r][nb2][2 * pr + 1] : 0.f;
+          else if constexpr (sg == 4) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
+          else if constexpr (sg == 5) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
+          else {
+            a2[pr].x = i_fma(st.tp.x, st.tz.x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.tz.y, a2[pr].y);
+            st.y[nb2][pr] = st.ty;
+          }
+        }
+      } else {
+        if constexpr (sg == 0) {
+          st.y[nb2][pr].x = i_fma(st.acc[r][nb2][2 * pr], csc[pr].x, csh[pr].x); st.y[nb2][pr].y = i_fma(st.acc[r][nb2][2 * pr + 1], csc[pr].y, csh[pr].y);
+        } else if constexpr (mish) {
+          if constexpr (sg == 1) { st.ty.x = i_min_20(st.y[nb2][pr].x); st.ty.y = i_min_20(st.y[nb2][pr].y); }
+          else if constexpr (sg == 2) { st.ty.x = i_mul_log2e(st.ty.x); st.ty.y = i_mul_log2e(st.ty.y); }
+          else if constexpr (sg == 3) st.tu.x = i_exp2(st.ty.x);
+          else if constexpr (sg == 4) st.tu.y = i_exp2(st.ty.y);
+          else if constexpr (sg == 5) { st.tw.x = i_add2(st.tu.x); st.tw.y = i_add2(st.tu.y); }
+          else if constexpr (sg == 6) { st.tn.x = i_mul(st.tu.x, st.tw.x); st.tn.y = i_mul(st.tu.y, st.tw.y); }
+          else if constexpr (sg == 7) { st.tw.x = i_add2(st.tn.x); st.tw.y = i_add2(st.tn.y); }
+          else if constexpr (sg == 8) st.tr.x = i_rcp(st.tw.x);
+          else if constexpr (sg == 9) st.tr.y = i_rcp(st.tw.y);
+          else if constexpr (sg == 10) { st.tn.x = i_mul(st.tn.x, st.tr.x); st.tn.y = i_mul(st.tn.y, st.tr.y); }
+          else { st.y[nb2][pr].x = i_mul(st.y[nb2][pr].x, st.tn.x); st.y[nb2][pr].y = i_mul(st.y[nb2][pr].y, st.tn.y); }
+        } else if constexpr (ACT == VS_ACT_RELU) {
+          st.y[nb2][pr].x = i_max0(st.y[nb2][pr].x); st.y[nb2][pr].y = i_max0(st.y[nb2][pr].y);
+        } else if constexpr (STATS) {
+          if constexpr (sg == 1) {
+            const float m = ((st.ro + r < x.o1) & (vcol[nb2] != kOob)) ? 1.f : 0.f;
+            st.tp.x = i_mul(st.y[nb2][pr].x, m); st.tp.y = i_mul(st.y[nb2][pr].y, m);
+          } else if constexpr (sg == 2) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
+          else { a2[pr].x = i_fma(st.tp.x, st.y[nb2][pr].x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.y[nb2][pr].y, a2[pr].y); }
+        }
+      }
+    } else {
+      constexpr int sq = q - Q0 - NB * 2 * NSTAGE, nb2 = sq / 2;
+      if constexpr (sq % 2 == 0) {
+        st.pk[nb2] = u2v{vs_pack_bf16(st.y[nb2][0].x, st.y[nb2][0].y), vs_pack_bf16(st.y[nb2][1].x, st.y[nb2][1].y)};
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b64(st.pk[nb2], rout, vcol[nb2], row_offset(x, st.ro + r), 0);                 // out of range: dropped
+      }
+    }
+  }
+
   template <int RV, int r, int q>
   __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
-    if constexpr (!DY) {
+    if constexpr (EP == 1) {
+      micro_fine<RV, r, q>(x, st);
+    } else if constexpr (!DY) {
       // out = act(acc * scale + shift).  Mish(y) = y n / (n + 2), n = u (u + 2), u = e^y (y clamped at 20, where n / (n + 2)
       // is 1 to fp32): one exp2 and one rcp per channel, everything else packed, cut into stages like the dy form below
       if constexpr (q < NB * 2 * NSTAGE) {
@@ -392,7 +526,21 @@ struct ConvWalk {
     constexpr int r_lo = i - (KT - 1) > 0 ? i - (KT - 1) : 0, r_hi = i < RV - 1 ? i : RV - 1;
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
-    st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
+    if constexpr (EP == 1) {
+      // Volatile assembly: the builtin is a pure value to the compiler, which placed it on either side of the (volatile) stage
+      // instructions -- the micro-ops then clustered again.  Weights in AGPRs (all 50 fragments: read-only, every use is here),
+      // accumulators in VGPRs: the epilogue reads them without v_accvgpr_read (128 per group), and the first product of an
+      // accumulator takes the constant 0 as its addend instead of a cleared register (64 v_mov per group).  The compiler cannot see
+      // the MFMA inside, so nothing may read an accumulator sooner than the hardware allows: the first reader of row r's values is a
+      // micro-op of window row r + KT, >= 4 MFMAs (64 cycles) behind the last write.
+      constexpr bool first = (i == r) && df == 0 && kc == 0;
+      if constexpr (first)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
+      else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
+    } else {
+      st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
+    }
     if constexpr (MM == 0 && GI % 4 == 0 && GI / 4 < G::UNITS) row_unit<GI / 4>(bt);      // the next group's window: one row per unit
     if constexpr (DY && GI == 0 && MM == 0) {               // z of the group's first two rows
       load_z<RV>(x, st, 0);
@@ -451,10 +599,12 @@ struct ConvWalk {
     for (int df = 0; df < KF; ++df)
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) st.vb[df][kc] = lds0 + (unsigned)(buf * G::WBUF + boff[df][kc]);
+    if constexpr (EP == 0) {
 #pragma unroll
-    for (int r = 0; r < RV; ++r)
+      for (int r = 0; r < RV; ++r)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) st.acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; ++nb) st.acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (DY) {
 #pragma unroll
       for (int nb2 = 0; nb2 < NB; ++nb2) st.cok[nb2] = (x.strip * STRIP + nb2 * 16 + n < a.F) ? 1.f : 0.f;
@@ -462,6 +612,12 @@ struct ConvWalk {
     st.bq[0] = frag<RV>(st, 0);
     st.bq[1] = frag<RV>(st, 1);
     gsteps<RV>(x, st, std::make_integer_sequence<int, (RV + H) * KF * 2 * NB>());
+    // EP = 1: the last row's accumulators were written by the group's last two MFMAs, which the compiler cannot see inside their
+    // assembly statements: the wait states between a matrix-pipe write and a VALU read of the same register (11 for an 8-pass
+    // instruction) are ours to provide here; everywhere else >= 4 MFMAs lie between the last write and the first read
+    // (the statement takes the row's accumulators as in-out operands: a bare s_nop does not keep the compiler from moving the first
+    // reads above it -- it did, in the Mish instance: the first channel pair of every group's last row came out wrong now and then)
+    if constexpr (EP == 1) asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
     last_row<RV>(x, st, std::make_integer_sequence<int, NMICRO>());
   }
 
@@ -494,11 +650,11 @@ struct ConvWalk {
   }
 };
 
-template <int KT, int KF, int ACT, bool STATS, bool DY>
+template <int KT, int KF, int ACT, bool STATS, bool DY, int EP = 0>
 __device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsigned char* smem) {
   using G = Geo<KT, KF>;
   if (a.prio) __builtin_amdgcn_s_setprio(3);
-  ConvWalk<KT, KF, ACT, STATS, DY> wk(a, (const lds_byte*)smem);
+  ConvWalk<KT, KF, ACT, STATS, DY, EP> wk(a, (const lds_byte*)smem);
 
   // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
   Item pf;
@@ -560,6 +716,12 @@ void nhwc_conv_scalar_kernel(NhwcConvArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
   nhwc_conv_body<KT, KF, ACT, STATS, DY>(a, smem);
 }
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
+__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
+void nhwc_conv_fine_kernel(NhwcConvArgs a) {           // EP = 1: one scalar micro-op per MFMA
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
+  nhwc_conv_body<KT, KF, ACT, STATS, DY, 1>(a, smem);
+}
 
 // w [co][ci][KT][KF] fp32 -> per-wave A fragments: [q][tap][kc][lane][j] = w'[16q + (lane&15)][32kc + 8(lane>>4) + j][tap]
 // (transpose_flip: w'[m][k][dt][df] = w[k][m][KT-1-dt][KF-1-df], the data gradient's weights)
@@ -612,7 +774,9 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   // 2 (default): per instance what measured faster -- scalar for the activation epilogues of the forward, packed for the dy form
   const int sopt = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE);
   const bool scalar = sopt == 1 || (sopt == 2 && !a.z2 && act != VS_ACT_NONE);
-#define VS_NHWC_LAUNCH3(A, S, D) do { if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
+  const bool fine = vs_opt(VS_OPT_CONV_EPILOGUE) == 1;
+#define VS_NHWC_LAUNCH3(A, S, D) do { if (fine) hipLaunchKernelGGL((nhwc_conv_fine_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
+                                      else if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
                                       else hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); } while (0)
 #define VS_NHWC_LAUNCH(A, S) VS_NHWC_LAUNCH3(A, S, false)
   if (a.z2) {            // data gradient with the activation-derivative epilogue: act = the activation whose derivative is taken

@@ -518,6 +518,90 @@ class SpecWavDataset:
         return emb, target, mixed, seq_len, target_wav, phase
 
 
+def host_collate(items) -> tuple:
+    """The CPU half of ``SpecWavDataset.collate`` (train_collate_fn, utils/dataset.py:84-114, without the per-item librosa STFT):
+    drops items whose embedding is [0] (:93-95) and stacks the rest -> (emb [B,E], target [B,T,F], wav [B,S], seq_len [B],
+    target_wav [B,S]), or None when nothing is left.  Runs in the DataLoader's worker processes."""
+    items = [it for it in items if it[0].tolist() != [0]]
+    if not items:
+        return None
+    return (torch.stack([it[0].float().reshape(-1) for it in items]), torch.stack([it[1].float() for it in items]),
+            torch.stack([it[2] for it in items]), torch.stack([it[3] for it in items]).reshape(-1), torch.stack([it[4] for it in items]))
+
+
+class BatchFeeder:
+    """Feeds ``Trainer.fit`` from the on-disk training set so that the step never waits for its input (the
+    reference: ``DataLoader(num_workers=14, pin_memory=True)``, utils/dataset.py:60-68, with librosa's STFT inside every worker).
+
+      * items are read by ``num_workers`` worker processes (``c.train_config['num_workers']``) of a ``torch.utils.data.DataLoader``
+        whose batch sampler is this rank's ``EpochShard`` -- the sharding is exactly the synchronous loop's -- into pinned memory;
+      * batch k + 1 goes host -> device on a copy stream while step k runs (the stream first waits for what the caller's stream has
+        been given so far: its buffers may be blocks that work still reads);
+      * the GPU front end (``audio.wav_to_spec``: wav -> normalised dB spectrogram + phase for the whole batch) of batch k + 1 is
+        enqueued on the caller's stream when the consumer comes back for it, i.e. behind step k's optimizer.
+    ``feeder.epoch(e)`` yields what ``SpecWavDataset.collate`` returns: (emb, target, mixed, seq_len, target_wav, phase), or six Nones
+    for a batch whose items were all filtered out.  On a CPU device (tests) the copies are plain and there are no streams."""
+
+    def __init__(self, dataset: "SpecWavDataset", shard: EpochShard, device, num_workers: Optional[int] = None, prefetch_factor: int = 2):
+        self.ds, self.shard, self.device = dataset, shard, torch.device(device)
+        nw = dataset.c.train_config.get("num_workers", 0) if num_workers is None else num_workers
+        self.num_workers = max(0, int(nw))
+        self.prefetch_factor = prefetch_factor
+        self.cuda = self.device.type == "cuda"
+        self._copy = torch.cuda.Stream(self.device) if self.cuda else None
+        self.acfg = dataset.c.audio[dataset.c.audio["backend"]]
+
+    def host_batches(self, epoch: int):
+        """The DataLoader of one epoch: host tuples (``host_collate``) in ``EpochShard`` order."""
+        from torch.utils.data import DataLoader
+        kw = dict(batch_sampler=list(self.shard.epoch(epoch)), collate_fn=host_collate, num_workers=self.num_workers,
+                  pin_memory=self.cuda)
+        if self.num_workers > 0:
+            kw.update(prefetch_factor=self.prefetch_factor, persistent_workers=False)
+        return DataLoader(self.ds, **kw)
+
+    def _start(self, host):
+        """host tuple -> device buffers being filled on the copy stream (+ the event that says they are)"""
+        if host is None:
+            return None
+        emb, target, wav, seq_len, target_wav = host
+        if not self.cuda:
+            return (emb.to(self.device), target.to(self.device), wav.to(self.device), seq_len.to(self.device), target_wav), None
+        dst = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in (emb, target, wav, seq_len)]
+        self._copy.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._copy):
+            for d, t in zip(dst, (emb, target, wav, seq_len)):
+                d.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return (dst[0], dst[1], dst[2], dst[3], target_wav), (ev, host)       # the pinned source stays referenced until the copy is done
+
+    def _finish(self, staged):
+        """the front end of a staged batch on the caller's stream"""
+        from . import audio
+        if staged is None:
+            return (None,) * 6
+        (emb, target, wav, seq_len, target_wav), ev = staged
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev[0])
+        mixed, phase = audio.wav_to_spec(wav, self.acfg, want_phase=True)
+        return emb, target, mixed, seq_len, target_wav, phase
+
+    def epoch(self, epoch: int):
+        it = iter(self.host_batches(epoch))
+        host = next(it, _END)
+        if host is _END:
+            return
+        cur = self._finish(self._start(host))
+        while True:
+            host = next(it, _END)                              # already waiting in the loader's queue in the steady state
+            staged = self._start(host) if host is not _END else _END
+            yield cur                                          # the consumer enqueues its step on this batch
+            if staged is _END:
+                return
+            cur = self._finish(staged)                         # behind that step on the caller's stream
+
+
 def synthetic_batches(steps: int, B: int, T: int, F: int, E: int, hop: int, device, seed: int = 0):
     """Batches of the reference's shape with random content (bench.py, smoke tests): one fixed batch
     per distinct seed, yielded ``steps`` times."""
@@ -576,7 +660,8 @@ def main(argv=None):
     else:
         ds = SpecWavDataset(c, train=True)
         shard = EpochShard(len(ds), b, rank, world, c.train_config["seed"])
-        batches = lambda e: (ds.collate([ds[i] for i in idx], dev) for idx in shard.epoch(e))
+        feeder = BatchFeeder(ds, shard, dev)                  # worker processes + copy stream: the step never waits for its input
+        batches = feeder.epoch
     log = lambda step, loss: print(("validation" if step <= 0 else "step %d" % step) + " loss %.5f" % loss, flush=True)
     tr.fit(batches, args.epochs, log_dir, log)
     if world > 1:
