@@ -221,6 +221,18 @@ def main():
                     help="training mode: the reference's SI-SNR loss through the GPU iSTFT (default), or a fixed upstream gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / bf16 / fp32_strict sub-objects of the training line")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="train mode at --gpus 1: run the N > 1 code path of the step (bucket all-reduces over a one-rank RCCL group, "
+                         "loss through the host ring, skip flag in the bucket) -- what one GPU can measure of it")
+    ap.add_argument("--split-allreduce", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1 (or --force-collectives): start the BiLSTM + head segment of the gradient all-reduce at the library's "
+                         "leaves event, beside the conv backward.  auto: both forms are timed for a few untimed steps and the faster one is kept")
+    ap.add_argument("--loss-lag", type=int, default=0, choices=[0, 1],
+                    help="N > 1: 1 = train_step returns the loss of the step before (the host never waits for the device)")
+    ap.add_argument("--data", default="resident", choices=["resident", "files"],
+                    help="train mode: 'files' writes a synthetic on-disk training set to /tmp and times Trainer.fit over it through "
+                         "BatchFeeder (worker processes, pinned memory, copy stream, GPU STFT) instead of one batch resident in HBM")
+    ap.add_argument("--workers", type=int, default=None, help="--data files: DataLoader worker processes (default: min(14, cores - 2))")
     ap.add_argument("--serial-backward", action="store_true",
                     help="weight gradients in order on the one stream (default: on the library's side stream, "
                          "beside the BatchNorm backward passes; same results)")
@@ -246,6 +258,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    forced = args.force_collectives and world == 1 and args.mode == "train"
+    if forced:
+        from voicesplit_amd.sharding import init_single_rank_group
+        init_single_rank_group("nccl", device_id=dev)
 
     import voicesplit_amd as V
     from voicesplit_amd import _lib
@@ -294,28 +310,105 @@ def main():
     # --loss fixed: a fixed d(loss)/d(mask) instead of the loss head
     dmask = (torch.randn(nb, T_FRAMES, N_FREQ, generator=g) / nb).to(dev)
 
-    def make_trainer(m):
-        # the product's own training step (voicesplit_amd/trainer.py = train.py:86-117 per rank):
-        # forward, criterion, backward, one flat gradient all-reduce, Adam, loss.item()
-        from voicesplit_amd.trainer import Trainer
+    def train_cfg():
         cfg = V.default_config(model_name=args.model)
         cfg.loss["loss_name"] = {"sisnr": "si_snr", "powerlaw": "power_law_compression", "fixed": "si_snr"}[args.loss]
         cfg.train_config["learning_rate"] = 1e-4                    # random data: keep the weights finite
+        return cfg
+
+    def make_trainer(m, split=None):
+        # the product's own training step (voicesplit_amd/trainer.py = train.py:86-117 per rank):
+        # forward, criterion, backward, the gradient all-reduce, Adam, the loss value on the host
+        from voicesplit_amd.trainer import Trainer
         fixed = (lambda mask, mixed, tgt, sl, ph: (mask * dmask).sum()) if args.loss == "fixed" else None
-        tr = Trainer(m, cfg, rank, world, criterion=fixed)
+        tr = Trainer(m, train_cfg(), rank, world, criterion=fixed, force_collectives=forced, loss_lag=args.loss_lag,
+                     split_allreduce=(args.split_allreduce != "off") if split is None else split)
         if os.environ.get("VOICESPLIT_EARLY_LOSS") == "0":           # A/B: the blocking loss.item() behind optimizer.step()
             tr.early_loss_read = False
         return tr
 
     units_per_step = B                                              # utterances (windows) per rank and step
+    split_choice = None
     if train:
         trainer = make_trainer(model)
         bucket = trainer.bucket
         batch = (dvec, target, spec, seq_len, None, phase)
+        comm_path = world > 1 or forced
 
         def step():
-            trainer.train_step(batch)
+            # N > 1: the steady state of Trainer.fit -- the skip decision came with an earlier step's bucket, this rank's flag for the
+            # batch two steps ahead rides in this one (a resident batch is never missing)
+            if comm_path:
+                trainer.train_step(batch, have=True, next_missing=0.0)
+            else:
+                trainer.train_step(batch)
             return bucket.flat
+
+        feed_info = None
+        if args.data == "files":
+            # the step fed from the on-disk training set instead of one resident batch.  A synthetic set in the
+            # reference's layout (utils/dataset.py:8-41: *-emb.pt, *-target.pt, *-mixed.wav, *-target.wav), 4 batches per rank; read by
+            # worker processes, pinned, copied on a side stream, STFT on the GPU (voicesplit_amd/trainer.py: BatchFeeder).
+            import shutil
+            import numpy as np
+            from scipy.io import wavfile
+            from voicesplit_amd.trainer import BatchFeeder, EpochShard, SpecWavDataset
+            root = f"/tmp/vs_bench_data_r{rank}"
+            shutil.rmtree(root, ignore_errors=True)
+            os.makedirs(root)
+            n_items = 4 * B
+            rng = np.random.default_rng(5 + rank)
+            gd = torch.Generator().manual_seed(5 + rank)
+            t_w = time.perf_counter()
+            for i in range(n_items):
+                stem = os.path.join(root, "%06d" % i)
+                e_ = torch.randn(EMB, generator=gd)
+                torch.save(e_ / e_.norm(), stem + "-emb.pt")
+                torch.save(torch.rand(T_FRAMES, N_FREQ, generator=gd), stem + "-target.pt")
+                wavfile.write(stem + "-mixed.wav", 16000, (rng.standard_normal(160 * (T_FRAMES - 1)) * 0.1).astype(np.float32))
+                wavfile.write(stem + "-target.wav", 16000, (rng.standard_normal(160 * (T_FRAMES - 1)) * 0.1).astype(np.float32))
+            cfg_d = train_cfg()
+            cfg_d.dataset = {"train_dir": root, "test_dir": root,
+                             "format": {"emb": "*-emb.pt", "mixed": "*-mixed.pt", "target": "*-target.pt",
+                                        "target_wav": "*-target.wav", "mixed_wav": "*-mixed.wav"}}
+            ds = SpecWavDataset(cfg_d, train=True)
+            nw = args.workers if args.workers is not None else max(1, min(14, (os.cpu_count() or 4) - 2))
+            feeder = BatchFeeder(ds, EpochShard(len(ds), B, 0, 1, seed=1), dev, num_workers=nw)      # (each rank has its own directory)
+            fed = feeder.epoch(0, chain=(args.steps + args.warmup) // 4 + 8)
+            feed_info = {"items_on_disk": n_items, "workers": nw, "write_s": round(time.perf_counter() - t_w, 1),
+                         "mb_per_batch_read": round(B * (2 * 4 * 160 * (T_FRAMES - 1) + 4 * T_FRAMES * N_FREQ + 4 * EMB) / 1e6, 1)}
+
+            def step():                                                # noqa: F811
+                b_ = next(fed)
+                if comm_path:
+                    trainer.train_step(b_, have=True, next_missing=0.0)
+                else:
+                    trainer.train_step(b_)
+                return bucket.flat
+
+        if comm_path and args.split_allreduce == "auto" and trainer.split_allreduce:
+            # Which form of the exchange is faster on THIS node is a property of its fabric and of how RCCL's kernels share the CUs with
+            # the conv backward: time both for a few steps (outside the timed region, all ranks agree on the maximum) and keep the winner.
+            def probe(on, k=6):
+                trainer.split_allreduce = on
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                if dist:
+                    dist.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(k):
+                    step()
+                torch.cuda.synchronize()
+                t_ = torch.tensor([(time.perf_counter() - t0_) / k * 1e3], dtype=torch.float64, device=dev)
+                if dist:
+                    dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return float(t_.item())
+            ms_on, ms_off = probe(True), probe(False)
+            trainer.split_allreduce = ms_on <= ms_off
+            split_choice = {"chosen": "split" if trainer.split_allreduce else "one collective behind the backward",
+                            "ms_per_step_split": round(ms_on, 3), "ms_per_step_single": round(ms_off, 3),
+                            "note": "6 untimed steps each before the warm-up, maximum over ranks"}
     elif args.mode == "forward":
         def step():
             with torch.no_grad():
@@ -365,7 +458,7 @@ def main():
         return el, ms, calls
 
     if train and world > 1:
-        # N > 1 self-diagnosis: HIP events around every gradient all-reduce, host time of the EmptyBatch MIN-reduce; the communicator's
+        # N > 1 self-diagnosis: HIP events around every gradient all-reduce; the communicator's
         # first collectives (ring setup, buffer registration) run in the warm-up -- at least one warm-up step even with --warmup 0
         if args.warmup < 1:
             step()
@@ -376,21 +469,32 @@ def main():
     comm = None
     if train and world > 1:
         ar = bucket.collective_ms()[-args.steps:]
+        ae = bucket.collective_ms(early=True)[-args.steps:]
         fl = trainer.flag_ms[-args.steps:]
         trainer.set_comm_timing(False)
-        mine = torch.tensor([elapsed_local[0] / args.steps * 1e3, sum(ar) / max(1, len(ar)), max(ar) if ar else 0.0,
-                             sum(fl) / max(1, len(fl))], dtype=torch.float64, device=dev)
+        mean_ = lambda v: sum(v) / max(1, len(v))
+        mine = torch.tensor([elapsed_local[0] / args.steps * 1e3, mean_(ar), max(ar) if ar else 0.0, mean_(ae), max(ae) if ae else 0.0,
+                             float(len(fl))], dtype=torch.float64, device=dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rows = torch.stack(allr).cpu()
         comm = {"step_ms_per_rank_min": round(float(rows[:, 0].min()), 3), "step_ms_per_rank_max": round(float(rows[:, 0].max()), 3),
-                "allreduce_ms": round(float(rows[:, 1].mean()), 3), "allreduce_ms_max_over_ranks_and_steps": round(float(rows[:, 2].max()), 3),
-                "flag_ms": round(float(rows[:, 3].mean()), 3),
-                "note": "allreduce_ms: HIP-event time of the flat 75.5 MB gradient all-reduce per step (bucket.all_reduce, trainer.py), mean over ranks "
-                        "and timed steps; it includes waiting for the slowest rank's backward.  flag_ms: host wall time of the EmptyBatch MIN-reduce "
-                        "(a 4-byte all-reduce + .item()) in front of every step.  step_ms_per_rank_*: each rank's own clock around its timed steps "
-                        "(before the closing barrier)"}
+                "allreduce_tail_ms": round(float(rows[:, 1].mean()), 3), "allreduce_tail_ms_max_over_ranks_and_steps": round(float(rows[:, 2].max()), 3),
+                "allreduce_early_ms": round(float(rows[:, 3].mean()), 3), "allreduce_early_ms_max_over_ranks_and_steps": round(float(rows[:, 4].max()), 3),
+                "split_allreduce": bool(trainer.split_allreduce), "loss_lag": trainer.loss_lag,
+                "blocking_flag_reduces_in_the_timed_steps": int(rows[:, 5].max()),
+                "note": "allreduce_tail_ms: HIP-event time of the collective behind the backward pass (bucket.all_reduce: the whole 75.5 MB bucket, or -- "
+                        "split_allreduce -- the conv stack's 2.2 MB + the two spare slots); it includes waiting for the slowest rank's backward.  "
+                        "allreduce_early_ms: the BiLSTM + head segment (73 MB) on the side stream, started at the library's leaves event beside the conv "
+                        "backward.  Mean over ranks and timed steps.  No per-step flag collective and no .item() in the step (trainer.py); "
+                        "step_ms_per_rank_*: each rank's own clock around its timed steps (before the closing barrier)"}
+        if split_choice:
+            comm["split_allreduce_calibration"] = split_choice
 
+    if train and forced:
+        comm = {"forced_collectives_on_one_rank": True, "split_allreduce": bool(trainer.split_allreduce), "loss_lag": trainer.loss_lag}
+        if split_choice:
+            comm["split_allreduce_calibration"] = split_choice
     # ---- RCCL leg (outside the timed region) ---------------------------------------------------------
     # N > 1: every rank must hold the same bucket after the step's all-reduce (a checksum per rank, gathered).
     # N = 1: the step's exchange is a no-op, so the device collective is exercised once on its own: a
@@ -411,7 +515,8 @@ def main():
             else:
                 # (under torch.distributed.run the group has to come from the launcher's store: see the helper)
                 from voicesplit_amd.sharding import init_single_rank_group
-                init_single_rank_group("nccl", device_id=dev)
+                if not forced:
+                    init_single_rank_group("nccl", device_id=dev)
                 keep = bucket.flat.clone()
                 bucket.all_reduce(1, force=True)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -424,6 +529,8 @@ def main():
                 rccl = {"rccl_ranks": 1, "bucket_mb": round(bucket.flat.numel() * 4 / 1e6, 1),
                         "one_rank_allreduce_ms": round(e0.elapsed_time(e1) / 5, 3),
                         "note": "one-rank ncclAllReduce of the gradient bucket on the device, outside the timed region"}
+                if comm:
+                    rccl.update(comm)
                 tdist.destroy_process_group()
         except AssertionError:
             raise
@@ -581,6 +688,34 @@ def main():
             leg["roofline"], leg["stage_ms"] = leg_roofline(fms, fcalls, FK, math, "forward" + ("" if math == "f16x3" else "_" + math))
         return leg
 
+    # ---- the reference's own eval shapes: validation() runs B = 1 (utils/generic_utils.py:495), the fast test B = 5 (:545) ----
+    def latency_leg(m):
+        m.eval()
+        prev = ops.get_conv_math()
+        out = {"note": "eval-mode forward of ONE call at the reference's own evaluation batch sizes (validation(): B = 1, utils/generic_utils.py:495; "
+                       "test_fast_all_checkpoints: B = 5, :545), 301 frames, weights prepared once; mean of 20 calls after 3 warm-up calls, "
+                       "host-timed around a device synchronize (latency, not throughput); cpu_baseline.forward_b1 is the same call on the host cores"}
+        try:
+            for math in ("f16x3", "bf16"):
+                ops.set_conv_math(math)
+                for b_ in (1, 5):
+                    xs, ds = spec[:b_].contiguous(), dvec[:b_].contiguous()
+                    with torch.no_grad():
+                        for _ in range(3):
+                            m(xs, ds)
+                        torch.cuda.synchronize()
+                        t0_ = time.perf_counter()
+                        for _ in range(20):
+                            m(xs, ds)
+                        torch.cuda.synchronize()
+                    ms_ = (time.perf_counter() - t0_) / 20 * 1e3
+                    out[f"b{b_}_{'fp32_class' if math == 'f16x3' else 'bf16'}_ms"] = round(ms_, 3)
+                    out[f"b{b_}_{'fp32_class' if math == 'f16x3' else 'bf16'}_utt_per_s"] = round(b_ / ms_ * 1e3, 1)
+        finally:
+            ops.set_conv_math(prev)
+            m.train()
+        return out
+
     # ---- BASELINE configs[4] next to the training line: 30 s clips as independent 301-frame windows, 256 per forward batch ----
     def longform_leg(m, math, clips=51, steps=2):
         from voicesplit_amd import sharding, streaming
@@ -647,11 +782,15 @@ def main():
         finally:
             ops.set_conv_math(prev)
 
-    fwd = fwd16 = other = strict = lform = None
+    fwd = fwd16 = other = strict = lform = lat = None
+    if not train:
+        feed_info = None
     if train and not args.no_extras:
         fwd = forward_leg(model, "f16x3" if conv_math == "bf16" else conv_math)      # configs[1]: fp32-class forward
         if conv_math == "bf16":
             fwd16 = forward_leg(model, "bf16")
+        if rank == 0 and B >= 5:
+            lat = latency_leg(model)
         ops.release_workspaces()
         torch.cuda.empty_cache()
         lform = {m_: longform_leg(model, m_) for m_ in (("bf16", "f16x3") if conv_math == "bf16" else (conv_math,))}
@@ -707,6 +846,34 @@ def main():
         }
         if args.mode == "longform":
             line["clips_per_s"] = round(world * args.clips * args.steps / elapsed, 2)
+        if train and feed_info is not None:
+            line["data"] = "synthetic, read from files"
+            line["feeding"] = dict(feed_info, note="every step's batch comes from disk through voicesplit_amd.trainer.BatchFeeder: DataLoader worker "
+                                                   "processes over SpecWavDataset.__getitem__ (2 wav reads + 2 torch.load per item), pinned memory, "
+                                                   "host -> device on a copy stream beside the step before, wav -> spectrogram + phase on the GPU")
+        # the sub-legs' headline numbers inside `config` (the driver's record keeps metric / value / config / roofline / cpu_baseline in
+        # full and only the NAMES of other keys)
+        also = {}
+        if fwd is not None:
+            also["configs[1] forward fp32-class"] = {"utt_per_s": fwd["value"], "ms_per_step": fwd["ms_per_step"],
+                                                     "conv5x5_frac_of_833TF": fwd.get("roofline", {}).get("frac"),
+                                                     "lstm_gemm_frac": fwd.get("roofline", {}).get("lstm_input_gemm", {}).get("frac")}
+        if fwd16 is not None:
+            also["forward bf16"] = {"utt_per_s": fwd16["value"], "ms_per_step": fwd16["ms_per_step"]}
+        if lform is not None:
+            also["configs[4] long-form"] = {k_: {"windows_per_s": v_["value"], "conv5x5_frac": v_.get("roofline", {}).get("frac")} for k_, v_ in lform.items()}
+        if other is not None:
+            also["training step " + ("fp32-class" if conv_math == "bf16" else "bf16")] = {"utt_per_s": other["value"], "ms_per_step": other["ms_per_step"]}
+        if lat is not None:
+            also["eval latency (reference's B = 1 / B = 5)"] = {k_: v_ for k_, v_ in lat.items() if k_.endswith("_ms")}
+        if roof.get("second_kernel"):
+            also["weight gradient 5x5 frac"] = roof["second_kernel"]["frac"]
+        if roof.get("lstm_input_gemm"):
+            also["lstm input GEMM stage frac"] = roof["lstm_input_gemm"]["frac"]
+        if also:
+            line["config"]["also_measured"] = also
+        if lat is not None:
+            line["eval_latency"] = lat
         if fwd is not None:
             line["forward"] = fwd
         if fwd16 is not None:

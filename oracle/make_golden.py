@@ -354,8 +354,33 @@ def main_real():
           f"-> {os.path.getsize(p) / 1e3:.0f} kB")
 
 
+def main_demo_clips():
+    """tests/golden/demo_clips.npz: four 3 s crops of the reference's demo mixtures (datasets/LibriSpeech/audios_demo/2_speakers/
+    noisy = the mixture, enhanced = the target speaker) as int16 -- data for the real-audio training test of the bf16 configuration
+    (tests/test_gpu_trainer.py: overfit at the reference's own Adam lr 1e-2, config.json:23-25).  A fixture is data: only samples."""
+    from scipy.io import wavfile
+    from oracle._refimport import REFERENCE_ROOT
+    root = os.path.join(REFERENCE_ROOT, "datasets/LibriSpeech/audios_demo/2_speakers")
+    names = ["1701-141760-0023.251-136532-0023.wav", "1988-147956-0028.84-121123-0026.wav",          # (the clips of >= 4.1 s)
+             "2078-142845-0028.4153-186222-0000.wav", "4831-18525-0005.3576-138058-0010.wav"]
+    mixed, target = [], []
+    for n in names:
+        sr, m = wavfile.read(os.path.join(root, "noisy", n))
+        sr2, t = wavfile.read(os.path.join(root, "enhanced", n))
+        assert sr == sr2 == 16000 and m.dtype == np.float32 and t.dtype == np.float32
+        lo = 16000
+        mixed.append(np.clip(np.round(m[lo:lo + 48000] * 32767.0), -32768, 32767).astype(np.int16))
+        target.append(np.clip(np.round(t[lo:lo + 48000] * 32767.0), -32768, 32767).astype(np.int16))
+    p = os.path.join(GOLDEN_DIR, "demo_clips.npz")
+    np.savez_compressed(p, mixed=np.stack(mixed), target=np.stack(target), sample_rate=np.array(16000),
+                        source=np.array([f"datasets/LibriSpeech/audios_demo/2_speakers/{{noisy,enhanced}}/{n}[16000:64000]" for n in names]))
+    print(f"demo_clips: {len(names)} clips -> {os.path.getsize(p) / 1e3:.0f} kB")
+
+
 if __name__ == "__main__":
-    if "--bf16-envelope" in sys.argv:
+    if "--demo-clips" in sys.argv:
+        main_demo_clips()
+    elif "--bf16-envelope" in sys.argv:
         main_bf16_envelope()
     elif "--audio" in sys.argv:
         main_audio()

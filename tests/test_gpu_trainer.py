@@ -505,3 +505,90 @@ def test_n_gt_1_step_on_one_rank_split_allreduce_pinned_loss_and_no_device_drain
     finally:
         torch.Tensor.item, torch.Tensor.tolist = real_item, real_tolist
         dist.destroy_process_group()
+
+
+def test_bf16_trains_on_real_audio_at_the_references_hyper_parameters():
+    """four 3 s crops of the reference's demo mixtures (tests/golden/demo_clips.npz: noisy = the mixture,
+    enhanced = the target speaker; oracle/make_golden.py --demo-clips), the full-size model, the reference's optimizer settings --
+    Adam lr 1e-2 (config.json:23-25), SI-SNR criterion (train.py:97-103) -- 150 steps on that one batch, once in the bf16 configuration
+    and once in the fp32-class arithmetic from the same initialisation.  Both must fit the batch, neither may explode or lose the
+    persistent recurrence, and the bf16 run must end where the fp32-class run ends (mean of the last 10 steps within 0.5 dB).
+    The trajectories are kept (gpurun_out/ -> profiles/)."""
+    import voicesplit_amd as V
+    from voicesplit_amd import audio
+    from voicesplit_amd.trainer import Trainer
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_clips.npz"))
+    mixed_wav = torch.from_numpy(d["mixed"].astype(np.float32) / 32767.0).cuda()
+    target_wav = torch.from_numpy(d["target"].astype(np.float32) / 32767.0).cuda()
+    c = V.default_config()
+    assert c.train_config["learning_rate"] == 1e-2 and c.train_config["optimizer"] == "adam"      # the reference's config.json values
+    acfg = c.audio[c.audio["backend"]]
+    mixed, phase = audio.wav_to_spec(mixed_wav, acfg, want_phase=True)
+    target, _ = audio.wav_to_spec(target_wav, acfg, want_phase=False)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(4, 256, generator=g)
+    emb = (emb / emb.norm(dim=1, keepdim=True)).cuda()            # (the GE2E encoder's weights are not part of the reference tree)
+    seq_len = torch.full((4,), mixed_wav.shape[1], dtype=torch.int32, device="cuda")
+    batch = (emb, target, mixed, seq_len, None, phase)
+    steps = 150
+    traj = {}
+    for math in ("f16x3", "bf16"):
+        torch.manual_seed(21)
+        with _math(math):
+            tr = Trainer(V.VoiceSplit(c).cuda(), c)
+            traj[math] = [tr.train_step(batch) for _ in range(steps)]           # raises LossExploded on NaN / > 1e8
+            assert tr.model.lstm_status() == 0
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "trajectory_real_audio_lr1e-2.json"), "w") as f:
+        json.dump(traj, f, indent=1)
+    f32, b16 = np.array(traj["f16x3"]), np.array(traj["bf16"])
+    assert np.isfinite(f32).all() and np.isfinite(b16).all()
+    start, end32, end16 = f32[:3].mean(), f32[-10:].mean(), b16[-10:].mean()
+    assert start - end32 > 3.0, f"the fp32-class run did not fit the batch: {start:.2f} -> {end32:.2f} dB"
+    assert b16[:3].mean() - end16 > 3.0, f"the bf16 run did not fit the batch: {b16[:3].mean():.2f} -> {end16:.2f} dB"
+    assert abs(end16 - end32) <= 0.5, (end16, end32)
+
+
+def test_batch_feeder_on_the_device_equals_the_synchronous_collate(tmp_path):
+    """BatchFeeder.epoch (worker processes -> pinned memory -> copy stream -> GPU front end behind the consumer's step) yields, batch for
+    batch and bit for bit, what the synchronous ``ds.collate([ds[i] for i in idx], dev)`` loop of round 5 produced -- also while the
+    consumer keeps the device busy between two batches -- and a batch whose items were all filtered out arrives as six Nones."""
+    from scipy.io import wavfile
+    import voicesplit_amd as V
+    from voicesplit_amd.trainer import BatchFeeder, EpochShard, SpecWavDataset
+    c = V.default_config()
+    rng = np.random.default_rng(1)
+    g = torch.Generator().manual_seed(1)
+    n = 10
+    for i in range(n):
+        stem = str(tmp_path / ("%06d" % i))
+        torch.save(torch.randn(256, generator=g) if i not in (4, 5) else torch.tensor([0]), stem + "-emb.pt")
+        torch.save(torch.rand(61, 601, generator=g), stem + "-target.pt")
+        wavfile.write(stem + "-mixed.wav", 16000, (rng.standard_normal(9600) * 0.1).astype(np.float32))
+        wavfile.write(stem + "-target.wav", 16000, (rng.standard_normal(9600) * 0.1).astype(np.float32))
+    c.dataset = {"train_dir": str(tmp_path), "test_dir": str(tmp_path),
+                 "format": {"emb": "*-emb.pt", "mixed": "*-mixed.pt", "target": "*-target.pt",
+                            "target_wav": "*-target.wav", "mixed_wav": "*-mixed.wav"}}
+    ds = SpecWavDataset(c)
+    dev = torch.device("cuda")
+    shard = EpochShard(n, 2, 0, 1, shuffle=False)                      # batches [0,1] [2,3] [4,5] (both filtered) [6,7] [8,9]
+    feeder = BatchFeeder(ds, shard, dev, num_workers=2)
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for b in feeder.epoch(0):
+        got.append(b)
+        for _ in range(20):                                            # the "step": the next batch's front end is enqueued behind it
+            busy = busy @ busy * 1e-3
+    torch.cuda.synchronize()
+    want = [ds.collate([ds[i] for i in idx], dev) for idx in shard.epoch(0)]
+    assert len(got) == len(want) == 5
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert (a[0] is None) == (b[0] is None) == (k == 2)
+        if a[0] is None:
+            assert all(t is None for t in a)
+            continue
+        for t, u in zip(a, b):
+            assert torch.equal(t.cpu(), u.cpu())
+    # two epochs chained into one loader pass: the second epoch's batches follow the first's
+    chained = list(feeder.epoch(0, chain=2))
+    assert len(chained) == 10 and torch.equal(chained[5][2], got[0][2])

@@ -126,6 +126,16 @@ struct ConvWalk {
   unsigned vcol[NB];
   int vdma;                                  // per-lane source offset of a DMA chunk inside a tensor row (launch constant)
   __amdgpu_buffer_rsrc_t rout, rz;
+  // EP = 2: the epilogues of a group's last three rows ride on the first MFMAs of the NEXT group (whichever item that belongs to), so
+  // what they need outlives the group: the accumulators, the rows' byte offsets (kOob: no such row -- the three dummies the launch
+  // starts with, the third row of a two-row tail group), the item's column offsets / masks and descriptors, and the ring of z values
+  // of the dy form (filled two epilogue rows ahead, across the group boundary).
+  f32x4 cacc[3][NB];
+  unsigned crow[3];
+  unsigned cvcol[NB];
+  float ccok[NB];
+  __amdgpu_buffer_rsrc_t crout, crz;
+  u2v zq3[3][NB];
   unsigned lds0;
   const lds_byte* smem;
 
@@ -154,6 +164,18 @@ struct ConvWalk {
       const int p = n + df;
       boff[df][0] = p * 128 + ((g ^ swz(p)) << 4);         // column block nb: + 2048 (the swizzle is 8-periodic in p)
       boff[df][1] = boff[df][0] ^ 64;
+    }
+    if constexpr (EP == 2) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        crow[j] = kOob;
+#pragma unroll
+        for (int nb2 = 0; nb2 < NB; ++nb2) { cacc[j][nb2] = f32x4{0.f, 0.f, 0.f, 0.f}; zq3[j][nb2] = u2v{0u, 0u}; }
+      }
+#pragma unroll
+      for (int nb2 = 0; nb2 < NB; ++nb2) { cvcol[nb2] = kOob; ccok[nb2] = 0.f; }
+      crout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out), 0, 0, 0x00020000);      // no records: every access out of range
+      crz = crout;
     }
     {
       const int px = lane >> 3;                            // chunk c of a row: pixel 8 c + lane / 8, LDS piece lane % 8 holds channel
@@ -240,7 +262,11 @@ struct ConvWalk {
     }
   }
   __device__ __forceinline__ unsigned row_offset(const Item& x, int k) const {
-    return k < x.o1 ? (unsigned)((x.cls + k * a.dil) * a.F) * 128u : kOob;
+    // (the product through an opaque scalar multiply: written in C++ the compiler branched around it -- a jump per row and store
+    // inside the group's straight-line block)
+    unsigned off;
+    asm("s_mul_i32 %0, %1, %2" : "=s"(off) : "s"(x.cls + k * a.dil), "s"(a.F * 128));
+    return k < x.o1 ? off : kOob;
   }
 
   // One group: output rows ro .. ro+RV-1 of item x (RV = R, or the even tail of the item; rows >= x.o1 are computed and
@@ -268,7 +294,7 @@ struct ConvWalk {
   // is what fits behind one MFMA without holding up the next), NB stores.
   static constexpr int NSTAGE = EP == 0 ? (DY ? 9 : ACT == VS_ACT_MISH ? 7 : 1)
                                         : (DY ? (ACT == VS_ACT_MISH ? 19 : 7) : ACT == VS_ACT_MISH ? 12 : ACT == VS_ACT_RELU ? 2 : STATS ? 4 : 1);
-  static constexpr int NSTORE = EP == 0 ? NB : 2 * NB;               // EP = 1: pack and store are two micro-ops
+  static constexpr int NSTORE = EP == 0 ? NB : 2 * NB;               // EP >= 1: pack and store are two micro-ops
   static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + NSTORE;
 
   template <int RV>
@@ -345,19 +371,73 @@ struct ConvWalk {
   static __device__ __forceinline__ float i_bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 #endif
 
-  template <int RV, int r, int q>
-  __device__ __forceinline__ void micro_fine(const Item& x, GroupState<RV>& st) {
+  // The row an epilogue works on.  MODE 1 (EP = 1): row IDX of the group being computed.  MODE 2 (EP = 2): position IDX of the group's
+  // epilogue sequence -- 0..2 the rows carried over from the previous group, 3 + r row r of this one; MODE 3: the carried rows once more,
+  // behind the launch's last group (nothing to prefetch).
+  static constexpr int epi_rows(int RV) { return RV >= 4 ? RV : 3; }          // EP = 2: epilogue rows a group works off (three carried in + its own but the last three)
+  template <int RV, int MODE, int IDX, int nb2, int e>
+  __device__ __forceinline__ float acc_of(GroupState<RV>& st) const {
+    if constexpr (MODE >= 2 && IDX < 3) return cacc[IDX][nb2][e];
+    else return st.acc[MODE == 1 ? IDX : IDX - 3][nb2][e];
+  }
+  template <int RV, int MODE, int IDX>
+  __device__ __forceinline__ unsigned rowoff_of(const Item& x, const GroupState<RV>& st) const {
+    if constexpr (MODE >= 2 && IDX < 3) return crow[IDX];
+    else return row_offset(x, st.ro + (MODE == 1 ? IDX : IDX - 3));
+  }
+  template <int RV, int MODE, int IDX, int nb2>
+  __device__ __forceinline__ unsigned vcol_of() const {
+    if constexpr (MODE >= 2 && IDX < 3) return cvcol[nb2];
+    else return vcol[nb2];
+  }
+  template <int RV, int MODE, int IDX, int nb2>
+  __device__ __forceinline__ u2v z_of(const GroupState<RV>& st) const {
+    if constexpr (MODE >= 2) return zq3[IDX % 3][nb2];
+    else return st.zq[IDX % 3][nb2];
+  }
+  // EP = 2, dy form: position IDX's first micro-op fetches z for the position two further on -- a row of this group, one of the rows it
+  // will carry out (the next group's positions 0 and 1), or (IDX = 0) the third carried row
+  template <int RV, int MODE, int IDX>
+  __device__ __forceinline__ void prefetch_z(const Item& x, GroupState<RV>& st) {
+    if constexpr (MODE == 1) {
+      if constexpr (IDX + 2 < RV) load_z<RV>(x, st, IDX + 2);
+    } else {
+      constexpr int t = IDX + 2, P_ = epi_rows(RV);
+      if constexpr (MODE == 3) {
+        if constexpr (t == 2) {
+#pragma unroll
+          for (int nb2 = 0; nb2 < NB; ++nb2) zq3[2][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(crz, cvcol[nb2], crow[2], 0));
+        }
+      } else if constexpr (t == 2) {
+#pragma unroll
+        for (int nb2 = 0; nb2 < NB; ++nb2) zq3[2][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(crz, cvcol[nb2], crow[2], 0));
+      } else {
+        constexpr int row = t < P_ ? t - 3 : (RV >= 4 ? RV - 3 : 0) + (t - P_);      // in-group row, or carry-out row t - P_ (0 or 1)
+        const unsigned so = row_offset(x, st.ro + row);
+#pragma unroll
+        for (int nb2 = 0; nb2 < NB; ++nb2) zq3[t % 3][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rz, vcol[nb2], so, 0));
+      }
+    }
+  }
+
+  template <int RV, int MODE, int IDX, int q>
+  __device__ __forceinline__ void epi(const Item& x, GroupState<RV>& st) {
     constexpr bool mish = ACT == VS_ACT_MISH;
     constexpr int Q0 = DY ? 1 : 0;
+    constexpr bool carried = MODE >= 2 && IDX < 3;
+    constexpr int r = MODE == 1 ? IDX : IDX - 3;               // the row inside the group (not for carried rows)
     if constexpr (DY && q == 0) {
-      if constexpr (r + 2 < RV) load_z<RV>(x, st, r + 2);
+      prefetch_z<RV, MODE, IDX>(x, st);
 #pragma unroll
-      for (int nb2 = 0; nb2 < NB; ++nb2) st.mk[nb2] = (st.ro + r < x.o1) ? st.cok[nb2] : 0.f;
+      for (int nb2 = 0; nb2 < NB; ++nb2) {
+        if constexpr (carried) st.mk[nb2] = crow[IDX] != kOob ? ccok[nb2] : 0.f;
+        else st.mk[nb2] = (st.ro + r < x.o1) ? st.cok[nb2] : 0.f;
+      }
     } else if constexpr (q < Q0 + NB * 2 * NSTAGE) {
       constexpr int v = (q - Q0) / NSTAGE, sg = (q - Q0) % NSTAGE, nb2 = v / 2, pr = v % 2;
       if constexpr (DY) {
         if constexpr (sg == 0) {
-          const unsigned u = st.zq[r % 3][nb2][pr];
+          const unsigned u = z_of<RV, MODE, IDX, nb2>(st)[pr];
           st.tz.x = i_bf_lo(u); st.tz.y = i_bf_hi(u);
         } else if constexpr (sg == 1) {
           st.ty.x = i_fma(st.tz.x, csc[pr].x, csh[pr].x); st.ty.y = i_fma(st.tz.y, csc[pr].y, csh[pr].y);
@@ -375,7 +455,7 @@ struct ConvWalk {
           else if constexpr (sg == 12) { st.tq.x = i_mul_4ln2(st.tr.x); st.tq.y = i_mul_4ln2(st.tr.y); }                                  // y was scaled by log2(e)
           else if constexpr (sg == 13) { st.tn.x = i_fma(st.tp.x, st.tq.x, st.tn.x); st.tn.y = i_fma(st.tp.y, st.tq.y, st.tn.y); }
           else if constexpr (sg == 14) { st.tw.x = i_mul(st.tr.x, st.tn.x); st.tw.y = i_mul(st.tr.y, st.tn.y); }                          // Mish'
-          else if constexpr (sg == 15) { st.ty.x = i_mul(st.acc[r][nb2][2 * pr], st.tw.x); st.ty.y = i_mul(st.acc[r][nb2][2 * pr + 1], st.tw.y); }
+          else if constexpr (sg == 15) { st.ty.x = i_mul(acc_of<RV, MODE, IDX, nb2, 2 * pr>(st), st.tw.x); st.ty.y = i_mul(acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st), st.tw.y); }
           else if constexpr (sg == 16) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
           else if constexpr (sg == 17) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else {
@@ -383,8 +463,8 @@ struct ConvWalk {
             st.y[nb2][pr] = st.ty;
           }
         } else {                       // ReLU (ACT_NONE is not a dy instance)
-          if constexpr (sg == 2) st.ty.x = st.ty.x > 0.f ? st.acc[r][nb2][2 * pr] : 0.f;
-          else if constexpr (sg == 3) st.ty.y = st.ty.y > 0.f ? st.acc[r][nb2][2 * pr + 1] : 0.f;
+          if constexpr (sg == 2) st.ty.x = st.ty.x > 0.f ? acc_of<RV, MODE, IDX, nb2, 2 * pr>(st) : 0.f;
+          else if constexpr (sg == 3) st.ty.y = st.ty.y > 0.f ? acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st) : 0.f;
           else if constexpr (sg == 4) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
           else if constexpr (sg == 5) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else {
@@ -394,7 +474,7 @@ struct ConvWalk {
         }
       } else {
         if constexpr (sg == 0) {
-          st.y[nb2][pr].x = i_fma(st.acc[r][nb2][2 * pr], csc[pr].x, csh[pr].x); st.y[nb2][pr].y = i_fma(st.acc[r][nb2][2 * pr + 1], csc[pr].y, csh[pr].y);
+          st.y[nb2][pr].x = i_fma(acc_of<RV, MODE, IDX, nb2, 2 * pr>(st), csc[pr].x, csh[pr].x); st.y[nb2][pr].y = i_fma(acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st), csc[pr].y, csh[pr].y);
         } else if constexpr (mish) {
           if constexpr (sg == 1) { st.ty.x = i_min_20(st.y[nb2][pr].x); st.ty.y = i_min_20(st.y[nb2][pr].y); }
           else if constexpr (sg == 2) { st.ty.x = i_mul_log2e(st.ty.x); st.ty.y = i_mul_log2e(st.ty.y); }
@@ -411,7 +491,7 @@ struct ConvWalk {
           st.y[nb2][pr].x = i_max0(st.y[nb2][pr].x); st.y[nb2][pr].y = i_max0(st.y[nb2][pr].y);
         } else if constexpr (STATS) {
           if constexpr (sg == 1) {
-            const float m = ((st.ro + r < x.o1) & (vcol[nb2] != kOob)) ? 1.f : 0.f;
+            const float m = ((rowoff_of<RV, MODE, IDX>(x, st) != kOob) & (vcol_of<RV, MODE, IDX, nb2>() != kOob)) ? 1.f : 0.f;
             st.tp.x = i_mul(st.y[nb2][pr].x, m); st.tp.y = i_mul(st.y[nb2][pr].y, m);
           } else if constexpr (sg == 2) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else { a2[pr].x = i_fma(st.tp.x, st.y[nb2][pr].x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.y[nb2][pr].y, a2[pr].y); }
@@ -422,7 +502,8 @@ struct ConvWalk {
       if constexpr (sq % 2 == 0) {
         st.pk[nb2] = u2v{vs_pack_bf16(st.y[nb2][0].x, st.y[nb2][0].y), vs_pack_bf16(st.y[nb2][1].x, st.y[nb2][1].y)};
       } else {
-        __builtin_amdgcn_raw_buffer_store_b64(st.pk[nb2], rout, vcol[nb2], row_offset(x, st.ro + r), 0);                 // out of range: dropped
+        if constexpr (carried) __builtin_amdgcn_raw_buffer_store_b64(st.pk[nb2], crout, cvcol[nb2], crow[IDX], 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(st.pk[nb2], rout, vcol[nb2], row_offset(x, st.ro + r), 0);              // out of range: dropped
       }
     }
   }
@@ -430,7 +511,7 @@ struct ConvWalk {
   template <int RV, int r, int q>
   __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
     if constexpr (EP == 1) {
-      micro_fine<RV, r, q>(x, st);
+      epi<RV, 1, r, q>(x, st);
     } else if constexpr (!DY) {
       // out = act(acc * scale + shift).  Mish(y) = y n / (n + 2), n = u (u + 2), u = e^y (y clamped at 20, where n / (n + 2)
       // is 1 to fp32): one exp2 and one rcp per channel, everything else packed, cut into stages like the dy form below
@@ -520,13 +601,57 @@ struct ConvWalk {
     }
   }
 
+  // ---- EP = 2: which micro-ops ride behind which MFMA ---------------------------------------------------------------------------------
+  // A group's MFMAs are numbered in issue order (slots); its epilogue work is ONE list: the micro-ops of the three carried rows, then
+  // of its own rows 0 .. RV - 4.  Carried rows can start at slot 0, row r behind the first MFMA of window row r + KT (its last
+  // product was four or more MFMAs earlier).  The list is dealt out at an even pace over the slots that are left -- one micro-op per
+  // slot for 5x5 groups of eight rows: 648 micro-ops of the dy form on 800 MFMAs, where EP = 1 left the last four rows' epilogues on
+  // 120 MFMAs and none -- limited by what is available; what does not fit runs behind the group's last MFMA.
+  static constexpr int nm_of(int RV, int i) { return (i < RV - 1 ? i : RV - 1) - (i - (KT - 1) > 0 ? i - (KT - 1) : 0) + 1; }
+  static constexpr int slot_base(int RV, int i) { int s = 0; for (int k = 0; k < i; ++k) s += 2 * NB * KF * nm_of(RV, k); return s; }
+  template <int RV>
+  struct Plan {
+    static constexpr int NSLOT = slot_base(RV, RV + H);
+    static constexpr int P_ = epi_rows(RV);
+    static constexpr int L = P_ * NMICRO;
+    struct Tab { short lo[NSLOT + 1]; };
+    static constexpr Tab make() {
+      Tab t{};
+      int c = 0, s = 0;
+      for (int i = 0; i < RV + H; ++i) {
+        int rows = i - H;                                  // own rows whose epilogue may have started: r + H + 1 <= i
+        if (rows < 0) rows = 0;
+        if (rows > P_ - 3) rows = P_ - 3;
+        const int avail = (3 + rows) * NMICRO;
+        for (int k = 0; k < 2 * NB * KF * nm_of(RV, i); ++k) {
+          t.lo[s] = (short)c;
+          const int left = NSLOT - s;
+          int want = (L - c + left - 1) / left;
+          if (want < 1) want = 1;
+          int n = avail - c;
+          if (n > want) n = want;
+          if (n < 0) n = 0;
+          c += n;
+          ++s;
+        }
+      }
+      t.lo[NSLOT] = (short)c;
+      return t;
+    }
+    static constexpr Tab tab = make();
+  };
+  template <int RV, int MODE, int M0, int... Ds>
+  __device__ __forceinline__ void epis(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Ds...>) {
+    (epi<RV, MODE, (M0 + Ds) / NMICRO, (M0 + Ds) % NMICRO>(x, st), ...);
+  }
+
   template <int RV, int GI, int MM>
   __device__ __forceinline__ void gmfma(const Item& x, GroupState<RV>& st) {
     constexpr int nb = GI % NB, kc = (GI / NB) % 2, df = (GI / (2 * NB)) % KF, i = GI / (2 * NB * KF), ls = GI % (2 * NB * KF);
     constexpr int r_lo = i - (KT - 1) > 0 ? i - (KT - 1) : 0, r_hi = i < RV - 1 ? i : RV - 1;
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
-    if constexpr (EP == 1) {
+    if constexpr (EP >= 1) {
       // Volatile assembly: the builtin is a pure value to the compiler, which placed it on either side of the (volatile) stage
       // instructions -- the micro-ops then clustered again.  Weights in AGPRs (all 50 fragments: read-only, every use is here),
       // accumulators in VGPRs: the epilogue reads them without v_accvgpr_read (128 per group), and the first product of an
@@ -542,11 +667,16 @@ struct ConvWalk {
       st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
     }
     if constexpr (MM == 0 && GI % 4 == 0 && GI / 4 < G::UNITS) row_unit<GI / 4>(bt);      // the next group's window: one row per unit
-    if constexpr (DY && GI == 0 && MM == 0) {               // z of the group's first two rows
+    if constexpr (EP == 2) {
+      constexpr int sl = slot_base(RV, i) + ls * nm + MM;
+      constexpr int m0 = Plan<RV>::tab.lo[sl], m1 = Plan<RV>::tab.lo[sl + 1];
+      epis<RV, 2, m0>(x, st, std::make_integer_sequence<int, m1 - m0>());
+    }
+    if constexpr (EP != 2 && DY && GI == 0 && MM == 0) {    // z of the group's first two rows
       load_z<RV>(x, st, 0);
       if constexpr (RV > 1) load_z<RV>(x, st, 1);
     }
-    if constexpr (i >= H + 1) {
+    if constexpr (EP != 2 && i >= H + 1) {
       // The epilogue micro-ops of the row completed before window row i ride on its MFMAs: every stride-th MFMA
       // carries `per` of them (stride > 1 when the row has more MFMAs than micro-ops: spread them out; per > 1 near
       // the end of a group, where a window row has few MFMAs -- 7x1: 4 -- and several micro-ops must share one)
@@ -618,7 +748,58 @@ struct ConvWalk {
     // (the statement takes the row's accumulators as in-out operands: a bare s_nop does not keep the compiler from moving the first
     // reads above it -- it did, in the Mish instance: the first channel pair of every group's last row came out wrong now and then)
     if constexpr (EP == 1) asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
-    last_row<RV>(x, st, std::make_integer_sequence<int, NMICRO>());
+    if constexpr (EP != 2) {
+      last_row<RV>(x, st, std::make_integer_sequence<int, NMICRO>());
+    } else {
+      using PL = Plan<RV>;
+      epis<RV, 2, PL::tab.lo[PL::NSLOT]>(x, st, std::make_integer_sequence<int, PL::L - PL::tab.lo[PL::NSLOT]>());       // what did not fit (two-row tail groups)
+      // hand the last three rows over to the next group.  The last row's accumulators come from the group's final MFMAs: wait them out
+      // (in-out operands: see above) before anything copies them.
+      asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
+      constexpr int first = RV >= 4 ? RV - 3 : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (first + j < RV) {
+          crow[j] = row_offset(x, st.ro + first + j);
+#pragma unroll
+          for (int nb2 = 0; nb2 < NB; ++nb2) cacc[j][nb2] = st.acc[first + j < RV ? first + j : 0][nb2];
+        } else {
+          crow[j] = kOob;
+        }
+      }
+#pragma unroll
+      for (int nb2 = 0; nb2 < NB; ++nb2) {
+        cvcol[nb2] = vcol[nb2];
+        if constexpr (DY) ccok[nb2] = st.cok[nb2];
+      }
+      crout = rout;
+      if constexpr (DY) {
+        crz = rz;
+        // the z ring was filled at this group's phase: position PL::P_ of it is the next group's position 0
+        constexpr int sh = PL::P_ % 3;
+        if constexpr (sh != 0) {
+          u2v tmp[3][NB];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int nb2 = 0; nb2 < NB; ++nb2) tmp[k][nb2] = zq3[(k + sh) % 3][nb2];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int nb2 = 0; nb2 < NB; ++nb2) zq3[k][nb2] = tmp[k][nb2];
+        }
+      }
+    }
+  }
+
+  // EP = 2: behind the launch's last group the three carried rows still owe their epilogue
+  __device__ __forceinline__ void flush_carry() {
+    if constexpr (EP == 2) {
+      Item x{};
+      GroupState<2> st;
+      st.ro = 0;
+      epis<2, 3, 0>(x, st, std::make_integer_sequence<int, 3 * NMICRO>());
+    }
   }
 
   __device__ __forceinline__ void flush_stats() {
@@ -696,6 +877,7 @@ __device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsi
       cbuf ^= 1;
     }
   }
+  wk.flush_carry();
   wk.flush_stats();
 }
 
@@ -721,6 +903,12 @@ __global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
 void nhwc_conv_fine_kernel(NhwcConvArgs a) {           // EP = 1: one scalar micro-op per MFMA
   __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
   nhwc_conv_body<KT, KF, ACT, STATS, DY, 1>(a, smem);
+}
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
+__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
+void nhwc_conv_carry_kernel(NhwcConvArgs a) {          // EP = 2: ... and the last three rows' epilogues behind the NEXT group's first MFMAs
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
+  nhwc_conv_body<KT, KF, ACT, STATS, DY, 2>(a, smem);
 }
 
 // w [co][ci][KT][KF] fp32 -> per-wave A fragments: [q][tap][kc][lane][j] = w'[16q + (lane&15)][32kc + 8(lane>>4) + j][tap]
@@ -774,8 +962,9 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   // 2 (default): per instance what measured faster -- scalar for the activation epilogues of the forward, packed for the dy form
   const int sopt = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE);
   const bool scalar = sopt == 1 || (sopt == 2 && !a.z2 && act != VS_ACT_NONE);
-  const bool fine = vs_opt(VS_OPT_CONV_EPILOGUE) == 1;
-#define VS_NHWC_LAUNCH3(A, S, D) do { if (fine) hipLaunchKernelGGL((nhwc_conv_fine_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
+  const bool fine = vs_opt(VS_OPT_CONV_EPILOGUE) == 1, carry = vs_opt(VS_OPT_CONV_EPILOGUE) == 2;
+#define VS_NHWC_LAUNCH3(A, S, D) do { if (carry) hipLaunchKernelGGL((nhwc_conv_carry_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
+                                      else if (fine) hipLaunchKernelGGL((nhwc_conv_fine_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
                                       else if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
                                       else hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); } while (0)
 #define VS_NHWC_LAUNCH(A, S) VS_NHWC_LAUNCH3(A, S, false)

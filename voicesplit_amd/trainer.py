@@ -551,10 +551,13 @@ class BatchFeeder:
         self._copy = torch.cuda.Stream(self.device) if self.cuda else None
         self.acfg = dataset.c.audio[dataset.c.audio["backend"]]
 
-    def host_batches(self, epoch: int):
-        """The DataLoader of one epoch: host tuples (``host_collate``) in ``EpochShard`` order."""
+    def host_batches(self, epoch: int, chain: int = 1):
+        """The DataLoader of one epoch: host tuples (``host_collate``) in ``EpochShard`` order.  chain > 1: the index batches of
+        epochs epoch .. epoch + chain - 1 behind one another in ONE loader pass (a benchmark over a small set: the worker processes
+        start once, not every few steps)."""
         from torch.utils.data import DataLoader
-        kw = dict(batch_sampler=list(self.shard.epoch(epoch)), collate_fn=host_collate, num_workers=self.num_workers,
+        index_batches = [idx for e in range(epoch, epoch + chain) for idx in self.shard.epoch(e)]
+        kw = dict(batch_sampler=index_batches, collate_fn=host_collate, num_workers=self.num_workers,
                   pin_memory=self.cuda)
         if self.num_workers > 0:
             kw.update(prefetch_factor=self.prefetch_factor, persistent_workers=False)
@@ -587,8 +590,8 @@ class BatchFeeder:
         mixed, phase = audio.wav_to_spec(wav, self.acfg, want_phase=True)
         return emb, target, mixed, seq_len, target_wav, phase
 
-    def epoch(self, epoch: int):
-        it = iter(self.host_batches(epoch))
+    def epoch(self, epoch: int, chain: int = 1):
+        it = iter(self.host_batches(epoch, chain))
         host = next(it, _END)
         if host is _END:
             return
