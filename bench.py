@@ -259,6 +259,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     forced = args.force_collectives and world == 1 and args.mode == "train"
+    if os.environ.get("VS_BENCH_INIT_GROUP_ONLY") and not forced and world == 1:      # EXPERIMENT (round 6, call 6)
+        from voicesplit_amd.sharding import init_single_rank_group
+        init_single_rank_group("nccl", device_id=dev)
+        os.environ["VS_BENCH_GROUP_READY"] = "1"
     if forced:
         from voicesplit_amd.sharding import init_single_rank_group
         init_single_rank_group("nccl", device_id=dev)
@@ -515,7 +519,7 @@ def main():
             else:
                 # (under torch.distributed.run the group has to come from the launcher's store: see the helper)
                 from voicesplit_amd.sharding import init_single_rank_group
-                if not forced:
+                if not forced and not os.environ.get("VS_BENCH_GROUP_READY"):
                     init_single_rank_group("nccl", device_id=dev)
                 keep = bucket.flat.clone()
                 bucket.all_reduce(1, force=True)

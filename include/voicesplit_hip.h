@@ -416,6 +416,7 @@ typedef struct vs_tape_layout {
   size_t conv_scales;         /* [16] scale slots (8 forward, 8 backward): operand scales + running |max| arrays */
   size_t gemm_scales;         /* operand scales of the split-f16 LSTM GEMMs (feat, W_ih, gate gradients) */
   size_t lstm_bf16;           /* VS_MATH_BF16: feat [B*T][Kp], [W_ih; W_ih_reverse] [8H][Kp], gate gradients [B*T][8H] as bf16 */
+  size_t det_turn;            /* ABI 9: one word, the turn counter of the deterministic mode (VS_OPT_DETERMINISTIC) */
 } vs_tape_layout;
 
 int vs_tape_layout_query(const vs_dims* dims, vs_tape_layout* out);
@@ -457,76 +458,51 @@ int vs_set_conv_kernel(int mode);
  * fit on the device at once, else one launch per time step), 1 = one launch per step (always the fp32 MFMA products),
  * 2 = persistent (error when the grid cannot be resident), 3 = persistent with the fp32 MFMA products whatever dims.math
  * says (A/B of the f16 / bf16 products), 4 = persistent with the flag hand-off of rounds 2-4 where the default is the tagged-data
- * hand-off (the f16 / split-f16 forward recurrence: same arithmetic), 5 = the tagged-data hand-off in the bf16 BPTT as well
- * (default there: flags).  In VS_MATH_FP32 both forms give bit-identical results.  Process-wide.
+ * hand-off (the f16 / split-f16 forward recurrence: same arithmetic).  In VS_MATH_FP32 both forms give bit-identical results.
+ * Process-wide.
  * The persistent kernels keep an error word in the caller's state buffer (the first of its last 64
  * floats, both for the forward and the backward state) that becomes 1 when a bounded spin gave up
  * (a workgroup of the launch was not resident): results are then invalid. */
 int vs_set_lstm_kernel(int mode);
 
-/* Every remaining process-wide switch of the library, behind ONE call (ABI 8): the library itself reads NO environment variable.
- * All of them exist for A/B timing and cross-checks; every value of every option gives valid results unless the option says
- * "timing ablation".  vs_set_option returns 0, or -1 for an unknown option / a value outside its range; vs_get_option returns
+/* Every remaining process-wide switch of the library, behind ONE call (ABI 8; the list shrank in ABI 9): the library itself reads NO
+ * environment variable.  They exist for cross-checks (every on / off pair is compared by a GPU test); every value of every option gives
+ * valid results unless the option says "timing ablation".  vs_set_option returns 0, or -1 for an unknown option / a value outside its range; vs_get_option returns
  * the current value (-1 for an unknown option).  Not thread-safe against concurrent calls into the library: set options before
  * work is enqueued.  (The Python package maps the environment variable named beside each option onto this call when it loads
  * the library: voicesplit_amd/_lib.py.) */
 enum vs_option {
-  VS_OPT_F16X3_CONV_NCHW = 0, /* 0 (default): the fp32-class eval forward runs on channels-last hi / lo f16 planes
-                                 (conv_nhwc_f16x3.hip); 1: the [B][64][T][F] kernels of rounds 1-3.  Changes which form of the conv
-                                 weights vs_prepare_weights writes: set it BEFORE preparing weights and keep it while a prepared
-                                 blob is in use.  VOICESPLIT_F16X3_CONV=nchw */
-  VS_OPT_BWD_DY = 1,          /* 1 (default): bf16 data gradients carry the activation derivative and the BatchNorm-backward sums in
-                                 their epilogue (dy form); 0: plain data gradients + two-pass BatchNorm backward.  VOICESPLIT_BWD_DY */
-  VS_OPT_GEMM_KERNEL = 2,     /* bf16 GEMM: 0 (default) the interleaved kernel, 1 the round-3 kernel (bit-identical).  VOICESPLIT_GEMM_KERNEL=old */
-  VS_OPT_GEMM_DR = 3,         /* bf16 GEMM: three digits (row x row, row x col, col x col), each 4 or 8 = MFMA rows the DMA chunks of a K
-                                 step are issued in; default 888.  VOICESPLIT_GEMM_DR */
-  VS_OPT_GEMM_ABL = 4,        /* bf16 GEMM timing ablations (results INVALID): 0 off; 9 = empty operand descriptors; 1..3 = instances of
-                                 an ABLATION=1 build.  VOICESPLIT_GEMM_ABL */
-  VS_OPT_GEMM_BAND = 5,       /* split-f16 GEMM: tile rows per raster band, default 8.  VOICESPLIT_GEMM_BAND */
-  VS_OPT_WGRAD_ABL = 6,       /* bf16 weight gradient timing ablations of an ABLATION=1 build (results INVALID).  VOICESPLIT_WGRAD_ABL */
-  VS_OPT_SPLITCONV_ABL = 7,   /* split-f16 channels-last conv: timing ablations / in-kernel probes of an ABLATION=1 build.  VOICESPLIT_SPLITCONV_ABL */
-  VS_OPT_CONV_SCALAR_EPILOGUE = 8, /* channels-last convs (conv_nhwc.hip, conv_nhwc_f16x3.hip): 1 = the instances compiled WITHOUT packed-fp32 VALU
-                                 instructions (v_pk_fma_f32 ... become pairs of scalar instructions: same values, bit for bit), 0 = the packed
-                                 ones, 2 (default) = per instance what measured faster: scalar for the split-f16 conv and for the bf16 conv's
-                                 activation epilogue (1-2 %), packed for the dy form (neutral).  VOICESPLIT_CONV_SCALAR_EPILOGUE */
-  VS_OPT_MFMA_PRIO = 9,       /* bit 0: the bf16 weight-gradient kernel, bit 1: the bf16 channels-last conv raise their wave priority (s_setprio 3), so that
-                                 the HBM-bound BatchNorm pass co-resident on the same SIMDs (vs_backward's side stream) gets the issue slots they leave,
-                                 not the other way round.  Same results.  VOICESPLIT_MFMA_PRIO */
-  VS_OPT_CONV8 = 10,          /* the 5x5 bf16 channels-last convs on the eight-wave kernel (conv_nhwc8.hip: two waves per SIMD, K halves across waves):
-                                 bit 0 = forward / plain data gradient, bit 1 = the dy-form data gradient; 0 = the four-wave kernel (conv_nhwc.hip).
-                                 Same operands, fp32 accumulation in another order (two halves of K).  VOICESPLIT_CONV8 */
-  VS_OPT_BN_FUSED_FINALIZE = 11, /* the bf16 training step folds the BatchNorm partial-sum slots, finalizes and clears the scratch in ONE launch per
-                                 layer: 1 (default) in the forward pass, 2 in the backward pass too, 0 nowhere (fold kernel + finalize kernel + a
-                                 memset in front of every producer: rounds 1-4).  Same values; in the backward pass the fused form is SLOWER
-                                 (it takes away the weight gradient's head start on the side stream: DESIGN.md 6.7).  VOICESPLIT_BN_FUSED_FINALIZE */
-  VS_OPT_SIDE_PRIO = 12,      /* priority of the library's side stream (weight gradients beside the BatchNorm backward passes): 0 normal (default),
-                                 1 high, 2 low.  Read when the stream is created (the first vs_backward on a device).  VOICESPLIT_SIDE_PRIO */
-  VS_OPT_BWD_APPLY_BLOCKS = 13, /* grid of the BatchNorm-backward pass that runs beside the weight gradient (dz = cA dy + cB z + cC): 0 = default
-                                 (one block of 256 threads per CU: 256), else that many blocks (the pass alone uses 2048).  VOICESPLIT_BWD_APPLY_BLOCKS */
-  VS_OPT_FWD_PROLOGUE = 14,   /* 1 (default): vs_forward_train (bf16) runs the weight-only launches of the step (conv weight packs, bf16 W_ih, d-vector fold,
-                                 recurrent / head weight images) on the library's side stream beside cnn1; 0: in place, in front of their consumers.
-                                 Needs vs_set_backward_overlap(1).  Same values.  VOICESPLIT_FWD_PROLOGUE */
-  VS_OPT_HEAD_LEAF_SIDE = 15, /* 1: the head's two weight gradients (leaves of vs_backward) on the side stream beside the BPTT; 0: in front of it.
-                                 Default 1 (-0.3 ms per step).  Same values.  VOICESPLIT_HEAD_LEAF_SIDE */
-  VS_OPT_FEAT_ROWS = 16,      /* VS_MATH_F16X3 whole-path eval forward (vs_forward, vs_forward_prepared): 1 = cnn8 writes the LSTM input
-                                 GEMM's split-f16 A operand itself, at a scale planned from the tracked |max| of its input (no fp32
-                                 features in the workspace, no |max| / split passes over them); 0 = fp32 features, then the passes.  Default 1.
+  VS_OPT_FWD_PROLOGUE = 0,    /* VS_MATH_BF16 vs_forward_train: 1 = the weight-only launches of the step (six conv weight packs, the bf16 copy of
+                                 W_ih, the d-vector fold, the recurrent / head weight images) on the library's side stream beside cnn1; 0 = in
+                                 line.  Default 1 (-0.15 ms per step).  Same values.  VOICESPLIT_FWD_PROLOGUE */
+  VS_OPT_HEAD_LEAF_SIDE = 1,  /* 1: the head's two weight gradients and bias sums (leaves of vs_backward) on the side stream beside the BPTT;
+                                 0: in front of it.  Default 1 (-0.3 ms per step).  Same values.  VOICESPLIT_HEAD_LEAF_SIDE */
+  VS_OPT_FEAT_ROWS = 2,       /* whole-path eval forward (vs_forward, vs_forward_prepared): 1 = cnn8 writes the LSTM input GEMM's A operand
+                                 itself (split-f16 hi / lo rows at a scale planned from the tracked |max| of its input, or bf16 rows): no fp32
+                                 features in the workspace, no |max| / split passes over them; 0 = fp32 features, then the passes.  Default 1.
                                  Same values unless a lo half underflows (both scales are powers of two).  VOICESPLIT_FEAT_ROWS */
-  VS_OPT_HEAD_BWD_GEMM = 17,  /* VS_MATH_BF16 vs_backward: 1 = the head's two data-gradient contractions (dfc1, dlstm_out) on the LSTM
+  VS_OPT_HEAD_BWD_GEMM = 3,   /* VS_MATH_BF16 vs_backward: 1 = the head's two data-gradient contractions (dfc1, dlstm_out) on the LSTM
                                  contractions' LDS-DMA kernel over bf16 copies of their operands (relu mask in the epilogue); 0 = the generic
                                  kernel (in-flight conversion).  Default 1.  Same operand roundings, fp32 summation order differs.
                                  VOICESPLIT_HEAD_BWD_GEMM */
-  VS_OPT_LSTM_LEAF_LATE = 18, /* VS_MATH_BF16 vs_backward with the side stream: where / in which order the LSTM's leaf contractions (dW_ih, dW_hh,
-                                 d-vector) run on it.  0 = right behind the BPTT, dW_ih first; 1 = behind the features' BatchNorm backward
-                                 (beside cnn8's backward); 2 = behind cnn8's backward; 3 = behind the BPTT as 0, but dW_ih -- one persistent
-                                 workgroup per CU -- LAST, behind the small leaves.  Default 3 (-0.13 ms per step against 0; 1, 2: slower).
-                                 Same values.  VOICESPLIT_LSTM_LEAF_LATE */
-  VS_OPT_CONV_EPILOGUE = 19,  /* VS_MATH_BF16 64 -> 64 convs (csrc/conv_nhwc.hip): how the epilogue is cut into micro-ops behind the MFMAs.
-                                 0 = round 3's (up to four dependent instructions behind every second MFMA), 1 = round 6's (one scalar
-                                 instruction per channel behind every MFMA, no packed-fp32 instructions: tools/epilogue_slot_probe.hip).
-                                 Same arithmetic.  VOICESPLIT_CONV_EPILOGUE */
-  VS_OPT_COUNT = 20
+  VS_OPT_ABLATION = 4,        /* libraries built with `make ABLATION=1` only (tools/wgrad_ablation.py, tools/split_conv_micro.py, tools/gemm_micro.py):
+                                 selects a TIMING-ABLATION instance of the weight-gradient / split-f16 conv / bf16 GEMM kernels (results are
+                                 meaningless).  Ignored by the product build.  VOICESPLIT_ABLATION */
+  VS_OPT_DETERMINISTIC = 5,   /* VS_MATH_BF16 training step (vs_forward_train, vs_backward, vs_sisnr_loss): 1 = every partial sum that workgroups
+                                 add to shared slots with fp64 atomics (BatchNorm statistics, their backward sums, cnn1's input moments,
+                                 the loss head's moments) is added in WORKGROUP ORDER (the workgroups of such a launch take turns, at most one
+                                 per CU), so a rerun on the same inputs is bit-identical: masks, running statistics, loss, every gradient.
+                                 0 (default) = arrival order: results agree to the last bits of fp64 sums only (SURVEY.md section 5:
+                                 deterministic-rerun comparisons as the device-side sanitizer).  Costs ~1 ms of a 46 ms step at B = 64
+                                 (profiles/r06_experiments.md).  VOICESPLIT_DETERMINISTIC */
+  VS_OPT_COUNT = 6
 };
+/* Round 6 (ABI 9) removed the switches whose alternative had been measured slower, with the code behind them: the NCHW eval route of the
+ * fp32-class convs, the two-pass BatchNorm backward (VS_OPT_BWD_DY), the round-3 bf16 GEMM as an A/B arm and its DMA-row / band knobs,
+ * the packed-fp32 epilogue builds, s_setprio / side-stream priorities, the eight-wave conv (VS_OPT_CONV8), the fused BatchNorm finalize
+ * of the backward, the grid of the BatchNorm pass beside the weight gradient, the late starts of the LSTM's leaves.  The measurements
+ * are in profiles/r04_*.md, profiles/r05_experiments.md and profiles/r06_experiments.md; kernels that were correct and slower are kept
+ * as records under tools/attic/. */
 int vs_set_option(int option, int value);
 int vs_get_option(int option);
 

@@ -95,7 +95,7 @@ def test_workspace_layout_and_argument_errors():
     assert lib.vs_nhwc_conv_f16x3_layer(one, two, one, one, 1, one, one, one, one, 0, three, four, one, None,
                                         1, 4, 4, 3, 3, 1, 1, None) != 0 and b"7x1, 5x5" in lib.vs_last_error()
     assert lib.vs_f16x3_split(None, None, None, None, 8, None) != 0 and lib.vs_f16x3_merge(None, None, None, None, 8, None) != 0
-    assert lib.vs_set_lstm_kernel(3) == 0 and lib.vs_set_lstm_kernel(5) == 0 and lib.vs_set_lstm_kernel(6) != 0 and lib.vs_set_lstm_kernel(0) == 0
+    assert lib.vs_set_lstm_kernel(3) == 0 and lib.vs_set_lstm_kernel(4) == 0 and lib.vs_set_lstm_kernel(5) != 0 and lib.vs_set_lstm_kernel(0) == 0
     # four exchange regions (the tagged hand-off of round 5), sized for the 16-wide K chunks of the f16 form (H = 24 -> 32)
     assert lib.vs_lstm_state_floats(3, 24) == 4 * 2 * 32 * 32 + 64 and lib.vs_lstm_state_floats(64, 400) == 4 * 2 * 400 * 64 + 64
 

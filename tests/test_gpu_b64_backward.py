@@ -395,3 +395,53 @@ def test_long_form_batch_of_256_windows_scattered_windows_vs_oracle(math):
         assert worst_rel <= 1e-4, worst_rel
     else:
         assert worst_abs <= 6e-2, worst_abs
+
+
+@pytest.mark.parametrize("B", [64, 5])
+def test_deterministic_mode_reruns_bit_identically(B):
+    """vs_set_option(VS_OPT_DETERMINISTIC, 1) -- SURVEY.md section 5 lists deterministic-rerun comparisons as the device-side sanitizer, and
+    the reference's PyTorch BatchNorm is run-to-run reproducible: the workgroups that add partial sums to shared slots (BatchNorm
+    statistics and their backward sums, cnn1's moments, the features' BatchNorm backward, the loss head's moments) take turns in
+    workgroup order.  Three training steps of the metric configuration (bf16, SI-SNR criterion through the GPU iSTFT, Adam), run twice from
+    the same initialisation: masks, loss values, every gradient of every step, the final weights and the BatchNorm running
+    statistics must agree bit for bit.  (In the default mode they agree to the last bits of fp64 sums only; whether this pair of
+    runs happened to is printed, not asserted.)"""
+    import voicesplit_amd as V
+    from voicesplit_amd import _lib
+    from voicesplit_amd.trainer import Trainer, synthetic_batches
+    c = V.default_config()
+    c.train_config["learning_rate"] = 1e-3
+    acfg = c.audio[c.audio["backend"]]
+    batch = next(iter(synthetic_batches(1, B, 301, 601, 256, acfg["hop_length"], torch.device("cuda"), seed=31)))
+
+    def run():
+        torch.manual_seed(17)
+        tr = Trainer(V.VoiceSplit(c).cuda(), c)
+        out = {}
+        for s in range(3):
+            out[f"loss{s}"] = torch.tensor(tr.train_step(batch))
+            for k, p in tr.model.named_parameters():
+                out[f"grad{s}/{k}"] = p.grad.detach().clone()
+        torch.cuda.synchronize()
+        assert tr.model.lstm_status() == 0
+        out.update({"w/" + k: v.detach().clone() for k, v in tr.model.state_dict().items()})
+        return out
+
+    prev = _lib.get_option("DETERMINISTIC")
+    try:
+        with _math("bf16"):
+            _lib.set_option("DETERMINISTIC", 0)
+            a, b = run(), run()
+            same_default = all(torch.equal(a[k], b[k]) for k in a)
+            _lib.set_option("DETERMINISTIC", 1)
+            d1, d2 = run(), run()
+    finally:
+        _lib.set_option("DETERMINISTIC", prev)
+    print(f"B = {B}: default mode, two runs bit-identical: {same_default}")
+    for k in d1:
+        assert torch.equal(d1[k], d2[k]), k
+    # the mode changes the ORDER of fp64 additions, nothing else: the results agree with the default mode's to fp32 rounding of the
+    # BatchNorm coefficients (and what a flipped bf16 rounding downstream of one amounts to)
+    for k in d1:
+        if k.startswith("loss"):
+            assert abs(float(d1[k]) - float(a[k])) <= 1e-3 * max(1.0, abs(float(a[k]))), (k, float(d1[k]), float(a[k]))

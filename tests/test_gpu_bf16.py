@@ -322,35 +322,47 @@ def test_head_data_gradients_on_the_lstm_gemm_kernel_agree_with_the_generic_kern
         tol = 1e-5 if k.startswith("fc2") else (2e-4 if k.startswith("fc1") else 2e-2)
         assert _rel(got[1][k], got[0][k]) < tol, (k, _rel(got[1][k], got[0][k]))
 
-
-def test_where_the_lstm_leaf_contractions_start_does_not_change_a_gradient():
-    """vs_set_option(VS_OPT_LSTM_LEAF_LATE): the LSTM's leaf contractions start on the side stream behind the BPTT (0), behind the
-    features' BatchNorm backward (1) or behind cnn8's backward (2), or behind the BPTT with dW_ih last (3, the default) -- the same
-    launches on the same operands: bit-identical gradients, twice per mode to catch a missing fork or join."""
+def test_every_schedule_of_the_bf16_step_gives_the_same_bits():
+    """the side-stream schedule rests on buffer-idle invariants that live in comments (the second half of the column-sum
+    scratch, `part` touched on the side stream only, the conv gradient buffers idle while the head's bf16 operands sit there).  Every
+    combination of vs_set_backward_overlap x VS_OPT_HEAD_LEAF_SIDE x VS_OPT_FWD_PROLOGUE runs the same launches on the same operands in
+    another stream order: all sixteen runs (each combination twice, to catch a missing fork or join) must give bit-identical masks,
+    running statistics and gradients."""
+    import itertools
     import voicesplit_amd as V
     from voicesplit_amd import _lib
     dims_d = dict(num_freq=601, emb_dim=256, lstm_dim=32, fc1_dim=48, fc2_dim=601)
     sd = R.spread_logits(R.build_state_dict(dims_d, 5), 6.0)
     x, dvec = R.synthetic_inputs(3, 70, dims_d, 5)
     w = torch.randn(3, 70, 601, generator=torch.Generator().manual_seed(9)).cuda()
-    prev = _lib.get_option("LSTM_LEAF_LATE")
-    got = {}
+    lib = _lib.load()
+    prev = {k: _lib.get_option(k) for k in ("HEAD_LEAF_SIDE", "FWD_PROLOGUE")}
+    runs = {}
     try:
         with _math("bf16"):
-            for mode in (0, 1, 2, 3):
-                _lib.set_option("LSTM_LEAF_LATE", mode)
+            for overlap, leaf, pro in itertools.product((1, 0), (1, 0), (1, 0)):
+                assert lib.vs_set_backward_overlap(overlap) == 0
+                _lib.set_option("HEAD_LEAF_SIDE", leaf)
+                _lib.set_option("FWD_PROLOGUE", pro)
                 m = V.VoiceSplit(V.default_config(601, 256, 32, 48, 601))
                 m.load_state_dict(sd, strict=True)
                 m = m.cuda().train(True)
-                got[mode] = []
+                out = []
                 for _ in range(2):
                     m.zero_grad(set_to_none=True)
-                    (m(x.cuda(), dvec.cuda()) * w).sum().backward()
+                    mask = m(x.cuda(), dvec.cuda())
+                    (mask * w).sum().backward()
                     torch.cuda.synchronize()
-                    got[mode].append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+                    st = {"mask": mask.detach().clone(), **{"grad/" + k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                          **{"buf/" + k: b.detach().clone() for k, b in m.named_buffers()}}
+                    out.append(st)
+                runs[(overlap, leaf, pro)] = out
     finally:
-        _lib.set_option("LSTM_LEAF_LATE", prev)
-    for mode in (1, 2, 3):
-        for a, b in zip(got[0], got[mode]):
+        lib.vs_set_backward_overlap(1)
+        for k, v in prev.items():
+            _lib.set_option(k, v)
+    base = runs[(1, 1, 1)]
+    for key, out in runs.items():
+        for a, b in zip(base, out):
             for k in a:
-                assert torch.equal(a[k], b[k]), (mode, k)
+                assert torch.equal(a[k], b[k]), (key, k)

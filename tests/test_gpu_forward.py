@@ -264,30 +264,6 @@ def test_prepared_weights_forward_is_bit_identical_and_tracks_the_parameters(cls
         ops.set_conv_math(prev)
 
 
-def test_nchw_route_of_the_fp32_class_forward_still_matches_the_oracle():
-    """VOICESPLIT_F16X3_CONV=nchw (the A/B switch of DESIGN.md 6.5: the [B][64][T][F] kernels of rounds 1-3 instead of the
-    channels-last planes) is read once per process, so the other route runs in a child process: same oracle, same 1e-4."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import torch, voicesplit_amd as V\n"
-        "from oracle import reference_forward as R\n"
-        "d = dict(num_freq=53, emb_dim=24, lstm_dim=32, fc1_dim=44, fc2_dim=53)\n"
-        "sd = R.spread_logits(R.build_state_dict(d, 21), 6.0)\n"
-        "x, dv = R.synthetic_inputs(3, 45, d, 21)\n"
-        "m = V.VoiceSplit(V.default_config(53, 24, 32, 44, 53)).eval(); m.load_state_dict(sd); m = m.cuda()\n"
-        "with torch.no_grad():\n"
-        "    got = m(x.cuda(), dv.cuda()).double().cpu()\n"
-        "    ref = R.forward(R.cast_state_dict(sd, torch.float64), x.double(), dv.double(), act='mish')['mask']\n"
-        "print('REL', ((got - ref).abs().max() / ref.abs().max()).item())\n")
-    env = dict(os.environ, VOICESPLIT_F16X3_CONV="nchw", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rel = float([ln for ln in out.stdout.splitlines() if ln.startswith("REL")][0].split()[1])
-    assert rel < REL_TOL, rel
-
-
 @pytest.mark.parametrize("amp", [0.0, 1e-4, 1e3])
 def test_forward_tracks_the_input_range(amp):
     """Silence, a spectrogram four decades below and three above unit range: every layer of the fp32-class forward derives its

@@ -173,8 +173,9 @@ def test_fp32_selector_overrides_the_math():
 @pytest.mark.parametrize("B", [64, 2])
 def test_tagged_handoff_soak_and_agrees_with_the_flag_handoff(B):
     """Round 5: the persistent forward recurrence hands the hidden vector over as its own flag (four exchange buffers armed with a
-    sentinel, lstm16_tagged_kernel; the bf16 BPTT has the same hand-off behind vs_set_lstm_kernel(5)).  A protocol error shows as a
-    wrong or poisoned sequence, possibly only once in many launches: 1000 forward (+ 300 tagged BPTT) launches in the bf16
+    sentinel, lstm16_tagged_kernel; the same hand-off in the bf16 BPTT was 5 % slower and left the library in round 6:
+    tools/attic/).  A protocol error shows as a
+    wrong or poisoned sequence, possibly only once in many launches: 1000 forward launches in the bf16
     configuration's arithmetic and 200 in the split-f16 one, at the metric batch (two batch tiles, 200 resident workgroups) and at
     B = 2: every launch bit-identical to the first of its kind, the error word 0 throughout (ops raises on 1), and the result the
     flag hand-off's of rounds 2-4 (bit for bit in the f16 / bf16 kernels; the split-f16 pair differs by fp32 roundings: 4e-7)."""
@@ -190,7 +191,7 @@ def test_tagged_handoff_soak_and_agrees_with_the_flag_handoff(B):
             assert lib.vs_set_lstm_kernel(4) == 0                    # the flag hand-off everywhere
             out_f, gates_f, c_f = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
             dxg_f = ops.bilstm_recurrent_bwd(gates_f, c_f, dout, whh[0], whh[1], math=math)
-            assert lib.vs_set_lstm_kernel(5) == 0                    # tagged forward and (bf16) tagged BPTT
+            assert lib.vs_set_lstm_kernel(0) == 0                    # the default: tagged forward, flag BPTT
             first = ops.bilstm_recurrent_train(xg, whh[0], whh[1], math=math)
             if math == _lib.MATH_BF16:
                 assert all(torch.equal(a, b) for a, b in zip(first, (out_f, gates_f, c_f)))
@@ -202,10 +203,10 @@ def test_tagged_handoff_soak_and_agrees_with_the_flag_handoff(B):
                 if it % 50 == 0 or it == n - 1:
                     assert all(torch.equal(a, b) for a, b in zip(got, first)), (int(math), it)
             assert torch.equal(ops.bilstm_recurrent(xg, whh[0], whh[1], math=math), first[0])
-            if math == _lib.MATH_BF16:
-                for it in range(300):
+            if math == _lib.MATH_BF16:                               # the BPTT (flags) run to run
+                for it in range(100):
                     dxg = ops.bilstm_recurrent_bwd(gates_f, c_f, dout, whh[0], whh[1], math=math)
-                    if it % 50 == 0 or it == 299:
+                    if it % 50 == 0 or it == 99:
                         assert torch.equal(dxg, dxg_f), it
     finally:
         lib.vs_set_lstm_kernel(0)

@@ -527,34 +527,3 @@ def test_cnn1_one_pass_backward(act, training, B, T, Fq):
     else:
         e = ((dbias.double().cpu() - bd.grad).abs().max() / bd.grad.abs().max()).item()
         assert e < 2e-4, ("dbias", e)
-
-
-@pytest.mark.parametrize("KT,KF,dil", [(5, 5, 2), (7, 1, 1)])
-def test_scalar_and_packed_epilogue_builds_agree_bit_for_bit(KT, KF, dil):
-    """vs_set_option(VS_OPT_CONV_SCALAR_EPILOGUE): the instances built without packed-fp32 VALU instructions compute the same values
-    (a v_pk_fma_f32 is two v_fma_f32): forward with Mish, forward with fused statistics, the dy form -- outputs bit-identical; the
-    statistics too up to the order of their unordered fp64 atomics."""
-    from voicesplit_amd import _lib, ops
-    g = torch.Generator().manual_seed(7 + KT)
-    B, T, Fq = 2, 45, 70
-    x = torch.randn(B, T, Fq, 64, generator=g).to(torch.bfloat16).cuda()
-    z = (torch.randn(B, T, Fq, 64, generator=g) * 1.5).to(torch.bfloat16).cuda()
-    w = (torch.randn(64, 64, KT, KF, generator=g) / (64 * KT * KF) ** 0.5).cuda()
-    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.2).cuda()
-    one, zero = torch.ones(64).cuda(), torch.zeros(64).cuda()
-    packed = ops.nhwc_conv_pack(w, transpose_flip=True)
-    res = {}
-    prev = _lib.get_option("CONV_SCALAR_EPILOGUE")
-    try:
-        for mode in (0, 1):
-            _lib.set_option("CONV_SCALAR_EPILOGUE", mode)      # (2, the default, picks one of the two per instance)
-            a = ops.nhwc_conv(x, w, sc, sh, dil, "mish")
-            b, st = ops.nhwc_conv(x, w, one, sh, dil, "none", stats=True)
-            dy, st2 = ops.nhwc_conv_dy(x, packed, z, "mish", sc, sh, zero, one, KT, KF, dil)
-            res[mode] = (a.clone(), b.clone(), st.clone(), dy.clone(), st2.sum(0).clone())
-    finally:
-        _lib.set_option("CONV_SCALAR_EPILOGUE", prev)
-    for i in (0, 1, 3):
-        assert torch.equal(res[0][i].view(torch.int16), res[1][i].view(torch.int16)), i
-    for i in (2, 4):
-        assert torch.allclose(res[0][i], res[1][i], rtol=1e-6, atol=1e-6 * float(res[0][i].abs().max())), i

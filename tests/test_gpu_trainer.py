@@ -511,9 +511,14 @@ def test_bf16_trains_on_real_audio_at_the_references_hyper_parameters():
     """four 3 s crops of the reference's demo mixtures (tests/golden/demo_clips.npz: noisy = the mixture,
     enhanced = the target speaker; oracle/make_golden.py --demo-clips), the full-size model, the reference's optimizer settings --
     Adam lr 1e-2 (config.json:23-25), SI-SNR criterion (train.py:97-103) -- 150 steps on that one batch, once in the bf16 configuration
-    and once in the fp32-class arithmetic from the same initialisation.  Both must fit the batch, neither may explode or lose the
-    persistent recurrence, and the bf16 run must end where the fp32-class run ends (mean of the last 10 steps within 0.5 dB).
-    The trajectories are kept (gpurun_out/ -> profiles/)."""
+    and once in the fp32-class arithmetic from the same initialisation; then the same with lr 1e-3.  Neither run may explode or lose
+    the persistent recurrence, and the bf16 trajectory must stay with the fp32-class one.  What the trajectories look like (recorded:
+    gpurun_out/ -> profiles/r06_trajectory_real_audio.json): at the reference's lr 1e-2 BOTH arithmetics drop by 1 dB in two steps and
+    then sit still at 19.7 (the four-clip batch drives the mask into saturation at that step size) -- bound: every step within 0.5 dB
+    (measured 0.03).  At 1e-3 both fit the batch, 20.7 -> -10 dB in 150 steps, along the same curve for the first hundred steps (10-step
+    means within 0.6 dB; measured 0.33) and then with the spikes of a run at the edge of its step size, which fall on different steps
+    in the two arithmetics (the fp32-class run's worst one is 4 dB high at step 121): bound there = both below -7 dB at the end, the
+    means of the last 10 steps within 1.5 dB (measured: -9.7 fp32-class, -10.4 bf16)."""
     import voicesplit_amd as V
     from voicesplit_amd import audio
     from voicesplit_amd.trainer import Trainer
@@ -532,21 +537,30 @@ def test_bf16_trains_on_real_audio_at_the_references_hyper_parameters():
     batch = (emb, target, mixed, seq_len, None, phase)
     steps = 150
     traj = {}
-    for math in ("f16x3", "bf16"):
-        torch.manual_seed(21)
-        with _math(math):
-            tr = Trainer(V.VoiceSplit(c).cuda(), c)
-            traj[math] = [tr.train_step(batch) for _ in range(steps)]           # raises LossExploded on NaN / > 1e8
-            assert tr.model.lstm_status() == 0
+    for lr in (1e-2, 1e-3):
+        c.train_config["learning_rate"] = lr
+        for math in ("f16x3", "bf16"):
+            torch.manual_seed(21)
+            with _math(math):
+                tr = Trainer(V.VoiceSplit(c).cuda(), c)
+                traj[f"{math} lr={lr:g}"] = [tr.train_step(batch) for _ in range(steps)]           # raises LossExploded on NaN / > 1e8
+                assert tr.model.lstm_status() == 0
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "trajectory_real_audio_lr1e-2.json"), "w") as f:
+    with open(os.path.join("gpurun_out", "trajectory_real_audio.json"), "w") as f:
         json.dump(traj, f, indent=1)
-    f32, b16 = np.array(traj["f16x3"]), np.array(traj["bf16"])
-    assert np.isfinite(f32).all() and np.isfinite(b16).all()
-    start, end32, end16 = f32[:3].mean(), f32[-10:].mean(), b16[-10:].mean()
-    assert start - end32 > 3.0, f"the fp32-class run did not fit the batch: {start:.2f} -> {end32:.2f} dB"
-    assert b16[:3].mean() - end16 > 3.0, f"the bf16 run did not fit the batch: {b16[:3].mean():.2f} -> {end16:.2f} dB"
-    assert abs(end16 - end32) <= 0.5, (end16, end32)
+    for lr in (1e-2, 1e-3):
+        f32, b16 = np.array(traj[f"f16x3 lr={lr:g}"]), np.array(traj[f"bf16 lr={lr:g}"])
+        assert np.isfinite(f32).all() and np.isfinite(b16).all()
+        assert f32[0] - f32[2:].min() > 0.8 and b16[0] - b16[2:].min() > 0.8, (lr, f32[:4], b16[:4])          # both take the first steps down
+        if lr == 1e-2:
+            assert np.abs(b16 - f32).max() <= 0.5, (lr, float(np.abs(b16 - f32).max()))
+        else:
+            k = np.ones(10) / 10
+            m32, m16 = np.convolve(f32, k, "valid"), np.convolve(b16, k, "valid")
+            assert np.abs(m16 - m32)[:90].max() <= 0.6, float(np.abs(m16 - m32)[:90].max())
+            assert f32[-10:].mean() < -7.0 and b16[-10:].mean() < -7.0, (f32[-10:].mean(), b16[-10:].mean())
+            assert abs(b16[-10:].mean() - f32[-10:].mean()) <= 1.5, (b16[-10:].mean(), f32[-10:].mean())
+
 
 
 def test_batch_feeder_on_the_device_equals_the_synchronous_collate(tmp_path):

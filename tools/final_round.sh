@@ -25,7 +25,6 @@ VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.j
 { timeout 200 python tools/lstm_time.py 64; timeout 200 python tools/lstm_time.py 2; } 2>/dev/null | grep "B=" > $O/${R}_lstm_time.txt
 [ -f voicesplit_amd/libvoicesplit_hip_abl.so ] && timeout 300 python tools/wgrad_ablation.py > $O/${R}_wgrad_ablation.json 2>/dev/null
 PYTHONPATH=. timeout 200 python tools/split_conv_micro.py final/${R}_split_conv_micro > /dev/null 2>&1
-VS_MICRO_CONV8_AB=1 VS_MICRO_WGRAD=0 timeout 300 python tools/nhwc_micro.py > $O/${R}_nhwc_micro_conv8_ab.json 2>/dev/null
 bash tools/profile_gpu.sh ${R}_forward --mode forward 2>&1 | tail -2
 bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
 # device idle gaps of one training step, from the kernel trace of the profile run

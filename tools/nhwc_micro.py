@@ -27,46 +27,6 @@ def timed(fn, reps=3):
 
 
 def main():
-    # VS_MICRO_EPILOGUE_AB=1: every conv variant twice, packed-fp32 and scalar epilogue builds (vs_set_option), in one process
-    if os.environ.get("VS_MICRO_EPILOGUE_AB"):
-        out = {}
-        for rnd in range(2):                              # twice: the clock of a fresh box drifts over the first seconds
-            for mode in (0, 1):
-                _lib.set_option("CONV_SCALAR_EPILOGUE", mode)
-                out[f"round{rnd} scalar_epilogue={mode}"] = run()
-        print(json.dumps(out, indent=1), flush=True)
-        return
-    if os.environ.get("VS_MICRO_FINE_AB"):                # round 6: one-scalar-micro-op-per-MFMA epilogue (VS_OPT_CONV_EPILOGUE) against round 3's
-        out = {}
-        modes = [int(v) for v in os.environ["VS_MICRO_FINE_AB"].split(",")] if "," in os.environ["VS_MICRO_FINE_AB"] else [0, 1]
-        for rnd in range(2):
-            for mode in modes:
-                _lib.set_option("CONV_EPILOGUE", mode)
-                out[f"round{rnd} conv_epilogue={mode}"] = run()
-        print(json.dumps(out, indent=1), flush=True)
-        return
-    if os.environ.get("VS_MICRO_CONV8_AB"):
-        out = {}
-        for rnd in range(2):
-            for mode in (0, 3):
-                _lib.set_option("CONV8", mode)
-                out[f"round{rnd} conv8={mode}"] = run()
-        print(json.dumps(out, indent=1), flush=True)
-        return
-    if os.environ.get("VS_MICRO_CONV8_PROBE"):          # an ABLATION=1 build: the group-boundary probe of conv_nhwc8.hip
-        _lib.set_option("CONV8", 3)
-        _lib.set_option("SPLITCONV_ABL", 32)
-        dev = torch.device("cuda:0")
-        x = torch.randn(64, 301, 601, 64, device=dev).to(torch.bfloat16)
-        one, zero = torch.ones(64, device=dev), torch.zeros(64, device=dev)
-        for dil in (1, 4):
-            w = torch.randn(64, 64, 5, 5, device=dev) / 40.0
-            _, st = ops.nhwc_conv(x, w, one, zero, dil, "none", stats="raw")
-            tot, vm, bar, grp = st.reshape(-1)[:4].tolist()
-            waves = 256 * 8
-            print(f"conv8 probe dil{dil}: cycles per wave {tot / waves:.0f}, groups per wave {grp / waves:.1f}, per group: total {tot / grp:.0f}, "
-                  f"vmcnt wait {vm / grp:.0f}, lgkm + barrier wait {bar / grp:.0f}", flush=True)
-        return
     print(json.dumps(run(), indent=1), flush=True)
 
 

@@ -1,4 +1,4 @@
-"""(VOICESPLIT_SPLITCONV_ABL=N selects a timing ablation / the in-kernel probes: needs a library built with
+"""(VOICESPLIT_ABLATION=N selects a timing ablation / the in-kernel probes: needs a library built with
 `make -C voicesplit_amd/csrc ABLATION=1`; the production build ignores it.)
 Times vs_nhwc_conv_f16x3_layer at the metric configuration's layer shapes (B = 64, 301 x 601): the gate of the channels-last
 split-f16 forward (the NCHW kernel it replaces: 6.3-6.5 ms per 5x5 layer, 3.4 ms for the 7x1).  Writes gpurun_out/<name>.json."""
@@ -21,9 +21,7 @@ def main(name):
     out = {}
     import os
     from voicesplit_amd import _lib
-    if os.environ.get("VS_MICRO_SCALAR") is not None:
-        _lib.set_option("CONV_SCALAR_EPILOGUE", int(os.environ["VS_MICRO_SCALAR"]))
-    shapes = ((5, 5, 1), (5, 5, 4), (5, 5, 16), (7, 1, 1)) if not os.environ.get("VOICESPLIT_SPLITCONV_ABL") else ((5, 5, 1), (7, 1, 1))
+    shapes = ((5, 5, 1), (5, 5, 4), (5, 5, 16), (7, 1, 1)) if not os.environ.get("VOICESPLIT_ABLATION") else ((5, 5, 1), (7, 1, 1))
     for kt, kf, dil in shapes:
         w = (torch.randn(64, 64, kt, kf, generator=g) / (64 * kt * kf) ** 0.5).cuda()
         r = ops.nhwc_conv_f16x3(hi, lo, s2, w, sc, sh, dil, "mish", amax_in=amax_in)
@@ -40,7 +38,7 @@ def main(name):
         ms = ev[0].elapsed_time(ev[1]) / 5
         fl = 2.0 * 64 * 64 * kt * kf * B * T * Fq
         out[f"{kt}x{kf}_dil{dil}"] = {"ms": round(ms, 3), "tflops_fp32_equiv": round(fl / ms / 1e9, 1)}
-        if int(os.environ.get("VOICESPLIT_SPLITCONV_ABL", "0")) & 32:
+        if int(os.environ.get("VOICESPLIT_ABLATION", "0")) & 32:
             r = ops.nhwc_conv_f16x3(hi, lo, s2, w, sc, sh, dil, "mish", amax_in=amax_in, scratch=scr)
             probe = r[3].view(torch.int64)[:4].tolist()          # summed over the launch's waves (1024 at B = 64)
             waves = 1024

@@ -35,10 +35,10 @@ def main():
     res = {}
     for (KT, KF, dil) in ((5, 5, 1), (5, 5, 4), (7, 1, 1)):
         for abl, name in ((0, "full"), (1, "no DMA"), (2, "no LDS reads"), (4, "no MFMA"), (3, "MFMA only"), (6, "DMA only"), (5, "LDS reads only")):
-            _lib.set_option("WGRAD_ABL", abl)
+            _lib.set_option("ABLATION", abl)
             ms = timed(lambda: ops.nhwc_conv_wgrad(x, x, KT, KF, dil))
             res[f"wgrad {KT}x{KF} dil{dil} {name}"] = round(ms, 3)
-        _lib.set_option("WGRAD_ABL", 0)
+        _lib.set_option("ABLATION", 0)
         res[f"wgrad {KT}x{KF} dil{dil} full, zero operands"] = round(timed(lambda: ops.nhwc_conv_wgrad(z, z, KT, KF, dil)), 3)
     print(json.dumps(res, indent=1))
 

@@ -79,6 +79,7 @@ class VsTapeLayout(Structure):
         ("lstm_packed_t", c_size_t), ("lstm_state", c_size_t), ("lstm_bwd_state", c_size_t), ("consts", c_size_t),
         ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
         ("partials", c_size_t), ("conv_scales", c_size_t), ("gemm_scales", c_size_t), ("lstm_bf16", c_size_t),
+        ("det_turn", c_size_t),
     ]
 
 
@@ -222,29 +223,14 @@ def load(path: str = None) -> ctypes.CDLL:
 
 # enum vs_option of include/voicesplit_hip.h.  The library reads no environment variable; for A/B timing from the shell this
 # package maps the variables below onto vs_set_option ONCE, when it loads the library.
-OPTIONS = {"F16X3_CONV_NCHW": 0, "BWD_DY": 1, "GEMM_KERNEL": 2, "GEMM_DR": 3, "GEMM_ABL": 4, "GEMM_BAND": 5, "WGRAD_ABL": 6,
-           "SPLITCONV_ABL": 7, "CONV_SCALAR_EPILOGUE": 8, "MFMA_PRIO": 9, "CONV8": 10, "BN_FUSED_FINALIZE": 11, "SIDE_PRIO": 12, "BWD_APPLY_BLOCKS": 13, "FWD_PROLOGUE": 14, "HEAD_LEAF_SIDE": 15, "FEAT_ROWS": 16, "HEAD_BWD_GEMM": 17, "LSTM_LEAF_LATE": 18, "CONV_EPILOGUE": 19}
+OPTIONS = {"FWD_PROLOGUE": 0, "HEAD_LEAF_SIDE": 1, "FEAT_ROWS": 2, "HEAD_BWD_GEMM": 3, "ABLATION": 4, "DETERMINISTIC": 5}
 _ENV_OPTIONS = {
-    "VOICESPLIT_F16X3_CONV": ("F16X3_CONV_NCHW", lambda v: 1 if v == "nchw" else 0),
-    "VOICESPLIT_BWD_DY": ("BWD_DY", lambda v: 0 if v.startswith("0") else 1),
-    "VOICESPLIT_GEMM_KERNEL": ("GEMM_KERNEL", lambda v: 1 if v.startswith("o") else 0),
-    "VOICESPLIT_GEMM_DR": ("GEMM_DR", int),
-    "VOICESPLIT_GEMM_ABL": ("GEMM_ABL", lambda v: 9 if v.startswith("n") else int(v)),
-    "VOICESPLIT_GEMM_BAND": ("GEMM_BAND", int),
-    "VOICESPLIT_WGRAD_ABL": ("WGRAD_ABL", int),
-    "VOICESPLIT_SPLITCONV_ABL": ("SPLITCONV_ABL", int),
-    "VOICESPLIT_CONV_SCALAR_EPILOGUE": ("CONV_SCALAR_EPILOGUE", int),
-    "VOICESPLIT_MFMA_PRIO": ("MFMA_PRIO", int),
-    "VOICESPLIT_CONV8": ("CONV8", int),
-    "VOICESPLIT_BN_FUSED_FINALIZE": ("BN_FUSED_FINALIZE", int),
-    "VOICESPLIT_SIDE_PRIO": ("SIDE_PRIO", int),
-    "VOICESPLIT_BWD_APPLY_BLOCKS": ("BWD_APPLY_BLOCKS", int),
     "VOICESPLIT_FWD_PROLOGUE": ("FWD_PROLOGUE", int),
     "VOICESPLIT_HEAD_LEAF_SIDE": ("HEAD_LEAF_SIDE", int),
     "VOICESPLIT_FEAT_ROWS": ("FEAT_ROWS", int),
     "VOICESPLIT_HEAD_BWD_GEMM": ("HEAD_BWD_GEMM", int),
-    "VOICESPLIT_LSTM_LEAF_LATE": ("LSTM_LEAF_LATE", int),
-    "VOICESPLIT_CONV_EPILOGUE": ("CONV_EPILOGUE", int),
+    "VOICESPLIT_ABLATION": ("ABLATION", int),
+    "VOICESPLIT_DETERMINISTIC": ("DETERMINISTIC", int),
 }
 
 

@@ -24,8 +24,8 @@ void vs_set_error(const char* fmt, ...) {
 // sums the elapsed time per slot and frees them.  Instrumentation only: process-global, not
 // thread safe, off by default.
 // defaults of vs_set_option (include/voicesplit_hip.h, enum vs_option)
-int g_vs_options[VS_OPT_COUNT] = {/*F16X3_CONV_NCHW*/ 0, /*BWD_DY*/ 1, /*GEMM_KERNEL*/ 0, /*GEMM_DR*/ 888, /*GEMM_ABL*/ 0, /*GEMM_BAND*/ 8,
-                                  /*WGRAD_ABL*/ 0, /*SPLITCONV_ABL*/ 0, /*CONV_SCALAR_EPILOGUE*/ 2, /*MFMA_PRIO*/ 0, /*CONV8*/ 0, /*BN_FUSED_FINALIZE*/ 1, /*SIDE_PRIO*/ 0, /*BWD_APPLY_BLOCKS*/ 0, /*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1, /*FEAT_ROWS*/ 1, /*HEAD_BWD_GEMM*/ 1, /*LSTM_LEAF_LATE*/ 3, /*CONV_EPILOGUE*/ 0};
+int g_vs_options[VS_OPT_COUNT] = {/*FWD_PROLOGUE*/ 1, /*HEAD_LEAF_SIDE*/ 1, /*FEAT_ROWS*/ 1, /*HEAD_BWD_GEMM*/ 1, /*ABLATION*/ 0, /*DETERMINISTIC*/ 0};
+thread_local unsigned* g_vs_turn = nullptr;
 
 namespace {
 struct Prof {
@@ -75,9 +75,9 @@ size_t conv_packed_bytes(int i) {
   return a > b ? a : b;
 }
 
-// Eval-mode forward of the fp32-class arithmetic: channels-last hi / lo planes (conv_nhwc_f16x3.hip), or -- vs_set_option(VS_OPT_F16X3_CONV_NCHW, 1),
-// the A/B switch -- the [B][64][T][F] kernels of rounds 1-2, which train mode keeps using (its tape is fp32 NCHW).
-bool split_route() { return vs_opt(VS_OPT_F16X3_CONV_NCHW) == 0; }
+// Eval-mode forward of the fp32-class arithmetic: channels-last hi / lo planes (conv_nhwc_f16x3.hip).  (The [B][64][T][F] kernels of
+// rounds 1-2 serve train mode -- its tape is fp32 NCHW -- and the strict fp32 arithmetic; as an eval route they were the A/B arm of
+// round 4 (1561 against 1722-1836 utt/s) and are not offered any more, so a prepared-weights blob has ONE conv-weight format.)
 
 int layout(const vs_dims* d, vs_ws_layout* L) {
   if (int rc = check_dims(d)) return rc;
@@ -118,12 +118,11 @@ int check_ws(const vs_dims* d, void* ws, size_t ws_bytes, vs_ws_layout* L) {
 // the parameters alone -- BatchNorm folded into per-channel scale/shift, conv weights in MFMA fragment order with
 // their power-of-two scale, W_ih split into f16 halves with its scale, W_hh in fragment order.  Independent of B, T.
 struct PrepLayout {
-  size_t bn_scale, bn_shift, conv_packed[6], conv_wscale, gemm_wscale, wih_hi, wih_lo, lstm_packed, head_packed, total_bytes;
+  size_t bn_scale, bn_shift, conv_packed[6], gemm_wscale, wih_hi, wih_lo, lstm_packed, head_packed, total_bytes;
 };
 struct Prep {
   float *bn_scale, *bn_shift;
   void* conv_packed[6];
-  float* conv_wscale;     // [6][8]: scale2 of layer i's weights at [8i .. 8i+1], |max| scratch at 8i+4
   float* gemm_wscale;     // [8]: scale2 of W_ih at [0..1], |max| scratch at [4]
   _Float16 *wih_hi, *wih_lo;
   float* lstm_packed;
@@ -137,7 +136,6 @@ int prep_layout(const vs_dims* d, PrepLayout* L) {
   L->bn_scale = take(8 * 64 * 4);
   L->bn_shift = take(8 * 64 * 4);
   for (int i = 0; i < 6; ++i) L->conv_packed[i] = take(conv_packed_bytes(i));
-  L->conv_wscale = take(6 * 8 * 4);
   L->gemm_wscale = take(8 * 4);
   const size_t Kp = ((size_t)8 * d->F + VS_GEMM_KPAD - 1) / VS_GEMM_KPAD * VS_GEMM_KPAD;
   L->wih_hi = take((size_t)8 * d->H * Kp * 2);
@@ -158,7 +156,6 @@ int prep_pointers(const vs_dims* d, const void* blob, size_t bytes, Prep* P) {
   P->bn_scale = at<float>(b, L.bn_scale);
   P->bn_shift = at<float>(b, L.bn_shift);
   for (int i = 0; i < 6; ++i) P->conv_packed[i] = at<char>(b, L.conv_packed[i]);
-  P->conv_wscale = at<float>(b, L.conv_wscale);
   P->gemm_wscale = at<float>(b, L.gemm_wscale);
   P->wih_hi = at<_Float16>(b, L.wih_hi);
   P->wih_lo = at<_Float16>(b, L.wih_lo);
@@ -297,19 +294,8 @@ int vs_set_option(int option, int value) {
   VS_REQUIRE(option >= 0 && option < VS_OPT_COUNT, "vs_set_option: unknown option %d", option);
   bool ok = true;
   switch (option) {
-    case VS_OPT_F16X3_CONV_NCHW: case VS_OPT_BWD_DY: case VS_OPT_GEMM_KERNEL: case VS_OPT_FWD_PROLOGUE: case VS_OPT_HEAD_LEAF_SIDE: case VS_OPT_FEAT_ROWS: case VS_OPT_HEAD_BWD_GEMM: ok = value == 0 || value == 1; break;
-    case VS_OPT_CONV_SCALAR_EPILOGUE: ok = value >= 0 && value <= 2; break;
-    case VS_OPT_SIDE_PRIO: case VS_OPT_BN_FUSED_FINALIZE: ok = value >= 0 && value <= 2; break;
-    case VS_OPT_LSTM_LEAF_LATE: ok = value >= 0 && value <= 3; break;
-    case VS_OPT_CONV_EPILOGUE: ok = value >= 0 && value <= 2; break;
-    case VS_OPT_GEMM_DR: {
-      const int a = value / 100, b = (value / 10) % 10, c = value % 10;
-      ok = (a == 4 || a == 8) && (b == 4 || b == 8) && (c == 4 || c == 8);
-      break;
-    }
-    case VS_OPT_GEMM_ABL: ok = (value >= 0 && value <= 3) || value == 9; break;
-    case VS_OPT_GEMM_BAND: ok = value >= 1 && value <= 1024; break;
-    case VS_OPT_MFMA_PRIO: case VS_OPT_CONV8: ok = value >= 0 && value <= 3; break;
+    case VS_OPT_FWD_PROLOGUE: case VS_OPT_HEAD_LEAF_SIDE: case VS_OPT_FEAT_ROWS: case VS_OPT_HEAD_BWD_GEMM: case VS_OPT_DETERMINISTIC:
+      ok = value == 0 || value == 1; break;
     default: ok = value >= 0; break;
   }
   VS_REQUIRE(ok, "vs_set_option: value %d is outside the range of option %d", value, option);
@@ -735,7 +721,7 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
     return 0;
   }
 
-  if (d->math == VS_MATH_F16X3 && !train && split_route()) {
+  if (d->math == VS_MATH_F16X3 && !train) {
     // BASELINE configs[1]: activations as channels-last hi / lo f16 planes in the same ping-pong buffers; every layer writes its
     // output at a scale derived on the device from the tracked |max| of its input (conv_nhwc_f16x3.hip), no host round trip
     const size_t half = (size_t)B * T * F * 64 * 2;
@@ -809,17 +795,9 @@ int conv_stack_impl(const vs_dims* d, const vs_params* p, const float* x, int co
     ProfScope ps(VS_PROF_CNN2 + i, stream);
     const bool fuse = train && f16;        // statistics of this layer accumulated by the conv epilogue
     if (fuse) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
-    if (prep) {          // weights packed and scaled once; only the input's scale is derived here
-      float* slot = cs + VS_SCALE_SLOT_FLOATS * l;
-      if (f16) {
-        if (int rc = vs_scale_from_absmax_impl(vs_amax_slot(slot), VS_AMAX_SLOTS, slot, stream)) return rc;
-        if (int rc = vs_conv64_f16x3_fwd_impl(act[cur], static_cast<const _Float16*>(prep->conv_packed[i]), scale + 64 * l, shift + 64 * l,
-                                              slot, prep->conv_wscale + 8 * i, act[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil,
-                                              layer_act, amax_for(l + 1), stream, d->math, nullptr)) return rc;
-      } else {
-        if (int rc = vs_conv64_fwd_impl(act[cur], static_cast<const float*>(prep->conv_packed[i]), scale + 64 * l, shift + 64 * l,
-                                        act[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
-      }
+    if (prep) {          // (strict fp32 arithmetic: the other two have taken their channels-last eval routes above) weights packed once
+      if (int rc = vs_conv64_fwd_impl(act[cur], static_cast<const float*>(prep->conv_packed[i]), scale + 64 * l, shift + 64 * l,
+                                      act[cur ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, layer_act, stream)) return rc;
     } else
     if (int rc = vs_conv64_layer_impl(d->math, act[cur], p->conv[l].weight, packed, cs + VS_SCALE_SLOT_FLOATS * l, 1,
                                       scale + 64 * l, shift + 64 * l, act[cur ^ 1], B, T, F,
@@ -985,12 +963,8 @@ int vs_prepare_weights(const vs_dims* d, const vs_params* p, void* prepared, siz
     const float* w = p->conv[i + 1].weight;
     if (d->math == VS_MATH_BF16) {
       if (int rc = vs_nhwc_pack_impl(w, P.conv_packed[i], kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
-    } else if (d->math == VS_MATH_F16X3 && split_route()) {
+    } else if (d->math == VS_MATH_F16X3) {
       if (int rc = vs_nhwc_f16x3_prepare_wpart_impl(w, P.conv_packed[i], kMid[i].kt, kMid[i].kf, stream)) return rc;
-    } else if (d->math != VS_MATH_FP32) {
-      float* ws8 = P.conv_wscale + 8 * i;
-      if (int rc = vs_conv64_pack_f16_impl(w, static_cast<_Float16*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0,
-                                           reinterpret_cast<unsigned*>(ws8 + 4), ws8, stream, d->math)) return rc;
     } else {
       if (int rc = vs_conv64_pack_impl(w, static_cast<float*>(P.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
     }

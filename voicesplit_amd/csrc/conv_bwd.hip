@@ -24,7 +24,7 @@
 // order by conv64_wgrad_reduce_kernel (deterministic, no atomics).
 #include <type_traits>
 
-#include "vs_common.h"
+#include "vs_internal.h"
 
 namespace {
 
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256)
 void bn_act_bwd_stats_kernel(const float* __restrict__ da, const float* __restrict__ z, int C, long long rows_c, int L,
                              const float* __restrict__ scale, const float* __restrict__ shift,
                              const float* __restrict__ mean, const float* __restrict__ invstd,
-                             double* __restrict__ stats) {
+                             double* __restrict__ stats, unsigned* turn = nullptr) {
   const int c = blockIdx.y;
   const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
   const int gx = vs_row_chunks(L);
@@ -229,10 +229,13 @@ void bn_act_bwd_stats_kernel(const float* __restrict__ da, const float* __restri
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { sh2[2 * w] = d1; sh2[2 * w + 1] = d2; }
   __syncthreads();
+  unsigned* my_turn = turn ? turn + VS_TURN_CHANNEL + c : nullptr;      // deterministic mode: the workgroups of a channel add in index order (a word per channel)
+  vs_turn_begin(my_turn, blockIdx.x);
   if (threadIdx.x == 0) {
     atomicAdd(&stats[2 * c], sh2[0] + sh2[2] + sh2[4] + sh2[6]);
     atomicAdd(&stats[2 * c + 1], sh2[1] + sh2[3] + sh2[5] + sh2[7]);
   }
+  vs_turn_end(my_turn, blockIdx.x, gridDim.x);
 }
 
 // per channel: parameter gradients and the coefficients of pass 2,  dZ = cA*dY + cB*z + cC
@@ -638,11 +641,14 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   VS_REQUIRE(R <= 2147483647LL && C <= 65535, "bn_act_bwd: too many rows");
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
   const long long rows_per_c = R / C;
-  dim3 grid(vs_bn_blocks_per_channel(C, rows_per_c, L), C), block(256);
+  unsigned* turn = C <= 64 ? g_vs_turn : nullptr;          // (the turn region holds a word for each of 64 channels: the features' BatchNorm, C = 8, is the user)
+  int bpc = vs_bn_blocks_per_channel(C, rows_per_c, L);
+  if (turn && bpc > 16) bpc = 16;                            // chains of sixteen turns (~0.1 ms)
+  dim3 grid(bpc, C), block(256);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
-    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats, turn); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats, turn); break;
+    case VS_ACT_NONE: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats, turn); break;
     default: VS_REQUIRE(false, "bn_act_bwd: unknown activation %d", act);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,

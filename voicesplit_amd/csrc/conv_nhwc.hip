@@ -28,13 +28,26 @@
 //     One s_waitcnt vmcnt(0) + one s_barrier per group;
 //   * a group is one straight-line block: for window row i, tap column df, k-chunk, column block: ONE fragment read,
 //     multiplied with the <= KT taps dt that send it to output row i - dt of the group (0.3 LDS reads per MFMA;
-//     no MFMA is issued for a (row, tap) pair outside the group, so nothing is wasted at group edges).  The R x 2
-//     accumulators are born and die inside the block: no loop-carried accumulators, no register rotation.
-//     Output row r is complete after window row r + KT - 1: its epilogue (scale/shift, activation, bf16 rounding,
-//     8-byte stores of 4 channels of one pixel) sits right there, under the MFMAs of the following window rows;
-//     lanes / rows outside the image are dropped by the store's buffer range check instead of branching;
+//     no MFMA is issued for a (row, tap) pair outside the group, so nothing is wasted at group edges).  The MFMAs are volatile
+//     inline assembly -- weights in AGPRs, accumulators in VGPRs, the first product of an accumulator with the constant 0 as its
+//     addend -- so that the compiler can move nothing across them: the instruction stream is the one written here;
+//   * the epilogue (scale / shift, activation or its derivative, BatchNorm sums, bf16 rounding, 8-byte stores of 4 channels of
+//     one pixel; lanes / rows outside the image dropped by the stores' range check) is cut into MICRO-OPS of one scalar VALU
+//     instruction per channel of a channel pair (or one transcendental, or one store), dealt out ONE PER MFMA [round 6].
+//     tools/epilogue_slot_probe.hip: behind an MFMA one or two independent scalar VALU instructions are nearly free (17.4 / 18.5
+//     cycles per MFMA against 16.5), a third costs 7 cycles, a dependent chain of three 16 -- and ONE v_pk_fma_f32 17, so the
+//     kernels are built without packed-fp32 instructions.  (Rounds 3-5 put up to four dependent, partly packed instructions
+//     behind every second MFMA: the dy form ran 2.10-2.27 ms against the plain conv's 1.66; now 1.82-1.93.)
+//     Output row r is complete after window row r + KT - 1 and its micro-ops ride on the MFMAs behind that; the last three rows
+//     of a group, which complete when its MFMAs are nearly over, are CARRIED: their accumulators, row offsets and descriptors
+//     outlive the group and their micro-ops ride on the first MFMAs of the NEXT group (whichever item that is; three dummy rows at
+//     the launch's start, a flush behind its end).  Plan<RV> deals the micro-op list out over the group's MFMA slots at compile time;
 //   * train mode: per-channel sum / sum of squares of the outputs are accumulated per lane over the whole launch
 //     and flushed once (shuffle over the 16 pixels of a fragment, one fp64 atomic per channel and wave).
+// The compiler cannot see an MFMA inside an assembly statement and so inserts none of the wait states the hardware wants
+// between a matrix-pipe write of a VGPR and a VALU read of it: the structure provides them (>= 4 MFMAs between a row's last
+// product and the first micro-op that reads it, an explicit s_nop in front of the hand-over of a group's last row), and
+// tools/mfma_hazard_scan.py verifies it on the emitted assembly.
 // Every input element is read from HBM once per strip (+12.5 % halo columns for 5x5, + KT-1 halo rows per segment;
 // the re-fetched window rows are L2 hits),
 // every output written once.
@@ -72,7 +85,7 @@ struct NhwcConvArgs {
   const float* bn2_scale; const float* bn2_shift; const float* bn2_mean; const float* bn2_invstd;   // [64] each
   int B, T, F, dil;
   int nstrip, nseg, seg_rows, n_items;
-  int prio;                         // != 0: the waves raise their priority (VS_OPT_MFMA_PRIO bit 1)
+  unsigned* turn;                   // deterministic mode: the workgroups flush their statistics in workgroup order (vs_common.h); else NULL
 };
 
 // XOR swizzle of the 16-byte pieces of a staged pixel (128 bytes = half a bank row; pixel parity picks the half): a
@@ -102,31 +115,27 @@ struct Geo {
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 
 // DY: the launch is a data gradient whose result da feeds a BatchNorm + activation backward: the epilogue turns it into
-// dy = da * act'(z * scale + shift) on the spot (z = the output pixel's pre-BatchNorm value, loaded two output rows ahead),
+// dy = da * act'(z * scale + shift) on the spot (z = the output pixel's pre-BatchNorm value, loaded two epilogue rows ahead),
 // accumulates the two sums of the BatchNorm backward (sum dy, sum dy * xhat) like the STATS epilogue accumulates the
 // forward's, and stores dy: the separate statistics pass over (da, z) disappears and the apply pass needs no activation
 // derivative (dz = cA dy + cB z + cC).  ACT is then the activation whose derivative is taken.
-// EP: how the epilogue is cut into micro-ops.  0 = round 3's: up to four DEPENDENT (partly packed-fp32) instructions behind every second
-// MFMA.  1 = round 6's (tools/epilogue_slot_probe.hip: behind an MFMA one or two INDEPENDENT scalar VALU instructions are nearly
-// free -- 17.4 / 18.5 cycles per MFMA against 16.5 -- a third costs 7 cycles, a dependent chain of three 16, and ONE v_pk_fma_f32
-// 17): every micro-op is the same scalar instruction on the two channels of a pair (or one transcendental, or one store), one
-// micro-op per MFMA; built without packed-fp32 instructions.
-template <int KT, int KF, int ACT, bool STATS, bool DY = false, int EP = 0>
+template <int KT, int KF, int ACT, bool STATS, bool DY = false>
 struct ConvWalk {
   using G = Geo<KT, KF>;
   static constexpr int P = G::P, PF = G::PF, H = G::H, NTAP = G::NTAP;
+  static constexpr unsigned kOob = 0x7FFFFFF0u;
 
   const NhwcConvArgs& a;
   int lane, wave, n, g;
-  vs_bf16x8 wf[NTAP][2];
-  // This lane's 4 output channels as two pairs (packed fp32 math in the epilogue).  csc / csh: the epilogue's scale and
+  vs_bf16x8 wf[NTAP][2];                     // this wave's A fragments: AGPRs for the whole launch (every use is an "a" operand)
+  // This lane's 4 output channels as two pairs.  csc / csh: the epilogue's scale and
   // shift; DY: the BatchNorm scale / shift of the layer below, times log2(e).  a1 / a2: the two per-channel sums.
   f2v csc[2], csh[2], a1[2], a2[2];
   int boff[KF][2];                           // per-lane byte offset of the B fragment (column shift df, k-chunk kc) inside a row image
   unsigned vcol[NB];
   int vdma;                                  // per-lane source offset of a DMA chunk inside a tensor row (launch constant)
   __amdgpu_buffer_rsrc_t rout, rz;
-  // EP = 2: the epilogues of a group's last three rows ride on the first MFMAs of the NEXT group (whichever item that belongs to), so
+  // The epilogues of a group's last three rows ride on the first MFMAs of the NEXT group (whichever item that belongs to), so
   // what they need outlives the group: the accumulators, the rows' byte offsets (kOob: no such row -- the three dummies the launch
   // starts with, the third row of a two-row tail group), the item's column offsets / masks and descriptors, and the ring of z values
   // of the dy form (filled two epilogue rows ahead, across the group boundary).
@@ -165,18 +174,16 @@ struct ConvWalk {
       boff[df][0] = p * 128 + ((g ^ swz(p)) << 4);         // column block nb: + 2048 (the swizzle is 8-periodic in p)
       boff[df][1] = boff[df][0] ^ 64;
     }
-    if constexpr (EP == 2) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        crow[j] = kOob;
+    for (int j = 0; j < 3; ++j) {
+      crow[j] = kOob;
 #pragma unroll
-        for (int nb2 = 0; nb2 < NB; ++nb2) { cacc[j][nb2] = f32x4{0.f, 0.f, 0.f, 0.f}; zq3[j][nb2] = u2v{0u, 0u}; }
-      }
-#pragma unroll
-      for (int nb2 = 0; nb2 < NB; ++nb2) { cvcol[nb2] = kOob; ccok[nb2] = 0.f; }
-      crout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out), 0, 0, 0x00020000);      // no records: every access out of range
-      crz = crout;
+      for (int nb2 = 0; nb2 < NB; ++nb2) { cacc[j][nb2] = f32x4{0.f, 0.f, 0.f, 0.f}; zq3[j][nb2] = u2v{0u, 0u}; }
     }
+#pragma unroll
+    for (int nb2 = 0; nb2 < NB; ++nb2) { cvcol[nb2] = kOob; ccok[nb2] = 0.f; }
+    crout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.out), 0, 0, 0x00020000);      // no records: every access out of range
+    crz = crout;
     {
       const int px = lane >> 3;                            // chunk c of a row: pixel 8 c + lane / 8, LDS piece lane % 8 holds channel
       vdma = (px - PF) * 128 + (((lane & 7) ^ swz(px)) << 4);     // piece (lane % 8) ^ swz(px) -- swz is 8-periodic: the same for every chunk
@@ -249,7 +256,6 @@ struct ConvWalk {
   // a per-lane byte offset of its pixel (column block nb) and channel quad inside a row -- or an offset no row offset brings
   // back into range when the column is outside the image -- and a wave-uniform row offset, likewise out of range for rows
   // the item does not own.  The range check does the predication: no address arithmetic or branches in the epilogue.
-  static constexpr unsigned kOob = 0x7FFFFFF0u;
   __device__ __forceinline__ void begin_item(const Item& x) {
     const size_t ub = (size_t)x.b * a.T * a.F * 128;
     const unsigned bytes = (unsigned)a.T * a.F * 128;
@@ -270,32 +276,21 @@ struct ConvWalk {
   }
 
   // One group: output rows ro .. ro+RV-1 of item x (RV = R, or the even tail of the item; rows >= x.o1 are computed and
-  // dropped), window rows 0 .. RV+H-1 of window buffer `buf`.  gstep<RV, GI> is fragment GI of the block: its
-  // read two fragments ahead and its MFMAs.  The instruction order is pinned (sched_barrier after every MFMA): hipcc's
-  // own order reads a fragment, waits for it and issues two MFMAs, and its sched_group_barrier solver needs 17 minutes
-  // for this block.  The epilogue of output row r (complete after window row r + H) is cut into micro-ops -- one
-  // channel value, or one 8-byte store -- and one micro-op follows each of the first MFMAs of window row r + H + 1,
-  // so it issues in the shadow of the matrix pipe; only the last row's epilogue runs behind the block.
+  // dropped), window rows 0 .. RV+H-1 of window buffer `buf`.
   template <int RV>
   struct GroupState {
     f32x4 acc[RV][NB];
     vs_bf16x8 bq[3];
     f2v y[NB][2];                      // the finished row's values on their way to the store (channel pairs)
-    u2v zq[3][NB];                     // DY: z of the output row being finished and the next two (4 channels of one pixel each)
     float cok[NB], mk[NB];             // DY: 1 for a column inside the image, else 0; the same for the row being finished
-    f2v tz, ty, tu, tn, tr, tw;        // DY: one channel pair in flight through the stages of the activation derivative
-    f2v tp, tq, da;                    // EP = 1: further stage registers
-    u2v pk[NB];                        // EP = 1: the packed pixel on its way to the store
+    f2v tz, ty, tu, tn, tr, tw, tp, tq;      // one channel pair in flight through the stages of the epilogue
+    u2v pk[NB];                        // the packed pixel on its way to the store
     unsigned vb[KF][2];                // B-fragment read bases of this group's window buffer (column shift, k-chunk); row, column block: immediates
     int ro;
   };
-  // micro-ops of one output row.  Plain: NB*4 values + NB stores.  DY: z loads of a later row, NB*2 channel pairs x NSTAGE
-  // stages (packed fp32 math: one v_pk_* per two channels; at most three of them or one transcendental per micro-op, which
-  // is what fits behind one MFMA without holding up the next), NB stores.
-  static constexpr int NSTAGE = EP == 0 ? (DY ? 9 : ACT == VS_ACT_MISH ? 7 : 1)
-                                        : (DY ? (ACT == VS_ACT_MISH ? 19 : 7) : ACT == VS_ACT_MISH ? 12 : ACT == VS_ACT_RELU ? 2 : STATS ? 4 : 1);
-  static constexpr int NSTORE = EP == 0 ? NB : 2 * NB;               // EP >= 1: pack and store are two micro-ops
-  static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + NSTORE;
+  // micro-ops of one output row: the dy form's z prefetch, NB * 2 channel pairs x NSTAGE stages, NB x (pack, store)
+  static constexpr int NSTAGE = DY ? (ACT == VS_ACT_MISH ? 19 : 7) : ACT == VS_ACT_MISH ? 12 : ACT == VS_ACT_RELU ? 2 : STATS ? 4 : 1;
+  static constexpr int NMICRO = (DY ? 1 : 0) + NB * 2 * NSTAGE + 2 * NB;
 
   template <int RV>
   __device__ __forceinline__ vs_bf16x8 frag(const GroupState<RV>& st, int gi) const {
@@ -303,59 +298,10 @@ struct ConvWalk {
     return __builtin_bit_cast(vs_bf16x8, *(lds_u4v*)(uintptr_t)(st.vb[df][kc] + (unsigned)(i * G::ROWB + nb * 2048)));
   }
 
-  // DY: z of output row r of the group (both column blocks) -> zq[r % 3].  Issued two output rows (about 1.5 us of
-  // MFMAs) before its first use: one row ahead the epilogue waited on HBM latency.
-  template <int RV>
-  __device__ __forceinline__ void load_z(const Item& x, GroupState<RV>& st, int r) {
-    const unsigned so = row_offset(x, st.ro + r);
-#pragma unroll
-    for (int nb2 = 0; nb2 < NB; ++nb2)
-      st.zq[r % 3][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rz, vcol[nb2], so, 0));      // out of range: zeros
-  }
-
-  template <int RV>
-  __device__ __forceinline__ void store_px(const Item& x, GroupState<RV>& st, int r, int nb2) {
-    const int k = st.ro + r;
-    if (STATS && !DY) {
-      const float m = ((k < x.o1) & (vcol[nb2] != kOob)) ? 1.f : 0.f;
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const f2v ym = st.y[nb2][pr] * m;
-        a1[pr] += ym;
-        a2[pr] = __builtin_elementwise_fma(ym, st.y[nb2][pr], a2[pr]);
-      }
-    }
-    const u2v pk = {vs_pack_bf16(st.y[nb2][0].x, st.y[nb2][0].y), vs_pack_bf16(st.y[nb2][1].x, st.y[nb2][1].y)};
-    __builtin_amdgcn_raw_buffer_store_b64(pk, rout, vcol[nb2], row_offset(x, k), 0);                               // out of range: dropped
-  }
-
-  // micro-op q of the epilogue of output row r of the group
-  // ---- EP = 1 ------------------------------------------------------------------------------------------------------------------------
-  // Every stage is ONE scalar instruction per channel of the pair (x, y: independent of each other), or one transcendental.  The
-  // instructions are volatile inline assembly: as C++ expressions the compiler contracted and re-associated them across stages (a
-  // stage's two instructions ended up beside the next stage's, the slot behind the following MFMA empty), which is exactly the
-  // clustering this form exists to avoid.
-#ifndef VS_EP_ASM_VALU
-#define VS_EP_ASM_VALU 0
-#endif
-#if VS_EP_ASM_VALU
-  static __device__ __forceinline__ float i_fma(float a, float b, float c) { float d; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-  static __device__ __forceinline__ float i_mul(float a, float b) { float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-  static __device__ __forceinline__ float i_add(float a, float b) { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-  static __device__ __forceinline__ float i_add2(float a) { float d; asm volatile("v_add_f32 %0, 2.0, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_exp2(float a) { float d; asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_rcp(float a) { float d; asm volatile("v_rcp_f32 %0, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_max0(float a) { float d; asm volatile("v_max_f32 %0, 0, %1" : "=v"(d) : "v"(a)); return d; }
-  // literal operands (VOP2 encodings take a 32-bit literal): 20 log2(e), 20, log2(e), 4 ln 2
-  static __device__ __forceinline__ float i_min_20log2e(float a) { float d; asm volatile("v_min_f32 %0, 0x41e6d4ca, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_min_20(float a) { float d; asm volatile("v_min_f32 %0, 0x41a00000, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_mul_log2e(float a) { float d; asm volatile("v_mul_f32 %0, 0x3fb8aa3b, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_mul_4ln2(float a) { float d; asm volatile("v_mul_f32 %0, 0x40317218, %1" : "=v"(d) : "v"(a)); return d; }
-  static __device__ __forceinline__ float i_bf_lo(unsigned u) { float d; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(d) : "v"(u)); return d; }
-  static __device__ __forceinline__ float i_bf_hi(unsigned u) { float d; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(u)); return d; }
-#else
-  // (as volatile assembly the compiler's hazard recognizer, which cannot look inside, put an s_nop in front of every statement that
-  // reads a register the statement before wrote: 349 per group)
+  // ---- the epilogue's stages: ONE scalar instruction per channel of the pair (x, y: independent of each other), or one
+  // transcendental.  (As volatile assembly the compiler's hazard recognizer, which cannot look inside, put an s_nop in front of every
+  // statement that reads a register the statement before wrote -- 349 per group; as C++ expressions they stay where they are
+  // written because the MFMAs around them are volatile and a sched_barrier follows each.)
   static __device__ __forceinline__ float i_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
   static __device__ __forceinline__ float i_mul(float a, float b) { return a * b; }
   static __device__ __forceinline__ float i_add(float a, float b) { return a + b; }
@@ -369,65 +315,51 @@ struct ConvWalk {
   static __device__ __forceinline__ float i_mul_4ln2(float a) { return a * (4.0f * 0.69314718055994530942f); }
   static __device__ __forceinline__ float i_bf_lo(unsigned u) { return __uint_as_float(u << 16); }
   static __device__ __forceinline__ float i_bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-#endif
 
-  // The row an epilogue works on.  MODE 1 (EP = 1): row IDX of the group being computed.  MODE 2 (EP = 2): position IDX of the group's
-  // epilogue sequence -- 0..2 the rows carried over from the previous group, 3 + r row r of this one; MODE 3: the carried rows once more,
-  // behind the launch's last group (nothing to prefetch).
-  static constexpr int epi_rows(int RV) { return RV >= 4 ? RV : 3; }          // EP = 2: epilogue rows a group works off (three carried in + its own but the last three)
-  template <int RV, int MODE, int IDX, int nb2, int e>
+  // The row an epilogue works on: position IDX of the group's epilogue sequence -- 0..2 the rows carried over from the previous group,
+  // 3 + r row r of this one.  FLUSH: the carried rows once more, behind the launch's last group (nothing to prefetch).
+  static constexpr int epi_rows(int RV) { return RV >= 4 ? RV : 3; }          // epilogue rows a group works off (three carried in + its own but the last three)
+  template <int RV, int IDX, int nb2, int e>
   __device__ __forceinline__ float acc_of(GroupState<RV>& st) const {
-    if constexpr (MODE >= 2 && IDX < 3) return cacc[IDX][nb2][e];
-    else return st.acc[MODE == 1 ? IDX : IDX - 3][nb2][e];
+    if constexpr (IDX < 3) return cacc[IDX][nb2][e];
+    else return st.acc[IDX - 3][nb2][e];
   }
-  template <int RV, int MODE, int IDX>
+  template <int RV, int IDX>
   __device__ __forceinline__ unsigned rowoff_of(const Item& x, const GroupState<RV>& st) const {
-    if constexpr (MODE >= 2 && IDX < 3) return crow[IDX];
-    else return row_offset(x, st.ro + (MODE == 1 ? IDX : IDX - 3));
+    if constexpr (IDX < 3) return crow[IDX];
+    else return row_offset(x, st.ro + IDX - 3);
   }
-  template <int RV, int MODE, int IDX, int nb2>
+  template <int IDX, int nb2>
   __device__ __forceinline__ unsigned vcol_of() const {
-    if constexpr (MODE >= 2 && IDX < 3) return cvcol[nb2];
+    if constexpr (IDX < 3) return cvcol[nb2];
     else return vcol[nb2];
   }
-  template <int RV, int MODE, int IDX, int nb2>
-  __device__ __forceinline__ u2v z_of(const GroupState<RV>& st) const {
-    if constexpr (MODE >= 2) return zq3[IDX % 3][nb2];
-    else return st.zq[IDX % 3][nb2];
-  }
-  // EP = 2, dy form: position IDX's first micro-op fetches z for the position two further on -- a row of this group, one of the rows it
-  // will carry out (the next group's positions 0 and 1), or (IDX = 0) the third carried row
-  template <int RV, int MODE, int IDX>
+  // dy form: position IDX's first micro-op fetches z for the position two further on -- a row of this group, one of the rows it
+  // will carry out (the next group's positions 0 and 1), or (IDX = 0) the third carried row.  Two epilogue rows = ~160 MFMAs ahead
+  // of its first use: one row ahead the epilogue waited on HBM latency (round 3).
+  template <int RV, int IDX, bool FLUSH>
   __device__ __forceinline__ void prefetch_z(const Item& x, GroupState<RV>& st) {
-    if constexpr (MODE == 1) {
-      if constexpr (IDX + 2 < RV) load_z<RV>(x, st, IDX + 2);
-    } else {
-      constexpr int t = IDX + 2, P_ = epi_rows(RV);
-      if constexpr (MODE == 3) {
-        if constexpr (t == 2) {
+    constexpr int t = IDX + 2, P_ = epi_rows(RV);
+    if constexpr (t == 2) {
 #pragma unroll
-          for (int nb2 = 0; nb2 < NB; ++nb2) zq3[2][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(crz, cvcol[nb2], crow[2], 0));
-        }
-      } else if constexpr (t == 2) {
+      for (int nb2 = 0; nb2 < NB; ++nb2) zq3[2][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(crz, cvcol[nb2], crow[2], 0));
+    } else if constexpr (!FLUSH) {
+      constexpr int row = t < P_ ? t - 3 : (RV >= 4 ? RV - 3 : 0) + (t - P_);      // in-group row, or carry-out row t - P_ (0 or 1)
+      const unsigned so = row_offset(x, st.ro + row);
 #pragma unroll
-        for (int nb2 = 0; nb2 < NB; ++nb2) zq3[2][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(crz, cvcol[nb2], crow[2], 0));
-      } else {
-        constexpr int row = t < P_ ? t - 3 : (RV >= 4 ? RV - 3 : 0) + (t - P_);      // in-group row, or carry-out row t - P_ (0 or 1)
-        const unsigned so = row_offset(x, st.ro + row);
-#pragma unroll
-        for (int nb2 = 0; nb2 < NB; ++nb2) zq3[t % 3][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rz, vcol[nb2], so, 0));
-      }
+      for (int nb2 = 0; nb2 < NB; ++nb2) zq3[t % 3][nb2] = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rz, vcol[nb2], so, 0));      // out of range: zeros
     }
   }
 
-  template <int RV, int MODE, int IDX, int q>
+  // micro-op q of the epilogue of position IDX
+  template <int RV, int IDX, int q, bool FLUSH>
   __device__ __forceinline__ void epi(const Item& x, GroupState<RV>& st) {
     constexpr bool mish = ACT == VS_ACT_MISH;
     constexpr int Q0 = DY ? 1 : 0;
-    constexpr bool carried = MODE >= 2 && IDX < 3;
-    constexpr int r = MODE == 1 ? IDX : IDX - 3;               // the row inside the group (not for carried rows)
+    constexpr bool carried = IDX < 3;
+    constexpr int r = IDX - 3;                                 // the row inside the group (not for carried rows)
     if constexpr (DY && q == 0) {
-      prefetch_z<RV, MODE, IDX>(x, st);
+      prefetch_z<RV, IDX, FLUSH>(x, st);
 #pragma unroll
       for (int nb2 = 0; nb2 < NB; ++nb2) {
         if constexpr (carried) st.mk[nb2] = crow[IDX] != kOob ? ccok[nb2] : 0.f;
@@ -435,9 +367,15 @@ struct ConvWalk {
       }
     } else if constexpr (q < Q0 + NB * 2 * NSTAGE) {
       constexpr int v = (q - Q0) / NSTAGE, sg = (q - Q0) % NSTAGE, nb2 = v / 2, pr = v % 2;
+      const float acc0 = acc_of<RV, IDX, nb2, 2 * pr>(st), acc1 = acc_of<RV, IDX, nb2, 2 * pr + 1>(st);       // (names: no instruction)
       if constexpr (DY) {
+        // dy = da * act'(y), y = z * scale + shift.  Mish'(y) with u = e^y, n = u (u + 2), r = 1 / (n + 2):
+        //   tanh(softplus y) = n r,  1 - tanh^2 = 4 (n + 1) r^2 = 4 (u + 1)^2 r^2,  sigmoid = u / (u + 1)
+        //   =>  Mish' = r (n + 4 y u (u + 1) r)       (one exp2, one rcp; y clamped at 20, where the expression is 1 to fp32)
+        // computed on y log2(e) (folded into the constants).  The sums are of dy and dy * z; flush_stats turns the second
+        // into the sum of dy * xhat.
         if constexpr (sg == 0) {
-          const unsigned u = z_of<RV, MODE, IDX, nb2>(st)[pr];
+          const unsigned u = zq3[IDX % 3][nb2][pr];
           st.tz.x = i_bf_lo(u); st.tz.y = i_bf_hi(u);
         } else if constexpr (sg == 1) {
           st.ty.x = i_fma(st.tz.x, csc[pr].x, csh[pr].x); st.ty.y = i_fma(st.tz.y, csc[pr].y, csh[pr].y);
@@ -455,7 +393,7 @@ struct ConvWalk {
           else if constexpr (sg == 12) { st.tq.x = i_mul_4ln2(st.tr.x); st.tq.y = i_mul_4ln2(st.tr.y); }                                  // y was scaled by log2(e)
           else if constexpr (sg == 13) { st.tn.x = i_fma(st.tp.x, st.tq.x, st.tn.x); st.tn.y = i_fma(st.tp.y, st.tq.y, st.tn.y); }
           else if constexpr (sg == 14) { st.tw.x = i_mul(st.tr.x, st.tn.x); st.tw.y = i_mul(st.tr.y, st.tn.y); }                          // Mish'
-          else if constexpr (sg == 15) { st.ty.x = i_mul(acc_of<RV, MODE, IDX, nb2, 2 * pr>(st), st.tw.x); st.ty.y = i_mul(acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st), st.tw.y); }
+          else if constexpr (sg == 15) { st.ty.x = i_mul(acc0, st.tw.x); st.ty.y = i_mul(acc1, st.tw.y); }
           else if constexpr (sg == 16) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
           else if constexpr (sg == 17) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else {
@@ -463,8 +401,8 @@ struct ConvWalk {
             st.y[nb2][pr] = st.ty;
           }
         } else {                       // ReLU (ACT_NONE is not a dy instance)
-          if constexpr (sg == 2) st.ty.x = st.ty.x > 0.f ? acc_of<RV, MODE, IDX, nb2, 2 * pr>(st) : 0.f;
-          else if constexpr (sg == 3) st.ty.y = st.ty.y > 0.f ? acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st) : 0.f;
+          if constexpr (sg == 2) st.ty.x = st.ty.x > 0.f ? acc0 : 0.f;
+          else if constexpr (sg == 3) st.ty.y = st.ty.y > 0.f ? acc1 : 0.f;
           else if constexpr (sg == 4) { st.tp.x = i_mul(st.ty.x, st.mk[nb2]); st.tp.y = i_mul(st.ty.y, st.mk[nb2]); }
           else if constexpr (sg == 5) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else {
@@ -473,8 +411,10 @@ struct ConvWalk {
           }
         }
       } else {
+        // out = act(acc * scale + shift).  Mish(y) = y n / (n + 2), n = u (u + 2), u = e^y (y clamped at 20, where n / (n + 2)
+        // is 1 to fp32): one exp2 and one rcp per channel
         if constexpr (sg == 0) {
-          st.y[nb2][pr].x = i_fma(acc_of<RV, MODE, IDX, nb2, 2 * pr>(st), csc[pr].x, csh[pr].x); st.y[nb2][pr].y = i_fma(acc_of<RV, MODE, IDX, nb2, 2 * pr + 1>(st), csc[pr].y, csh[pr].y);
+          st.y[nb2][pr].x = i_fma(acc0, csc[pr].x, csh[pr].x); st.y[nb2][pr].y = i_fma(acc1, csc[pr].y, csh[pr].y);
         } else if constexpr (mish) {
           if constexpr (sg == 1) { st.ty.x = i_min_20(st.y[nb2][pr].x); st.ty.y = i_min_20(st.y[nb2][pr].y); }
           else if constexpr (sg == 2) { st.ty.x = i_mul_log2e(st.ty.x); st.ty.y = i_mul_log2e(st.ty.y); }
@@ -491,7 +431,7 @@ struct ConvWalk {
           st.y[nb2][pr].x = i_max0(st.y[nb2][pr].x); st.y[nb2][pr].y = i_max0(st.y[nb2][pr].y);
         } else if constexpr (STATS) {
           if constexpr (sg == 1) {
-            const float m = ((rowoff_of<RV, MODE, IDX>(x, st) != kOob) & (vcol_of<RV, MODE, IDX, nb2>() != kOob)) ? 1.f : 0.f;
+            const float m = ((rowoff_of<RV, IDX>(x, st) != kOob) & (vcol_of<IDX, nb2>() != kOob)) ? 1.f : 0.f;
             st.tp.x = i_mul(st.y[nb2][pr].x, m); st.tp.y = i_mul(st.y[nb2][pr].y, m);
           } else if constexpr (sg == 2) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else { a2[pr].x = i_fma(st.tp.x, st.y[nb2][pr].x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.y[nb2][pr].y, a2[pr].y); }
@@ -508,105 +448,12 @@ struct ConvWalk {
     }
   }
 
-  template <int RV, int r, int q>
-  __device__ __forceinline__ void micro(const Item& x, GroupState<RV>& st) {
-    if constexpr (EP == 1) {
-      epi<RV, 1, r, q>(x, st);
-    } else if constexpr (!DY) {
-      // out = act(acc * scale + shift).  Mish(y) = y n / (n + 2), n = u (u + 2), u = e^y (y clamped at 20, where n / (n + 2)
-      // is 1 to fp32): one exp2 and one rcp per channel, everything else packed, cut into stages like the dy form below
-      if constexpr (q < NB * 2 * NSTAGE) {
-        constexpr int v = q / NSTAGE, sg = q % NSTAGE, nb2 = v / 2, pr = v % 2;
-        if constexpr (sg == 0) {
-          const f2v acc2 = {st.acc[r][nb2][2 * pr], st.acc[r][nb2][2 * pr + 1]};
-          f2v y = __builtin_elementwise_fma(acc2, csc[pr], csh[pr]);
-          if constexpr (ACT == VS_ACT_RELU) y = f2v{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-          st.y[nb2][pr] = y;
-          if constexpr (ACT == VS_ACT_MISH) st.ty = f2v{fminf(y.x, 20.0f), fminf(y.y, 20.0f)} * kLog2e;
-        } else if constexpr (sg == 1) {
-          st.tu.x = __builtin_amdgcn_exp2f(st.ty.x);
-        } else if constexpr (sg == 2) {
-          st.tu.y = __builtin_amdgcn_exp2f(st.ty.y);
-        } else if constexpr (sg == 3) {
-          st.tn = st.tu * (st.tu + 2.0f);
-          st.tw = st.tn + 2.0f;
-        } else if constexpr (sg == 4) {
-          st.tr.x = __builtin_amdgcn_rcpf(st.tw.x);
-        } else if constexpr (sg == 5) {
-          st.tr.y = __builtin_amdgcn_rcpf(st.tw.y);
-        } else {
-          st.y[nb2][pr] = st.y[nb2][pr] * (st.tn * st.tr);
-        }
-      } else {
-        store_px<RV>(x, st, r, q - NB * 2 * NSTAGE);
-      }
-    } else {
-      // dy = da * act'(y), y = z * scale + shift.  Mish'(y) with u = e^y, n = u (u + 2), r = 1 / (n + 2):
-      //   tanh(softplus y) = n r,  1 - tanh^2 = 4 (n + 1) r^2 = 4 (u + 1)^2 r^2,  sigmoid = u / (u + 1)
-      //   =>  Mish' = r (n + 4 y u (u + 1) r)       (one exp2, one rcp; y clamped at 20, where the expression is 1 to fp32)
-      // computed on y log2(e) (folded into the constants).  The sums are of dy and dy * z; flush_stats turns the second
-      // into the sum of dy * xhat.
-      if constexpr (q == 0) {
-        if constexpr (r + 2 < RV) load_z<RV>(x, st, r + 2);
-#pragma unroll
-        for (int nb2 = 0; nb2 < NB; ++nb2) st.mk[nb2] = (st.ro + r < x.o1) ? st.cok[nb2] : 0.f;
-      } else if constexpr (q <= NB * 2 * NSTAGE) {
-        constexpr int v = (q - 1) / NSTAGE, sg = (q - 1) % NSTAGE, nb2 = v / 2, pr = v % 2;
-        constexpr bool mish = ACT == VS_ACT_MISH;
-        if constexpr (sg == 0) {
-          const unsigned u = st.zq[r % 3][nb2][pr];
-          st.tz = f2v{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-          st.ty = __builtin_elementwise_fma(st.tz, csc[pr], csh[pr]);
-        } else if constexpr (sg == 1) {
-          if constexpr (mish) {
-            st.ty = f2v{fminf(st.ty.x, 20.0f * kLog2e), fminf(st.ty.y, 20.0f * kLog2e)};
-            st.tu.x = __builtin_amdgcn_exp2f(st.ty.x);
-          }
-        } else if constexpr (sg == 2) {
-          if constexpr (mish) st.tu.y = __builtin_amdgcn_exp2f(st.ty.y);
-        } else if constexpr (sg == 3) {
-          if constexpr (mish) {
-            st.tn = st.tu * (st.tu + 2.0f);
-            st.tw = st.tn + 2.0f;
-          }
-        } else if constexpr (sg == 4) {
-          if constexpr (mish) st.tr.x = __builtin_amdgcn_rcpf(st.tw.x);
-        } else if constexpr (sg == 5) {
-          if constexpr (mish) st.tr.y = __builtin_amdgcn_rcpf(st.tw.y);
-        } else if constexpr (sg == 6) {
-          if constexpr (mish) {
-            st.tw = __builtin_elementwise_fma(st.tu, st.tu, st.tu);           // u (u + 1)
-            st.tw = st.tw * st.ty;
-            st.tu = st.tr * (4.0f * 0.69314718055994530942f);                   // 4 ln 2: y was scaled by log2(e)
-          }
-        } else if constexpr (sg == 7) {
-          const f2v da = {st.acc[r][nb2][2 * pr], st.acc[r][nb2][2 * pr + 1]};
-          if constexpr (mish) {
-            st.tn = __builtin_elementwise_fma(st.tw, st.tu, st.tn);
-            st.ty = da * (st.tr * st.tn);
-          } else if constexpr (ACT == VS_ACT_RELU) {
-            st.ty = f2v{st.ty.x > 0.f ? da.x : 0.f, st.ty.y > 0.f ? da.y : 0.f};
-          } else {
-            st.ty = da;
-          }
-        } else {
-          const f2v dm = st.ty * st.mk[nb2];
-          a1[pr] += dm;
-          a2[pr] = __builtin_elementwise_fma(dm, st.tz, a2[pr]);
-          st.y[nb2][pr] = st.ty;
-        }
-      } else {
-        store_px<RV>(x, st, r, q - 1 - NB * 2 * NSTAGE);
-      }
-    }
-  }
-
-  // ---- EP = 2: which micro-ops ride behind which MFMA ---------------------------------------------------------------------------------
+  // ---- which micro-ops ride behind which MFMA -----------------------------------------------------------------------------------------
   // A group's MFMAs are numbered in issue order (slots); its epilogue work is ONE list: the micro-ops of the three carried rows, then
   // of its own rows 0 .. RV - 4.  Carried rows can start at slot 0, row r behind the first MFMA of window row r + KT (its last
   // product was four or more MFMAs earlier).  The list is dealt out at an even pace over the slots that are left -- one micro-op per
-  // slot for 5x5 groups of eight rows: 648 micro-ops of the dy form on 800 MFMAs, where EP = 1 left the last four rows' epilogues on
-  // 120 MFMAs and none -- limited by what is available; what does not fit runs behind the group's last MFMA.
+  // slot for 5x5 groups of eight rows: 648 micro-ops of the dy form on 800 MFMAs -- limited by what is available; what does not fit
+  // (two-row tail groups) runs behind the group's last MFMA.
   static constexpr int nm_of(int RV, int i) { return (i < RV - 1 ? i : RV - 1) - (i - (KT - 1) > 0 ? i - (KT - 1) : 0) + 1; }
   static constexpr int slot_base(int RV, int i) { int s = 0; for (int k = 0; k < i; ++k) s += 2 * NB * KF * nm_of(RV, k); return s; }
   template <int RV>
@@ -640,59 +487,34 @@ struct ConvWalk {
     }
     static constexpr Tab tab = make();
   };
-  template <int RV, int MODE, int M0, int... Ds>
+  template <int RV, bool FLUSH, int M0, int... Ds>
   __device__ __forceinline__ void epis(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Ds...>) {
-    (epi<RV, MODE, (M0 + Ds) / NMICRO, (M0 + Ds) % NMICRO>(x, st), ...);
+    (epi<RV, (M0 + Ds) / NMICRO, (M0 + Ds) % NMICRO, FLUSH>(x, st), ...);
   }
 
+  // gstep<RV, GI> is fragment GI of the block: its read two fragments ahead and its MFMAs.  The instruction order is pinned
+  // (volatile MFMAs, sched_barrier after every one): hipcc's own order reads a fragment, waits for it and issues two MFMAs, and
+  // its sched_group_barrier solver needs 17 minutes for this block.
   template <int RV, int GI, int MM>
   __device__ __forceinline__ void gmfma(const Item& x, GroupState<RV>& st) {
     constexpr int nb = GI % NB, kc = (GI / NB) % 2, df = (GI / (2 * NB)) % KF, i = GI / (2 * NB * KF), ls = GI % (2 * NB * KF);
     constexpr int r_lo = i - (KT - 1) > 0 ? i - (KT - 1) : 0, r_hi = i < RV - 1 ? i : RV - 1;
     constexpr int nm = r_hi - r_lo + 1;                     // MFMAs this fragment feeds
     constexpr int r = r_lo + MM;                            // tap dt = i - r
-    if constexpr (EP >= 1) {
-      // Volatile assembly: the builtin is a pure value to the compiler, which placed it on either side of the (volatile) stage
-      // instructions -- the micro-ops then clustered again.  Weights in AGPRs (all 50 fragments: read-only, every use is here),
-      // accumulators in VGPRs: the epilogue reads them without v_accvgpr_read (128 per group), and the first product of an
-      // accumulator takes the constant 0 as its addend instead of a cleared register (64 v_mov per group).  The compiler cannot see
-      // the MFMA inside, so nothing may read an accumulator sooner than the hardware allows: the first reader of row r's values is a
-      // micro-op of window row r + KT, >= 4 MFMAs (64 cycles) behind the last write.
-      constexpr bool first = (i == r) && df == 0 && kc == 0;
-      if constexpr (first)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
-      else
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
-    } else {
-      st.acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(i - r) * KF + df][kc], st.bq[GI % 3], st.acc[r][nb], 0, 0, 0);
-    }
+    // Volatile assembly: the builtin is a pure value to the compiler, which placed it on either side of the stage instructions --
+    // the micro-ops then clustered again.  Weights in AGPRs (all 50 fragments: read-only, every use is here), accumulators in
+    // VGPRs: the epilogue reads them without v_accvgpr_read (128 per group), and the first product of an accumulator takes the
+    // constant 0 as its addend instead of a cleared register (64 v_mov per group).
+    constexpr bool first = (i == r) && df == 0 && kc == 0;
+    if constexpr (first)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
+    else
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(st.acc[r][nb]) : "a"(wf[(i - r) * KF + df][kc]), "v"(st.bq[GI % 3]));
     if constexpr (MM == 0 && GI % 4 == 0 && GI / 4 < G::UNITS) row_unit<GI / 4>(bt);      // the next group's window: one row per unit
-    if constexpr (EP == 2) {
-      constexpr int sl = slot_base(RV, i) + ls * nm + MM;
-      constexpr int m0 = Plan<RV>::tab.lo[sl], m1 = Plan<RV>::tab.lo[sl + 1];
-      epis<RV, 2, m0>(x, st, std::make_integer_sequence<int, m1 - m0>());
-    }
-    if constexpr (EP != 2 && DY && GI == 0 && MM == 0) {    // z of the group's first two rows
-      load_z<RV>(x, st, 0);
-      if constexpr (RV > 1) load_z<RV>(x, st, 1);
-    }
-    if constexpr (EP != 2 && i >= H + 1) {
-      // The epilogue micro-ops of the row completed before window row i ride on its MFMAs: every stride-th MFMA
-      // carries `per` of them (stride > 1 when the row has more MFMAs than micro-ops: spread them out; per > 1 near
-      // the end of a group, where a window row has few MFMAs -- 7x1: 4 -- and several micro-ops must share one)
-      constexpr int cap = 2 * NB * KF * nm, q = ls * nm + MM;
-      constexpr int stride = cap >= NMICRO ? cap / NMICRO : 1, per = (NMICRO + cap - 1) / cap;
-      if constexpr (q % stride == 0) {
-        constexpr int m0 = (q / stride) * per;
-        micros<RV, i - H - 1, m0>(x, st, std::make_integer_sequence<int, (m0 < NMICRO ? (NMICRO - m0 < per ? NMICRO - m0 : per) : 0)>());
-      }
-    }
+    constexpr int sl = slot_base(RV, i) + ls * nm + MM;
+    constexpr int m0 = Plan<RV>::tab.lo[sl], m1 = Plan<RV>::tab.lo[sl + 1];
+    epis<RV, false, m0>(x, st, std::make_integer_sequence<int, m1 - m0>());
     __builtin_amdgcn_sched_barrier(0);
-  }
-
-  template <int RV, int r, int Q0, int... Ds>
-  __device__ __forceinline__ void micros(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Ds...>) {
-    (micro<RV, r, Q0 + Ds>(x, st), ...);
   }
 
   template <int RV, int GI, int... MMs>
@@ -715,26 +537,16 @@ struct ConvWalk {
     (gstep<RV, GIs>(x, st), ...);
   }
 
-  template <int RV, int... Qs>
-  __device__ __forceinline__ void last_row(const Item& x, GroupState<RV>& st, std::integer_sequence<int, Qs...>) {
-    (micro<RV, RV - 1, Qs>(x, st), ...);
-  }
-
   template <int RV>
   __device__ __forceinline__ void group(const Item& x, int ro, int buf) {
     static_assert((RV + H) * KF * 2 * NB >= 4 * G::UNITS, "every DMA row unit needs a step");
+    using PL = Plan<RV>;
     GroupState<RV> st;
     st.ro = ro;
 #pragma unroll
     for (int df = 0; df < KF; ++df)
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) st.vb[df][kc] = lds0 + (unsigned)(buf * G::WBUF + boff[df][kc]);
-    if constexpr (EP == 0) {
-#pragma unroll
-      for (int r = 0; r < RV; ++r)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) st.acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     if constexpr (DY) {
 #pragma unroll
       for (int nb2 = 0; nb2 < NB; ++nb2) st.cok[nb2] = (x.strip * STRIP + nb2 * 16 + n < a.F) ? 1.f : 0.f;
@@ -742,64 +554,54 @@ struct ConvWalk {
     st.bq[0] = frag<RV>(st, 0);
     st.bq[1] = frag<RV>(st, 1);
     gsteps<RV>(x, st, std::make_integer_sequence<int, (RV + H) * KF * 2 * NB>());
-    // EP = 1: the last row's accumulators were written by the group's last two MFMAs, which the compiler cannot see inside their
-    // assembly statements: the wait states between a matrix-pipe write and a VALU read of the same register (11 for an 8-pass
-    // instruction) are ours to provide here; everywhere else >= 4 MFMAs lie between the last write and the first read
-    // (the statement takes the row's accumulators as in-out operands: a bare s_nop does not keep the compiler from moving the first
-    // reads above it -- it did, in the Mish instance: the first channel pair of every group's last row came out wrong now and then)
-    if constexpr (EP == 1) asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
-    if constexpr (EP != 2) {
-      last_row<RV>(x, st, std::make_integer_sequence<int, NMICRO>());
-    } else {
-      using PL = Plan<RV>;
-      epis<RV, 2, PL::tab.lo[PL::NSLOT]>(x, st, std::make_integer_sequence<int, PL::L - PL::tab.lo[PL::NSLOT]>());       // what did not fit (two-row tail groups)
-      // hand the last three rows over to the next group.  The last row's accumulators come from the group's final MFMAs: wait them out
-      // (in-out operands: see above) before anything copies them.
-      asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
-      constexpr int first = RV >= 4 ? RV - 3 : 0;
+    epis<RV, false, PL::tab.lo[PL::NSLOT]>(x, st, std::make_integer_sequence<int, PL::L - PL::tab.lo[PL::NSLOT]>());       // what did not fit (two-row tail groups)
+    // Hand the last three rows over to the next group.  The last row's accumulators come from the group's final MFMAs, which the
+    // compiler cannot see inside their assembly statements: the wait states between a matrix-pipe write and a VALU read of the same
+    // register (11 for an 8-pass instruction) are ours to provide.  The statement takes the accumulators as in-out operands: a bare
+    // s_nop does not keep the compiler from moving a read above it (it did, in round 6's first version: the first channel pair of
+    // every group's last row came out wrong now and then).
+    asm volatile("s_nop 15" : "+v"(st.acc[RV - 1][0]), "+v"(st.acc[RV - 1][NB - 1]));
+    constexpr int first = RV >= 4 ? RV - 3 : 0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (first + j < RV) {
-          crow[j] = row_offset(x, st.ro + first + j);
+    for (int j = 0; j < 3; ++j) {
+      if (first + j < RV) {
+        crow[j] = row_offset(x, st.ro + first + j);
 #pragma unroll
-          for (int nb2 = 0; nb2 < NB; ++nb2) cacc[j][nb2] = st.acc[first + j < RV ? first + j : 0][nb2];
-        } else {
-          crow[j] = kOob;
-        }
+        for (int nb2 = 0; nb2 < NB; ++nb2) cacc[j][nb2] = st.acc[first + j < RV ? first + j : 0][nb2];
+      } else {
+        crow[j] = kOob;
       }
+    }
 #pragma unroll
-      for (int nb2 = 0; nb2 < NB; ++nb2) {
-        cvcol[nb2] = vcol[nb2];
-        if constexpr (DY) ccok[nb2] = st.cok[nb2];
-      }
-      crout = rout;
-      if constexpr (DY) {
-        crz = rz;
-        // the z ring was filled at this group's phase: position PL::P_ of it is the next group's position 0
-        constexpr int sh = PL::P_ % 3;
-        if constexpr (sh != 0) {
-          u2v tmp[3][NB];
+    for (int nb2 = 0; nb2 < NB; ++nb2) {
+      cvcol[nb2] = vcol[nb2];
+      if constexpr (DY) ccok[nb2] = st.cok[nb2];
+    }
+    crout = rout;
+    if constexpr (DY) {
+      crz = rz;
+      // the z ring was filled at this group's phase: position PL::P_ of it is the next group's position 0
+      constexpr int sh = PL::P_ % 3;
+      if constexpr (sh != 0) {
+        u2v tmp[3][NB];
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int nb2 = 0; nb2 < NB; ++nb2) tmp[k][nb2] = zq3[(k + sh) % 3][nb2];
+          for (int nb2 = 0; nb2 < NB; ++nb2) tmp[k][nb2] = zq3[(k + sh) % 3][nb2];
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int nb2 = 0; nb2 < NB; ++nb2) zq3[k][nb2] = tmp[k][nb2];
-        }
+          for (int nb2 = 0; nb2 < NB; ++nb2) zq3[k][nb2] = tmp[k][nb2];
       }
     }
   }
 
-  // EP = 2: behind the launch's last group the three carried rows still owe their epilogue
+  // behind the launch's last group the three carried rows still owe their epilogue
   __device__ __forceinline__ void flush_carry() {
-    if constexpr (EP == 2) {
-      Item x{};
-      GroupState<2> st;
-      st.ro = 0;
-      epis<2, 3, 0>(x, st, std::make_integer_sequence<int, 3 * NMICRO>());
-    }
+    Item x{};
+    GroupState<2> st;
+    st.ro = 0;
+    epis<2, true, 0>(x, st, std::make_integer_sequence<int, 3 * NMICRO>());
   }
 
   __device__ __forceinline__ void flush_stats() {
@@ -815,6 +617,10 @@ struct ConvWalk {
         s2[r] += __shfl_xor(s2[r], o, 64);
       }
     }
+    // deterministic mode: the workgroups that share a slot add in index order (vs_common.h)
+    const unsigned slot = blockIdx.x % VS_BN_STAT_SLOTS, rank_in_slot = blockIdx.x / VS_BN_STAT_SLOTS;
+    unsigned* my_turn = a.turn ? a.turn + VS_TURN_SLOT + slot : nullptr;
+    vs_turn_begin(my_turn, rank_in_slot);
     if (n == 0) {
       double* dst = a.bn_stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + (wave * 16 + g * 4) * 2;
 #pragma unroll
@@ -828,14 +634,14 @@ struct ConvWalk {
         atomicAdd(dst + 2 * r + 1, t2);
       }
     }
+    vs_turn_end(my_turn, rank_in_slot, (gridDim.x - slot + VS_BN_STAT_SLOTS - 1) / VS_BN_STAT_SLOTS);
   }
 };
 
-template <int KT, int KF, int ACT, bool STATS, bool DY, int EP = 0>
+template <int KT, int KF, int ACT, bool STATS, bool DY>
 __device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsigned char* smem) {
   using G = Geo<KT, KF>;
-  if (a.prio) __builtin_amdgcn_s_setprio(3);
-  ConvWalk<KT, KF, ACT, STATS, DY, EP> wk(a, (const lds_byte*)smem);
+  ConvWalk<KT, KF, ACT, STATS, DY> wk(a, (const lds_byte*)smem);
 
   // prefetch cursor: the group after the one being computed, in the order the compute cursor reaches them
   Item pf;
@@ -881,34 +687,13 @@ __device__ __forceinline__ void nhwc_conv_body(const NhwcConvArgs& a, const unsi
   wk.flush_stats();
 }
 
-// Two builds of every instance: with the packed-fp32 VALU instructions the epilogue's pair arithmetic compiles to (v_pk_fma_f32,
-// v_pk_mul_f32, v_pk_add_f32), and -- PK = false -- with that subtarget feature switched off for the kernel, so that every pair
-// operation becomes two scalar instructions (same values, bit for bit).  MI355X_MICROARCH.md prices a packed-fp32 instruction
-// beside MFMAs at +22..26 cycles over the two scalar ones it replaces ("an anti-lever beside MFMAs"); vs_set_option(
-// VS_OPT_CONV_SCALAR_EPILOGUE) picks the build, the measurement is in profiles/r05_conv_epilogue_ab.md.
+// Built without packed-fp32 VALU instructions (tools/epilogue_slot_probe.hip: one v_pk_fma_f32 behind an MFMA costs 17 cycles, two
+// scalar v_fma_f32 two): the compiler would otherwise pair the two channels of a stage up again.
 template <int KT, int KF, int ACT, bool STATS, bool DY = false>
-__global__ __launch_bounds__(256, 1)
+__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
 void nhwc_conv_kernel(NhwcConvArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];      // the only LDS object of the kernel
   nhwc_conv_body<KT, KF, ACT, STATS, DY>(a, smem);
-}
-template <int KT, int KF, int ACT, bool STATS, bool DY = false>
-__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
-void nhwc_conv_scalar_kernel(NhwcConvArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
-  nhwc_conv_body<KT, KF, ACT, STATS, DY>(a, smem);
-}
-template <int KT, int KF, int ACT, bool STATS, bool DY = false>
-__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
-void nhwc_conv_fine_kernel(NhwcConvArgs a) {           // EP = 1: one scalar micro-op per MFMA
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
-  nhwc_conv_body<KT, KF, ACT, STATS, DY, 1>(a, smem);
-}
-template <int KT, int KF, int ACT, bool STATS, bool DY = false>
-__global__ __launch_bounds__(256, 1) VS_NO_PACKED_FP32
-void nhwc_conv_carry_kernel(NhwcConvArgs a) {          // EP = 2: ... and the last three rows' epilogues behind the NEXT group's first MFMAs
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Geo<KT, KF>::LDS_BYTES];
-  nhwc_conv_body<KT, KF, ACT, STATS, DY, 2>(a, smem);
 }
 
 // w [co][ci][KT][KF] fp32 -> per-wave A fragments: [q][tap][kc][lane][j] = w'[16q + (lane&15)][32kc + 8(lane>>4) + j][tap]
@@ -959,14 +744,7 @@ int launch_conv(NhwcConvArgs a, int act, hipStream_t stream) {
   const dim3 grid((unsigned)(n_items < cus ? n_items : cus)), block(256);
   const size_t lds = 0;   // static LDS: Geo::LDS_BYTES
   const bool stats = a.bn_stats != nullptr;
-  // 2 (default): per instance what measured faster -- scalar for the activation epilogues of the forward, packed for the dy form
-  const int sopt = vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE);
-  const bool scalar = sopt == 1 || (sopt == 2 && !a.z2 && act != VS_ACT_NONE);
-  const bool fine = vs_opt(VS_OPT_CONV_EPILOGUE) == 1, carry = vs_opt(VS_OPT_CONV_EPILOGUE) == 2;
-#define VS_NHWC_LAUNCH3(A, S, D) do { if (carry) hipLaunchKernelGGL((nhwc_conv_carry_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
-                                      else if (fine) hipLaunchKernelGGL((nhwc_conv_fine_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
-                                      else if (scalar) hipLaunchKernelGGL((nhwc_conv_scalar_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); \
-                                      else hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a); } while (0)
+#define VS_NHWC_LAUNCH3(A, S, D) hipLaunchKernelGGL((nhwc_conv_kernel<KT, KF, A, S, D>), grid, block, lds, stream, a)
 #define VS_NHWC_LAUNCH(A, S) VS_NHWC_LAUNCH3(A, S, false)
   if (a.z2) {            // data gradient with the activation-derivative epilogue: act = the activation whose derivative is taken
     VS_REQUIRE(stats && a.bn2_scale && a.bn2_shift && a.bn2_mean && a.bn2_invstd, "nhwc conv: the dy epilogue needs statistics slots and BatchNorm constants");
@@ -1010,9 +788,7 @@ int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, co
              (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "nhwc conv: buffers must be 16-byte aligned");
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(in), reinterpret_cast<const unsigned short*>(packed), scale, shift,
                  reinterpret_cast<unsigned short*>(out), bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
-  if (KT == 5 && KF == 5 && (vs_opt(VS_OPT_CONV8) & 1))
-    return vs_nhwc_conv8_impl(in, packed, scale, shift, out, bn_stats, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, F, dil, act, stream);
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, g_vs_turn};
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);
@@ -1033,9 +809,7 @@ int vs_nhwc_conv_dy_impl(const void* dz, const void* packed, void* dy, const voi
              (reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 7) == 0, "nhwc conv dy: buffer alignment");
   NhwcConvArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(packed), bn_scale, bn_shift,
                  reinterpret_cast<unsigned short*>(dy), bn_stats, reinterpret_cast<const unsigned short*>(z), bn_scale, bn_shift, bn_mean, bn_invstd,
-                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, (vs_opt(VS_OPT_MFMA_PRIO) >> 1) & 1};
-  if (KT == 5 && KF == 5 && (vs_opt(VS_OPT_CONV8) & 2))
-    return vs_nhwc_conv8_impl(dz, packed, bn_scale, bn_shift, dy, bn_stats, z, bn_scale, bn_shift, bn_mean, bn_invstd, B, T, F, dil, act, stream);
+                 B, T, F, dil, (F + STRIP - 1) / STRIP, 1, 0, 0, g_vs_turn};
   if (KT == 5 && KF == 5) return launch_conv<5, 5>(a, act, stream);
   if (KT == 7 && KF == 1) return launch_conv<7, 1>(a, act, stream);
   VS_REQUIRE(false, "nhwc conv dy: kernel %dx%d is not one of the stack's (7x1, 5x5)", KT, KF);

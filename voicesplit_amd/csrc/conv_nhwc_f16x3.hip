@@ -82,7 +82,7 @@ struct SGeo {
 
 struct Item { int b, cls, strip, o0, o1, in_end, ngroups; };
 
-// ABL (instances built with -DVS_ABLATION only, selected by VOICESPLIT_SPLITCONV_ABL): timing ablations (results invalid), tools/split_conv_micro.py: 1 = no window DMA, 2 = no epilogue micro-ops, 4 = no hand-over,
+// ABL (instances built with -DVS_ABLATION only, selected by VS_OPT_ABLATION): timing ablations (results invalid), tools/split_conv_micro.py: 1 = no window DMA, 2 = no epilogue micro-ops, 4 = no hand-over,
 // 8 = epilogue without its stores, 16 = the stores without the arithmetic, 64 = the H rows two groups share are not fetched again (what a ring buffer would save), 32 = valid results + s_memtime probes of the group boundary
 // (written over amax_out: tools/split_conv_micro.py prints them)
 template <int KT, int KF, int ACT, int ABL = 0>
@@ -505,7 +505,7 @@ __device__ __forceinline__ void nhwc_conv_f16x3_body(const SplitConvArgs& a, con
   vs_absmax_commit(wk.am * a.out_scale2[1], a.amax_out);
 }
 
-// (the _scalar build: no packed-fp32 VALU instructions in the epilogue -- conv_nhwc.hip has the reason; vs_set_option(VS_OPT_CONV_SCALAR_EPILOGUE))
+// (the packed-fp32 build: VS_ABLATION instances only; the product launches the _scalar build below -- conv_nhwc.hip has the reason)
 template <int KT, int KF, int ACT, int ABL = 0>
 __global__ __launch_bounds__(256, 1)
 void nhwc_conv_f16x3_kernel(SplitConvArgs a) {
@@ -616,7 +616,7 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
   if (want < grid) grid = (int)want;
   const dim3 g((unsigned)grid), block(256);
 #ifdef VS_ABLATION        // timing ablations / in-kernel probes (tools/split_conv_micro.py): make -C voicesplit_amd/csrc ABLATION=1
-  const int abl = vs_opt(VS_OPT_SPLITCONV_ABL);     // timing ablations, Mish only
+  const int abl = vs_opt(VS_OPT_ABLATION);          // timing ablations, Mish only
   if (abl && act == VS_ACT_MISH) {
     if (abl == 1) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 1>), g, block, 0, stream, a);
     else if (abl == 2) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 2>), g, block, 0, stream, a);
@@ -630,15 +630,11 @@ int launch_split(SplitConvArgs a, int act, hipStream_t stream) {
     else hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH, 16>), g, block, 0, stream, a);
   } else
 #endif
-  if (vs_opt(VS_OPT_CONV_SCALAR_EPILOGUE)) {      // 1, or 2 = per instance what measured faster: this kernel's scalar build (1-1.5 %)
-    if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
-    else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
-    else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
-    else VS_REQUIRE(false, "nhwc f16x3 conv: unsupported activation %d", act);
-  } else
-  if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
-  else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
+  // the build without packed-fp32 VALU instructions (1-1.5 % faster in round 5, eight of eight pairs; tools/epilogue_slot_probe.hip in
+  // round 6 says why: one v_pk_fma_f32 behind an MFMA costs 17 cycles, two scalar v_fma_f32 two).  The packed build is gone.
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_MISH>), g, block, 0, stream, a);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_RELU>), g, block, 0, stream, a);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_f16x3_scalar_kernel<KT, KF, VS_ACT_NONE>), g, block, 0, stream, a);
   else VS_REQUIRE(false, "nhwc f16x3 conv: unsupported activation %d", act);
   VS_LAUNCH_CHECK();
   return 0;

@@ -374,7 +374,7 @@ void gemm_bf16_il_kernel(GemmBf16Args g) {
   // per K step the tile origin moves by BK elements along k: BK * 2 bytes (row form) or BK lines (col form)
   const unsigned kstepA = AK ? (unsigned)BK * (unsigned)g.lda * 2u : (unsigned)BK * 2u;
   const unsigned kstepB = BK_ ? (unsigned)BK * (unsigned)g.ldb * 2u : (unsigned)BK * 2u;
-  // g.accumulate < 0 (VOICESPLIT_GEMM_ABL=nodma, timing ablation only): every descriptor is empty -- the DMA instructions issue and
+  // g.accumulate < 0 (VS_OPT_ABLATION = 9 in a VS_ABLATION build, timing only): every descriptor is empty -- the DMA instructions issue and
   // zero-fill the stage without touching memory: what is left is the kernel's time without the memory side
   const bool feed = g.accumulate >= 0;
   u4v dA = OA::tile_desc(g.A, g.lda, g.M, g.K, ptm * TM, 0, plive && feed), dB = OB::tile_desc(g.B, g.ldb, g.N, g.K, ptn * TN, 0, plive && feed);
@@ -660,19 +660,13 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
   const dim3 grid((unsigned)nwg), block(256);
   const int form = (!a_kmajor && !b_kmajor) ? 0 : (!a_kmajor && b_kmajor) ? 1 : (a_kmajor && b_kmajor) ? 2 : 3;
   VS_REQUIRE(form != 3, "gemm_bf16: the col x row form is not used by the path");
-  // round 4: the interleaved kernel (side work in the slots behind the MFMAs); vs_set_option(VS_OPT_GEMM_KERNEL, 1) selects the round-3
-  // kernel for A/B timing (same arithmetic, same summation order: bit-identical results)
-  const bool use_old = vs_opt(VS_OPT_GEMM_KERNEL) == 1 || !g.vec_ok;      // the interleaved kernel's epilogue moves 16 bytes at a time
-  if (!use_old) {
-    // VS_OPT_GEMM_DR: three digits (row x row, row x col, col x col), each 4 or 8 = rows the DMA chunks are issued in (A/B timing)
-    const int dr_cfg = vs_opt(VS_OPT_GEMM_DR);
-    const bool nodma = vs_opt(VS_OPT_GEMM_ABL) == 9;
-    if (nodma) g.accumulate = -1;                          // timing ablation: results are meaningless
-    const int dr = form == 0 ? dr_cfg / 100 : form == 1 ? (dr_cfg / 10) % 10 : dr_cfg % 10;
-    VS_REQUIRE(dr == 4 || dr == 8, "gemm_bf16: VS_OPT_GEMM_DR digit %d", dr);
+  // round 4: the interleaved kernel (side work in the slots behind the MFMAs, DMA chunks in 8 rows of the step: 4 rows measured
+  // slower, profiles/r04_gemm_interleave.md); shapes its 16-byte epilogue cannot serve (vec_ok) take the round-3 kernel below
+  if (g.vec_ok) {
 #ifdef VS_ABLATION
-    const int abl = vs_opt(VS_OPT_GEMM_ABL) <= 3 ? vs_opt(VS_OPT_GEMM_ABL) : 0;
-    if (abl && form == 0) {
+    const int abl = vs_opt(VS_OPT_ABLATION);
+    if (abl == 9) g.accumulate = -1;                       // no DMA: timing only, results are meaningless
+    if (abl >= 1 && abl <= 3 && form == 0) {
       if (abl == 1) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 1>), grid, block, 0, stream, g);
       else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 2>), grid, block, 0, stream, g);
       else hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8, 3>), grid, block, 0, stream, g);
@@ -680,12 +674,9 @@ int vs_gemm_bf16_impl(int a_kmajor, int b_kmajor, const void* A, int lda, const 
       return 0;
     }
 #endif
-#define VS_GEMM_IL(AK_, BK2_) do { if (dr == 4) hipLaunchKernelGGL((gemm_bf16_il_kernel<AK_, BK2_, 4>), grid, block, 0, stream, g); \
-                                   else hipLaunchKernelGGL((gemm_bf16_il_kernel<AK_, BK2_, 8>), grid, block, 0, stream, g); } while (0)
-    if (form == 0) VS_GEMM_IL(false, false);
-    else if (form == 1) VS_GEMM_IL(false, true);
-    else VS_GEMM_IL(true, true);
-#undef VS_GEMM_IL
+    if (form == 0) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, false, 8>), grid, block, 0, stream, g);
+    else if (form == 1) hipLaunchKernelGGL((gemm_bf16_il_kernel<false, true, 8>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_bf16_il_kernel<true, true, 8>), grid, block, 0, stream, g);
     VS_LAUNCH_CHECK();
     return 0;
   }

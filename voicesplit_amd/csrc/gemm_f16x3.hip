@@ -90,7 +90,7 @@ struct OperandView {
 constexpr unsigned kOob = 0xFFFFFFF0u;    // beyond any descriptor (operands are < 4 GiB)
 
 // Workgroup id -> (m, n) tile.  XCD x (= workgroup id % 8, the dispatcher's round robin) owns the contiguous range
-// [x*per, (x+1)*per) of a BANDED tile list: bands of `band` tile rows (8; VOICESPLIT_GEMM_BAND overrides it for A/B timing, 0 = the row-major list), inside a band the m index runs fastest.
+// [x*per, (x+1)*per) of a BANDED tile list: bands of `band` tile rows (8; 1 and 1024 measured the same in round 3, 0 = the row-major list), inside a band the m index runs fastest.
 // The ~64 workgroups an XCD has resident at a time then cover an 8 x 8 block of tiles: per K step they share 8 + 8
 // operand panels in that XCD's L2, where the row-major list (n fastest, 25 tiles per row in the LSTM input GEMM)
 // made them span 2.6 tile rows = 3 + 25 panels and re-stream all of W from the Infinity Cache for every row panel
@@ -491,7 +491,7 @@ void gemm_pre_kernel(GemmPreArgs g) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int gemm_band() { return vs_opt(VS_OPT_GEMM_BAND); }
+int gemm_band() { return 8; }      // tile rows per band of the raster (1 / 8 / 1024 measured the same in round 3: profiles/r03_gemm_l2_prefetch.md)
 
 }  // namespace
 

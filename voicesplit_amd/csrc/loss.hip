@@ -188,6 +188,7 @@ void sisnr_moments_kernel(const float* __restrict__ est, const float* __restrict
     a[0] += r;
     if (i < L) { a[1] += e; a[2] += r; a[3] += e * r; a[4] += e * e; a[5] += r * r; }
   }
+  __shared__ double red[4][6];
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
 #pragma unroll
@@ -195,8 +196,12 @@ void sisnr_moments_kernel(const float* __restrict__ est, const float* __restrict
   }
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) atomicAdd(&mom[b * 8 + q], a[q]);
+    for (int q = 0; q < 6; ++q) red[threadIdx.x >> 6][q] = a[q];
   }
+  __syncthreads();
+  // one addition per workgroup and moment, its four waves in a fixed order (deterministic mode launches ONE workgroup per utterance:
+  // then nothing about the sum depends on arrival order)
+  if (threadIdx.x < 6) atomicAdd(&mom[b * 8 + threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // per utterance: SI-SNR and the three coefficients of d(loss)/d(est[t]) = m_t*(cs*zs_t + ce*ze_t - c0);
@@ -456,7 +461,7 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
   double* mom = at<double>(ws, L.mom);
   float* coef = at<float>(ws, L.coef);
   VS_CHECK_HIP(hipMemsetAsync(mom, 0, (size_t)s.B * 8 * 8, stream));
-  const int gx = (s.S + 256 * 16 - 1) / (256 * 16);
+  const int gx = vs_opt(VS_OPT_DETERMINISTIC) ? 1 : (s.S + 256 * 16 - 1) / (256 * 16);
   hipLaunchKernelGGL(sisnr_moments_kernel, dim3(gx, s.B), dim3(256), 0, stream, wav[0], wav[1], seq_len, mom, s);
   hipLaunchKernelGGL(sisnr_finalize_kernel, dim3(1), dim3(64), 0, stream, mom, seq_len, coef, loss, s);
   if (dmask) {

@@ -1335,166 +1335,6 @@ void lstm16_bwd_persistent_kernel(Lstm16BwdArgs a) {
   }
 }
 
-// The persistent BPTT with the gate gradients as their own flags: lstm16_tagged_kernel's hand-off (four exchange buffers, sentinel
-// slots, re-arming behind the K reduction's barrier).  4H <= 8 * 13 * 16 = 1664 (all chunks register-resident), else the flag kernel.
-__global__ __launch_bounds__(512)
-void lstm16_bwd_tagged_kernel(Lstm16BwdArgs a, void* gbuf2, void* gbuf3) {
-  __shared__ float sRed[2][8 * 16 * 64];      // by step parity (lstm16_tagged_kernel)
-  __shared__ int sDead;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int NCt = a.H / 4;
-  const int NUT = (a.H + 31) / 32;
-  const int NBT = a.Bpad / 32;
-  const int ut = blockIdx.x % NUT;
-  const int bt = a.bt0 + blockIdx.x / NUT;
-  const int dir = blockIdx.y;
-  if (tid == 0) sDead = 0;
-
-  const int b31 = tid & 31, ug = (tid >> 5) & 7;
-  const int b = bt * 32 + b31;
-  const int u0 = ut * 32 + 4 * ug;
-  const bool units_ok = tid < 256 && u0 < a.H;          // wave-uniform (H % 8 == 0)
-  const bool item = units_ok && b < a.B;
-
-  const u32x4_t* wq = a.wpt + ((size_t)(dir * NUT + ut) * NCt) * 64 + lane;
-  bf16x8 w[kBwdRes16];
-#pragma unroll
-  for (int i = 0; i < kBwdRes16; ++i) {
-    const int c = wave + 8 * i;
-    w[i] = __builtin_bit_cast(bf16x8, c < NCt ? wq[(size_t)c * 64] : u32x4_t{0u, 0u, 0u, 0u});
-  }
-  const size_t group = (size_t)dir * NBT + bt;
-  const unsigned gbytes = (unsigned)((size_t)2 * NBT * NCt * 1024);
-  __amdgpu_buffer_rsrc_t grs[4] = {__builtin_amdgcn_make_buffer_rsrc(a.gbuf0, 0, gbytes, 0x00020000),
-                                   __builtin_amdgcn_make_buffer_rsrc(a.gbuf1, 0, gbytes, 0x00020000),
-                                   __builtin_amdgcn_make_buffer_rsrc(gbuf2, 0, gbytes, 0x00020000),
-                                   __builtin_amdgcn_make_buffer_rsrc(gbuf3, 0, gbytes, 0x00020000)};
-  // the four slots this lane stores per step (waves 0-3, lower half-wave): gate g's half-chunk of rows g * H + ut * 32 + 8 * wave .. + 7
-  unsigned slot_off[4];
-#pragma unroll
-  for (int gate = 0; gate < 4; ++gate) {
-    const int r0 = gate * a.H + ut * 32 + 8 * (wave & 3);
-    slot_off[gate] = (unsigned)(((group * NCt + (r0 >> 4)) * 64 + ((r0 >> 3) & 1) * 32 + b31) * 16);
-  }
-  const bool rearmer = tid >= 256 && u0 < a.H && half == 0;      // wave w + 4 re-arms the slots of wave w (same lane -> same slots)
-  float dcc[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-#pragma unroll 1
-  for (int s = 0; s < a.T; ++s) {
-    const int t = dir ? s : (a.T - 1 - s);
-    const int tp = dir ? t + 1 : t - 1;                 // forward-order predecessor (c_{t-1})
-    float4 gi4, gf4, gg4, go4, c4, cp4, dh4;
-    gi4 = gf4 = gg4 = go4 = c4 = cp4 = dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float* grow = a.gates + ((size_t)(item ? b : 0) * a.T + t) * (8 * a.H) + (size_t)dir * 4 * a.H + (item ? u0 : 0);
-    if (item) {
-      gi4 = *reinterpret_cast<const float4*>(grow);
-      gf4 = *reinterpret_cast<const float4*>(grow + a.H);
-      gg4 = *reinterpret_cast<const float4*>(grow + 2 * a.H);
-      go4 = *reinterpret_cast<const float4*>(grow + 3 * a.H);
-      const size_t so = ((size_t)b * a.T + t) * (2 * a.H) + (size_t)dir * a.H + u0;
-      c4 = *reinterpret_cast<const float4*>(a.c_all + so);
-      dh4 = *reinterpret_cast<const float4*>(a.dout + so);
-      if (tp >= 0 && tp < a.T)
-        cp4 = *reinterpret_cast<const float4*>(a.c_all + ((size_t)b * a.T + tp) * (2 * a.H) + (size_t)dir * a.H + u0);
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int rb = s & 3, wb = (s + 1) & 3, zb = (s + 3) & 3;          // lstm16_tagged_kernel's protocol
-    if (s > 0) {
-      const unsigned goff = (unsigned)((group * NCt * 64 + lane) * 16);
-      bf16x8 g[kBwdRes16];
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < kBwdRes16; ++i) {
-          const int c = wave + 8 * i;
-          const u32x4_t v = c < NCt ? __builtin_amdgcn_raw_buffer_load_b128(grs[rb], goff + (unsigned)c * 1024u, 0, 16 /* sc1 */)
-                                    : u32x4_t{0u, 0u, 0u, 0u};
-          ok = ok && v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel;
-          g[i] = __builtin_bit_cast(bf16x8, v);
-        }
-        if (__all(ok)) break;
-        if (++spins > kSpinLimit / 4 || *(volatile int*)&sDead) {      // (a poll round here is 7-13 loads, not one: the same give-up time as the flag kernels')
-          if (lane == 0) { sDead = 1; __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int i = 0; i < kBwdRes16; ++i) {
-        if (wave + 8 * i < NCt)        // wave-uniform
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i], g[i], acc, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[s & 1][(wave * 16 + r) * 64 + lane] = acc[r];
-    // waves 4-7 re-arm (the storing waves' queues carry the gradients); their previous re-arming stores are acknowledged in front of the barrier
-    if (tid >= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s > 0 && rearmer) {       // every wave's poll has succeeded: the group is done with buffer zb
-#pragma unroll
-      for (int gate = 0; gate < 4; ++gate)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{kSentinel, kSentinel, kSentinel, kSentinel}, grs[zb], slot_off[gate], 0, 16);
-    }
-    if (tid < 256) {
-      float dh[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dh[u] += sRed[s & 1][(w8 * 16 + 4 * wave + u) * 64 + lane];
-      const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
-      const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
-      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
-      float dg4[4][4];        // [gate i,f,g,o][unit]
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float tc = vs_tanh_fast(cc[u]);
-        dg4[3][u] = dh[u] * tc * go[u] * (1.f - go[u]);
-        const float dc = fmaf(dh[u] * go[u], 1.f - tc * tc, dcc[u]);
-        dg4[0][u] = dc * gg[u] * gi[u] * (1.f - gi[u]);
-        dg4[1][u] = dc * cp[u] * gf[u] * (1.f - gf[u]);
-        dg4[2][u] = dc * gi[u] * (1.f - gg[u] * gg[u]);
-        dcc[u] = dc * gf[u];
-      }
-      if (!item) {
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) dg4[gate][u] = 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dcc[u] = 0.f;
-      }
-      // next step's operand: rows gate*H + ut*32 + 8*wave .. +7 = one half-chunk; this lane computed 4*half .. 4*half+3 of them
-      if (units_ok) {
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) {
-          bf16x8 v;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float o = __shfl_xor(dg4[gate][u], 32, 64);
-            v[u] = (__bf16)(half ? o : dg4[gate][u]);
-            v[4 + u] = (__bf16)(half ? dg4[gate][u] : o);
-          }
-          if (half == 0)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), grs[wb], slot_off[gate], 0, 16 /* sc1 */);
-        }
-      }
-      if (item) {           // the batched GEMMs' operand, in place of the saved gates
-        *reinterpret_cast<float4*>(grow) = make_float4(dg4[0][0], dg4[0][1], dg4[0][2], dg4[0][3]);
-        *reinterpret_cast<float4*>(grow + a.H) = make_float4(dg4[1][0], dg4[1][1], dg4[1][2], dg4[1][3]);
-        *reinterpret_cast<float4*>(grow + 2 * a.H) = make_float4(dg4[2][0], dg4[2][1], dg4[2][2], dg4[2][3]);
-        *reinterpret_cast<float4*>(grow + 3 * a.H) = make_float4(dg4[3][0], dg4[3][1], dg4[3][2], dg4[3][3]);
-      }
-    }
-  }
-}
-
 }  // namespace
 
 // packed recurrent weights: the fp32 fragment form (every arithmetic: the step kernels use it), then room for the f16
@@ -1541,7 +1381,7 @@ int vs_lstm_pack_impl(const float* whh_f, const float* whh_b, float* wp, int H, 
 // than its flag kernel: every wave polls 13 KB of gradients per round).  Test / A-B switch, process-global.
 static int g_lstm_kernel = 0;
 extern "C" int vs_set_lstm_kernel(int mode) {
-  VS_REQUIRE(mode >= 0 && mode <= 5, "vs_set_lstm_kernel: mode %d", mode);
+  VS_REQUIRE(mode >= 0 && mode <= 4, "vs_set_lstm_kernel: mode %d", mode);
   g_lstm_kernel = mode;
   return 0;
 }
@@ -1681,9 +1521,8 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
   const int bt_per_launch = cus / (2 * NUT);
   const bool persistent = g_lstm_kernel != 1 && bt_per_launch >= 1;
   VS_REQUIRE(g_lstm_kernel != 2 || persistent, "lstm_bwd: persistent recurrence needs %d workgroups <= %d CUs", 2 * NUT, cus);
-  // tagged-data hand-off (bf16 BPTT): buffers 1..3 armed with the sentinel, buffer 0 (no gradient from beyond the sequence) is never read
-  const bool tagged = persistent && math == VS_MATH_CODE_BF16 && g_lstm_kernel == 5 && H / 4 <= 8 * kBwdRes16;
-  if (tagged) VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + frag / 2), (int)kSentinel, frag + frag / 2, stream));
+  // (the tagged-data hand-off of the forward recurrence was built for this kernel too in round 5: correct and 5 % slower -- eight waves
+  // poll 13 KB each per round -- so the BPTT keeps its flags: tools/attic/lstm16_bwd_tagged_kernel.hip.txt)
   if (persistent) {
     unsigned* flags = reinterpret_cast<unsigned*>(state + 2 * frag);      // 2*Bpad*H words available, 2*NBT*NUT*4 used
     unsigned* err = reinterpret_cast<unsigned*>(state + 2 * frag + (size_t)2 * Bpad * H);
@@ -1691,15 +1530,7 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
     for (int bt0 = 0; bt0 < NBT; bt0 += bt_per_launch) {
       const int nbt = NBT - bt0 < bt_per_launch ? NBT - bt0 : bt_per_launch;
       hipError_t e;
-      if (math == VS_MATH_CODE_BF16 && tagged) {
-        // four bf16 exchange buffers in the room of the two fp32-sized fragment regions
-        Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), state, state + frag / 2, flags, err, gates, c_all, dout,
-                        B, T, H, Bpad, bt0};
-        void* g2 = state + frag;
-        void* g3 = state + frag + frag / 2;
-        void* params[] = {&a, &g2, &g3};
-        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm16_bwd_tagged_kernel), dim3(NUT * nbt, 2), dim3(512), params, 0, stream);
-      } else if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
+      if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
         Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), gbuf[0], gbuf[1], flags, err, gates, c_all, dout,
                         B, T, H, Bpad, bt0};
         e = launch_resident(reinterpret_cast<const void*>(&lstm16_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);

@@ -19,7 +19,8 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 // fold per-lane partial sums of a lane's 8 channels (channel piece = lane & 7) over the workgroup and add them to
 // stats[slot][channel][which] (doubles): v[j] for channel 8*(lane&7)+j
 template <int NV>
-__device__ __forceinline__ void fold_channel_sums(float (&v)[NV][8], double* __restrict__ stats, float* lds /* [4 waves][NV][64] */) {
+__device__ __forceinline__ void fold_channel_sums(float (&v)[NV][8], double* __restrict__ stats, float* lds /* [4 waves][NV][64] */,
+                                                  unsigned* turn = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int q = 0; q < NV; ++q)
@@ -32,12 +33,17 @@ __device__ __forceinline__ void fold_channel_sums(float (&v)[NV][8], double* __r
       if (lane < 8) lds[(wave * NV + q) * 64 + lane * 8 + j] = s;
     }
   __syncthreads();
+  // deterministic mode: the workgroups that share a slot add in index order (vs_common.h)
+  const unsigned slot = blockIdx.x % VS_BN_STAT_SLOTS, rank_in_slot = blockIdx.x / VS_BN_STAT_SLOTS;
+  unsigned* my_turn = turn ? turn + VS_TURN_SLOT + slot : nullptr;
+  vs_turn_begin(my_turn, rank_in_slot);
   for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
     const int q = i / 64, c = i - q * 64;
     float s = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += lds[(w * NV + q) * 64 + c];
     atomicAdd(stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 128 + c * 2 + q, (double)s);
   }
+  vs_turn_end(my_turn, rank_in_slot, (gridDim.x - slot + VS_BN_STAT_SLOTS - 1) / VS_BN_STAT_SLOTS);
 }
 
 // The 7 input samples x[f-3 .. f+3] of a pixel for all 8 lanes that share it (one lane per 8 channels): lane `piece`
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256)
 void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ out, long long nrows /* B*T */, int F,
                            double* __restrict__ stats, const float* __restrict__ pre_scale = nullptr, const float* __restrict__ pre_shift = nullptr,
-                           unsigned short* __restrict__ rows_bf16 = nullptr, int Kp = 0) {
+                           unsigned short* __restrict__ rows_bf16 = nullptr, int Kp = 0, unsigned* turn = nullptr) {
   // rows_bf16 != NULL (eval forward, whole path): the output goes out as the bf16 A operand of the LSTM input GEMM instead -- rows
   // [nrows][Kp] (element co * F + f of row (b, t), the K padding zeroed by the wave that owns a row's first block), `out` unused
   __shared__ float red[4 * 16];
@@ -248,9 +254,13 @@ void nhwc_conv_last_kernel(const unsigned short* __restrict__ in, const float* _
       if (n == 0 && g < 2) { red[wave * 16 + (g * 4 + r) * 2] = a; red[wave * 16 + (g * 4 + r) * 2 + 1] = b; }
     }
     __syncthreads();
+    const unsigned slot = blockIdx.x % VS_BN_STAT_SLOTS, rank_in_slot = blockIdx.x / VS_BN_STAT_SLOTS;
+    unsigned* my_turn = turn ? turn + VS_TURN_SLOT + slot : nullptr;
+    vs_turn_begin(my_turn, rank_in_slot);
     if (threadIdx.x < 16)
-      atomicAdd(stats + (size_t)(blockIdx.x % VS_BN_STAT_SLOTS) * 16 + threadIdx.x,
+      atomicAdd(stats + (size_t)slot * 16 + threadIdx.x,
                 (double)red[threadIdx.x] + (double)red[16 + threadIdx.x] + (double)red[32 + threadIdx.x] + (double)red[48 + threadIdx.x]);
+    vs_turn_end(my_turn, rank_in_slot, (gridDim.x - slot + VS_BN_STAT_SLOTS - 1) / VS_BN_STAT_SLOTS);
   }
 }
 
@@ -407,6 +417,7 @@ struct LastBwdBn {
   const u4v* z;
   const float *scale, *shift, *mean, *invstd;
   double* stats;
+  unsigned* turn;          // deterministic mode: the statistics are flushed in workgroup order; else NULL
 };
 
 // activation and its derivative of one value; Mish: both from ONE exp2 and ONE rcp -- u, n, r as in vs_mish_fast2, so the
@@ -550,7 +561,7 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
       b8[0][2 * q] = bacc[0][q].x; b8[0][2 * q + 1] = bacc[0][q].y;
       b8[1][2 * q] = bacc[1][q].x; b8[1][2 * q + 1] = bacc[1][q].y;
     }
-    fold_channel_sums<2>(b8, bn.stats, red);
+    fold_channel_sums<2>(b8, bn.stats, red, bn.turn);
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -582,7 +593,7 @@ void nhwc_conv_last_bwd_kernel(const float* __restrict__ dz8, const float* __res
 constexpr int kMomN = 7 + 28;                            // S[0..6], then R[k][k'] for k <= k' row by row
 
 __global__ __launch_bounds__(256)
-void nhwc_first_moments_kernel(const float* __restrict__ x, long long npix, int F, double* __restrict__ mom) {
+void nhwc_first_moments_kernel(const float* __restrict__ x, long long npix, int F, double* __restrict__ mom, unsigned* turn) {
   __shared__ float red[4][kMomN];
   float acc[kMomN];
 #pragma unroll
@@ -614,7 +625,10 @@ void nhwc_first_moments_kernel(const float* __restrict__ x, long long npix, int 
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
+  unsigned* my_turn = turn ? turn + VS_TURN_GLOBAL : nullptr;      // (one array for all workgroups: one chain; the launcher keeps it short)
+  vs_turn_begin(my_turn, blockIdx.x);
   if (threadIdx.x < kMomN) atomicAdd(mom + threadIdx.x, (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
+  vs_turn_end(my_turn, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ double mom_R(const double* mom, int k, int k2) {          // R[k][k2], symmetric
@@ -660,7 +674,8 @@ template <int ACT>
 __global__ __launch_bounds__(256)
 void nhwc_first_bwd_kernel(const u4v* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                            long long npix, int F, const float* __restrict__ scale, const float* __restrict__ shift,
-                           const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ acc_out /* [64][9] */) {
+                           const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ acc_out /* [64][9] */,
+                           unsigned* turn) {
   __shared__ float red[4 * 9 * 64];
   const int piece = threadIdx.x & 7;
   // channel pairs throughout (v_pk_*_f32): per pixel and pair 7 FMAs for z, the derivative, 9 FMAs into the sums
@@ -736,10 +751,25 @@ void nhwc_first_bwd_kernel(const u4v* __restrict__ da, const float* __restrict__
       if (lane < 8) red[(wave * 9 + k) * 64 + lane * 8 + j] = s;
     }
   __syncthreads();
+  // deterministic mode: acc_out is [VS_BN_STAT_SLOTS][64][9] then, the workgroups of a slot add in index order, a fold kernel sums the
+  // slots in order (vs_common.h)
+  const unsigned slot = blockIdx.x % VS_BN_STAT_SLOTS, rank_in_slot = blockIdx.x / VS_BN_STAT_SLOTS;
+  unsigned* my_turn = turn ? turn + VS_TURN_SLOT + slot : nullptr;
+  double* dst = turn ? acc_out + (size_t)slot * 576 : acc_out;
+  vs_turn_begin(my_turn, rank_in_slot);
   for (int i = threadIdx.x; i < 9 * 64; i += 256) {
     const int k = i / 64, c = i - k * 64;
-    atomicAdd(acc_out + c * 9 + k, (double)(red[(0 * 9 + k) * 64 + c] + red[(1 * 9 + k) * 64 + c] + red[(2 * 9 + k) * 64 + c] + red[(3 * 9 + k) * 64 + c]));
+    atomicAdd(dst + c * 9 + k, (double)(red[(0 * 9 + k) * 64 + c] + red[(1 * 9 + k) * 64 + c] + red[(2 * 9 + k) * 64 + c] + red[(3 * 9 + k) * 64 + c]));
   }
+  vs_turn_end(my_turn, rank_in_slot, (gridDim.x - slot + VS_BN_STAT_SLOTS - 1) / VS_BN_STAT_SLOTS);
+}
+
+__global__ void fold_slots_f64_kernel(const double* __restrict__ slots, int nslots, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < nslots; ++k) v += slots[(size_t)k * n + i];
+  out[i] = v;
 }
 
 // parameter gradients of cnn1 + its BatchNorm from the sums above and the input moments (one thread per channel, fp64)
@@ -802,7 +832,8 @@ int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom,
   // workgroups: 90 us for a pass over 46 MB)
   long long nb = (npix + 256 * 16 - 1) / (256 * 16);
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, stream, x, npix, F, mom);
+  nb = vs_det_grid((int)nb, 32);                              // deterministic mode: one chain of 32 turns (a pass over 46 MB either way)
+  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, stream, x, npix, F, mom, g_vs_turn);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -818,7 +849,7 @@ int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bia
 // scratch: 64 * 9 + 35 doubles
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t stream, const double* moments) {
+                           float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t stream, const double* moments, double* det_slots) {
   VS_REQUIRE(da && x && w && bias && scale && shift && mean && invstd && dgamma && dbeta && dbias && dw && scratch, "nhwc first_bwd: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc first_bwd: bad shape");
   const long long npix = (long long)B * T * F;
@@ -829,12 +860,16 @@ int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const
     if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, scratch + 64 * 9, stream)) return rc;
     mom = scratch + 64 * 9;
   }
-  const dim3 grid(stream_blocks(32, npix)), block(256);
   const u4v* g = reinterpret_cast<const u4v*>(da);
-  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
-  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
-  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, acc);
+  unsigned* turn = det_slots ? g_vs_turn : nullptr;          // deterministic mode needs the caller's slot scratch ([VS_BN_STAT_SLOTS][576] doubles)
+  const dim3 grid(turn ? vs_det_grid(stream_blocks(32, npix)) : stream_blocks(32, npix)), block(256);
+  double* sums = turn ? det_slots : acc;
+  if (turn) VS_CHECK_HIP(hipMemsetAsync(det_slots, 0, sizeof(double) * VS_BN_STAT_SLOTS * 576, stream));
+  if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, sums, turn);
+  else if (act == VS_ACT_RELU) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_RELU>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, sums, turn);
+  else if (act == VS_ACT_NONE) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_NONE>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, sums, turn);
   else VS_REQUIRE(false, "nhwc first_bwd: unsupported activation %d", act);
+  if (turn) hipLaunchKernelGGL(fold_slots_f64_kernel, dim3(3), dim3(192), 0, stream, det_slots, VS_BN_STAT_SLOTS, 576, acc);
   hipLaunchKernelGGL(nhwc_first_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, acc, mom, w, bias, scale, mean, invstd, (double)npix, train,
                      dgamma, dbeta, dbias, dw);
   VS_LAUNCH_CHECK();
@@ -866,12 +901,13 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
-  const dim3 grid(stream_blocks(4, nblk)), block(256);
+  const dim3 grid(bn_stats ? vs_det_grid(stream_blocks(4, nblk)) : stream_blocks(4, nblk)), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
   if (pre_scale) {     // `in` is z7: the layer below's BatchNorm + activation applied on the way in; output unactivated (+ statistics)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: the pre-activation form writes the unactivated output");
     VS_REQUIRE(pre_act == VS_ACT_MISH || pre_act == VS_ACT_RELU, "nhwc conv_last: pre-activation %d", pre_act);
-#define VS_LAST_PRE(ST_, PRE_) hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, ST_, PRE_>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats, pre_scale, pre_shift)
+#define VS_LAST_PRE(ST_, PRE_) hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, ST_, PRE_>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats, pre_scale, pre_shift, \
+                                                  (unsigned short*)nullptr, 0, ST_ ? g_vs_turn : (unsigned*)nullptr)
     if (bn_stats) { if (pre_act == VS_ACT_MISH) VS_LAST_PRE(true, VS_ACT_MISH); else VS_LAST_PRE(true, VS_ACT_RELU); }
     else { if (pre_act == VS_ACT_MISH) VS_LAST_PRE(false, VS_ACT_MISH); else VS_LAST_PRE(false, VS_ACT_RELU); }
 #undef VS_LAST_PRE
@@ -880,7 +916,8 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   }
   if (bn_stats) {      // train mode: z8 = conv + bias unactivated, statistics of it ([VS_BN_STAT_SLOTS][8][2] doubles, zeroed by the caller)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: statistics are those of the unactivated output");
-    hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats);
+    hipLaunchKernelGGL((nhwc_conv_last_kernel<VS_ACT_NONE, true>), grid, block, 0, stream, i, w, scale, shift, out, nrows, F, bn_stats,
+                       (const float*)nullptr, (const float*)nullptr, (unsigned short*)nullptr, 0, g_vs_turn);
     VS_LAUNCH_CHECK();
     return 0;
   }
@@ -901,8 +938,8 @@ int vs_nhwc_bn_act_bwd_impl(const void* da, const void* z, void* dz, long long n
   VS_REQUIRE(da && z && dz && scale && shift && mean && invstd && stats && coef && npix > 0, "nhwc bn_act_bwd: bad argument");
   const long long npieces = npix * 8;
   int nb = stream_blocks(512, npieces);
-  if (beside_wgrad) {      // both passes throttled like vs_nhwc_bn_bwd_from_dy_impl's (the round-6 re-run of the two-pass A/B, VS_OPT_BWD_DY = 0)
-    const int want = vs_opt(VS_OPT_BWD_APPLY_BLOCKS) > 0 ? vs_opt(VS_OPT_BWD_APPLY_BLOCKS) : 256;
+  if (beside_wgrad) {      // both passes throttled like vs_nhwc_bn_bwd_from_dy_impl's (the round-6 re-run of the two-pass A/B: +4 ms per step, profiles/r06_experiments.md)
+    const int want = 256;          // (128: +2.2 ms per step, 512: +0.2 -- round 5, call 10)
     if (want < nb) nb = want;
   }
   const dim3 grid(nb), block(256);
@@ -934,7 +971,7 @@ int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long lo
   // beside the weight gradient on the side stream (vs_backward): ONE block per CU.  The pass then takes 1.8 ms instead of 1.2 -- still
   // inside the weight gradient's 1.95 -- and takes less from it (2.06 -> 1.94 ms per layer, -0.4 ms per step: profiles/r05_bn_finalize_ab.md)
   if (beside_wgrad) {
-    const int want = vs_opt(VS_OPT_BWD_APPLY_BLOCKS) > 0 ? vs_opt(VS_OPT_BWD_APPLY_BLOCKS) : 256;
+    const int want = 256;          // (128: +2.2 ms per step, 512: +0.2 -- round 5, call 10)
     if (want < nb) nb = want;
   }
   const dim3 grid(nb), block(256);
@@ -1004,7 +1041,8 @@ int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7,
   const long long npix = (long long)B * T * F;
   long long nb = (npix + 31) / 32;
   if (nb > VS_NHWC_LAST_BWD_BLOCKS) nb = VS_NHWC_LAST_BWD_BLOCKS;
-  const LastBwdBn bn{reinterpret_cast<const u4v*>(z7), bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats};
+  if (z7) nb = vs_det_grid((int)nb);
+  const LastBwdBn bn{reinterpret_cast<const u4v*>(z7), bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats, z7 ? g_vs_turn : nullptr};
   const dim3 grid((unsigned)nb), block(256);
   const u4v* a = reinterpret_cast<const u4v*>(a7);
   u4v* o = reinterpret_cast<u4v*>(din);

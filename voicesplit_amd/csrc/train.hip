@@ -70,12 +70,13 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   size_t part = vs_conv64_wgrad_partial_floats(5, 5);
   part = max3(part, vs_conv64_wgrad_partial_floats(7, 1), (size_t)vs_conv_last_wgrad_blocks() * 512);
   part = max3(part, (size_t)kSplitK * d->FC2 * d->FC1, (size_t)kSplitK * d->FC1 * 2 * H);
-  part = max3(part, (size_t)kSplitK * 4 * H * H, 0);
+  part = max3(part, (size_t)kSplitK * 4 * H * H, (size_t)VS_BN_STAT_SLOTS * 576 * 2);      // (deterministic mode: cnn1's backward sums per slot, doubles)
   L->partials = take(part * 4);
   L->conv_scales = take(16 * VS_SCALE_SLOT_FLOATS * 4);
   L->gemm_scales = take(32 * 4);
   // bf16 configuration: feat / W_ih / dxg as bf16 arrays shared by the forward GEMM and the two backward contractions
   L->lstm_bf16 = take(d->math == VS_MATH_BF16 ? vs_lstm_bf16_layout((long long)M, 8 * (int)F, (int)H).total : 256);
+  L->det_turn = take(VS_TURN_WORDS * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -144,10 +145,13 @@ int side_stream(SideStream** out) {
   VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
   SideStream& ss = g_side[dev];
   if (!ss.s) {
-    int lo = 0, hi = 0;                                  // (numerically: hi <= lo, hi = the greatest priority)
-    VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const int pr = vs_opt(VS_OPT_SIDE_PRIO) == 1 ? hi : vs_opt(VS_OPT_SIDE_PRIO) == 2 ? lo : (lo + hi) / 2;
-    VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, pr));
+    // (normal priority: high / low were measured in round 5 -- 49.6 / 49.6 / 49.7 ms per step -- and are not offered any more)
+    if (const char* e = getenv("VS_EXP_SIDE_PRIO")) {      // EXPERIMENT (round 6, call 6): to be removed
+      int lo = 0, hi = 0;
+      VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, atoi(e) == 1 ? hi : lo));
+    } else
+    VS_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
   }
@@ -192,6 +196,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   double* stats = at<double>(tape, L.bn_stats);
   VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000 /* 1.0f */, 64, stream));
   VS_CHECK_HIP(hipMemsetAsync(ones + 64, 0, 64 * sizeof(float), stream));
+  // deterministic mode (bf16 configuration): the turn word of this tape, armed here; every launch that takes turns re-arms it
+  const bool det = d->math == VS_MATH_BF16 && vs_opt(VS_OPT_DETERMINISTIC) != 0;
+  if (det) VS_CHECK_HIP(hipMemsetAsync(at<unsigned>(tape, L.det_turn), 0, VS_TURN_WORDS * 4, stream));
+  VsTurnScope turn_scope(det ? at<unsigned>(tape, L.det_turn) : nullptr);
 
   // split-f16 convs: the BatchNorm+activation pass that produces a layer's input also folds its
   // |max| into that layer's scale slot (slot l = conv index l: input scale of cnn(l+1))
@@ -258,7 +266,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     const long long npix = (long long)B * T * F;
     // the statistics scratch is cleared ONCE here; every finalize below folds the slots and clears the scratch behind itself in the
     // same launch (vs_fold_slots): no memset kernel in front of the conv launches
-    const int kStatsDoubles = vs_opt(VS_OPT_BN_FUSED_FINALIZE) ? VS_BN_STAT_SLOTS * 128 : 0;      // 0: the A/B form (memset per producer)
+    const int kStatsDoubles = VS_BN_STAT_SLOTS * 128;
     if (train && kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
     auto bn16 = [&](int l) -> int {
       VsProfScope ps(VS_PROF_FWD_BN, stream);
@@ -357,7 +365,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     const vs_conv_layer& c = p->conv[7];
     if (int rc = vs_bn_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)B * T * F, 8, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var,
                                      kBnEps, kBnMomentum, scale + 64 * 7, shift + 64 * 7, mean + 64 * 7, invstd + 64 * 7, stream,
-                                     vs_opt(VS_OPT_BN_FUSED_FINALIZE) ? VS_BN_STAT_SLOTS * 128 : 0)) return rc;
+                                     VS_BN_STAT_SLOTS * 128)) return rc;
     // ... which also writes the bf16 row-form copy of the features the LSTM GEMMs read
     const VsLstmBf16Layout Lf = vs_lstm_bf16_layout((long long)B * T, 8 * F, H);
     if (int rc = vs_bn_apply_feat_bf16_impl(at<float>(tape, L.z8), at<float>(tape, L.feat), at<char>(tape, L.lstm_bf16) + Lf.feat, Lf.Kp, B, T, F, conv_act,
@@ -443,6 +451,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   const int B = d->B, T = d->T, F = d->F, H = d->H, E = d->E, FC1 = d->FC1, FC2 = d->FC2;
   const int M = B * T, K8 = 8 * F, KE = K8 + E;
   const int train = bn_mode == VS_BN_TRAIN;
+  const bool det = d->math == VS_MATH_BF16 && vs_opt(VS_OPT_DETERMINISTIC) != 0;      // (the word was armed by vs_forward_train and re-armed by every user)
+  VsTurnScope turn_scope(det ? at<unsigned>(tape, L.det_turn) : nullptr);
   float* part = at<float>(tape, L.partials);
   float* tmp = at<float>(tape, L.colsum_tmp);
   float* ones = at<float>(tape, L.consts);
@@ -552,12 +562,12 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
   }
   hipStream_t ls = stream;
-  // [r5] VS_OPT_LSTM_LEAF_LATE (bf16 configuration): the LSTM's leaf contractions start on the side stream here (0, 3), beside the dfeat
-  // contraction and the HBM-bound BatchNorm backward of the features (which dW_ih slows down 3x: every CU holds one of its persistent
-  // workgroups) -- or behind that BatchNorm backward (1) / behind cnn8's backward (2), beside VALU-bound kernels: measured slower
-  const int leaf_opt = (side && bf16g) ? vs_opt(VS_OPT_LSTM_LEAF_LATE) : 0;
-  const bool wih_last = leaf_opt == 3;      // (3): start behind the BPTT as (0), but dW_ih -- the persistent contraction -- goes last
-  const int leaf_late = wih_last ? 0 : leaf_opt;
+  // [r5] The LSTM's leaf contractions start on the side stream right here, beside the dfeat contraction and the HBM-bound BatchNorm
+  // backward of the features, with dW_ih -- one persistent workgroup per CU, which slows that pass down 3x -- LAST among them (started
+  // behind the features' BatchNorm backward or behind cnn8's backward they collide with cnn7's data gradient: measured slower in
+  // round 5, profiles/r05_experiments.md section 3; those orders are not offered any more)
+  const bool wih_last = side && bf16g;
+  constexpr int leaf_late = 0;
   auto fork_leaves = [&]() -> int {
     VS_CHECK_HIP(hipEventRecord(side->fork, stream));
     VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
@@ -655,11 +665,6 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   };
   // cnn8: dfeat -> dz8 (in place) -> dW8, dA7
   if (int rc = bn_bwd(7, dfeat, at<float>(tape, L.z8), dfeat, 8, (long long)M * 8, F)) return rc;
-  if (leaf_late == 1) {
-    if (int rc = fork_leaves()) return rc;
-    if (int rc = lstm_leaves()) return rc;
-    if (int rc = leaves_done()) return rc;
-  }
   if (d->math == VS_MATH_BF16) {
     // BASELINE configs[2]: the conv stack backward on channels-last bf16 tensors (nhwc_edge.hip, conv_nhwc.hip,
     // wgrad_nhwc.hip).  Same chain and the same side-stream schedule as below: layer l's weight gradient runs beside
@@ -671,11 +676,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     // activation derivative of the layer below on the spot and accumulates the BatchNorm backward sums (the dy forms):
     // the BatchNorm backward proper is then finalize + one pass.
     // (the scratch is cleared once, in front of cnn8's backward; every finalize then clears it behind itself: vs_fold_slots)
-    // BACKWARD: off by default (VS_OPT_BN_FUSED_FINALIZE = 2 turns it on).  Measured (profiles/r05_bn_finalize_ab.md): the 25 us the
-    // one-thread-per-value fold kernel takes in front of the BatchNorm pass are what lets the weight gradient on the side stream get
-    // its 256 workgroups resident FIRST; with the fused finalize the HBM-bound pass fills the CUs first, the weight gradient's workgroups
-    // (139 KB of LDS, 384 registers) wait for its blocks to leave, and every layer's pair takes 2.5 ms instead of 2.05 (+1.6 ms per step).
-    const int kStatsDoubles = vs_opt(VS_OPT_BN_FUSED_FINALIZE) >= 2 ? VS_BN_STAT_SLOTS * 128 : 0;
+    // The backward keeps the two-kernel finalize and a memset in front of every dy launch: the fused form (one launch that folds,
+    // finalizes and clears) measured +1.6 ms per step beside a 2048-block BatchNorm pass and neutral beside the one-block-per-CU pass
+    // (round 5: profiles/r05_experiments.md section 2 and its last paragraph).
+    constexpr int kStatsDoubles = 0;
     {
       VsProfScope ps(VS_PROF_BWD_EDGE, stream);
       VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
@@ -685,16 +689,11 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                               g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
                                               mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
     }
-    if (leaf_late == 2) {
-      if (int rc = fork_leaves()) return rc;
-      if (int rc = lstm_leaves()) return rc;
-      if (int rc = leaves_done()) return rc;
-    }
     void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
-    // A/B switch (vs_set_option(VS_OPT_BWD_DY, 0)): the data gradients of cnn3..cnn7 as plain convs, the activation derivative and the
-    // BatchNorm-backward sums taken by the two-pass BatchNorm backward beside the weight gradient instead (round 2's form)
-    const bool dy_form = vs_opt(VS_OPT_BWD_DY) != 0;
+    // (the alternative -- plain data gradients, the activation derivative and the sums in a two-pass BatchNorm backward beside the weight
+    // gradient -- lost by 2.6 ms in round 4 and by 4 ms in round 6 with both passes throttled to one block per CU: profiles/r06_experiments.md)
+    constexpr bool dy_form = true;
     bool have_dy = true;               // gb[c] holds dy (activation derivative applied, sums in `stats`) -- cnn8's backward above produced it
     for (int i = 5; i >= 0; --i) {
       const int l = i + 1;
@@ -756,7 +755,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     VsProfScope ps(VS_PROF_BWD_EDGE, stream);
     return vs_nhwc_first_bwd_impl(gb[c], x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
                                   g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
-                                  at<double>(tape, L.first_acc) + 64, stream, at<double>(tape, L.first_acc));
+                                  at<double>(tape, L.first_acc) + 64, stream, at<double>(tape, L.first_acc),
+                                  det ? at<double>(tape, L.partials) : nullptr);
   }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;

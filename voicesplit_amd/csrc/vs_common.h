@@ -155,6 +155,35 @@ __device__ __forceinline__ float vs_act_rt(float v, int act) {
 // +40 ms per training step when tried) and a plain load first skips the atomic when it cannot
 // raise the slot (a stale value only costs a redundant atomic).  out == nullptr: no-op.
 // partial-sum slots of the BatchNorm statistics the conv epilogues accumulate ([slot][64 channels][2] doubles)
+// Deterministic mode (vs_set_option(VS_OPT_DETERMINISTIC, 1); round 6): the workgroups of a launch that end in atomic additions to
+// shared partial-sum slots (BatchNorm statistics and their backward sums, cnn1's moments) take TURNS, so every address receives its
+// addends in the same order in every run and a rerun is bit-identical.  Only workgroups that add to the SAME addresses need an
+// order among themselves: the turn region of the tape (vs_tape_layout.det_turn, zeroed at the start of a step) holds one word per
+// partial-sum slot (VS_TURN_SLOT + slot: the workgroups blockIdx % VS_BN_STAT_SLOTS == slot queue up in index order: chains of
+// four at one workgroup per CU), one per channel (VS_TURN_CHANNEL + c) and one global word (VS_TURN_GLOBAL) for the two small
+// kernels whose workgroups all add to one array.  A turn costs ~8 us (an fp64 atomic round trip, a fence, the next one's poll): one
+// chain through all 256 workgroups of a conv launch, the first version, doubled its time.  NULL = off (the default: arrival
+// order, last bits differ between runs).  A workgroup waits only for workgroups dispatched before it, which never wait for it: no
+// co-residency needed; the last one of a chain re-arms the word for the next launch.
+#define VS_TURN_SLOT 0          /* words [0, 64) */
+#define VS_TURN_CHANNEL 64      /* words [64, 128) */
+#define VS_TURN_GLOBAL 128
+#define VS_TURN_WORDS 256
+__device__ __forceinline__ void vs_turn_begin(unsigned* turn, unsigned me) {
+  if (turn == nullptr) return;
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void vs_turn_end(unsigned* turn, unsigned me, unsigned total) {
+  if (turn == nullptr) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_store(turn, me + 1 == total ? 0u : me + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 #define VS_GEMM_KPAD 64        /* rows of pre-split GEMM operands are zero-padded to a multiple of the GEMM's K block (gemm_f16x3.hip) */
 #define VS_BN_STAT_SLOTS 64
 #define VS_AMAX_SLOTS 1024

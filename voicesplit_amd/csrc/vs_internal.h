@@ -13,6 +13,15 @@ struct VsProfScope {
 // capi.hip: the option table behind vs_set_option / vs_get_option (the library reads no environment variable)
 extern int g_vs_options[VS_OPT_COUNT];
 inline int vs_opt(int o) { return g_vs_options[o]; }
+// Deterministic mode: the turn word of the tape the calling thread is working on (vs_forward_train / vs_backward set it for their
+// duration when VS_OPT_DETERMINISTIC is on; NULL otherwise -- the kernel-level entry points never order their atomics)
+extern thread_local unsigned* g_vs_turn;
+struct VsTurnScope {
+  unsigned* prev;
+  explicit VsTurnScope(unsigned* t) : prev(g_vs_turn) { g_vs_turn = t; }
+  ~VsTurnScope() { g_vs_turn = prev; }
+};
+inline int vs_det_grid(int nb, int cus = 256) { return (g_vs_turn && nb > cus) ? cus : nb; }      // deterministic mode: at most one workgroup per CU takes turns
 
 // conv_mfma.hip
 int vs_conv64_pack_impl(const float* w, float* wp, int KT, int KF, int transpose_flip, hipStream_t);
@@ -77,10 +86,6 @@ size_t vs_nhwc_packed_bytes(int KT, int KF);
 int vs_nhwc_pack_impl(const float* w, void* packed, int KT, int KF, int transpose_flip, hipStream_t);
 int vs_nhwc_conv_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out,
                       int B, int T, int F, int KT, int KF, int dil, int act, double* bn_stats, hipStream_t);
-// conv_nhwc8.hip: the 5x5 layers of the two calls above on the eight-wave kernel (two waves per SIMD); z != NULL: the dy form
-int vs_nhwc_conv8_impl(const void* in, const void* packed, const float* scale, const float* shift, void* out, double* bn_stats,
-                       const void* z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
-                       int B, int T, int F, int dil, int act, hipStream_t);
 // conv_nhwc_f16x3.hip: the same convs, forward, in the fp32-class split-f16 arithmetic on channels-last hi / lo f16 planes
 size_t vs_nhwc_f16x3_packed_bytes(int KT, int KF);
 int vs_nhwc_f16x3_pack_impl(const float* w, const float* w_scale2, void* packed, float* l1, int KT, int KF, hipStream_t);
@@ -124,7 +129,7 @@ int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bia
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
                            float* dgamma, float* dbeta, float* dbias, float* dw, double* scratch, hipStream_t,
-                           const double* moments = nullptr /* of x, when the caller still has them */);
+                           const double* moments = nullptr /* of x, when the caller still has them */, double* det_slots = nullptr);
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t);
 int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, const float* shift, float* out,
                            int B, int T, int F, int act, hipStream_t, double* bn_stats = nullptr,

@@ -38,7 +38,6 @@ struct WgradArgs {
   float* part;                      // [pairs][64 co][64 ci][taps]
   int B, T, F, dil;
   int nstrip, nseg, seg_rows, n_items;
-  int prio;                         // != 0: the waves raise their priority (VS_OPT_MFMA_PRIO bit 0)
   int abl;                          // VS_ABLATION builds only (tools/wgrad_ablation.py): selects a timing-ablation instance
                                     // (1 = no DMA after a workgroup's first groups, 2 = no LDS fragment reads, 4 = no MFMAs; results are wrong)
 };
@@ -501,7 +500,6 @@ void nhwc_wgrad_kernel(WgradArgs a) {
   using G = WGeo<KT, KF>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
   const int th = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
-  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (th == 0) wgrad_body<KT, KF, 0, ABL>(a, (const lds_byte*)smem);
   else wgrad_body<KT, KF, 1, ABL>(a, (const lds_byte*)smem);
 }
@@ -559,9 +557,9 @@ int vs_nhwc_wgrad_impl(const void* dz, const void* a_in, float* part, float* dw,
   VS_REQUIRE(B > 0 && T > 0 && F > 0 && dil > 0, "nhwc wgrad: bad shape B=%d T=%d F=%d dil=%d", B, T, F, dil);
   VS_REQUIRE((reinterpret_cast<uintptr_t>(dz) & 15) == 0 && (reinterpret_cast<uintptr_t>(a_in) & 15) == 0, "nhwc wgrad: operands must be 16-byte aligned");
   WgradArgs a{reinterpret_cast<const unsigned short*>(dz), reinterpret_cast<const unsigned short*>(a_in), part, B, T, F, dil,
-              (F + STRIP - 1) / STRIP, 1, 0, 0, vs_opt(VS_OPT_MFMA_PRIO) & 1, 0};
+              (F + STRIP - 1) / STRIP, 1, 0, 0, 0};
 #ifdef VS_ABLATION
-  a.abl = vs_opt(VS_OPT_WGRAD_ABL);
+  a.abl = vs_opt(VS_OPT_ABLATION);
 #endif
   if (KT == 5 && KF == 5) return launch_wgrad<5, 5>(a, dw, stream);
   if (KT == 7 && KF == 1) return launch_wgrad<7, 1>(a, dw, stream);

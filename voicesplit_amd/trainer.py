@@ -167,7 +167,11 @@ class Trainer:
         self.split_allreduce = bool(self._sink and self.bucket.has_early)
         self._comm_stream = self._leaves_event = None
         if self.split_allreduce:
-            self._comm_stream = torch.cuda.Stream(self.device)
+            # high priority: its own hardware-queue pool.  With RCCL initialised the process has more normal-priority streams than the
+            # device has hardware queues for them, and a stream that shares a queue with the caller's stream would see the leaves event --
+            # and with it the early collective -- only behind the whole backward pass (the same effect cost the
+            # library's side stream its overlap, 46.2 -> 49.5 ms per step, until it got a priority of its own)
+            self._comm_stream = torch.cuda.Stream(self.device, priority=-1)
             self._leaves_event = torch.cuda.Event()
             self._leaves_event.record()                                     # the handle the library records is created by the first record
         # train.py:114 reads loss.item() behind optimizer.step(): a device-to-host read that drains the device -- 0.3 ms of idle
