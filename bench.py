@@ -259,10 +259,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     forced = args.force_collectives and world == 1 and args.mode == "train"
-    if os.environ.get("VS_BENCH_INIT_GROUP_ONLY") and not forced and world == 1:      # EXPERIMENT (round 6, call 6)
-        from voicesplit_amd.sharding import init_single_rank_group
-        init_single_rank_group("nccl", device_id=dev)
-        os.environ["VS_BENCH_GROUP_READY"] = "1"
     if forced:
         from voicesplit_amd.sharding import init_single_rank_group
         init_single_rank_group("nccl", device_id=dev)

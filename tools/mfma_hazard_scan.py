@@ -11,6 +11,11 @@ front of a group's last row -- and THIS script verifies it on what the compiler 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Iinclude -o /tmp/conv_nhwc.s voicesplit_amd/csrc/conv_nhwc.hip
     python tools/mfma_hazard_scan.py /tmp/conv_nhwc.s [kernel-name-substring]
 
+or, on what the build produced (tests/test_hazard_scan_cpu.py does this: seconds instead of a second compilation):
+
+    llvm-objdump --offloading conv_nhwc.o        # writes conv_nhwc.o.0.hipv4-amdgcn-amd-amdhsa--gfx950 beside its input
+    llvm-objdump -d <that file> > /tmp/conv_nhwc.dis && python tools/mfma_hazard_scan.py /tmp/conv_nhwc.dis
+
 For every v_mfma whose destination is a VGPR tuple it follows the instruction stream (fall-through order; the hot blocks are straight
 line) and counts wait states -- 4 per MFMA (it holds the issue port for its passes), N + 1 per s_nop N, 1 per other instruction --
 until the first non-MFMA instruction that reads one of the registers.  Fewer than MIN_WAIT (12) is reported; exit code 1 then."""
@@ -33,9 +38,11 @@ def scan(name, lines):
     ins = []
     for l in lines:
         l = l.strip()
-        if not l or l.startswith((".", ";")) or re.match(r"\.?LBB", l):
+        if not l or l.startswith((".", ";", "//")) or re.match(r"\.?LBB", l) or re.match(r"[0-9a-f]+ <", l):
             continue
-        ins.append(l.split(";")[0].strip())
+        l = l.split("//")[0].split(";")[0].strip()      # (assembly listings comment with ';', llvm-objdump with '//')
+        if l:
+            ins.append(l)
     pending = {}                                   # vgpr -> wait states since the MFMA that wrote it
     bad = []
     n_mfma = 0
@@ -80,12 +87,16 @@ def scan(name, lines):
 def main():
     text = open(sys.argv[1]).read()
     want = sys.argv[2] if len(sys.argv) > 2 else ""
-    starts = [(m.start(), m.group(1)) for m in re.finditer(r"^(_Z\w+):\s*; @", text, flags=re.M)]
+    objdump = "Disassembly of section" in text      # llvm-objdump -d of the code object instead of the compiler's -S listing
+    if objdump:
+        starts = [(m.start(), m.group(1)) for m in re.finditer(r"^[0-9a-f]+ <(_Z\w+)>:", text, flags=re.M)]
+    else:
+        starts = [(m.start(), m.group(1)) for m in re.finditer(r"^(_Z\w+):\s*; @", text, flags=re.M)]
     rc = 0
     for pos, name in starts:
         if want not in name:
             continue
-        end = text.find(".section", pos)
+        end = min([p for p, _ in starts if p > pos], default=-1) if objdump else text.find(".section", pos)
         n, bad = scan(name, text[pos:end if end > 0 else None].split("\n"))
         if n == 0:
             continue

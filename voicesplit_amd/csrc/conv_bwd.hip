@@ -642,8 +642,11 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, stream));
   const long long rows_per_c = R / C;
   unsigned* turn = C <= 64 ? g_vs_turn : nullptr;          // (the turn region holds a word for each of 64 channels: the features' BatchNorm, C = 8, is the user)
-  int bpc = vs_bn_blocks_per_channel(C, rows_per_c, L);
-  if (turn && bpc > 16) bpc = 16;                            // chains of sixteen turns (~0.1 ms)
+  const int bpc_full = vs_bn_blocks_per_channel(C, rows_per_c, L);
+  // deterministic mode: chains of at most 64 turns per channel behind the pass (~0.2 ms), 64 * C workgroups all resident at once; the
+  // apply pass below keeps the full grid (round 6: sixteen per channel on BOTH passes cost 4.2 ms at B = 64 -- 128 workgroups cannot
+  // stream 1.9 GB)
+  const int bpc = (turn && bpc_full > 64) ? 64 : bpc_full;
   dim3 grid(bpc, C), block(256);
   switch (act) {
     case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats, turn); break;
@@ -653,10 +656,11 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,
                      scale, mean, invstd, dgamma, dbeta, dbias, coef);
+  const dim3 grid_apply(bpc_full, C);
   switch (act) {
-    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
-    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
-    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
+    case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, grid_apply, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
+    case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, grid_apply, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
+    default: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_NONE>, grid_apply, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
   }
   VS_LAUNCH_CHECK();
   return 0;

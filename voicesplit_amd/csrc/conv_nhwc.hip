@@ -431,7 +431,7 @@ struct ConvWalk {
           st.y[nb2][pr].x = i_max0(st.y[nb2][pr].x); st.y[nb2][pr].y = i_max0(st.y[nb2][pr].y);
         } else if constexpr (STATS) {
           if constexpr (sg == 1) {
-            const float m = ((rowoff_of<RV, IDX>(x, st) != kOob) & (vcol_of<IDX, nb2>() != kOob)) ? 1.f : 0.f;
+            const float m = (int(rowoff_of<RV, IDX>(x, st) != kOob) & int(vcol_of<IDX, nb2>() != kOob)) ? 1.f : 0.f;
             st.tp.x = i_mul(st.y[nb2][pr].x, m); st.tp.y = i_mul(st.y[nb2][pr].y, m);
           } else if constexpr (sg == 2) { a1[pr].x = i_add(a1[pr].x, st.tp.x); a1[pr].y = i_add(a1[pr].y, st.tp.y); }
           else { a2[pr].x = i_fma(st.tp.x, st.y[nb2][pr].x, a2[pr].x); a2[pr].y = i_fma(st.tp.y, st.y[nb2][pr].y, a2[pr].y); }

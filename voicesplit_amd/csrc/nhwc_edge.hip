@@ -625,10 +625,20 @@ void nhwc_first_moments_kernel(const float* __restrict__ x, long long npix, int 
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
-  unsigned* my_turn = turn ? turn + VS_TURN_GLOBAL : nullptr;      // (one array for all workgroups: one chain; the launcher keeps it short)
-  vs_turn_begin(my_turn, blockIdx.x);
+  // deterministic mode: mom is [VS_BN_STAT_SLOTS][64] then (the workgroups of a slot add in index order, a fold kernel sums the slots)
+  const unsigned slot = blockIdx.x % VS_BN_STAT_SLOTS, rank_in_slot = blockIdx.x / VS_BN_STAT_SLOTS;
+  unsigned* my_turn = turn ? turn + VS_TURN_SLOT + slot : nullptr;
+  if (turn) mom += (size_t)slot * 64;
+  vs_turn_begin(my_turn, rank_in_slot);
   if (threadIdx.x < kMomN) atomicAdd(mom + threadIdx.x, (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
-  vs_turn_end(my_turn, blockIdx.x, gridDim.x);
+  vs_turn_end(my_turn, rank_in_slot, (gridDim.x - slot + VS_BN_STAT_SLOTS - 1) / VS_BN_STAT_SLOTS);
+}
+
+__global__ void fold_moment_slots_kernel(const double* __restrict__ slots, double* __restrict__ mom) {      // 64 threads
+  if (threadIdx.x >= kMomN) return;
+  double v = 0.0;
+  for (int k = 0; k < VS_BN_STAT_SLOTS; ++k) v += slots[(size_t)k * 64 + threadIdx.x];
+  mom[threadIdx.x] = v;
 }
 
 __device__ __forceinline__ double mom_R(const double* mom, int k, int k2) {          // R[k][k2], symmetric
@@ -824,7 +834,7 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
 }
 
 // cnn1 by recomputation: the input moments (35 doubles: S[7], R[k <= k'] row by row), the batch statistics of z1 they imply
-int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t stream) {
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t stream, double* det_slots) {
   VS_REQUIRE(x && mom && B > 0 && T > 0 && F > 0, "nhwc first_moments: bad argument");
   const long long npix = (long long)B * T * F;
   VS_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * kMomN, stream));
@@ -832,8 +842,12 @@ int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom,
   // workgroups: 90 us for a pass over 46 MB)
   long long nb = (npix + 256 * 16 - 1) / (256 * 16);
   if (nb > 512) nb = 512;
-  nb = vs_det_grid((int)nb, 32);                              // deterministic mode: one chain of 32 turns (a pass over 46 MB either way)
-  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, stream, x, npix, F, mom, g_vs_turn);
+  unsigned* turn = det_slots ? g_vs_turn : nullptr;           // deterministic mode needs the caller's slot scratch ([VS_BN_STAT_SLOTS][64] doubles)
+  if (turn) {      // (the full grid: a workgroup waits for the one 64 below it, which was dispatched before it -- see vs_turn_begin)
+    VS_CHECK_HIP(hipMemsetAsync(det_slots, 0, sizeof(double) * VS_BN_STAT_SLOTS * 64, stream));
+  }
+  hipLaunchKernelGGL(nhwc_first_moments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, stream, x, npix, F, turn ? det_slots : mom, turn);
+  if (turn) hipLaunchKernelGGL(fold_moment_slots_kernel, dim3(1), dim3(64), 0, stream, det_slots, mom);
   VS_LAUNCH_CHECK();
   return 0;
 }
@@ -862,7 +876,7 @@ int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const
   }
   const u4v* g = reinterpret_cast<const u4v*>(da);
   unsigned* turn = det_slots ? g_vs_turn : nullptr;          // deterministic mode needs the caller's slot scratch ([VS_BN_STAT_SLOTS][576] doubles)
-  const dim3 grid(turn ? vs_det_grid(stream_blocks(32, npix)) : stream_blocks(32, npix)), block(256);
+  const dim3 grid(stream_blocks(32, npix)), block(256);
   double* sums = turn ? det_slots : acc;
   if (turn) VS_CHECK_HIP(hipMemsetAsync(det_slots, 0, sizeof(double) * VS_BN_STAT_SLOTS * 576, stream));
   if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_first_bwd_kernel<VS_ACT_MISH>, grid, block, 0, stream, g, x, w, bias, npix, F, scale, shift, mean, invstd, sums, turn);
@@ -901,7 +915,7 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
-  const dim3 grid(bn_stats ? vs_det_grid(stream_blocks(4, nblk)) : stream_blocks(4, nblk)), block(256);
+  const dim3 grid(stream_blocks(4, nblk)), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
   if (pre_scale) {     // `in` is z7: the layer below's BatchNorm + activation applied on the way in; output unactivated (+ statistics)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: the pre-activation form writes the unactivated output");
@@ -1041,7 +1055,6 @@ int vs_nhwc_conv_last_bwd_impl(const float* dz8, const float* w, const void* a7,
   const long long npix = (long long)B * T * F;
   long long nb = (npix + 31) / 32;
   if (nb > VS_NHWC_LAST_BWD_BLOCKS) nb = VS_NHWC_LAST_BWD_BLOCKS;
-  if (z7) nb = vs_det_grid((int)nb);
   const LastBwdBn bn{reinterpret_cast<const u4v*>(z7), bn_scale, bn_shift, bn_mean, bn_invstd, bn_stats, z7 ? g_vs_turn : nullptr};
   const dim3 grid((unsigned)nb), block(256);
   const u4v* a = reinterpret_cast<const u4v*>(a7);

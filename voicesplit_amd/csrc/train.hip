@@ -145,13 +145,16 @@ int side_stream(SideStream** out) {
   VS_REQUIRE(dev >= 0 && dev < 16, "side stream: device index out of range");
   SideStream& ss = g_side[dev];
   if (!ss.s) {
-    // (normal priority: high / low were measured in round 5 -- 49.6 / 49.6 / 49.7 ms per step -- and are not offered any more)
-    if (const char* e = getenv("VS_EXP_SIDE_PRIO")) {      // EXPERIMENT (round 6, call 6): to be removed
-      int lo = 0, hi = 0;
-      VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, atoi(e) == 1 ? hi : lo));
-    } else
-    VS_CHECK_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    // [r6] LOW priority -- not for the priority but for the hardware queue.  HIP maps the streams of one priority onto a pool of (by
+    // default four) hardware queues; a process that has initialised RCCL holds more normal-priority streams than that, and this
+    // stream, created later, then SHARES a queue with the caller's stream: the two no longer run concurrently and every kernel of the
+    // backward pass runs alone (46.2 -> 49.4-49.7 ms per step with the process group merely initialised: bench.py --force-collectives,
+    // profiles/r06_experiments.md section 5).  A stream of another priority draws from another pool.  At N = 1 without RCCL the three
+    // priorities measure the same within 0.1 ms (46.3 / 46.4 / 46.4 ms normal / high / low, two rounds in one call); what runs here --
+    // weight gradients, leaves, weight packs -- is off the critical path by construction.
+    int lo = 0, hi = 0;                                  // (numerically: hi <= lo, lo = the least priority)
+    VS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, lo));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
   }
@@ -287,7 +290,8 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       const vs_conv_layer& c = p->conv[0];
       // (the moments stay in the tape for the backward pass: first_acc = [35 moments, padded to 64][backward scratch])
       double* mom = at<double>(tape, L.first_acc);
-      if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream)) return rc;
+      // (deterministic mode: per-slot sums in the backward pass's dfeat buffer, which nothing uses before the loss)
+      if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream, det ? at<double>(tape, L.dfeat) : nullptr)) return rc;
       if (train) {
         if (int rc = vs_nhwc_first_stats_impl(mom, c.weight, c.bias, (double)npix, stats, stream)) return rc;
         if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,

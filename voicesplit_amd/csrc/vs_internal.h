@@ -124,7 +124,7 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
 // cnn1 by recomputation (nhwc_edge.hip): input moments -> batch statistics of z1; one-pass backward
 #define VS_FIRST_MOMENTS 35
 #define VS_FIRST_BWD_SCRATCH_DOUBLES (64 * 9 + VS_FIRST_MOMENTS)
-int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t);
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t, double* det_slots = nullptr);
 int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bias, double count, double* stats, hipStream_t);
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
