@@ -80,6 +80,7 @@ class VsTapeLayout(Structure):
         ("bn_stats", c_size_t), ("bn_coef", c_size_t), ("first_acc", c_size_t), ("colsum_tmp", c_size_t),
         ("partials", c_size_t), ("conv_scales", c_size_t), ("gemm_scales", c_size_t), ("lstm_bf16", c_size_t),
         ("det_turn", c_size_t),
+        ("conv_packed_t", c_size_t * 6),
     ]
 
 

@@ -834,10 +834,10 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
 }
 
 // cnn1 by recomputation: the input moments (35 doubles: S[7], R[k <= k'] row by row), the batch statistics of z1 they imply
-int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t stream, double* det_slots) {
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t stream, double* det_slots, int mom_is_zero) {
   VS_REQUIRE(x && mom && B > 0 && T > 0 && F > 0, "nhwc first_moments: bad argument");
   const long long npix = (long long)B * T * F;
-  VS_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * kMomN, stream));
+  if (!mom_is_zero) VS_CHECK_HIP(hipMemsetAsync(mom, 0, sizeof(double) * kMomN, stream));
   // at most two workgroups per CU: every workgroup ends in 35 fp64 atomics on the SAME 35 addresses, which the L2 serialises (2048
   // workgroups: 90 us for a pass over 46 MB)
   long long nb = (npix + 256 * 16 - 1) / (256 * 16);

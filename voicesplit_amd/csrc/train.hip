@@ -77,6 +77,7 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   // bf16 configuration: feat / W_ih / dxg as bf16 arrays shared by the forward GEMM and the two backward contractions
   L->lstm_bf16 = take(d->math == VS_MATH_BF16 ? vs_lstm_bf16_layout((long long)M, 8 * (int)F, (int)H).total : 256);
   L->det_turn = take(VS_TURN_WORDS * 4);
+  for (int i = 0; i < 6; ++i) L->conv_packed_t[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
   L->total_bytes = off;
   return 0;
 }
@@ -114,6 +115,17 @@ int check_params(const vs_params* p) {
 // returns, so the fork is invisible outside (and legal under stream capture).
 // ---------------------------------------------------------------------------------------------
 int g_bwd_overlap = 1;
+// One launch in front of the bf16 forward pass: ones[64] = 1, zeros[64] = 0, up to three scratch arrays cleared (16-byte granules).
+struct ArmArgs { float* ones; void* z[3]; unsigned n16[3]; };
+__global__ __launch_bounds__(256)
+void forward_arm_kernel(ArmArgs a) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 64) { a.ones[i] = 1.f; a.ones[64 + i] = 0.f; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (i < a.n16[r]) reinterpret_cast<uint4*>(a.z[r])[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 SideStream g_side[16];
 // Every exit path of vs_backward after the fork -- the error returns included -- orders the caller's stream after what
@@ -197,18 +209,27 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
   float* mean = at<float>(tape, L.bn_mean);
   float* invstd = at<float>(tape, L.bn_invstd);
   double* stats = at<double>(tape, L.bn_stats);
+  // deterministic mode (bf16 configuration): the turn words of this tape, armed here; every launch that takes turns re-arms its own
+  const bool det = d->math == VS_MATH_BF16 && vs_opt(VS_OPT_DETERMINISTIC) != 0;
+  if (d->math == VS_MATH_BF16) {
+    // [r6] the constants and every scratch array the pass wants cleared, in ONE launch (they were six runtime fill dispatches, 54 us in
+    // front of the first kernel of the step: tools/dispatch_census.py)
+    ArmArgs arm{ones, {at<void>(tape, L.bn_stats), at<void>(tape, L.first_acc), det ? at<void>(tape, L.det_turn) : nullptr},
+                {VS_BN_STAT_SLOTS * 128 * 8 / 16, 64 * 8 / 16, (unsigned)(det ? VS_TURN_WORDS * 4 / 16 : 0)}};
+    unsigned most = 8;
+    for (unsigned n : arm.n16) most = n > most ? n : most;
+    hipLaunchKernelGGL(forward_arm_kernel, dim3((most + 255) / 256), dim3(256), 0, stream, arm);
+  } else {
   VS_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000 /* 1.0f */, 64, stream));
   VS_CHECK_HIP(hipMemsetAsync(ones + 64, 0, 64 * sizeof(float), stream));
-  // deterministic mode (bf16 configuration): the turn word of this tape, armed here; every launch that takes turns re-arms it
-  const bool det = d->math == VS_MATH_BF16 && vs_opt(VS_OPT_DETERMINISTIC) != 0;
-  if (det) VS_CHECK_HIP(hipMemsetAsync(at<unsigned>(tape, L.det_turn), 0, VS_TURN_WORDS * 4, stream));
+  }
   VsTurnScope turn_scope(det ? at<unsigned>(tape, L.det_turn) : nullptr);
 
   // split-f16 convs: the BatchNorm+activation pass that produces a layer's input also folds its
   // |max| into that layer's scale slot (slot l = conv index l: input scale of cnn(l+1))
   float* cs = at<float>(tape, L.conv_scales);
   const bool f16 = d->math != VS_MATH_FP32;
-  if (f16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 16 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));
+  if (f16 && d->math != VS_MATH_BF16) VS_CHECK_HIP(hipMemsetAsync(cs, 0, 16 * VS_SCALE_SLOT_FLOATS * sizeof(float), stream));      // (bf16: no operand scales)
   // conv + bias -> z (kept), then BatchNorm + activation -> a (kept)
   auto bn = [&](int l, const float* z, float* a, int C, bool feat_layout, int stats_slots = 0) -> int {
     VsProfScope ps(VS_PROF_FWD_BN, stream);
@@ -252,6 +273,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     hipStream_t ps = side->s;
     for (int i = 0; i < 6; ++i)
       if (int rc = vs_nhwc_pack_impl(p->conv[i + 1].weight, at<void>(tape, L.conv_packed[i]), kMid[i].kt, kMid[i].kf, 0, ps)) return rc;
+    // [r6] the backward pass's weight images too (same weights, idle side stream): they were 0.1 ms on the backward's critical path
+    for (int i = 0; i < 6; ++i)
+      if (int rc = vs_nhwc_pack_impl(p->conv[i + 1].weight, at<void>(tape, L.conv_packed_t[i]), kMid[i].kt, kMid[i].kf, 1, ps)) return rc;
+    if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], at<float>(tape, L.lstm_packed_t), H, ps, d->math)) return rc;
     for (int dir = 0; dir < 2; ++dir) {
       if (int rc = vs_gemm_nt_impl(dvec, d->E, p->w_ih[dir] + K, KE, dvbias + (size_t)dir * 4 * H, 8 * H, B, 4 * H, d->E,
                                    p->b_ih[dir], p->b_hh[dir], nullptr, 0, 1, 0, VS_ACT_NONE, ps)) return rc;
@@ -270,7 +295,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
     // the statistics scratch is cleared ONCE here; every finalize below folds the slots and clears the scratch behind itself in the
     // same launch (vs_fold_slots): no memset kernel in front of the conv launches
     const int kStatsDoubles = VS_BN_STAT_SLOTS * 128;
-    if (train && kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+    // (cleared by forward_arm_kernel above)
     auto bn16 = [&](int l) -> int {
       VsProfScope ps(VS_PROF_FWD_BN, stream);
       const vs_conv_layer& c = p->conv[l];
@@ -291,7 +316,7 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       // (the moments stay in the tape for the backward pass: first_acc = [35 moments, padded to 64][backward scratch])
       double* mom = at<double>(tape, L.first_acc);
       // (deterministic mode: per-slot sums in the backward pass's dfeat buffer, which nothing uses before the loss)
-      if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream, det ? at<double>(tape, L.dfeat) : nullptr)) return rc;
+      if (int rc = vs_nhwc_first_moments_impl(x, B, T, F, mom, stream, det ? at<double>(tape, L.dfeat) : nullptr, /*mom_is_zero=*/1)) return rc;
       if (train) {
         if (int rc = vs_nhwc_first_stats_impl(mom, c.weight, c.bias, (double)npix, stats, stream)) return rc;
         if (int rc = vs_bn_finalize_impl(stats, 1, (double)npix, 64, c.bn_weight, c.bn_bias, c.bn_running_mean, c.bn_running_var, kBnEps,
@@ -320,7 +345,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
       void* packed = at<void>(tape, L.conv_packed[i]);
       {
         VsProfScope ps(VS_PROF_CNN2 + i, stream);
-        if (!prologue) { if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc; }
+        if (!prologue) {
+          if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, packed, kMid[i].kt, kMid[i].kf, 0, stream)) return rc;
+          if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, at<void>(tape, L.conv_packed_t[i]), kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
+        }
         if (train && !kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
         if (int rc = vs_nhwc_conv_impl(at<void>(tape, L.a[l - 1]), packed, ones, p->conv[l].bias, at<void>(tape, L.z[l]), B, T, F,
                                        kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE, train ? stats : nullptr, stream)) return rc;
@@ -396,7 +424,10 @@ int vs_forward_train(const vs_dims* d, const vs_params* p, const float* x, const
                                          feat_bf16_ready)) return rc;
   }
   float* packed = at<float>(tape, L.lstm_packed);
-  if (!prologue) { if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc; }
+  if (!prologue) {
+    if (int rc = vs_lstm_pack_impl(p->w_hh[0], p->w_hh[1], packed, H, stream, d->math)) return rc;
+    if (nhwc) { if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], at<float>(tape, L.lstm_packed_t), H, stream, d->math)) return rc; }
+  }
   {
     VsProfScope ps(VS_PROF_LSTM_REC, stream);
     if (int rc = vs_bilstm_recurrent_impl(xg, packed, at<float>(tape, L.lstm_state), at<float>(tape, L.lstm_out), xg,
@@ -534,11 +565,13 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // ---- BiLSTM: BPTT, then the batched weight / input gradients ------------------------------
   float* dxg = at<float>(tape, L.gates);
   float* wpt = at<float>(tape, L.lstm_packed_t);
-  if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream, d->math)) return rc;
+  // (VS_MATH_BF16: vs_forward_train left the image in the tape [r6])
+  if (d->math != VS_MATH_BF16) { if (int rc = vs_lstm_pack_t_impl(p->w_hh[0], p->w_hh[1], wpt, H, stream, d->math)) return rc; }
   {
     VsProfScope ps(VS_PROF_BWD_LSTM_REC, stream);
     if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
-                                              B, T, H, stream, d->math)) return rc;
+                                              B, T, H, stream, d->math,
+                                              d->math == VS_MATH_BF16 ? at<char>(tape, L.lstm_bf16) + vs_lstm_bf16_layout(M, K8, H).dxg : nullptr)) return rc;
   }
   float* dsum = at<float>(tape, L.dsum);
   float* feat = at<float>(tape, L.feat);
@@ -550,8 +583,6 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   const bool f16g = d->math != VS_MATH_FP32;
   {
     VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
-    if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, stream)) return rc;
-    if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, stream)) return rc;
     // split-f16 mode: the two large contractions (dW_ih feat part, dfeat) reuse the forward's scales
     // of feat / W_ih (gemm_scales[0..3]) and one new scale for the gate gradients
     if (f16g && d->math != VS_MATH_BF16) {      // the bf16 contractions need no scale
@@ -561,10 +592,8 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   const bool bf16g = d->math == VS_MATH_BF16;
   const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K8, H);
   char* bfb = at<char>(tape, L.lstm_bf16);
-  if (bf16g) {      // the gate gradients as bf16 [M][8H]: row-form A of dfeat, col-form A of dW_ih (gemm_bf16.hip)
-    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
-    if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
-  }
+  // (bf16: the gate gradients as bf16 [M][8H] -- row-form A of dfeat, col-form A of dW_ih (gemm_bf16.hip) -- were written by the BPTT
+  // kernel beside the fp32 ones [r6]: the conversion pass was 0.13 ms on the critical path)
   hipStream_t ls = stream;
   // [r5] The LSTM's leaf contractions start on the side stream right here, beside the dfeat contraction and the HBM-bound BatchNorm
   // backward of the features, with dW_ih -- one persistent workgroup per CU, which slows that pass down 3x -- LAST among them (started
@@ -604,6 +633,10 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   }
   auto lstm_leaves = [&]() -> int {
     VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, ls);
+    // sum_t of the gate gradients per utterance, then over the batch: bias / d-vector-column gradients, all leaves [r6: here, on the
+    // leaves' stream, instead of in front of the dfeat contraction on the caller's]
+    if (int rc = vs_colsum_impl(dxg, 8 * H, B, T, 8 * H, dsum, 8 * H, ls)) return rc;
+    if (int rc = vs_colsum_impl(dsum, 8 * H, 1, B, 8 * H, tmp, 8 * H, ls)) return rc;
     for (int dir = 0; dir < 2; ++dir) {
       VS_CHECK_HIP(hipMemcpyAsync(g->b_ih[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
       VS_CHECK_HIP(hipMemcpyAsync(g->b_hh[dir], tmp + (size_t)dir * 4 * H, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, ls));
@@ -693,7 +726,6 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                               g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
                                               mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
     }
-    void* pack_t = at<void>(tape, L.pack_tmp);
     bool pending = false;
     // (the alternative -- plain data gradients, the activation derivative and the sums in a two-pass BatchNorm backward beside the weight
     // gradient -- lost by 2.6 ms in round 4 and by 4 ms in round 6 with both passes throttled to one block per CU: profiles/r06_experiments.md)
@@ -719,7 +751,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       }
       {
         VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
-        if (int rc = vs_nhwc_pack_impl(p->conv[l].weight, pack_t, kMid[i].kt, kMid[i].kf, 1, stream)) return rc;
+        const void* pack_t = at<void>(tape, L.conv_packed_t[i]);      // (written by vs_forward_train [r6])
         if (l == 1 || !dy_form) {
           // cnn2's data gradient is the plain conv: the activation derivative of cnn1 needs z1, which is recomputed from x by
           // cnn1's one-pass backward below (no dy epilogue here, no z1 tensor)

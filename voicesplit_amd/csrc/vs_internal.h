@@ -124,7 +124,7 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
 // cnn1 by recomputation (nhwc_edge.hip): input moments -> batch statistics of z1; one-pass backward
 #define VS_FIRST_MOMENTS 35
 #define VS_FIRST_BWD_SCRATCH_DOUBLES (64 * 9 + VS_FIRST_MOMENTS)
-int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t, double* det_slots = nullptr);
+int vs_nhwc_first_moments_impl(const float* x, int B, int T, int F, double* mom, hipStream_t, double* det_slots = nullptr, int mom_is_zero = 0);
 int vs_nhwc_first_stats_impl(const double* mom, const float* w, const float* bias, double count, double* stats, hipStream_t);
 int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const float* bias, int B, int T, int F, int act, int train,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
@@ -242,7 +242,7 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
                              int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_lstm_pack_t_impl(const float*, const float*, float*, int, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
-                                 int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
+                                 int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32, void* gates_bf16 = nullptr);
 // reduce.hip
 int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, long long n, hipStream_t);
 int vs_sigmoid_bwd_rows_impl(const float* dmask, const float* mask, float* dlogits, long long rows, int N, void* rows_bf16, int Kp, hipStream_t);

@@ -223,13 +223,15 @@ class _MaskNet(nn.Module):
     def _bump_bn_counters(self):
         if self.training:
             with torch.no_grad():
-                for m in self.conv:
-                    if isinstance(m, nn.BatchNorm2d):
-                        m.num_batches_tracked += 1           # running_mean/var were updated in place by the library
-                        # ... through raw pointers, which torch cannot see: advance their version counters so that every
-                        # cache keyed on them (ops.PreparedWeights) knows (no kernel launch)
-                        torch.autograd.graph.increment_version(m.running_mean)
-                        torch.autograd.graph.increment_version(m.running_var)
+                bns = [m for m in self.conv if isinstance(m, nn.BatchNorm2d)]
+                # ONE launch for the eight counters (eight `+= 1` were eight 6 us kernels between the head and the loss head: round 6,
+                # tools/dispatch_census.py)
+                torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+                for m in bns:
+                    # running_mean/var were updated in place by the library through raw pointers, which torch cannot see: advance
+                    # their version counters so that every cache keyed on them (ops.PreparedWeights) knows (no kernel launch)
+                    torch.autograd.graph.increment_version(m.running_mean)
+                    torch.autograd.graph.increment_version(m.running_var)
 
     def lstm_status(self):
         """0 when the persistent BiLSTM kernels of the last training forward / backward completed, 1 when one gave up
