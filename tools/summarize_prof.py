@@ -26,7 +26,21 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles", f"{tag}_rocprof")
     os.makedirs(dst, exist_ok=True)
-    shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
+    if os.path.isfile(stats):
+        shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
+    else:      # (rocprofv3 died before its --stats table: the same table from the kernel trace)
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))):
+            by[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        total = sum(sum(v) for v in by.values()) or 1
+        with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                m = sum(v) / len(v)
+                sd = (sum((x - m) ** 2 for x in v) / (len(v) - 1)) ** 0.5 if len(v) > 1 else 0.0
+                w.writerow([k, len(v), sum(v), round(m, 6), round(100.0 * sum(v) / total, 4), min(v), max(v), round(sd, 6)])
     if os.path.isfile(os.path.join(src, "sources.sha256")):
         shutil.copy(os.path.join(src, "sources.sha256"), os.path.join(dst, "sources.sha256"))
     per = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -1177,7 +1177,6 @@ struct Lstm16BwdArgs {
   const float* c_all;
   const float* dout;
   int B, T, H, Bpad, bt0;
-  unsigned short* gates_bf16;      // [B*T][8H] or NULL: the gate gradients once more, as the bf16 operand of the batched contractions [r6]
 };
 
 constexpr int kBwdRes16 = 13;   // 16-wide K chunks of W_hh^T per wave held in registers (4H <= 1664); the rest streams from L2
@@ -1331,12 +1330,6 @@ void lstm16_bwd_persistent_kernel(Lstm16BwdArgs a) {
         *reinterpret_cast<float4*>(grow + a.H) = make_float4(dg4[1][0], dg4[1][1], dg4[1][2], dg4[1][3]);
         *reinterpret_cast<float4*>(grow + 2 * a.H) = make_float4(dg4[2][0], dg4[2][1], dg4[2][2], dg4[2][3]);
         *reinterpret_cast<float4*>(grow + 3 * a.H) = make_float4(dg4[3][0], dg4[3][1], dg4[3][2], dg4[3][3]);
-        if (a.gates_bf16) {      // (vs_pack_bf16: the rounding of vs_cvt_rows_bf16_impl, the pass this store replaces)
-          unsigned short* brow = a.gates_bf16 + (grow - a.gates);
-#pragma unroll
-          for (int gate = 0; gate < 4; ++gate)
-            *reinterpret_cast<uint2*>(brow + gate * a.H) = make_uint2(vs_pack_bf16(dg4[gate][0], dg4[gate][1]), vs_pack_bf16(dg4[gate][2], dg4[gate][3]));
-        }
       }
     }
   }
@@ -1398,11 +1391,10 @@ namespace {
 // The word is only read by callers that ask (vs_lstm_status), so the result itself is made unusable: NaN in the first
 // 64 outputs -> NaN mask / NaN gradients -> the training loop's loss guard (train.py:112-114) and every isfinite check
 // fire instead of training on wrong numbers.
-__global__ void lstm_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ out, int n, unsigned short* __restrict__ out_bf16 = nullptr) {
+__global__ void lstm_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ out, int n) {
   if (*err == 0u) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = __uint_as_float(0x7fc00000u);
-  if (i < n && out_bf16) out_bf16[i] = 0x7fc0;
 }
 
 // Cooperative launch: the runtime checks the grid against the kernel's occupancy and refuses (instead of queueing
@@ -1514,10 +1506,8 @@ int vs_lstm_pack_t_impl(const float* whh_f, const float* whh_b, float* wp, int H
 // gates: activated gates from the training forward, overwritten with d(loss)/d(gate pre-activations).
 // state: step kernels = dgates fragments ping/pong + dc carry; persistent kernel = the two fragment
 // buffers, then (in the dc region) the flag words and the error word.
-// gates_bf16 (or NULL): [B*T][8H] bf16, written with the gate gradients as well -- by the bf16 persistent kernel itself, by a conversion
-// pass behind any other kernel
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
-                                 int B, int T, int H, hipStream_t stream, int math, void* gates_bf16) {
+                                 int B, int T, int H, hipStream_t stream, int math) {
   VS_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, "lstm_bwd: bad shape B=%d T=%d H=%d (H must be a multiple of 8)", B, T, H);
   if (g_lstm_kernel == 3) math = VS_MATH_CODE_FP32;
   const int Bpad = (B + 31) / 32 * 32;
@@ -1542,7 +1532,7 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
       hipError_t e;
       if (math == VS_MATH_CODE_BF16) {      // gate gradients and W_hh^T as bf16 (the fragment buffers are half as large)
         Lstm16BwdArgs a{reinterpret_cast<const u32x4_t*>(wpt + lstm_packed_t_fp32_floats(H)), gbuf[0], gbuf[1], flags, err, gates, c_all, dout,
-                        B, T, H, Bpad, bt0, reinterpret_cast<unsigned short*>(gates_bf16)};
+                        B, T, H, Bpad, bt0};
         e = launch_resident(reinterpret_cast<const void*>(&lstm16_bwd_persistent_kernel), dim3(NUT * nbt, 2), dim3(512), a, stream);
       } else {
         LstmBwdPersistArgs a{wpt, gbuf[0], gbuf[1], flags, err, gates, c_all, dout, B, T, H, Bpad, bt0};
@@ -1556,10 +1546,7 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
       }
     }
     if (launched) {
-      const bool in_kernel = math == VS_MATH_CODE_BF16;
-      if (gates_bf16 && !in_kernel) { if (int rc = vs_cvt_rows_bf16_impl(gates, (long long)B * T, 8 * H, 8 * H, gates_bf16, 8 * H, stream)) return rc; }
-      hipLaunchKernelGGL(lstm_poison_kernel, dim3(1), dim3(64), 0, stream, err, gates, 64 < B * T * 8 * H ? 64 : B * T * 8 * H,
-                         reinterpret_cast<unsigned short*>(gates_bf16));
+      hipLaunchKernelGGL(lstm_poison_kernel, dim3(1), dim3(64), 0, stream, err, gates, 64 < B * T * 8 * H ? 64 : B * T * 8 * H);
       VS_LAUNCH_CHECK();
       return 0;
     }
@@ -1572,6 +1559,5 @@ int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, c
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);
   }
   VS_LAUNCH_CHECK();
-  if (gates_bf16) return vs_cvt_rows_bf16_impl(gates, (long long)B * T, 8 * H, 8 * H, gates_bf16, 8 * H, stream);
   return 0;
 }

@@ -570,8 +570,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   {
     VsProfScope ps(VS_PROF_BWD_LSTM_REC, stream);
     if (int rc = vs_bilstm_bwd_recurrent_impl(wpt, at<float>(tape, L.lstm_bwd_state), dxg, at<float>(tape, L.cstate), dlstm,
-                                              B, T, H, stream, d->math,
-                                              d->math == VS_MATH_BF16 ? at<char>(tape, L.lstm_bf16) + vs_lstm_bf16_layout(M, K8, H).dxg : nullptr)) return rc;
+                                              B, T, H, stream, d->math)) return rc;
   }
   float* dsum = at<float>(tape, L.dsum);
   float* feat = at<float>(tape, L.feat);
@@ -592,8 +591,12 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   const bool bf16g = d->math == VS_MATH_BF16;
   const VsLstmBf16Layout Lb = vs_lstm_bf16_layout(M, K8, H);
   char* bfb = at<char>(tape, L.lstm_bf16);
-  // (bf16: the gate gradients as bf16 [M][8H] -- row-form A of dfeat, col-form A of dW_ih (gemm_bf16.hip) -- were written by the BPTT
-  // kernel beside the fp32 ones [r6]: the conversion pass was 0.13 ms on the critical path)
+  if (bf16g) {      // the gate gradients as bf16 [M][8H]: row-form A of dfeat, col-form A of dW_ih (gemm_bf16.hip)
+    // (round 6: the BPTT kernel storing this form itself beside the fp32 one saved the 0.13 ms pass and cost the recurrence 0.2 ms --
+    // 32 more scattered lines per store instruction in a loop bound by exactly those: profiles/r06_experiments.md section 9)
+    VsProfScope ps(VS_PROF_BWD_LSTM_GEMM, stream);
+    if (int rc = vs_cvt_rows_bf16_impl(dxg, M, 8 * H, 8 * H, bfb + Lb.dxg, 8 * H, stream)) return rc;
+  }
   hipStream_t ls = stream;
   // [r5] The LSTM's leaf contractions start on the side stream right here, beside the dfeat contraction and the HBM-bound BatchNorm
   // backward of the features, with dW_ih -- one persistent workgroup per CU, which slows that pass down 3x -- LAST among them (started
@@ -716,7 +719,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
     // The backward keeps the two-kernel finalize and a memset in front of every dy launch: the fused form (one launch that folds,
     // finalizes and clears) measured +1.6 ms per step beside a 2048-block BatchNorm pass and neutral beside the one-block-per-CU pass
     // (round 5: profiles/r05_experiments.md section 2 and its last paragraph).
-    constexpr int kStatsDoubles = 0;
+    constexpr int kStatsDoubles = 0;      // (re-measured in round 6, call 12: 46.85 ms either way, three alternating runs)
     {
       VsProfScope ps(VS_PROF_BWD_EDGE, stream);
       VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));

@@ -242,7 +242,7 @@ int vs_bilstm_recurrent_impl(const float* xg, const float* wp, float* state, flo
                              int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_lstm_pack_t_impl(const float*, const float*, float*, int, hipStream_t, int math = VS_MATH_CODE_FP32);
 int vs_bilstm_bwd_recurrent_impl(const float* wpt, float* state, float* gates, const float* c_all, const float* dout,
-                                 int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32, void* gates_bf16 = nullptr);
+                                 int B, int T, int H, hipStream_t, int math = VS_MATH_CODE_FP32);
 // reduce.hip
 int vs_sigmoid_bwd_impl(const float* dmask, const float* mask, float* dlogits, long long n, hipStream_t);
 int vs_sigmoid_bwd_rows_impl(const float* dmask, const float* mask, float* dlogits, long long rows, int N, void* rows_bf16, int Kp, hipStream_t);
