@@ -46,8 +46,16 @@ __device__ __forceinline__ float hann_w(int j, const LossShape& s) {
 // basis[j][k]: contribution of spectrum entry k (k < F: Re_k, else Im_{k-F}) to windowed sample j
 // of a frame (time index n = (n_fft-win)/2 + j): onesided irfft weights c_k/n_fft, c = 1 for DC and
 // Nyquist, 2 otherwise.
-__global__ void istft_basis_kernel(float* __restrict__ basis, LossShape s) {
+// scale2 (or NULL): {s, 1/s} of the split-f16 contractions for this operand, from its analytic bound 2 / n_fft (the rule of
+// scale_from_absmax_kernel, conv_f16x3.hip: the bound lands in [2^9, 2^10))
+__global__ void istft_basis_kernel(float* __restrict__ basis, LossShape s, float* __restrict__ scale2 = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0 && scale2) {
+    int e = 0;
+    (void)frexpf(2.0f / (float)s.n_fft, &e);
+    scale2[0] = ldexpf(1.f, 10 - e);
+    scale2[1] = ldexpf(1.f, e - 10);
+  }
   if (idx >= s.win * s.ldk) return;
   const int j = idx / s.ldk, k = idx - j * s.ldk;
   float v = 0.f;
@@ -83,8 +91,9 @@ __global__ void istft_envelope_kernel(float* __restrict__ env, LossShape s) {
 // reim[m][k] = mag * exp(cos phi) (k < F) | mag * exp(sin phi) (k >= F);  v = a*b (mixed*mask) or a
 __global__ __launch_bounds__(256)
 void spec_to_reim_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ phase,
-                         float* __restrict__ reim, LossShape s) {
+                         float* __restrict__ reim, LossShape s, unsigned* __restrict__ amax = nullptr) {
   const long long n = (long long)s.B * s.T * s.F;
+  float mx = 0.f;      // max |re|, |im| of what this thread wrote: the operand scale of the split-f16 contraction (vs_absmax_commit)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const long long m = i / s.F;
     const int f = (int)(i - m * s.F);
@@ -94,9 +103,13 @@ void spec_to_reim_kernel(const float* __restrict__ a, const float* __restrict__ 
     const float mag = expf(db * kLn10Over20);
     float sn, cs;
     sincosf(phase[i], &sn, &cs);
-    reim[m * s.ldk + f] = s.true_phase ? mag * cs : mag * expf(cs);
-    reim[m * s.ldk + s.F + f] = s.true_phase ? mag * sn : mag * expf(sn);
+    const float re = s.true_phase ? mag * cs : mag * expf(cs), im = s.true_phase ? mag * sn : mag * expf(sn);
+    reim[m * s.ldk + f] = re;
+    reim[m * s.ldk + s.F + f] = im;
+    if (f == 0) for (int c = s.K; c < s.ldk; ++c) reim[m * s.ldk + c] = 0.f;      // the row's ld padding (a contraction over ldk columns reads it)
+    mx = fmaxf(mx, fmaxf(fabsf(re), fabsf(im)));
   }
+  vs_absmax_commit(mx, amax);
 }
 
 // ---- analysis side: wav -> frames -> (re | im) -> normalised dB magnitude + phase ---------------
@@ -165,15 +178,20 @@ void overlap_add_kernel(const float* __restrict__ frames, const float* __restric
 
 // dframes[m][j] = dwav[b][sp] / env[sp],  sp = hop*t - win/2 + j  (0 outside the kept samples)
 __global__ __launch_bounds__(256)
-void overlap_add_bwd_kernel(const float* __restrict__ dwav, const float* __restrict__ env, float* __restrict__ dframes, LossShape s) {
+void overlap_add_bwd_kernel(const float* __restrict__ dwav, const float* __restrict__ env, float* __restrict__ dframes, LossShape s,
+                            unsigned* __restrict__ amax = nullptr) {
   const long long n = (long long)s.B * s.T * s.win;
+  float mx = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const long long m = i / s.win;
     const int j = (int)(i - m * s.win);
     const int b = (int)(m / s.T), t = (int)(m - (long long)b * s.T);
     const int sp = s.hop * t - s.win / 2 + j;
-    dframes[i] = (sp >= 0 && sp < s.S) ? dwav[(size_t)b * s.S + sp] / env[sp] : 0.f;
+    const float v = (sp >= 0 && sp < s.S) ? dwav[(size_t)b * s.S + sp] / env[sp] : 0.f;
+    dframes[i] = v;
+    mx = fmaxf(mx, fabsf(v));
   }
+  vs_absmax_commit(mx, amax);
 }
 
 // six fp64 moments per utterance: sum_all s, and over the unmasked samples: n, e, s, e*s, e^2, s^2
@@ -287,7 +305,7 @@ void reim_to_dmask_kernel(const float* __restrict__ mixed, const float* __restri
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
-struct LossLayout { size_t basis, fbasis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, total; };
+struct LossLayout { size_t basis, fbasis, env, reim_e, reim_t, frames_e, frames_t, wav_e, wav_t, dwav, mom, coef, amax, scales, total; };
 
 // ---- PowerLaw_Compressed_Loss (utils/generic_utils.py:353-373), the criterion train.py:74-75 picks
 // for loss_name == 'power_law_compression' (the voicefilter configuration):
@@ -409,6 +427,8 @@ void make_layout(const LossShape& s, LossLayout* L) {
   L->dwav = take((size_t)s.B * s.S * 4);
   L->mom = take((size_t)s.B * 8 * 8);
   L->coef = take((size_t)s.B * 8 * 4);
+  L->amax = take((size_t)3 * VS_AMAX_SLOTS * 4);      // running |max| of the three fp32 operands of the split-f16 contractions (vs_sisnr_loss)
+  L->scales = take(4 * 2 * 4);                        // {s, 1/s}: reim (estimate), reim (target), d(frames), basis
   L->total = off;
 }
 
@@ -442,16 +462,34 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
   const unsigned gspec = (unsigned)((nspec + 255) / 256 < 16384 ? (nspec + 255) / 256 : 16384);
   float* basis = at<float>(ws, L.basis);
   float* env = at<float>(ws, L.env);
-  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s);
+  // [r6] The three contractions of this head (two iSTFTs, one backward) run as split-f16 products (gemm_f16x3.hip: fp32-class results from
+  // the f16 matrix pipe -- 0.31 + 0.32 + 0.23 ms on the fp32 pipe at B = 64 before) whenever the operands fit its
+  // 32-bit offsets; their power-of-two operand scales come from |max| values the producing kernels track themselves.
+  const bool split = (size_t)M * s.ldk * 4 < (1ull << 32) - 4096;
+  unsigned* amax = at<unsigned>(ws, L.amax);
+  float* scales = at<float>(ws, L.scales);
+  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s, scales + 6);
   hipLaunchKernelGGL(istft_envelope_kernel, dim3((s.S + 255) / 256), dim3(256), 0, stream, env, s);
   // both spectrograms -> (re | im) rows -> windowed frames (one GEMM each) -> waveforms
   float* reim[2] = {at<float>(ws, L.reim_e), at<float>(ws, L.reim_t)};
   float* frames[2] = {at<float>(ws, L.frames_e), at<float>(ws, L.frames_t)};
   float* wav[2] = {at<float>(ws, L.wav_e), at<float>(ws, L.wav_t)};
-  VS_CHECK_HIP(hipMemsetAsync(reim[0], 0, (size_t)M * s.ldk * 4 * 2, stream));      // the ld padding columns
-  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, mixed, mask, phase, reim[0], s);
-  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, target, (const float*)nullptr, phase, reim[1], s);
+  // (the ld padding columns are zeroed by spec_to_reim_kernel itself [r6]: the memset that did it wrote both arrays, 186 MB, for two
+  // floats per row)
+  if (split) VS_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)3 * VS_AMAX_SLOTS * 4, stream));
+  // with the |max| commit at the end of every wave (a load and maybe an atomic: ~3 us of latency) the grid is ONE resident round of
+  // long-lived workgroups -- 16384 short ones paid that latency eight times over (56 -> 100 us per launch, call 13)
+  const unsigned gamax = split && gspec > 2048 ? 2048 : gspec;
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gamax), dim3(256), 0, stream, mixed, mask, phase, reim[0], s, split ? amax : nullptr);
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gamax), dim3(256), 0, stream, target, (const float*)nullptr, phase, reim[1], s,
+                     split ? amax + VS_AMAX_SLOTS : nullptr);
   for (int q = 0; q < 2; ++q) {
+    if (split) {
+      if (int rc = vs_scale_from_absmax_impl(amax + q * VS_AMAX_SLOTS, VS_AMAX_SLOTS, scales + 2 * q, stream)) return rc;
+      if (int rc = vs_gemm_f16x3_impl(0, 0, reim[q], s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames[q], s.win, M, s.win, s.ldk,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, scales + 2 * q, scales + 6, stream,
+                                      VS_MATH_CODE_F16X3)) return rc;
+    } else
     if (int rc = vs_gemm_general_impl(0, 0, reim[q], s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames[q], s.win, M, s.win, s.K,
                                       nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
     hipLaunchKernelGGL(overlap_add_kernel, dim3((s.S + 255) / 256, s.B), dim3(256), 0, stream, frames[q], env, wav[q], s);
@@ -469,10 +507,16 @@ int vs_sisnr_loss(const vs_loss_dims* d, const float* mixed, const float* mask, 
     hipLaunchKernelGGL(sisnr_grad_kernel, dim3(gx, s.B), dim3(256), 0, stream, wav[0], wav[1], coef, dwav, s);
     float* dframes = frames[0];
     const long long nfr = (long long)M * s.win;
-    hipLaunchKernelGGL(overlap_add_bwd_kernel, dim3((unsigned)((nfr + 255) / 256 < 16384 ? (nfr + 255) / 256 : 16384)), dim3(256), 0, stream,
-                       dwav, env, dframes, s);
+    hipLaunchKernelGGL(overlap_add_bwd_kernel, dim3((unsigned)((nfr + 255) / 256 < (split ? 2048 : 16384) ? (nfr + 255) / 256 : (split ? 2048 : 16384))),
+                       dim3(256), 0, stream, dwav, env, dframes, s, split ? amax + 2 * VS_AMAX_SLOTS : nullptr);
     float* dreim = reim[0];
     // d(reim)[M][K] = d(frames)[M][win] @ basis[win][K]
+    if (split) {
+      if (int rc = vs_scale_from_absmax_impl(amax + 2 * VS_AMAX_SLOTS, VS_AMAX_SLOTS, scales + 4, stream)) return rc;
+      if (int rc = vs_gemm_f16x3_impl(0, 1, dframes, s.win, basis, nullptr, 0x7fffffff, s.ldk, dreim, s.ldk, M, s.K, s.win,
+                                      nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, scales + 4, scales + 6, stream,
+                                      VS_MATH_CODE_F16X3)) return rc;
+    } else
     if (int rc = vs_gemm_general_impl(0, 1, dframes, s.win, basis, nullptr, 0x7fffffff, s.ldk, dreim, s.ldk, M, s.K, s.win,
                                       nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
     hipLaunchKernelGGL(reim_to_dmask_kernel, dim3(gspec), dim3(256), 0, stream, mixed, mask, phase, dreim, dmask, s);
@@ -548,10 +592,21 @@ int vs_spec_to_wav(const vs_loss_dims* d, const float* spec, const float* mask, 
   float* env = at<float>(ws, L.env);
   float* reim = at<float>(ws, L.reim_e);
   float* frames = at<float>(ws, L.frames_e);
-  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s);
+  // (the contraction as split-f16 products, as in vs_sisnr_loss [r6])
+  const bool split = (size_t)M * s.ldk * 4 < (1ull << 32) - 4096;
+  unsigned* amax = at<unsigned>(ws, L.amax);
+  float* scales = at<float>(ws, L.scales);
+  hipLaunchKernelGGL(istft_basis_kernel, dim3((s.win * s.ldk + 255) / 256), dim3(256), 0, stream, basis, s, scales + 6);
   hipLaunchKernelGGL(istft_envelope_kernel, dim3((s.S + 255) / 256), dim3(256), 0, stream, env, s);
-  VS_CHECK_HIP(hipMemsetAsync(reim, 0, (size_t)M * s.ldk * 4, stream));
-  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(gspec), dim3(256), 0, stream, spec, mask, phase, reim, s);
+  if (split) VS_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)VS_AMAX_SLOTS * 4, stream));
+  hipLaunchKernelGGL(spec_to_reim_kernel, dim3(split && gspec > 2048 ? 2048 : gspec), dim3(256), 0, stream, spec, mask, phase, reim, s,
+                     split ? amax : nullptr);
+  if (split) {
+    if (int rc = vs_scale_from_absmax_impl(amax, VS_AMAX_SLOTS, scales, stream)) return rc;
+    if (int rc = vs_gemm_f16x3_impl(0, 0, reim, s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames, s.win, M, s.win, s.ldk,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, scales, scales + 6, stream,
+                                    VS_MATH_CODE_F16X3)) return rc;
+  } else
   if (int rc = vs_gemm_general_impl(0, 0, reim, s.ldk, basis, nullptr, 0x7fffffff, s.ldk, frames, s.win, M, s.win, s.K,
                                     nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
   hipLaunchKernelGGL(overlap_add_kernel, dim3((s.S + 255) / 256, s.B), dim3(256), 0, stream, frames, env, wav, s);
