@@ -430,7 +430,9 @@ int vs_forward_train(const vs_dims* dims, const vs_params* params, const float* 
                      int conv_act, int bn_mode, void* tape, size_t tape_bytes, float* mask, void* stream);
 
 /* Backward: dmask [B][T][FC2] = d(loss)/d(mask) -> every gradient in `grads`.  `mask` is the
- * tensor vs_forward_train returned; conv_act / bn_mode must match the forward call.  The
+ * tensor vs_forward_train returned; conv_act / bn_mode / dims / params must be those of the forward
+ * call and the parameters unchanged since (VS_MATH_BF16: the tape already holds this pass's weight
+ * images -- conv_packed_t, lstm_packed_t, the bf16 W_ih -- written by vs_forward_train).  The
  * gradient wrt the spectrogram x is not produced (the reference never asks for it: x is data). */
 int vs_backward(const vs_dims* dims, const vs_params* params, const float* x, const float* dvec,
                 int conv_act, int bn_mode, void* tape, size_t tape_bytes,
@@ -492,10 +494,10 @@ enum vs_option {
                                  meaningless).  Ignored by the product build.  VOICESPLIT_ABLATION */
   VS_OPT_DETERMINISTIC = 5,   /* VS_MATH_BF16 training step (vs_forward_train, vs_backward, vs_sisnr_loss): 1 = every partial sum that workgroups
                                  add to shared slots with fp64 atomics (BatchNorm statistics, their backward sums, cnn1's input moments,
-                                 the loss head's moments) is added in WORKGROUP ORDER (the workgroups of such a launch take turns, at most one
-                                 per CU), so a rerun on the same inputs is bit-identical: masks, running statistics, loss, every gradient.
+                                 the loss head's moments) is added in WORKGROUP ORDER (the workgroups of such a launch that add to the same
+                                 addresses take turns), so a rerun on the same inputs is bit-identical: masks, running statistics, loss, every gradient.
                                  0 (default) = arrival order: results agree to the last bits of fp64 sums only (SURVEY.md section 5:
-                                 deterministic-rerun comparisons as the device-side sanitizer).  Costs ~1 ms of a 46 ms step at B = 64
+                                 deterministic-rerun comparisons as the device-side sanitizer).  Costs 1.8 ms of a 46.0 ms step at B = 64
                                  (profiles/r06_experiments.md).  VOICESPLIT_DETERMINISTIC */
   VS_OPT_COUNT = 6
 };

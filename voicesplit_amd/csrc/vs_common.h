@@ -160,7 +160,7 @@ __device__ __forceinline__ float vs_act_rt(float v, int act) {
 // addends in the same order in every run and a rerun is bit-identical.  Only workgroups that add to the SAME addresses need an
 // order among themselves: the turn region of the tape (vs_tape_layout.det_turn, zeroed at the start of a step) holds one word per
 // partial-sum slot (VS_TURN_SLOT + slot: the workgroups blockIdx % VS_BN_STAT_SLOTS == slot queue up in index order: chains of
-// four at one workgroup per CU), one per channel (VS_TURN_CHANNEL + c) and one global word (VS_TURN_GLOBAL) for the two small
+// four in the persistent convs, of 32 behind a 2048-workgroup streaming pass), one per channel (VS_TURN_CHANNEL + c) and one global word (VS_TURN_GLOBAL) for the two small
 // kernels whose workgroups all add to one array.  A turn costs ~8 us (an fp64 atomic round trip, a fence, the next one's poll): one
 // chain through all 256 workgroups of a conv launch, the first version, doubled its time.  NULL = off (the default: arrival
 // order, last bits differ between runs).  A workgroup waits only for workgroups dispatched before it, which never wait for it: no
