@@ -116,8 +116,9 @@ void spec_to_reim_kernel(const float* __restrict__ a, const float* __restrict__ 
 // frames[m][j] = w[j] * wav_reflect[b][hop*t - win/2 + j]     (librosa.stft: center=True, reflect padding;
 // only the win samples under the centred window matter)
 __global__ __launch_bounds__(256)
-void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, LossShape s) {
+void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frames, LossShape s, unsigned* __restrict__ amax = nullptr) {
   const long long n = (long long)s.B * s.T * s.win;
+  float mx = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const long long m = i / s.win;
     const int j = (int)(i - m * s.win);
@@ -125,13 +126,17 @@ void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ frame
     int idx = s.hop * t - s.win / 2 + j;
     if (idx < 0) idx = -idx;
     if (idx >= s.S) idx = 2 * (s.S - 1) - idx;
-    frames[i] = hann_w(j, s) * wav[(size_t)b * s.S + idx];
+    const float v = hann_w(j, s) * wav[(size_t)b * s.S + idx];
+    frames[i] = v;
+    mx = fmaxf(mx, fabsf(v));
   }
+  vs_absmax_commit(mx, amax);
 }
 
 // fwd_basis[k][j]: Re_k = sum_j x_j cos(2 pi k n_j / N), Im_k = -sum_j x_j sin(...), n_j = (N-win)/2 + j
-__global__ void stft_basis_kernel(float* __restrict__ basis, LossShape s) {
+__global__ void stft_basis_kernel(float* __restrict__ basis, LossShape s, float* __restrict__ scale2 = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0 && scale2) { scale2[0] = 512.f; scale2[1] = 1.f / 512.f; }      // |cos|, |sin| <= 1 = 0.5 * 2^1 -> 2^(10 - 1) (scale_from_absmax_kernel's rule)
   if (idx >= s.K * s.win) return;
   const int k = idx / s.win, j = idx - k * s.win;
   const int kk = k < s.F ? k : k - s.F;
@@ -562,8 +567,20 @@ int vs_wav_to_spec(const vs_loss_dims* d, const float* wav, float* spec, float* 
   float* basis = at<float>(ws, L.fbasis);
   float* reim = at<float>(ws, L.reim_e);
   const long long nfr = (long long)M * s.win;
-  hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)((nfr + 255) / 256 < 16384 ? (nfr + 255) / 256 : 16384)), dim3(256), 0, stream, wav, frames, s);
-  hipLaunchKernelGGL(stft_basis_kernel, dim3((s.K * s.win + 255) / 256), dim3(256), 0, stream, basis, s);
+  // (the contraction as split-f16 products, as in vs_sisnr_loss [r6]; win % 4 != 0 falls to the kernel's scalar-load instance)
+  const bool split = (size_t)M * s.ldk * 4 < (1ull << 32) - 4096;
+  unsigned* amax = at<unsigned>(ws, L.amax);
+  float* scales = at<float>(ws, L.scales);
+  const unsigned gfr = (unsigned)((nfr + 255) / 256 < (split ? 2048 : 16384) ? (nfr + 255) / 256 : (split ? 2048 : 16384));
+  if (split) VS_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)VS_AMAX_SLOTS * 4, stream));
+  hipLaunchKernelGGL(stft_frames_kernel, dim3(gfr), dim3(256), 0, stream, wav, frames, s, split ? amax : nullptr);
+  hipLaunchKernelGGL(stft_basis_kernel, dim3((s.K * s.win + 255) / 256), dim3(256), 0, stream, basis, s, scales + 6);
+  if (split) {
+    if (int rc = vs_scale_from_absmax_impl(amax, VS_AMAX_SLOTS, scales, stream)) return rc;
+    if (int rc = vs_gemm_f16x3_impl(0, 0, frames, s.win, basis, nullptr, 0x7fffffff, s.win, reim, s.ldk, M, s.K, s.win,
+                                    nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, scales, scales + 6, stream,
+                                    VS_MATH_CODE_F16X3)) return rc;
+  } else
   if (int rc = vs_gemm_general_impl(0, 0, frames, s.win, basis, nullptr, 0x7fffffff, s.win, reim, s.ldk, M, s.K, s.win,
                                     nullptr, nullptr, nullptr, 0, 1, nullptr, 0, 0, 0, VS_ACT_NONE, 0, 0, 0, 1, nullptr, stream)) return rc;
   const long long nspec = (long long)M * s.F;
