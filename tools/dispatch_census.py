@@ -44,8 +44,18 @@ def main():
                     break
             census[(kind, nxt)] += 1
             total[kind] += 1
-    print(f"{len(rows)} dispatches in the trace, {len(by_queue)} queues; per step (/{steps}): "
-          + ", ".join(f"{k} {v / steps:.1f}" for k, v in total.items()) + f", all {len(rows) / steps:.1f}")
+    # inside the steps proper: the windows between consecutive starts of the step's first big kernel (--anchor, default cnn1's moments pass)
+    anchor = sys.argv[sys.argv.index("--anchor") + 1] if "--anchor" in sys.argv else "nhwc_first_moments_kernel"
+    marks = [key(r) for r in rows if anchor in r["Kernel_Name"]]
+    if len(marks) >= 2:
+        per = []
+        for a, b in zip(marks[:-1], marks[1:]):
+            w = [r for r in rows if a <= key(r) < b]
+            per.append((len(w), sum("fillBuffer" in r["Kernel_Name"] for r in w), sum("copyBuffer" in r["Kernel_Name"] for r in w)))
+        print("inside a step (between two starts of %s): " % anchor
+              + "; ".join(f"{n} dispatches, {f} fills, {c} copies" for n, f, c in per))
+    print(f"whole process: {len(rows)} dispatches on {len(by_queue)} queues, "
+          + ", ".join(f"{v} {k} kernels" for k, v in total.items()) + f"  (the table below: whole process / {steps})")
     for (kind, nxt), c in sorted(census.items(), key=lambda kv: -kv[1]):
         print(f"  {c / steps:7.2f}  {kind}  -> {nxt}")
 
