@@ -2,7 +2,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/r6c4
 mkdir -p $O
-VS_DEBUG_EP=2 python tools/r6/debug_fine.py 2>&1 | grep -v " 0 bad" | grep -v "identical to each other: True" | tail -30
+VS_DEBUG_EP=2 python profiles/r06_calls/scripts/debug_fine.py 2>&1 | grep -v " 0 bad" | grep -v "identical to each other: True" | tail -30
 VOICESPLIT_CONV_EPILOGUE=2 timeout 1200 python -m pytest tests/test_gpu_nhwc.py tests/test_gpu_bf16.py tests/test_gpu_forward.py -q --timeout=900 2>&1 | tail -8
 VS_MICRO_FINE_AB=0,1,2 VS_MICRO_WGRAD=0 timeout 900 python tools/nhwc_micro.py > $O/nhwc_micro_ab.json 2>$O/micro.err; python - <<'PY'
 import json

@@ -8,7 +8,9 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > $O/${R}_pytest_gpu.log; cat $O/${R}_pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+T0=$(date +%s)
 timeout 900 python bench.py 2> $O/bench_train.err | tail -1 > $O/${R}_bench_train.json; cut -c1-300 $O/${R}_bench_train.json
+echo "default bench.py run: $(( $(date +%s) - T0 )) s wall" | tee $O/${R}_bench_train_wall.txt
 timeout 300 python bench.py --mode forward --no-cpu-baseline 2> $O/bench_forward.err | tail -1 > $O/${R}_bench_forward.json; cut -c1-200 $O/${R}_bench_forward.json
 timeout 300 python bench.py --mode forward --conv-math bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_forward_bf16.json; cut -c1-200 $O/${R}_bench_forward_bf16.json
 timeout 300 python bench.py --mode longform --conv-math bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_longform_bf16.json; cut -c1-200 $O/${R}_bench_longform_bf16.json
