@@ -80,7 +80,9 @@ def committed_pmc_traffic(tag, kernel_substr, instance=None, source=None):
     on the GPU box by tools/profile_gpu.sh); a profile without that record, or of an older source, gives (None, why).
     Returns (GB or None, provenance string)."""
     import csv
-    for rnd in ("r05", "r04", "r03", "r02"):
+    import glob
+    rounds = sorted({os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{tag}_rocprof"))}, reverse=True)
+    for rnd in rounds:          # the newest round's counters first
         d = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_rocprof")
         path = os.path.join(d, "pmc_per_kernel.csv")
         if not os.path.isfile(path):
