@@ -38,4 +38,4 @@ bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
 # device idle gaps of one training step, from the kernel trace of the profile run
 F=$(find gpurun_out/prof_${R}_train_bf16/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$F" ] && python tools/step_timeline.py $F > $O/${R}_step_timeline.txt && head -3 $O/${R}_step_timeline.txt
-[ -n "$F" ] && python tools/dispatch_census.py $F --steps 4 > $O/${R}_dispatch_census.txt && head -2 $O/${R}_dispatch_census.txt
+[ -n "$F" ] && python tools/dispatch_census.py $F --steps 10 > $O/${R}_dispatch_census.txt && head -2 $O/${R}_dispatch_census.txt

@@ -11,7 +11,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # which kernel sources these counters belong to: bench.py reports a committed `traffic` only while the kernel's source file is unchanged
 (cd "$REPO/voicesplit_amd/csrc" && sha256sum *.hip *.h *.inc) > "$OUT/sources.sha256"
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
+# (ten steps: the first launch of a kernel in a process runs up to 2x long -- cold instruction cache, first touch of its operands -- and
+# weighed 1/20 in the four-step tables of rounds 2-5; 1/50 now)
+BENCH="python $REPO/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-extras $*"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -f csv -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
