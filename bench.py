@@ -650,8 +650,8 @@ def main():
                                      "achieved": round(B * GFLOP_CONV5X5 / wg_mean, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                      "frac": round(B * GFLOP_CONV5X5 / wg_mean / peak, 4),
                                      "launch_ms": [round(v, 3) for v in wg],
-                                     "note": ("timed on the library's side stream while the BatchNorm backward passes of the next layer run beside it "
-                                              "(vs_set_backward_overlap, DESIGN.md 6.7)"
+                                     "note": ("timed while the BatchNorm backward pass of the layer below runs beside it on the library's side stream "
+                                              "(bf16 configuration: the weight gradient on the caller's stream; vs_set_backward_overlap, DESIGN.md 6.7)"
                                               if not args.serial_backward else "serial schedule: the kernel alone")}
         if stage_ms.get("lstm_gemm"):
             nl = nbatch

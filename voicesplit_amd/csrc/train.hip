@@ -126,7 +126,7 @@ void forward_arm_kernel(ArmArgs a) {
     if (i < a.n16[r]) reinterpret_cast<uint4*>(a.z[r])[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr, leaves = nullptr; };
 SideStream g_side[16];
 // Every exit path of vs_backward after the fork -- the error returns included -- orders the caller's stream after what
 // the side stream has been given (it writes gradients and the shared partial-sum scratch), and leaves no unjoined fork
@@ -169,6 +169,7 @@ int side_stream(SideStream** out) {
     VS_CHECK_HIP(hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, lo));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
     VS_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+    VS_CHECK_HIP(hipEventCreateWithFlags(&ss.leaves, hipEventDisableTiming));
   }
   *out = &ss;
   return 0;
@@ -681,6 +682,7 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
   // on the stream the leaves ran on (the head's leaves were enqueued earlier on the same stream, or on `stream` ahead of the fork)
   auto leaves_done = [&]() -> int {
     if (g->leaves_event) VS_CHECK_HIP(hipEventRecord((hipEvent_t)g->leaves_event, ls));
+    if (side) VS_CHECK_HIP(hipEventRecord(side->leaves, side->s));      // (the shared partial-sum scratch `part` is free behind this)
     return 0;
   };
   if (!leaf_late) { if (int rc = lstm_leaves()) return rc; if (int rc = leaves_done()) return rc; }
@@ -729,73 +731,69 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
                                               g->conv[7].weight, B, T, F, at<void>(tape, L.z[6]), conv_act, scale + 64 * 6, shift + 64 * 6,
                                               mean + 64 * 6, invstd + 64 * 6, stats, stream)) return rc;
     }
-    bool pending = false;
-    // (the alternative -- plain data gradients, the activation derivative and the sums in a two-pass BatchNorm backward beside the weight
-    // gradient -- lost by 2.6 ms in round 4 and by 4 ms in round 6 with both passes throttled to one block per CU: profiles/r06_experiments.md)
-    constexpr bool dy_form = true;
-    bool have_dy = true;               // gb[c] holds dy (activation derivative applied, sums in `stats`) -- cnn8's backward above produced it
-    for (int i = 5; i >= 0; --i) {
-      const int l = i + 1;
-      {
-        VsProfScope ps(VS_PROF_BWD_BN, stream);
-        if (have_dy) {
-          if (int rc = vs_nhwc_bn_bwd_from_dy_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, train, scale + 64 * l, mean + 64 * l,
-                                                   invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                                   stats, coef, stream, kStatsDoubles, pending ? 1 : 0)) return rc;
-        } else {
-          if (int rc = vs_nhwc_bn_act_bwd_impl(gb[c], at<void>(tape, L.z[l]), gb[c], npix, conv_act, train, scale + 64 * l, shift + 64 * l,
-                                               mean + 64 * l, invstd + 64 * l, g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias,
-                                               stats, coef, stream, pending ? 1 : 0)) return rc;
+    {
+      // [r6] Roles of the two streams: the MATRIX kernels (data gradient, weight gradient) stay on the caller's stream, back to back; the
+      // HBM-bound pass that consumes the gradient a data gradient just produced -- layer l-1's BatchNorm backward, cnn1's one-pass backward
+      // behind cnn2's -- forks to the side stream and runs beside layer l's weight gradient.  Rounds 3-5 had it the other way round (weight
+      // gradients on the side stream): the weight gradient, the longer of each pair, then started a cross-stream wait (~25 us) late and the
+      // next data gradient waited for it across streams again; now the wait at the end of a pair is for a pass that ends ~0.1 ms before the
+      // weight gradient does, and cnn1's backward (0.95 ms alone, VALU-bound) runs beside cnn2's weight gradient (0.8 ms) instead of behind it
+      // (1.55 ms for the pair instead of 1.77).  45.46 -> 45.17 ms per step, three alternating runs (profiles/r06_experiments.md section 10).
+      auto from_dy = [&](int l, void* gbuf, hipStream_t s, int beside) -> int {
+        VsProfScope ps(VS_PROF_BWD_BN, s);
+        return vs_nhwc_bn_bwd_from_dy_impl(gbuf, at<void>(tape, L.z[l]), gbuf, npix, train, scale + 64 * l, mean + 64 * l, invstd + 64 * l,
+                                           g->conv[l].bn_weight, g->conv[l].bn_bias, g->conv[l].bias, stats, coef, s, kStatsDoubles, beside);
+      };
+      auto first_bwd = [&](void* gbuf, hipStream_t s) -> int {
+        VsProfScope ps(VS_PROF_BWD_EDGE, s);
+        // (deterministic mode's slot scratch: the features' gradient buffer, consumed long ago -- `part` belongs to the weight gradient beside it)
+        return vs_nhwc_first_bwd_impl(gbuf, x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
+                                      g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
+                                      at<double>(tape, L.first_acc) + 64, s, at<double>(tape, L.first_acc),
+                                      det ? at<double>(tape, L.dfeat) : nullptr);
+      };
+      if (int rc = from_dy(6, gb[c], stream, 0)) return rc;      // cnn7's BatchNorm backward: nothing to run beside yet
+      bool part_free = side == nullptr;
+      for (int i = 5; i >= 0; --i) {
+        const int l = i + 1;                                       // gb[c] = dz of layer l
+        {
+          VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
+          const void* pack_t = at<void>(tape, L.conv_packed_t[i]);      // (written by vs_forward_train [r6])
+          if (l == 1) {
+            // cnn2's data gradient is the plain conv: the activation derivative of cnn1 needs z1, which cnn1's one-pass backward recomputes from x
+            if (int rc = vs_nhwc_conv_impl(gb[c], pack_t, ones, zeros, gb[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE,
+                                           nullptr, stream)) return rc;
+          } else {
+            VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
+            if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
+                                              shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
+                                              B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+          }
         }
-      }
-      if (pending) {                 // the previous layer's weight gradient still reads the buffer this data gradient writes
-        VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
-        pending = false;
-      }
-      {
-        VsProfScope ps(VS_PROF_BWD_DGRAD + i, stream);
-        const void* pack_t = at<void>(tape, L.conv_packed_t[i]);      // (written by vs_forward_train [r6])
-        if (l == 1 || !dy_form) {
-          // cnn2's data gradient is the plain conv: the activation derivative of cnn1 needs z1, which is recomputed from x by
-          // cnn1's one-pass backward below (no dy epilogue here, no z1 tensor)
-          if (int rc = vs_nhwc_conv_impl(gb[c], pack_t, ones, zeros, gb[c ^ 1], B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, VS_ACT_NONE,
-                                         nullptr, stream)) return rc;
-          have_dy = false;
-        } else {
-          have_dy = true;
-          if (!kStatsDoubles) VS_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * VS_BN_STAT_SLOTS * 128, stream));
-          if (int rc = vs_nhwc_conv_dy_impl(gb[c], pack_t, gb[c ^ 1], at<void>(tape, L.z[l - 1]), conv_act, scale + 64 * (l - 1),
-                                            shift + 64 * (l - 1), mean + 64 * (l - 1), invstd + 64 * (l - 1), stats,
-                                            B, T, F, kMid[i].kt, kMid[i].kf, kMid[i].dil, stream)) return rc;
+        hipStream_t bs = stream;
+        if (side) {
+          VS_CHECK_HIP(hipEventRecord(side->fork, stream));
+          VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+          bs = side->s;
         }
+        if (l >= 2) { if (int rc = from_dy(l - 1, gb[c ^ 1], bs, side ? 1 : 0)) return rc; }
+        else { if (int rc = first_bwd(gb[c ^ 1], bs)) return rc; }
+        if (side) VS_CHECK_HIP(hipEventRecord(side->join, side->s));
+        if (!part_free) {      // the LSTM's leaf contractions on the side stream share the partial-sum scratch: long finished by now
+          VS_CHECK_HIP(hipStreamWaitEvent(stream, side->leaves, 0));
+          part_free = true;
+        }
+        {
+          VsProfScope ps(VS_PROF_BWD_WGRAD + i, stream);
+          if (int rc = vs_nhwc_wgrad_impl(gb[c], at<void>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf,
+                                          kMid[i].dil, stream)) return rc;
+        }
+        if (side) VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));      // (the pass beside it: done before the weight gradient is)
+        c ^= 1;
       }
-      hipStream_t ws = stream;
-      if (side) {
-        VS_CHECK_HIP(hipEventRecord(side->fork, stream));
-        VS_CHECK_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
-        ws = side->s;
-      }
-      {
-        VsProfScope ps(VS_PROF_BWD_WGRAD + i, ws);
-        if (int rc = vs_nhwc_wgrad_impl(gb[c], at<void>(tape, L.a[l - 1]), part, g->conv[l].weight, B, T, F, kMid[i].kt, kMid[i].kf,
-                                        kMid[i].dil, ws)) return rc;
-      }
-      if (side) {
-        VS_CHECK_HIP(hipEventRecord(side->join, side->s));
-        pending = true;
-      }
-      c ^= 1;
-    }
-    if (side) {
-      VS_CHECK_HIP(hipEventRecord(side->join, side->s));
-      VS_CHECK_HIP(hipStreamWaitEvent(stream, side->join, 0));
       side_join.forked = false;
+      return 0;
     }
-    VsProfScope ps(VS_PROF_BWD_EDGE, stream);
-    return vs_nhwc_first_bwd_impl(gb[c], x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
-                                  g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
-                                  at<double>(tape, L.first_acc) + 64, stream, at<double>(tape, L.first_acc),
-                                  det ? at<double>(tape, L.partials) : nullptr);
   }
   float* gbuf[2] = {at<float>(tape, L.grad0), at<float>(tape, L.grad1)};
   int cur = 0;
