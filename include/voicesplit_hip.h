@@ -15,8 +15,8 @@
  *    allocates device memory and keeps no caller pointer after return.
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
  *    synchronisation except where an entry point says so (vs_profile_end, vs_lstm_status).
- *  - library-owned state (all of it): (1) ONE side stream + two events per device, created on first use: vs_backward runs the
- *    weight gradients there beside the BatchNorm backward passes, vs_forward_train (VS_MATH_BF16) the weight-only launches of the
+ *  - library-owned state (all of it): (1) ONE side stream + three events per device, created on first use: vs_backward runs the
+ *    leaf gradients there and one kernel of every [weight gradient || BatchNorm backward pass] pair, vs_forward_train (VS_MATH_BF16) the weight-only launches of the
  *    step beside cnn1; both join it before they return, and the enqueue phase of concurrent calls on one device is serialised by a
  *    mutex while it is in use (vs_set_backward_overlap(0) turns it off); (2) the process-wide switches: vs_set_conv_kernel /
  *    vs_set_wgrad_kernel / vs_set_lstm_kernel / vs_set_backward_overlap and the option table behind vs_set_option (enum vs_option
