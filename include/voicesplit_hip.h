@@ -416,7 +416,7 @@ typedef struct vs_tape_layout {
   size_t conv_scales;         /* [16] scale slots (8 forward, 8 backward): operand scales + running |max| arrays */
   size_t gemm_scales;         /* operand scales of the split-f16 LSTM GEMMs (feat, W_ih, gate gradients) */
   size_t lstm_bf16;           /* VS_MATH_BF16: feat [B*T][Kp], [W_ih; W_ih_reverse] [8H][Kp], gate gradients [B*T][8H] as bf16 */
-  size_t det_turn;            /* ABI 9: the turn words of the deterministic mode (VS_OPT_DETERMINISTIC) */
+  size_t det_turn;            /* ABI 9: the turn words of the deterministic mode (VS_OPT_DETERMINISTIC), then its slot scratch for cnn1's backward */
   size_t conv_packed_t[6];    /* ABI 9, VS_MATH_BF16: the data-gradient weight images of cnn2..cnn7 (transposed, tap-flipped); written by
                                  vs_forward_train beside its own images (and the transposed W_hh image, lstm_packed_t), read by vs_backward */
 } vs_tape_layout;

@@ -70,13 +70,14 @@ int tape_layout(const vs_dims* d, vs_tape_layout* L) {
   size_t part = vs_conv64_wgrad_partial_floats(5, 5);
   part = max3(part, vs_conv64_wgrad_partial_floats(7, 1), (size_t)vs_conv_last_wgrad_blocks() * 512);
   part = max3(part, (size_t)kSplitK * d->FC2 * d->FC1, (size_t)kSplitK * d->FC1 * 2 * H);
-  part = max3(part, (size_t)kSplitK * 4 * H * H, (size_t)VS_BN_STAT_SLOTS * 576 * 2);      // (deterministic mode: cnn1's backward sums per slot, doubles)
+  part = max3(part, (size_t)kSplitK * 4 * H * H, (size_t)0);
   L->partials = take(part * 4);
   L->conv_scales = take(16 * VS_SCALE_SLOT_FLOATS * 4);
   L->gemm_scales = take(32 * 4);
   // bf16 configuration: feat / W_ih / dxg as bf16 arrays shared by the forward GEMM and the two backward contractions
   L->lstm_bf16 = take(d->math == VS_MATH_BF16 ? vs_lstm_bf16_layout((long long)M, 8 * (int)F, (int)H).total : 256);
-  L->det_turn = take(VS_TURN_WORDS * 4);
+  // (behind the turn words: the per-slot sums of cnn1's backward in deterministic mode, [VS_BN_STAT_SLOTS][576] doubles)
+  L->det_turn = take(VS_TURN_WORDS * 4 + (size_t)VS_BN_STAT_SLOTS * 576 * 8);
   for (int i = 0; i < 6; ++i) L->conv_packed_t[i] = take(vs_conv64_packed_floats(kMid[i].kt, kMid[i].kf) * 4);
   L->total_bytes = off;
   return 0;
@@ -746,11 +747,11 @@ int vs_backward(const vs_dims* d, const vs_params* p, const float* x, const floa
       };
       auto first_bwd = [&](void* gbuf, hipStream_t s) -> int {
         VsProfScope ps(VS_PROF_BWD_EDGE, s);
-        // (deterministic mode's slot scratch: the features' gradient buffer, consumed long ago -- `part` belongs to the weight gradient beside it)
+        // (deterministic mode's slot scratch: behind the turn words -- `part` belongs to the weight gradient beside it)
         return vs_nhwc_first_bwd_impl(gbuf, x, p->conv[0].weight, p->conv[0].bias, B, T, F, conv_act, train, scale, shift, mean, invstd,
                                       g->conv[0].bn_weight, g->conv[0].bn_bias, g->conv[0].bias, g->conv[0].weight,
                                       at<double>(tape, L.first_acc) + 64, s, at<double>(tape, L.first_acc),
-                                      det ? at<double>(tape, L.dfeat) : nullptr);
+                                      det ? at<double>(tape, L.det_turn) + VS_TURN_WORDS * 4 / 8 : nullptr);
       };
       if (int rc = from_dy(6, gb[c], stream, 0)) return rc;      // cnn7's BatchNorm backward: nothing to run beside yet
       bool part_free = side == nullptr;
