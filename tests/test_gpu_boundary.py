@@ -104,6 +104,28 @@ def _rel(got, ref):
     return ((got - ref).abs().max() / ref.abs().max()).item()
 
 
+@pytest.mark.parametrize("rows,K,ld,Kp,offset", [
+    (37, 64, 72, 128, 0),        # vector path (K % 8 == 0, ld % 4 == 0, aligned): eight pieces of data, eight of padding per row
+    (301, 3200, 3200, 3200, 0),  # the gate gradients' shape class: no padding
+    (37, 61, 72, 64, 0),         # K % 8 != 0: element-wise path, the last piece half data half padding
+    (37, 64, 70, 128, 0),        # ld % 4 != 0: element-wise path
+    (37, 64, 72, 128, 1),        # source not 16-byte aligned: element-wise path
+])
+def test_cvt_rows_bf16_is_round_to_nearest_even_with_zero_padding(rows, K, ld, Kp, offset):
+    """vs_cvt_rows_bf16 (the operand conversion of every bf16 contraction; round 6 gave it a vector path): bit for bit torch's
+    float -> bfloat16 conversion on the K data columns, zeros in the Kp - K padding columns, on both kernel paths."""
+    from voicesplit_amd import ops
+    g = torch.Generator().manual_seed(rows + K + ld)
+    base = torch.randn(rows * ld + 8, generator=g).cuda()
+    base[5] = float("inf")
+    x = base[offset:offset + rows * ld].view(rows, ld)
+    out = ops.cvt_rows_bf16(x, K, Kp)
+    assert out.shape == (rows, Kp)
+    ref = x[:, :K].to(torch.bfloat16)
+    assert torch.equal(out[:, :K].view(torch.int16), ref.view(torch.int16))
+    assert (out[:, K:].view(torch.int16) == 0).all()
+
+
 def test_gemm_bf16_production_shapes():
     """B = 8 of the metric configuration: M = 8 * 301 = 2408 rows, N = 8H = 3200, K = 8F = 4808 (padded to 4864) --
     xg = feat @ W_ih^T (row x row, with the d-vector row bias), dfeat = dxg @ W_ih (row x col), dW_ih = dxg^T @ feat
