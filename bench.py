@@ -610,8 +610,10 @@ def main():
                                         "instruction count have not moved the time: the clock follows (power-bound)")
         else:
             kname, peak, extra, ksub, ksrc = "conv64_mfma_kernel<5,5>", PEAK_FP32_MFMA_TFLOPS, {}, "conv64_mfma_kernel", "conv_mfma.hip"
-        no64 = (None, "counters were collected at B = 64 only")
-        traffic, rnd = committed_pmc_traffic(tag, ksub, kinst, source=ksrc) if B == 64 else no64
+        no64 = (None, "counters were collected at B = 64 (forward, training step) and at 256 windows (long-form) only")
+        if B == 256 and not is_train:                                       # the long-form batch has its own counters (tag longform[_math])
+            tag = tag.replace("forward", "longform")
+        traffic, rnd = committed_pmc_traffic(tag, ksub, kinst, source=ksrc) if B == 64 or tag.startswith("longform") else no64
         algo_gb = B * 2 * 64 * T_FRAMES * N_FREQ * act_bytes / 1e9
         by_instance = None
         if math == "bf16" and is_train:
