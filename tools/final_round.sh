@@ -35,6 +35,11 @@ VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.j
 PYTHONPATH=. timeout 200 python tools/split_conv_micro.py final/${R}_split_conv_micro > /dev/null 2>&1
 bash tools/profile_gpu.sh ${R}_forward --mode forward 2>&1 | tail -2
 bash tools/profile_gpu.sh ${R}_train_bf16 --conv-math bf16 2>&1 | tail -2
+# [r6] counters for the other legs' roofline.traffic: bf16 forward, long-form (256 windows per batch) in both arithmetics, the fp32-class step
+bash tools/profile_gpu.sh ${R}_forward_bf16 --mode forward --conv-math bf16 2>&1 | tail -1
+bash tools/profile_gpu.sh ${R}_longform --mode longform 2>&1 | tail -1
+bash tools/profile_gpu.sh ${R}_longform_bf16 --mode longform --conv-math bf16 2>&1 | tail -1
+bash tools/profile_gpu.sh ${R}_train_f16x3 --conv-math f16x3 2>&1 | tail -1
 # device idle gaps of one training step, from the kernel trace of the profile run
 F=$(find gpurun_out/prof_${R}_train_bf16/trace -name "*kernel_trace.csv" | head -1)
 [ -n "$F" ] && python tools/step_timeline.py $F > $O/${R}_step_timeline.txt && head -3 $O/${R}_step_timeline.txt
