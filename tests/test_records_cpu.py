@@ -9,7 +9,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-ROUND = "r05" if os.path.isfile(os.path.join(PROF, "r05_bench_train.json")) else "r04"
+import glob
+
+# the newest round that has a committed default line (bench.py's own counter lookup discovers the newest round the same way)
+ROUND = max(os.path.basename(p)[:3] for p in glob.glob(os.path.join(PROF, "r[0-9][0-9]_bench_train.json")))
 
 
 def _line(name):
@@ -45,9 +48,16 @@ def test_headline_line_keeps_the_bench_contract():
     ("train_bf16", [("nhwc_conv_kernel<5, 5", "true, false>"), ("nhwc_conv_kernel<5, 5", "false, true>"), ("nhwc_wgrad_kernel<5, 5", ""),
                     ("gemm_bf16_il_kernel", "")]),
     ("forward", [("nhwc_conv_f16x3", "5, 5")]),
+    # round 6, call 24: the legs whose `traffic` used to be null
+    ("forward_bf16", [("nhwc_conv_kernel<5, 5", "")]),
+    ("longform", [("nhwc_conv_f16x3", "5, 5")]),
+    ("longform_bf16", [("nhwc_conv_kernel<5, 5", "")]),
+    ("train_f16x3", [("conv64_f16x3_pk_kernel", ""), ("conv64_wgrad_ring4_kernel", "")]),
 ])
 def test_rocprof_summaries_hold_the_rows_bench_py_looks_up(tag, needles):
     d = os.path.join(PROF, f"{ROUND}_{tag}_rocprof")
+    if ROUND < "r06" and tag not in ("train_bf16", "forward"):
+        pytest.skip("collected from round 6 on")
     stats = os.path.join(d, "kernel_stats.csv")
     pmc = os.path.join(d, "pmc_per_kernel.csv")
     assert os.path.isfile(stats) and os.path.isfile(pmc), d
@@ -64,3 +74,30 @@ def test_rocprof_summaries_hold_the_rows_bench_py_looks_up(tag, needles):
         assert os.path.isfile(rec)
         listed = {ln.split()[1].lstrip("*") for ln in open(rec) if ln.strip()}
         assert {"conv_nhwc.hip", "conv_nhwc_f16x3.hip", "gemm_bf16.hip"} <= listed
+
+
+@pytest.mark.parametrize("tag,kernel,instance,source", [
+    ("train_bf16", "nhwc_conv_kernel<5, 5", "true, false>", "conv_nhwc.hip"),
+    ("train_bf16", "nhwc_conv_kernel<5, 5", "false, true>", "conv_nhwc.hip"),
+    ("forward", "nhwc_conv_f16x3", "<5, 5", "conv_nhwc_f16x3.hip"),
+    ("forward_bf16", "nhwc_conv_kernel", None, "conv_nhwc.hip"),
+    ("longform", "nhwc_conv_f16x3", "<5, 5", "conv_nhwc_f16x3.hip"),
+    ("longform_bf16", "nhwc_conv_kernel", None, "conv_nhwc.hip"),
+    ("train_f16x3", "conv64_f16x3_pk_kernel", None, "conv_f16x3_pk.hip"),
+])
+def test_committed_counters_belong_to_the_kernel_sources_of_this_tree(tag, kernel, instance, source):
+    """bench.py reports `roofline.traffic` only while the kernel's source file is byte-identical to the one the counters were collected
+    on (sources.sha256 beside the summary): a kernel edit without a new profile must show up HERE, not as a silent null in the driver's
+    line.  Traffic within 1.0-1.35x of the algorithmic bytes is also what DESIGN.md section 7 states for every leg."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    if ROUND < "r06":
+        pytest.skip("every leg has counters from round 6 on")
+    gb, why = bench.committed_pmc_traffic(tag, kernel, instance, source=source)
+    assert gb is not None, why
+    assert why == ROUND, why
+    one = 64 * 64 * 301 * 601 / 1e9                      # elements of one [64, 64, 301, 601] activation tensor, in G
+    algo = {"train_bf16": (2 if instance and instance.startswith("true") else 3) * one * 2, "forward": 2 * one * 4, "forward_bf16": 2 * one * 2,
+            "longform": 4 * 2 * one * 4, "longform_bf16": 4 * 2 * one * 2, "train_f16x3": 2 * one * 4}[tag]
+    assert 1.0 <= gb / algo <= 1.35, (gb, algo)
