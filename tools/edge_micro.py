@@ -52,6 +52,9 @@ def main():
     rec("cnn1 input moments", timed(lambda: ops.nhwc_first_moments(x)), B * T * F * 4 / 1e9)
     rec("cnn1 one-pass backward (mish)", timed(lambda: ops.nhwc_first_bwd(da16, x, w1, b1, "mish", True, sc, sh, zero, one)), big)
     rec("BatchNorm + mish apply", timed(lambda: ops.nhwc_bn_apply(act16, sc, sh, "mish")), 2 * big)
+    # the same pass without the activation's arithmetic (what the memory system alone allows this access pattern) and with relu
+    rec("BatchNorm apply, no activation", timed(lambda: ops.nhwc_bn_apply(act16, sc, sh, "none")), 2 * big)
+    rec("BatchNorm + relu apply", timed(lambda: ops.nhwc_bn_apply(act16, sc, sh, "relu")), 2 * big)
     st = torch.zeros(64, 64, 2, dtype=torch.float64, device=dev)
     rec("BatchNorm backward from dy (one pass)", timed(lambda: ops.nhwc_bn_bwd_from_dy(da16, act16, st, True, sc, zero, one)), 3 * big)
     rec("cnn8 forward on z7 (BatchNorm + mish of cnn7 applied on the way in) + statistics",

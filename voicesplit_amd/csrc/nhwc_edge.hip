@@ -812,6 +812,16 @@ int stream_blocks(long long items_per_block_sweep, long long total) {
   if (nb > 2048) nb = 2048;
   return nb < 1 ? 1 : (int)nb;
 }
+// The pure elementwise passes (no sums, no per-block flush): ONE sweep -- a workgroup per `items_per_block_sweep`, no grid-stride loop.
+// [r6, calls 28-29] A 2048-block grid-stride loop over a 1.48 GB tensor (stride 8 MB) reads and writes at 4.7-5.3 TB/s; the same kernel
+// launched with a workgroup per 512 pieces at 6.35 (BatchNorm apply 0.627 -> 0.467 ms, the backward pass from dy 0.918 -> 0.758), and the
+// rate rises monotonically with the grid in between (tools/stream_probe.hip, profiles/r06_experiments.md section 15): workgroups dispatched in
+// index order walk the tensor as one front, a strided loop keeps 2048 fronts 4 KB wide in flight.
+int stream_blocks_wide(long long items_per_block_sweep, long long total) {
+  long long nb = (total + items_per_block_sweep - 1) / items_per_block_sweep;
+  if (nb > (1LL << 24)) nb = 1LL << 24;
+  return nb < 1 ? 1 : (int)nb;
+}
 
 }  // namespace
 
@@ -894,7 +904,7 @@ int vs_nhwc_first_bwd_impl(const void* da, const float* x, const float* w, const
 int vs_nhwc_bn_apply_impl(const void* z, void* a, long long npix, int act, const float* scale, const float* shift, hipStream_t stream) {
   VS_REQUIRE(z && a && scale && shift && npix > 0, "nhwc bn_apply: bad argument");
   const long long npieces = npix * 8;
-  const dim3 grid(stream_blocks(512, npieces)), block(256);
+  const dim3 grid(stream_blocks_wide(512, npieces)), block(256);
   const u4v* zi = reinterpret_cast<const u4v*>(z);
   u4v* ao = reinterpret_cast<u4v*>(a);
   if (act == VS_ACT_MISH) hipLaunchKernelGGL(nhwc_bn_apply_kernel<VS_ACT_MISH>, grid, block, 0, stream, zi, ao, scale, shift, npieces);
@@ -981,7 +991,7 @@ int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long lo
                                 int beside_wgrad) {
   VS_REQUIRE(dy && z && dz && scale && mean && invstd && stats && coef && npix > 0, "nhwc bn_bwd_from_dy: bad argument");
   const long long npieces = npix * 8;
-  int nb = stream_blocks(512, npieces);
+  int nb = beside_wgrad ? stream_blocks(512, npieces) : stream_blocks_wide(512, npieces);
   // beside the weight gradient on the side stream (vs_backward): ONE block per CU.  The pass then takes 1.8 ms instead of 1.2 -- still
   // inside the weight gradient's 1.95 -- and takes less from it (2.06 -> 1.94 ms per layer, -0.4 ms per step: profiles/r05_bn_finalize_ab.md)
   if (beside_wgrad) {
