@@ -659,11 +659,12 @@ int vs_cvt_rows_bf16_impl(const float* src, long long rows, int K, int ld, void*
   VS_REQUIRE(src && dst && rows > 0 && K > 0 && ld >= K && Kp >= K && Kp % 8 == 0, "cvt_rows_bf16: bad argument");
   const long long total = rows * (Kp >> 3);
   const long long nb = (total + 255) / 256;
+  const long long ccap = 1LL << 24;      // [r6, call 31] one sweep instead of a 4096-block grid-stride loop: 32.8 -> 21.7 us mean over the step's six conversions
   const bool vec = K % 8 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(cvt_rows_bf16_kernel<true>, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, src, rows, K, ld,
+  if (vec) hipLaunchKernelGGL(cvt_rows_bf16_kernel<true>, dim3((unsigned)(nb < ccap ? nb : ccap)), dim3(256), 0, stream, src, rows, K, ld,
                               reinterpret_cast<unsigned short*>(dst), Kp);
   else
-  hipLaunchKernelGGL(cvt_rows_bf16_kernel<false>, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, src, rows, K, ld,
+  hipLaunchKernelGGL(cvt_rows_bf16_kernel<false>, dim3((unsigned)(nb < ccap ? nb : ccap)), dim3(256), 0, stream, src, rows, K, ld,
                      reinterpret_cast<unsigned short*>(dst), Kp);
   VS_LAUNCH_CHECK();
   return 0;

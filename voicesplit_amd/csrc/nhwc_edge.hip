@@ -807,9 +807,9 @@ __global__ void nhwc_first_bwd_finalize_kernel(const double* __restrict__ acc /*
   }
 }
 
-int stream_blocks(long long items_per_block_sweep, long long total) {
+int stream_blocks(long long items_per_block_sweep, long long total, long long cap = 2048) {
   long long nb = (total + items_per_block_sweep - 1) / items_per_block_sweep;
-  if (nb > 2048) nb = 2048;
+  if (nb > cap) nb = cap;
   return nb < 1 ? 1 : (int)nb;
 }
 // The pure elementwise passes (no sums, no per-block flush): ONE sweep -- a workgroup per `items_per_block_sweep`, no grid-stride loop.
@@ -830,7 +830,7 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
   VS_REQUIRE(x && w && scale && shift && out, "nhwc conv_first: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_first: bad shape");
   const long long npix = (long long)B * T * F;
-  const dim3 grid(stream_blocks(32, npix)), block(256);
+  const dim3 grid(stream_blocks(32, npix, 8192)      /* [r6, call 31] 2048: 437 us, 4096: 412, 16384: 408, 65536: 508 (per-lane weights), one sweep: 1885 */), block(256);
   unsigned short* o = reinterpret_cast<unsigned short*>(out);
   if (bn_stats) {
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_first: fused statistics go with no activation");
@@ -925,7 +925,7 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
-  const dim3 grid(stream_blocks(4, nblk)), block(256);
+  const dim3 grid(stream_blocks(4, nblk, 8192)      /* [r6, call 31] 2048: 427 us, 4096: 411, 8192: 403, 16384: 444 (the statistics flush), 32768: 548 */), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
   if (pre_scale) {     // `in` is z7: the layer below's BatchNorm + activation applied on the way in; output unactivated (+ statistics)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: the pre-activation form writes the unactivated output");
@@ -995,8 +995,8 @@ int vs_nhwc_bn_bwd_from_dy_impl(const void* dy, const void* z, void* dz, long lo
   // beside the weight gradient on the side stream (vs_backward): ONE block per CU.  The pass then takes 1.8 ms instead of 1.2 -- still
   // inside the weight gradient's 1.95 -- and takes less from it (2.06 -> 1.94 ms per layer, -0.4 ms per step: profiles/r05_bn_finalize_ab.md)
   if (beside_wgrad) {
-    const int want = 256;          // (128: +2.2 ms per step, 512: +0.2 -- round 5, call 10)
-    if (want < nb) nb = want;
+    const int want = 256;          // (128: +2.2 ms per step, 512: +0.2 -- round 5, call 10; [r6, call 32] a contiguous part per workgroup instead of
+    if (want < nb) nb = want;      // the strided loop: the pass 1.9 -> 1.7 ms, the weight gradient beside it and the step unchanged -- not kept)
   }
   const dim3 grid(nb), block(256);
   if (int rc = vs_bn_bwd_finalize_impl(stats, VS_BN_STAT_SLOTS, (double)npix, train, 64, scale, mean, invstd, dgamma, dbeta, dbias, coef, stream,
