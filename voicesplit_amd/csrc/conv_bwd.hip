@@ -646,7 +646,14 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   // deterministic mode: chains of at most 64 turns per channel behind the pass (~0.2 ms), 64 * C workgroups all resident at once; the
   // apply pass below keeps the full grid (round 6: sixteen per channel on BOTH passes cost 4.2 ms at B = 64 -- 128 workgroups cannot
   // stream 1.9 GB)
-  const int bpc = (turn && bpc_full > 64) ? 64 : bpc_full;
+  int bpc = (turn && bpc_full > 64) ? 64 : bpc_full;
+  int bpc_apply = bpc_full;
+  if (C <= 8) {      // [r6, calls 34-35] the features' BatchNorm (8 channels of 601-element rows): more, shorter-lived workgroups -- statistics pass
+    // 256 -> 512 per channel (373 -> 330 us; 4096: 736, its flush), apply pass 256 -> 4096 (304 -> 216 us; all rows: 250); step -0.09 ms
+    const long long items = rows_per_c * vs_row_chunks(L);
+    if (!turn && bpc < 512) bpc = (int)(items < 512 ? items : 512);
+    if (bpc_apply < 4096) bpc_apply = (int)(items < 4096 ? items : 4096);
+  }
   dim3 grid(bpc, C), block(256);
   switch (act) {
     case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_stats_kernel<VS_ACT_RELU>, grid, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, mean, invstd, stats, turn); break;
@@ -656,7 +663,7 @@ int vs_bn_act_bwd_impl(const float* da, const float* z, float* dz, int C, long l
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, (double)rows_per_c * L, train, C,
                      scale, mean, invstd, dgamma, dbeta, dbias, coef);
-  const dim3 grid_apply(bpc_full, C);
+  const dim3 grid_apply(bpc_apply, C);
   switch (act) {
     case VS_ACT_RELU: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_RELU>, grid_apply, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
     case VS_ACT_MISH: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VS_ACT_MISH>, grid_apply, block, 0, stream, da, z, C, rows_per_c, L, scale, shift, coef, dz, amax_out); break;
