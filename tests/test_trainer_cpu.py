@@ -248,25 +248,30 @@ def test_batch_feeder_worker_processes_yield_exactly_the_epoch_shards_batches(tm
 
 
 def test_gradient_bucket_layout_spare_slots_in_front_and_an_early_segment():
-    """flat = [extra | late parameters | early parameters]: the views cover it exactly once, .grad is the view, the early segment
-    is contiguous at the end and the spare slots sit in front of the small segment (sharding.GradientBucket)."""
+    """flat = [extra | late parameters | early parameters], every view on a 16-byte boundary (zero padding between them): the views do
+    not overlap, .grad is the view, the early segment is contiguous at the end and the spare slots sit in front of the small segment
+    (sharding.GradientBucket)."""
     from voicesplit_amd.sharding import GradientBucket
     m = _Standin()
     params = list(m.parameters())                     # a.weight, a.bias, b.weight, b.bias
     early = [m.b.weight, m.b.bias]
     bk = GradientBucket(params, extra=2, early=early).attach()
-    n_late = m.a.weight.numel() + m.a.bias.numel()
-    assert bk.flat.numel() == 2 + sum(p.numel() for p in params) and bk.split == 2 + n_late and bk.has_early
-    assert bk.extra.data_ptr() == bk.flat.data_ptr() and bk.extra.numel() == 2 and bk.grads.numel() == bk.numel
+    up = lambda n: (n + 3) // 4 * 4
+    assert bk.has_early and bk.extra.data_ptr() == bk.flat.data_ptr() and bk.extra.numel() == 2
     off = {id(p): (v.data_ptr() - bk.flat.data_ptr()) // 4 for p, v in zip(bk.params, bk.views)}
-    assert off[id(m.a.weight)] == 2 and off[id(m.a.bias)] == 2 + m.a.weight.numel()
-    assert off[id(m.b.weight)] == bk.split and off[id(m.b.bias)] == bk.split + m.b.weight.numel()
+    assert all(o % 4 == 0 for o in off.values())                                        # 16-byte boundaries
+    assert off[id(m.a.weight)] == 4 and off[id(m.a.bias)] == up(4 + m.a.weight.numel())
+    assert bk.split == up(off[id(m.a.bias)] + m.a.bias.numel())
+    assert off[id(m.b.weight)] == bk.split and off[id(m.b.bias)] == up(bk.split + m.b.weight.numel())
+    assert bk.flat.numel() == up(off[id(m.b.bias)] + m.b.bias.numel()) and bk.grads.data_ptr() == bk.flat.data_ptr() + 16
     assert all(p.grad is v and v.shape == p.shape for p, v in zip(bk.params, bk.views))
     for i, v in enumerate(bk.views):
         v.fill_(float(i + 1))
     order = {id(p): i for i, p in enumerate(params)}           # (list.index would compare tensors element-wise)
-    want = torch.cat([torch.zeros(2)] + [torch.full((p.numel(),), float(order[id(p)] + 1)) for p in (m.a.weight, m.a.bias, m.b.weight, m.b.bias)])
-    assert torch.equal(bk.flat, want)
+    want = torch.zeros(bk.flat.numel())
+    for p in params:
+        want[off[id(p)]:off[id(p)] + p.numel()] = float(order[id(p)] + 1)
+    assert torch.equal(bk.flat, want)                          # the views cover their ranges once; spare slots and padding stay zero
     # no early segment: the old layout but for the spare slots in front
     bk2 = GradientBucket(params, extra=1)
     assert not bk2.has_early and bk2.split == bk2.flat.numel() and bk2.all_reduce_early(1) is None
