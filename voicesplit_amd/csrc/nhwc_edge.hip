@@ -1335,7 +1335,7 @@ int vs_nhwc_conv_first_split_impl(const float* x, const float* w, const float* s
   VS_REQUIRE(x && w && scale && shift && out_scale2 && out_hi && out_lo, "nhwc conv_first_split: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_first_split: bad shape");
   const long long npix = (long long)B * T * F;
-  const dim3 grid(stream_blocks(32, npix)), block(256);
+  const dim3 grid(stream_blocks(32, npix, 8192)), block(256);
   unsigned short* oh = reinterpret_cast<unsigned short*>(out_hi);
   unsigned short* ol = reinterpret_cast<unsigned short*>(out_lo);
   if (act == VS_ACT_NONE) hipLaunchKernelGGL((nhwc_conv_first_split_kernel<VS_ACT_NONE>), grid, block, 0, stream, x, w, scale, shift, out_scale2, oh, ol, amax_out, npix, F);
@@ -1354,7 +1354,7 @@ int vs_nhwc_conv_last_split_impl(const void* in_hi, const void* in_lo, const flo
   VS_REQUIRE(!row_hi || (row_lo && out_scale2 && Kp >= 8 * F), "nhwc conv_last_split: bad row-form arguments (Kp = %d)", Kp);
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
-  const dim3 grid(stream_blocks(4, nblk)), block(256);
+  const dim3 grid(stream_blocks(4, nblk, 8192)), block(256);
   const unsigned short* ih = reinterpret_cast<const unsigned short*>(in_hi);
   const unsigned short* il = reinterpret_cast<const unsigned short*>(in_lo);
   unsigned short* rh = reinterpret_cast<unsigned short*>(row_hi);
