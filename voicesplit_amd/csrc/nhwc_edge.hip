@@ -830,7 +830,8 @@ int vs_nhwc_conv_first_impl(const float* x, const float* w, const float* scale, 
   VS_REQUIRE(x && w && scale && shift && out, "nhwc conv_first: NULL argument");
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_first: bad shape");
   const long long npix = (long long)B * T * F;
-  const dim3 grid(stream_blocks(32, npix, 8192)      /* [r6, call 31] 2048: 437 us, 4096: 412, 16384: 408, 65536: 508 (per-lane weights), one sweep: 1885 */), block(256);
+  // [r6, call 31] 2048 workgroups: 437 us, 4096: 412, 16384: 408, 65536: 508 (per-lane weights), one sweep: 1885
+  const dim3 grid(stream_blocks(32, npix, (bn_stats && g_vs_turn) ? 2048 : 8192)), block(256);
   unsigned short* o = reinterpret_cast<unsigned short*>(out);
   if (bn_stats) {
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_first: fused statistics go with no activation");
@@ -925,7 +926,9 @@ int vs_nhwc_conv_last_impl(const void* in, const float* w, const float* scale, c
   VS_REQUIRE(B > 0 && T > 0 && F > 0, "nhwc conv_last: bad shape");
   const long long nrows = (long long)B * T;
   const long long nblk = nrows * ((F + 15) / 16);
-  const dim3 grid(stream_blocks(4, nblk, 8192)      /* [r6, call 31] 2048: 427 us, 4096: 411, 8192: 403, 16384: 444 (the statistics flush), 32768: 548 */), block(256);
+  // [r6, call 31] 2048 workgroups: 427 us, 4096: 411, 8192: 403, 16384: 444 (the statistics flush), 32768: 548; deterministic mode keeps 2048 (its
+  // workgroups take turns per statistics slot: 128 turns instead of 32 cost the step 1.4 ms)
+  const dim3 grid(stream_blocks(4, nblk, (bn_stats && g_vs_turn) ? 2048 : 8192)), block(256);
   const unsigned short* i = reinterpret_cast<const unsigned short*>(in);
   if (pre_scale) {     // `in` is z7: the layer below's BatchNorm + activation applied on the way in; output unactivated (+ statistics)
     VS_REQUIRE(act == VS_ACT_NONE, "nhwc conv_last: the pre-activation form writes the unactivated output");
