@@ -29,7 +29,7 @@ timeout 200 python tools/edge_micro.py > $O/${R}_edge_micro.json 2>/dev/null
 timeout 200 python tools/gemm_epilogue_probe.py > $O/${R}_gemm_epilogue_probe.json 2>/dev/null
 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_train_torchrun_n1.json; cut -c1-160 $O/${R}_bench_train_torchrun_n1.json
 VS_MICRO_ONLY=bf16 timeout 300 python tools/gemm_micro.py > $O/${R}_gemm_micro.json 2>/dev/null
-{ for p in gemm_issue_probe occupancy_probe epilogue_slot_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
+{ for p in gemm_issue_probe occupancy_probe epilogue_slot_probe stream_probe; do echo "== tools/$p"; timeout 120 tools/$p; done; } > $O/${R}_probes.txt 2>&1
 { timeout 200 python tools/lstm_time.py 64; timeout 200 python tools/lstm_time.py 2; } 2>/dev/null | grep "B=" > $O/${R}_lstm_time.txt
 [ -f voicesplit_amd/libvoicesplit_hip_abl.so ] && timeout 300 python tools/wgrad_ablation.py > $O/${R}_wgrad_ablation.json 2>/dev/null
 PYTHONPATH=. timeout 200 python tools/split_conv_micro.py final/${R}_split_conv_micro > /dev/null 2>&1
